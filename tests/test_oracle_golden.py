@@ -1,0 +1,129 @@
+"""Pins oracle/np_ref.py (the numpy-half restatement) to golden vectors captured from the
+imported reference (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from oracle import np_ref
+from tests import synth
+
+
+def sha(*arrs):
+    h = hashlib.sha1()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8)
+
+
+def test_anchor_tables(golden):
+    assert (np_ref.get_anchors([128, 256, 512]) == golden["anchors9"]).all()
+    assert (np_ref.get_anchors([16, 32, 64, 128, 256, 512]) == golden["anchors18"]).all()
+
+
+def test_conv_dims(golden):
+    got = [np_ref.conv_dims_resnet(int(d), int(d))[0] for d in golden["kat_conv_dims_in"]]
+    assert got == list(golden["kat_conv_dims_resnet"])
+    assert np_ref.conv_dims_vgg(600, 1000) == (37, 62)
+
+
+def test_anchors_image(golden):
+    a9, a18 = golden["anchors9"], golden["anchors18"]
+    got = np_ref.anchors_image(3, 4, a9, 16)
+    assert got.dtype == np.float32 and (got == golden["anc_img_3x4"]).all()
+    c2 = np_ref.anchors_image(38, 63, a9, 16)
+    c4 = np_ref.anchors_image(38, 94, a18, 16)
+    assert (c2 == golden["anc_img_c2_i16"]).all() and (c4 == golden["anc_img_c4_i16"]).all()
+    assert (np.nonzero(np_ref.oob_mask(c2, 1000, 600))[0] == golden["oob_c2"]).all()
+    assert (np.nonzero(np_ref.oob_mask(c4, 1500, 600))[0] == golden["oob_c4"]).all()
+
+
+def test_cross_ious(golden):
+    c2 = golden["anc_img_c2_i16"].astype(np.float32)
+    got = np_ref.cross_ious(c2, golden["gt5"])
+    assert got.dtype == np.float32 and np.array_equal(got, golden["iou_c2_gt5"])
+    kat = np_ref.cross_ious(golden["kat_boxes"], np.array([[0, 0, 10, 10], [4, 4, 12, 12]], dtype=np.float32))
+    assert np.array_equal(kat, golden["kat_iou"])
+    assert np.array_equal(np_ref.cross_ious(golden["iou_i16_boxes"], golden["iou_i16_gt"]), golden["iou_i16"])
+
+
+CASES = {
+    "rpn_img5_vgg": ("img5_gt", 0, np_ref.conv_dims_vgg, "anchors9"),
+    "rpn_img5rs_vgg": ("img5_rs_gt", 2, np_ref.conv_dims_vgg, "anchors9"),
+    "rpn_img5rs_res": ("img5_rs_gt", 2, np_ref.conv_dims_resnet, "anchors9"),
+    "rpn_c2": ("gt5", (1000, 600), np_ref.conv_dims_resnet, "anchors9"),
+    "rpn_c4": ("gt5", (1500, 600), np_ref.conv_dims_resnet, "anchors18"),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_rpn_targets(golden, name):
+    gt_key, dims, dims_fn, anc_key = CASES[name]
+    if isinstance(dims, int):
+        w, h = golden["img5_dims"][dims:dims + 2]
+    else:
+        w, h = dims
+    anc = golden[anc_key]
+    rows, cols = dims_fn(int(h), int(w))
+    can_use, is_pos, bbreg, _ = np_ref.rpn_assign(golden[gt_key], rows, cols, anc, 16, int(w), int(h))
+    assert (np.nonzero(is_pos)[0] == golden[name + "_is_pos"]).all()
+    assert (np.packbits(can_use) == golden[name + "_can_use"]).all()
+    assert np.array_equal(bbreg[is_pos], golden[name + "_bbreg_rows"])
+    assert (sha(can_use, is_pos, bbreg) == golden[name + "_sha"]).all()
+    random.seed(1)
+    cu = np_ref.apply_sampling(is_pos, can_use.copy())
+    y_class, y_bbreg = np_ref.rpn_pack(cu, is_pos, bbreg, rows, cols, len(anc))
+    assert list(y_class.shape + y_bbreg.shape) == list(golden[name + "_ycls_shape"])
+    assert y_class.dtype == bool and y_bbreg.dtype == np.float32
+    assert (sha(y_class, y_bbreg) == golden[name + "_ycls_sha"]).all()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "c2", "c4"])
+def test_proposals(golden, tag):
+    rows, cols, A = synth.SHAPES[tag]
+    anc = golden["anchors9"] if A == 9 else golden["anchors18"]
+    regr, cls = synth.rpn_outputs(tag)
+    assert (sha(np_ref.anchors_conv(rows, cols, anc // 16)) == golden[f"prop_{tag}_anc_conv_sha"]).all()
+    rois = np_ref.get_rois(regr, anc, 16)
+    assert rois.dtype == np.float32 and (rois == golden[f"prop_{tag}_rois_i16"]).all()
+    valid = np.nonzero(np_ref.valid_mask(rois))[0]
+    assert len(valid) == golden[f"prop_{tag}_nvalid"][0]
+    probs = cls.reshape(-1)
+    for pre, post in ((8000, 300), (12000, 2000)):
+        order = valid[np_ref.score_order(probs[valid], pre)]
+        assert (order == golden[f"prop_{tag}_{pre}_order"]).all()
+        kept, kp, cand, cp, pick = np_ref.proposals(regr, cls, anc, 16, pre, post)
+        assert (pick == golden[f"prop_{tag}_{pre}_pick"]).all()
+        assert kept.dtype == np.int16 and (kept == golden[f"prop_{tag}_{pre}_kept"]).all()
+
+
+def test_nms_kats(golden):
+    kb = golden["kat_boxes"].astype(np.int16)
+    ks = np.array([.9, .8, .95, .5, .6], dtype=np.float32)
+    assert (np_ref.nms(kb, ks, 0.7, 300)[0] == golden["kat_nms_7"]).all()
+    assert (np_ref.nms(kb, ks, 0.5, 300)[0] == golden["kat_nms_5"]).all()
+    assert np_ref.nms(np.zeros((0, 4)), np.zeros(0))[0] == []
+    kept, kp, _ = np_ref.nms(golden["nms_f64_boxes"], golden["nms_f64_scores"], 0.5, 2000)
+    assert np.array_equal(kept, golden["nms_f64_kept"]) and np.array_equal(kp, golden["nms_f64_kept_scores"])
+
+
+def test_det_targets(golden):
+    kept = golden["prop_c2_12000_kept"]
+    e_rois, onehot, bb = np_ref.rois_to_truth(kept, synth.GT5, golden["truth_gt_cls"], 21, stride=16)
+    assert np.array_equal(e_rois, golden["truth_c2_rois"])
+    assert (onehot.argmax(axis=1) == golden["truth_c2_cls"]).all() and onehot.dtype == np.int32
+    assert (sha(bb) == golden["truth_c2_bbreg_sha"]).all()
+    np.random.seed(1337)
+    assert np_ref.det_samples(onehot[:, -1] == 0, 64) == list(golden["truth_c2_samples"])
+
+
+def test_scalar_kats(golden):
+    t = np_ref.reg_params_f64(np.array([0, 0, 10, 10]), np.array([2, 3, 8, 13]), gt_is_f32=False)
+    assert np.array_equal(t, golden["kat_reg_params"])
+    assert np.array_equal(np.array(np_ref.transform_f64([0, 0, 8, 8], [.1, -.2, .3, -.4])), golden["kat_transform"])
+    got = np_ref.decode_f32(np.array([[0, 0, 8, 8], [3, 2, 8, 13]], dtype=np.float32),
+                            np.array([[.1, -.2, .3, -.4], [0, 0, 0, 0]], dtype=np.float32))
+    assert np.array_equal(got, golden["kat_transform_np"])
+    assert np.array_equal(np_ref.get_rois(np.zeros((1, 2, 3, 36), dtype=np.float32), golden["anchors9"], 16),
+                          golden["kat_rois_zero"])
