@@ -1,0 +1,76 @@
+"""ctypes binding of libfrcnn_hip.so (include/frcnn_hip.h).
+
+The library is the product: there is NO CPU fallback.  Importing this module never touches
+the GPU; the first compute call on a machine without the built library or without a HIP
+device raises ``FrcnnError``.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfrcnn_hip.so")
+
+
+class FrcnnError(RuntimeError):
+    pass
+
+
+P = c_void_p
+I = c_int
+# name -> (restype, argtypes).  Must list every symbol include/frcnn_hip.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it).
+SIGNATURES = {
+    "frcnn_last_error": (c_char_p, []),
+    "frcnn_version": (I, []),
+    "frcnn_device_count": (I, []),
+    "frcnn_anchors_image": (I, [I, I, P, I, I, P, P]),
+    "frcnn_anchors_conv": (I, [I, I, P, I, P, P]),
+    "frcnn_cross_ious_f32": (I, [P, I, P, I, P, P]),
+    "frcnn_cross_ious_i16": (I, [P, I, P, I, P, P]),
+    "frcnn_rpn_assign_workspace_bytes": (c_size_t, [I, I, I, I]),
+    "frcnn_rpn_assign": (I, [I, I, P, I, I, P, I, I, I, P, P, P, P, P, c_size_t, P]),
+    "frcnn_decode_proposals": (I, [P, I, I, P, I, P, P, P]),
+    "frcnn_transform_inplace": (I, [P, P, I, P]),
+    "frcnn_topk_workspace_bytes": (c_size_t, [I]),
+    "frcnn_topk_order": (I, [P, P, I, I, P, P, P, c_size_t, P]),
+    "frcnn_gather_candidates": (I, [P, P, P, P, I, P, P, P]),
+    "frcnn_nms_workspace_bytes": (c_size_t, [I]),
+    "frcnn_nms_i16": (I, [P, P, I, c_double, I, P, P, P, c_size_t, P]),
+    "frcnn_nms_f64": (I, [P, P, I, c_double, I, P, P, P, c_size_t, P]),
+    "frcnn_gather_rois": (I, [P, P, P, I, I, P, P]),
+    "frcnn_roi_targets": (I, [P, I, P, P, P, I, I, P, P, P, P]),
+    "frcnn_roi_crop_resize_fwd": (I, [P, I, I, I, P, I, I, P, P]),
+    "frcnn_roi_crop_resize_bwd": (I, [P, I, I, I, P, I, I, P, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FrcnnError(
+            f"{LIB_PATH} is missing: build it with `python -m faster_rcnn_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().frcnn_last_error()
+        raise FrcnnError(f"{what or 'frcnn call'} failed ({code}): {msg.decode() if msg else ''}")
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise FrcnnError on a non-zero status."""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,360 @@
+// Anchor generation, IoU, RPN target assignment, proposal decode, detector targets.
+// gfx950 (CDNA4) only.  These kernels are HBM/latency bound integer + IEEE-float work:
+// one thread per anchor / RoI, coalesced 16-byte stores, wave64 reductions for the
+// per-GT arg-max.  This translation unit is compiled with -ffp-contract=off: every
+// float expression below must round exactly where the reference's numpy code rounds.
+#include "common.h"
+
+namespace frcnn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------
+// anchors.  image space: centre = int(stride*(x+.5)) (rpn_util.py:184-189), conv space:
+// centre = cell index (det_util.py:165).  x1 = c - w//2, x2 = x1 + w (rpn_util.py:293-296).
+__device__ __forceinline__ float4 anchor_box(int cx, int cy, int h, int w) {
+    const int x1 = cx - (w >> 1), y1 = cy - (h >> 1);
+    return make_float4((float)x1, (float)y1, (float)(x1 + w), (float)(y1 + h));
+}
+
+__global__ void k_anchors(int rows, int cols, AnchorTable t, int A, int stride, int image_space, float4* out) {
+    const int n = rows * cols * A;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int a = i % A, cell = i / A, x = cell % cols, y = cell / cols;
+        // int32(stride*(x+0.5)): exact in double, truncation toward zero (values are >= 0)
+        const int cx = image_space ? (int)((double)stride * ((double)x + 0.5)) : x;
+        const int cy = image_space ? (int)((double)stride * ((double)y + 0.5)) : y;
+        out[i] = anchor_box(cx, cy, t.h[a], t.w[a]);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// IoU, no +1 convention (util.py:155-175).  All f32; the order of operations is the
+// reference's: area1, area2, max/min, max(0,.), w*h, (area1 + area2) - inter, inter/union.
+__device__ __forceinline__ float iou_f32(float4 b, float area_b, float4 g, float area_g) {
+    const float ix1 = fmaxf(b.x, g.x), iy1 = fmaxf(b.y, g.y);
+    const float ix2 = fminf(b.z, g.z), iy2 = fminf(b.w, g.w);
+    const float iw = fmaxf(0.0f, ix2 - ix1), ih = fmaxf(0.0f, iy2 - iy1);
+    const float inter = iw * ih;
+    const float uni = area_b + area_g - inter;
+    return inter / uni;      // IEEE correctly rounded division (no fast-math)
+}
+
+__device__ __forceinline__ float box_area(float4 b) { return (b.z - b.x) * (b.w - b.y); }
+
+template <typename BoxT>
+__device__ __forceinline__ void load_box(const BoxT* p, int i, float4& b, float& area);
+
+template <>
+__device__ __forceinline__ void load_box<float>(const float* p, int i, float4& b, float& area) {
+    b = reinterpret_cast<const float4*>(p)[i];
+    area = box_area(b);
+}
+// int16 boxes: numpy forms the area in int16 (util.py:152) and promotes to f32 when it
+// meets the f32 GT; coordinates promote to f32 inside maximum/minimum.
+template <>
+__device__ __forceinline__ void load_box<int16_t>(const int16_t* p, int i, float4& b, float& area) {
+    const short4 s = reinterpret_cast<const short4*>(p)[i];
+    b = make_float4((float)s.x, (float)s.y, (float)s.z, (float)s.w);
+    area = (float)(int16_t)((int16_t)(s.z - s.x) * (int16_t)(s.w - s.y));
+}
+
+template <typename BoxT>
+__global__ void k_cross_ious(const BoxT* boxes1, int M, const float4* boxes2, int G, float* out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        float4 b; float ab;
+        load_box<BoxT>(boxes1, i, b, ab);
+        for (int g = 0; g < G; ++g) {
+            const float4 gb = boxes2[g];
+            out[(size_t)i * G + g] = iou_f32(b, ab, gb, box_area(gb));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Regression targets (util.py:180-206) in f64 as numpy evaluates them for integer anchors.
+// GT_F32: rpn_util.py:91 passes f32 GT -> centre sum and width are formed in f32.
+__device__ __forceinline__ void reg_params(int ax1, int ay1, int ax2, int ay2,
+                                           double gcx, double gcy, double gw, double gh, double t[4]) {
+    const double acx = (double)(ax2 + ax1) / 2.0, acy = (double)(ay2 + ay1) / 2.0;
+    const double aw = (double)(ax2 - ax1), ah = (double)(ay2 - ay1);
+    t[0] = (gcx - acx) / aw;
+    t[1] = (gcy - acy) / ah;
+    t[2] = log(gw / aw);
+    t[3] = log(gh / ah);
+}
+
+// pass 1: per anchor max/argmax over GT; per GT max/argmax over anchors via packed atomicMax.
+// key = iou_bits << 32 | ~idx : larger IoU wins, ties -> smaller anchor index (np.argmax).
+__global__ void k_rpn_pass1(int rows, int cols, AnchorTable t, int A, int stride,
+                            const float4* gt, int G, float* max_iou, int32_t* argmax_gt,
+                            unsigned long long* best_by_gt) {
+    const int n = rows * cols * A;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    float4 b = make_float4(0, 0, 1, 1);
+    if (live) {
+        const int a = i % A, cell = i / A, x = cell % cols, y = cell / cols;
+        b = anchor_box((int)((double)stride * ((double)x + 0.5)), (int)((double)stride * ((double)y + 0.5)), t.h[a], t.w[a]);
+    }
+    const float ab = box_area(b);
+    float best = 0.0f; int barg = 0;
+    for (int g = 0; g < G; ++g) {
+        const float4 gb = gt[g];
+        const float v = live ? iou_f32(b, ab, gb, box_area(gb)) : -1.0f;
+        if (g == 0 || v > best) { best = v; barg = g; }     // first maximum wins (np.argmax)
+        // wave-level arg-max, then one atomic per wave
+        unsigned long long key = live ? (((unsigned long long)__float_as_uint(v)) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off);
+            key = o > key ? o : key;
+        }
+        if ((threadIdx.x & 63) == 0) atomicMax(&best_by_gt[g], key);
+    }
+    if (live) { max_iou[i] = best; if (argmax_gt) argmax_gt[i] = barg; }
+}
+
+__global__ void k_rpn_pass2(int rows, int cols, AnchorTable t, int A, int stride,
+                            const float4* gt, int G, int img_w, int img_h,
+                            const float* max_iou, const int32_t* argmax_gt_ws,
+                            const unsigned long long* best_by_gt,
+                            uint8_t* can_use, uint8_t* is_pos, float4* bbreg) {
+    const int n = rows * cols * A;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int a = i % A, cell = i / A, x = cell % cols, y = cell / cols;
+    const int cx = (int)((double)stride * ((double)x + 0.5)), cy = (int)((double)stride * ((double)y + 0.5));
+    const int w = t.w[a], h = t.h[a];
+    const int x1 = cx - (w >> 1), y1 = cy - (h >> 1), x2 = x1 + w, y2 = y1 + h;
+    const float m = G > 0 ? max_iou[i] : 0.0f;
+    bool pos = G > 0 && m > 0.7f;                       // f32 compare (rpn_util.py:75)
+    for (int g = 0; g < G; ++g) {                       // per-GT best anchor with IoU > 0 (:77-78)
+        const unsigned long long key = best_by_gt[g];
+        const float v = __uint_as_float((unsigned)(key >> 32));
+        if (v > 0.0f && (unsigned)(~(unsigned)key) == (unsigned)i) pos = true;
+    }
+    float4 tgt = make_float4(0, 0, 0, 0);
+    if (pos) {
+        const float4 gb = gt[argmax_gt_ws[i]];
+        // f32 sums / differences first (np.float32 scalars), halving exact, then f64
+        const double gcx = (double)((gb.z + gb.x) / 2.0f), gcy = (double)((gb.w + gb.y) / 2.0f);
+        const double gw = (double)(gb.z - gb.x), gh = (double)(gb.w - gb.y);
+        double r[4];
+        reg_params(x1, y1, x2, y2, gcx, gcy, gw, gh, r);
+        // BBREG_MULTIPLIERS (f32) * f64 tuple -> f64 product, stored to f32 (rpn_util.py:93)
+        tgt = make_float4((float)(10.0 * r[0]), (float)(10.0 * r[1]), (float)(5.0 * r[2]), (float)(5.0 * r[3]));
+    }
+    const bool neg = !pos && (G == 0 || m < 0.3f);        // :95
+    const bool oob = x1 < 0 || y1 < 0 || x2 >= img_w || y2 >= img_h;   // :302-310
+    can_use[i] = (pos || neg) && !oob;                  // can_use[oob]=0 but is_pos stays (:97)
+    is_pos[i] = pos;
+    bbreg[i] = tgt;
+}
+
+// ------------------------------------------------------------------------------------
+// proposal decode: util.transform_np_inplace (util.py:111-142) in f32 with np.round
+// (half-to-even), then det_util._sanitize_boxes_inplace (:179-192) and validity (:196-205).
+__device__ __forceinline__ float exp_f32(float x) {
+    // numpy's f32 exp is a <=2.5-ulp SIMD routine; no device libm reproduces it bit for
+    // bit.  We return the correctly rounded f32 value (via f64), which differs from any
+    // faithful expf by at most a couple of ulps: see DESIGN.md "decode rounding boundary".
+    return (float)exp((double)x);
+}
+
+__device__ __forceinline__ float4 transform_f32(float4 c, float4 d) {
+    float w = c.z - c.x, h = c.w - c.y;
+    float cx = c.x + w / 2.0f, cy = c.y + h / 2.0f;
+    cx = cx + d.x * w;
+    cy = cy + d.y * h;
+    w = w * exp_f32(d.z);
+    h = h * exp_f32(d.w);
+    float x1 = cx - w / 2.0f, y1 = cy - h / 2.0f;
+    x1 = rintf(x1); y1 = rintf(y1); w = rintf(w); h = rintf(h);
+    return make_float4(x1, y1, x1 + w, y1 + h);
+}
+
+__global__ void k_decode(const float4* regr, int rows, int cols, AnchorTable t, int A,
+                         float4* rois, uint8_t* valid) {
+    const int n = rows * cols * A;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int a = i % A, cell = i / A, x = cell % cols, y = cell / cols;
+        const float4 anc = anchor_box(x, y, t.h[a], t.w[a]);
+        float4 d = regr[i];
+        d.x = d.x / 10.0f; d.y = d.y / 10.0f; d.z = d.z / 5.0f; d.w = d.w / 5.0f;   // det_util.py:376
+        float4 r = transform_f32(anc, d);
+        r.z = fmaxf(r.x + 1.0f, r.z);
+        r.w = fmaxf(r.y + 1.0f, r.w);
+        r.x = fmaxf(0.0f, r.x);
+        r.y = fmaxf(0.0f, r.y);
+        r.z = fminf((float)(cols - 1), r.z);
+        r.w = fminf((float)(rows - 1), r.w);
+        rois[i] = r;
+        valid[i] = (r.z > r.x) && (r.w > r.y);
+    }
+}
+
+__global__ void k_transform_inplace(float4* coords, const float4* deltas, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        coords[i] = transform_f32(coords[i], deltas[i]);
+}
+
+// ------------------------------------------------------------------------------------
+// detector targets (det_util.py:310-366), one thread per RoI.
+__global__ void k_roi_targets(const int16_t* rois, int E, const float4* gt32, const double* gt64,
+                              const int32_t* gt_cls, int G, int bg_idx,
+                              uint8_t* eligible, int32_t* cls, float4* targets) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E) return;
+    float4 b; float ab;
+    load_box<int16_t>(rois, i, b, ab);
+    float best = 0.0f; int barg = 0;
+    for (int g = 0; g < G; ++g) {
+        const float4 gb = gt32[g];
+        const float v = iou_f32(b, ab, gb, box_area(gb));
+        if (g == 0 || v > best) { best = v; barg = g; }
+    }
+    const bool elig = G > 0 && best >= 0.1f;            // f32 compares (det_util.py:317,320)
+    const bool pos = G > 0 && best >= 0.5f;
+    float4 tgt = make_float4(0, 0, 0, 0);
+    if (pos) {
+        const double* g = gt64 + 4 * barg;                // gt_box.corners are f64 (det_util.py:349)
+        double r[4];
+        reg_params((int)b.x, (int)b.y, (int)b.z, (int)b.w, (g[2] + g[0]) / 2.0, (g[3] + g[1]) / 2.0, g[2] - g[0], g[3] - g[1], r);
+        // stored to f32 first (:350), THEN multiplied by the f32 multipliers (:351)
+        tgt = make_float4((float)r[0] * 10.0f, (float)r[1] * 10.0f, (float)r[2] * 5.0f, (float)r[3] * 5.0f);
+    }
+    eligible[i] = elig;
+    cls[i] = pos ? gt_cls[barg] : bg_idx;
+    targets[i] = tgt;
+}
+
+static inline int grid_for(int n, int block = 256, int cap = 2048) {
+    int g = (n + block - 1) / block;
+    return g < 1 ? 1 : (g > cap ? cap : g);
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" {
+
+const char* frcnn_last_error(void) { return g_err; }
+int frcnn_version(void) { return 100; }
+int frcnn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int frcnn_anchors_image(int rows, int cols, const int32_t* anchor_hw_h, int A, int stride, float* out, void* stream) {
+    AnchorTable t;
+    if (int e = load_anchor_table(anchor_hw_h, A, &t)) return e;
+    if (rows <= 0 || cols <= 0 || stride <= 0 || !out) return fail(FRCNN_E_ARG, "anchors_image: bad argument");
+    k_anchors<<<grid_for(rows * cols * A), 256, 0, as_stream(stream)>>>(rows, cols, t, A, stride, 1, (float4*)out);
+    return check_launch("anchors_image");
+}
+
+int frcnn_anchors_conv(int rows, int cols, const int32_t* anchor_hw_conv_h, int A, float* out, void* stream) {
+    AnchorTable t;
+    if (int e = load_anchor_table(anchor_hw_conv_h, A, &t)) return e;
+    if (rows <= 0 || cols <= 0 || !out) return fail(FRCNN_E_ARG, "anchors_conv: bad argument");
+    k_anchors<<<grid_for(rows * cols * A), 256, 0, as_stream(stream)>>>(rows, cols, t, A, 1, 0, (float4*)out);
+    return check_launch("anchors_conv");
+}
+
+int frcnn_cross_ious_f32(const float* boxes1, int M, const float* boxes2, int G, float* out, void* stream) {
+    if (M < 0 || G < 0) return fail(FRCNN_E_ARG, "cross_ious: negative size");
+    if (M == 0 || G == 0) return FRCNN_OK;
+    if (!boxes1 || !boxes2 || !out) return fail(FRCNN_E_ARG, "cross_ious: null pointer");
+    k_cross_ious<float><<<grid_for(M), 256, 0, as_stream(stream)>>>(boxes1, M, (const float4*)boxes2, G, out);
+    return check_launch("cross_ious_f32");
+}
+
+int frcnn_cross_ious_i16(const int16_t* boxes1, int M, const float* boxes2, int G, float* out, void* stream) {
+    if (M < 0 || G < 0) return fail(FRCNN_E_ARG, "cross_ious: negative size");
+    if (M == 0 || G == 0) return FRCNN_OK;
+    if (!boxes1 || !boxes2 || !out) return fail(FRCNN_E_ARG, "cross_ious: null pointer");
+    k_cross_ious<int16_t><<<grid_for(M), 256, 0, as_stream(stream)>>>(boxes1, M, (const float4*)boxes2, G, out);
+    return check_launch("cross_ious_i16");
+}
+
+size_t frcnn_rpn_assign_workspace_bytes(int rows, int cols, int A, int G) {
+    const size_t n = (size_t)rows * cols * A;
+    return align_up((size_t)(G > 0 ? G : 1) * 8, 256) + align_up(n * 4, 256) + align_up(n * 4, 256);
+}
+
+int frcnn_rpn_assign(int rows, int cols, const int32_t* anchor_hw_h, int A, int stride,
+                     const float* gt, int G, int img_w, int img_h,
+                     uint8_t* can_use, uint8_t* is_pos, float* bbreg, int32_t* argmax_gt,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    AnchorTable t;
+    if (int e = load_anchor_table(anchor_hw_h, A, &t)) return e;
+    if (rows <= 0 || cols <= 0 || stride <= 0 || G < 0 || !can_use || !is_pos || !bbreg || (G > 0 && !gt))
+        return fail(FRCNN_E_ARG, "rpn_assign: bad argument");
+    if (!workspace || workspace_bytes < frcnn_rpn_assign_workspace_bytes(rows, cols, A, G))
+        return fail(FRCNN_E_WORKSPACE, "rpn_assign: workspace needs %zu bytes", frcnn_rpn_assign_workspace_bytes(rows, cols, A, G));
+    const int n = rows * cols * A;
+    char* ws = (char*)workspace;
+    unsigned long long* best = (unsigned long long*)ws;
+    ws += align_up((size_t)(G > 0 ? G : 1) * 8, 256);
+    float* max_iou = (float*)ws;
+    ws += align_up((size_t)n * 4, 256);
+    int32_t* arg_ws = (int32_t*)ws;
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(best, 0, (size_t)(G > 0 ? G : 1) * 8, s) != hipSuccess) return fail(FRCNN_E_HIP, "rpn_assign: memset failed");
+    const int blocks = (n + 255) / 256;
+    if (G > 0) {
+        k_rpn_pass1<<<blocks, 256, 0, s>>>(rows, cols, t, A, stride, (const float4*)gt, G, max_iou, arg_ws, best);
+        if (int e = check_launch("rpn_assign pass1")) return e;
+    }
+    k_rpn_pass2<<<blocks, 256, 0, s>>>(rows, cols, t, A, stride, (const float4*)gt, G, img_w, img_h,
+                                       max_iou, arg_ws, best, can_use, is_pos, (float4*)bbreg);
+    if (int e = check_launch("rpn_assign pass2")) return e;
+    if (argmax_gt) {
+        if (G > 0) {
+            if (hipMemcpyAsync(argmax_gt, arg_ws, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return fail(FRCNN_E_HIP, "rpn_assign: copy failed");
+        } else if (hipMemsetAsync(argmax_gt, 0, (size_t)n * 4, s) != hipSuccess) {
+            return fail(FRCNN_E_HIP, "rpn_assign: memset failed");
+        }
+    }
+    return FRCNN_OK;
+}
+
+int frcnn_decode_proposals(const float* regr, int rows, int cols, const int32_t* anchor_hw_conv_h, int A,
+                           float* rois, uint8_t* valid, void* stream) {
+    AnchorTable t;
+    if (int e = load_anchor_table(anchor_hw_conv_h, A, &t)) return e;
+    if (rows <= 0 || cols <= 0 || !regr || !rois || !valid) return fail(FRCNN_E_ARG, "decode_proposals: bad argument");
+    k_decode<<<grid_for(rows * cols * A), 256, 0, as_stream(stream)>>>((const float4*)regr, rows, cols, t, A, (float4*)rois, valid);
+    return check_launch("decode_proposals");
+}
+
+int frcnn_transform_inplace(float* coords, const float* deltas, int n, void* stream) {
+    if (n < 0) return fail(FRCNN_E_ARG, "transform_inplace: negative size");
+    if (n == 0) return FRCNN_OK;
+    if (!coords || !deltas) return fail(FRCNN_E_ARG, "transform_inplace: null pointer");
+    k_transform_inplace<<<grid_for(n), 256, 0, as_stream(stream)>>>((float4*)coords, (const float4*)deltas, n);
+    return check_launch("transform_inplace");
+}
+
+int frcnn_roi_targets(const int16_t* rois, int E, const float* gt_f32, const double* gt_f64,
+                      const int32_t* gt_cls, int G, int bg_idx,
+                      uint8_t* eligible, int32_t* cls, float* targets, void* stream) {
+    if (E < 0 || G < 0) return fail(FRCNN_E_ARG, "roi_targets: negative size");
+    if (E == 0) return FRCNN_OK;
+    if (!rois || !eligible || !cls || !targets || (G > 0 && (!gt_f32 || !gt_f64 || !gt_cls)))
+        return fail(FRCNN_E_ARG, "roi_targets: null pointer");
+    k_roi_targets<<<(E + 255) / 256, 256, 0, as_stream(stream)>>>(rois, E, (const float4*)gt_f32, gt_f64, gt_cls, G, bg_idx,
+                                                                  eligible, cls, (float4*)targets);
+    return check_launch("roi_targets");
+}
+
+}  // extern "C"

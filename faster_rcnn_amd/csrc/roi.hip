@@ -1,0 +1,106 @@
+// RoI crop + bilinear resize (custom_layers.RoiResizeConv, custom_layers.py:35-56) for gfx950.
+//
+// The reference builds num_rois separate strided_slice + tf.image.resize_images nodes; here
+// all RoIs go through ONE launch: a workgroup per output pixel (roi, py, px), lanes sweep the
+// channel axis with 16-byte loads/stores (NHWC: the channel run of one feature-map pixel is
+// contiguous), so the conv4 map (<= 10 MB, L2/MALL resident) is gathered at full line width
+// and the [n][7][7][C] tile is written exactly once.  HBM bound: C*4 B read x4 taps (cache
+// hits) + C*4 B written per output pixel.
+//
+// TF 1.3 resize_bilinear, align_corners=False, no half-pixel centres:
+//   scale = in/out (f32); src = i*scale; lo = (int)src; hi = min(lo+1, in-1); t = src - lo
+//   top = tl + (tr - tl)*tx; bot = bl + (br - bl)*tx; out = top + (bot - top)*ty
+// Compiled with -ffp-contract=off so the three lerps round where TF's scalar code rounds.
+#include "common.h"
+
+namespace frcnn {
+
+struct Taps { int y_lo, y_hi, x_lo, x_hi; float ty, tx; bool ok; };
+
+__device__ __forceinline__ Taps roi_taps(const float4 roi, int py, int px, int pool, int rows, int cols) {
+    Taps t;
+    const int x1 = (int)roi.x, y1 = (int)roi.y, x2 = (int)roi.z, y2 = (int)roi.w;   // K.cast(.,'int32') truncates
+    const int h = y2 - y1, w = x2 - x1;
+    t.ok = h > 0 && w > 0 && x1 >= 0 && y1 >= 0 && x2 <= cols && y2 <= rows;
+    const float sy = (float)h / (float)pool, sx = (float)w / (float)pool;
+    const float fy = (float)py * sy, fx = (float)px * sx;
+    const int ly = (int)fy, lx = (int)fx;
+    t.ty = fy - (float)ly;
+    t.tx = fx - (float)lx;
+    t.y_lo = y1 + ly;
+    t.y_hi = y1 + min(ly + 1, h - 1);
+    t.x_lo = x1 + lx;
+    t.x_hi = x1 + min(lx + 1, w - 1);
+    return t;
+}
+
+__global__ void __launch_bounds__(256) k_roi_fwd(const float4* feat, int rows, int cols, int C4,
+                                                 const float4* rois, int pool, float4* out) {
+    const int pix = blockIdx.x;                 // (roi, py, px)
+    const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
+    float4* o = out + (size_t)pix * C4;
+    if (!t.ok) {
+        for (int c = threadIdx.x; c < C4; c += blockDim.x) o[c] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const float4* tl = feat + ((size_t)t.y_lo * cols + t.x_lo) * C4;
+    const float4* tr = feat + ((size_t)t.y_lo * cols + t.x_hi) * C4;
+    const float4* bl = feat + ((size_t)t.y_hi * cols + t.x_lo) * C4;
+    const float4* br = feat + ((size_t)t.y_hi * cols + t.x_hi) * C4;
+    for (int c = threadIdx.x; c < C4; c += blockDim.x) {
+        const float4 a = tl[c], b = tr[c], d = bl[c], e = br[c];
+        float4 v;
+#define LERP2(f) { const float top = a.f + (b.f - a.f) * t.tx; const float bot = d.f + (e.f - d.f) * t.tx; v.f = top + (bot - top) * t.ty; }
+        LERP2(x) LERP2(y) LERP2(z) LERP2(w)
+#undef LERP2
+        o[c] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_roi_bwd(const float* dout, int rows, int cols, int C,
+                                                 const float4* rois, int pool, float* dfeat) {
+    const int pix = blockIdx.x;
+    const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
+    if (!t.ok) return;
+    const float* g = dout + (size_t)pix * C;
+    float* tl = dfeat + ((size_t)t.y_lo * cols + t.x_lo) * C;
+    float* tr = dfeat + ((size_t)t.y_lo * cols + t.x_hi) * C;
+    float* bl = dfeat + ((size_t)t.y_hi * cols + t.x_lo) * C;
+    float* br = dfeat + ((size_t)t.y_hi * cols + t.x_hi) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float gv = g[c];
+        const float dtop = (1.0f - t.ty) * gv, dbot = t.ty * gv;      // TF ResizeBilinearGrad order
+        atomicAdd(tl + c, dtop * (1.0f - t.tx));
+        atomicAdd(tr + c, dtop * t.tx);
+        atomicAdd(bl + c, dbot * (1.0f - t.tx));
+        atomicAdd(br + c, dbot * t.tx);
+    }
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" {
+
+int frcnn_roi_crop_resize_fwd(const float* feat, int rows, int cols, int C, const float* rois, int n, int pool,
+                              float* out, void* stream) {
+    if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || (C & 3) || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd: bad shape (C must be a multiple of 4)");
+    if (n == 0) return FRCNN_OK;
+    if (!feat || !rois || !out) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd: null pointer");
+    k_roi_fwd<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool, (float4*)out);
+    return check_launch("roi_crop_resize_fwd");
+}
+
+int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C, const float* rois, int n, int pool,
+                              float* dfeat, void* stream) {
+    if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd: bad shape");
+    if (n == 0) return FRCNN_OK;
+    if (!dout || !rois || !dfeat) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd: null pointer");
+    k_roi_bwd<<<n * pool * pool, 256, 0, as_stream(stream)>>>(dout, rows, cols, C, (const float4*)rois, pool, dfeat);
+    return check_launch("roi_crop_resize_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// Score ordering (top-K) and greedy NMS for gfx950.
+//
+// top-K: rank-by-counting over packed 64-bit keys (score bits | ~index) -- every key is
+//        unique, so ranks are a permutation and the result is deterministic.  N <= 64 K
+//        anchors, so the N^2 compare sweep is a few tens of microseconds spread over the
+//        whole chip and needs no multi-pass radix machinery.
+// NMS:   (1) all-pairs suppression bit matrix, upper triangle only, one 64x64 tile per
+//        wave64 (a lane's 64 pair tests become one 64-bit word = one coalesced store);
+//        (2) a single-wave sequential scan that keeps the `removed` bitmap in registers,
+//        resolves each 64-candidate chunk with scalar bit tricks + v_readlane, ORs the kept
+//        rows' words in with independent (pipelined) loads and stops at max_boxes exactly
+//        like the reference loop does.
+// Compiled with -ffp-contract=off (the f64 overlap ratio must round like numpy's).
+#include "common.h"
+
+namespace frcnn {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned mono_f32(float f) {      // order-preserving float -> uint
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ------------------------------------------------------------------------------------ top-K
+__global__ void k_topk_keys(const float* scores, const uint8_t* valid, int N, u64* keys, int32_t* n_valid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool v = i < N && (!valid || valid[i]);
+    if (i < N) keys[i] = v ? (((u64)mono_f32(scores[i])) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+    const u64 b = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, __popcll(b));
+}
+
+constexpr int TOPK_BLOCK = 256;
+constexpr int TOPK_PER_THREAD = 4;      // keys ranked per thread: 4 compares per LDS read
+
+__global__ void __launch_bounds__(TOPK_BLOCK) k_topk_rank(const u64* keys, int N, int K, int32_t* order) {
+    __shared__ u64 tile[TOPK_BLOCK];
+    const int base = blockIdx.x * TOPK_BLOCK * TOPK_PER_THREAD;
+    u64 mine[TOPK_PER_THREAD];
+    int rank[TOPK_PER_THREAD];
+#pragma unroll
+    for (int r = 0; r < TOPK_PER_THREAD; ++r) {
+        const int i = base + r * TOPK_BLOCK + threadIdx.x;
+        mine[r] = i < N ? keys[i] : 0ull;
+        rank[r] = 0;
+    }
+    for (int t0 = 0; t0 < N; t0 += TOPK_BLOCK) {
+        const int j = t0 + threadIdx.x;
+        tile[threadIdx.x] = j < N ? keys[j] : 0ull;
+        __syncthreads();
+#pragma unroll 8
+        for (int jj = 0; jj < TOPK_BLOCK; ++jj) {
+            const u64 k = tile[jj];                    // LDS broadcast
+#pragma unroll
+            for (int r = 0; r < TOPK_PER_THREAD; ++r) rank[r] += k > mine[r];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < TOPK_PER_THREAD; ++r)
+        if (mine[r] != 0ull && rank[r] < K) order[rank[r]] = (int32_t)(~(unsigned)mine[r]);
+}
+
+__global__ void k_topk_finish(int32_t* n_valid_to_n_out, int K) {
+    if (threadIdx.x == 0 && *n_valid_to_n_out > K) *n_valid_to_n_out = K;
+}
+
+__global__ void k_gather_candidates(const float4* rois, const float* scores, const int32_t* order, const int32_t* n, int K,
+                                    short4* cand, float* cand_scores) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    short4 o = make_short4(0, 0, 0, 0);
+    float s = 0.0f;
+    if (k < *n) {
+        const int i = order[k];
+        const float4 r = rois[i];
+        o = make_short4((short)r.x, (short)r.y, (short)r.z, (short)r.w);   // astype('int16') (det_util.py:76)
+        s = scores[i];
+    }
+    cand[k] = o;
+    if (cand_scores) cand_scores[k] = s;
+}
+
+// ------------------------------------------------------------------------------------ NMS
+// overlap test of det_util.nms (det_util.py:237-250): "+1" convention; numpy evaluates the
+// int16 case in int16 and divides int/int in f64; the float case is f64 throughout.
+__device__ __forceinline__ bool suppresses(const short4 a, int area_a, const short4 b, int area_b, double thresh) {
+    const int w = max(0, min((int)a.z, (int)b.z) - max((int)a.x, (int)b.x) + 1);
+    const int h = max(0, min((int)a.w, (int)b.w) - max((int)a.y, (int)b.y) + 1);
+    const int inter = w * h;
+    const double overlap = (double)inter / (double)(area_a + area_b - inter);
+    return !(overlap <= thresh);
+}
+__device__ __forceinline__ int box_area1(const short4 b) { return ((int)b.z - b.x + 1) * ((int)b.w - b.y + 1); }
+
+__device__ __forceinline__ bool suppresses(const double4 a, double area_a, const double4 b, double area_b, double thresh) {
+    const double w = fmax(0.0, fmin(a.z, b.z) - fmax(a.x, b.x) + 1.0);
+    const double h = fmax(0.0, fmin(a.w, b.w) - fmax(a.y, b.y) + 1.0);
+    const double inter = w * h;
+    const double overlap = inter / (area_a + area_b - inter);
+    return !(overlap <= thresh);
+}
+__device__ __forceinline__ double box_area1(const double4 b) { return (b.z - b.x + 1.0) * (b.w - b.y + 1.0); }
+
+// One wave64 per 64x64 tile (row block rb <= column block cb).  Lane = row; its 64 tests
+// against the column block form one u64.  Bit j of mask[i][cb] <=> box i suppresses box
+// cb*64+j; only bits with column index > i are ever consumed.
+template <typename Box4>
+__global__ void __launch_bounds__(64) k_nms_mask(const Box4* boxes, const int32_t* n_ptr, int K, int W, double thresh, u64* mask) {
+    const int n = min(*n_ptr, K);
+    // linear tile id -> (rb, cb) of the upper triangle, row-major
+    int tid = blockIdx.x;
+    int rb = 0;
+    while (tid >= W - rb) { tid -= W - rb; ++rb; }
+    const int cb = rb + tid;
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    __shared__ Box4 cols[64];
+    const int lane = threadIdx.x;
+    const int j0 = cb * 64;
+    cols[lane] = j0 + lane < n ? boxes[j0 + lane] : boxes[0];
+    __syncthreads();
+    const int i = rb * 64 + lane;
+    if (i >= n) return;
+    const Box4 me = boxes[i];
+    const auto my_area = box_area1(me);
+    u64 bits = 0;
+    const int jmax = min(64, n - j0);
+    for (int j = 0; j < jmax; ++j) {
+        const Box4 o = cols[j];
+        if (j0 + j > i && suppresses(me, my_area, o, box_area1(o), thresh)) bits |= 1ull << j;
+    }
+    mask[(size_t)i * W + cb] = bits;
+}
+
+constexpr int NMS_SLOTS = FRCNN_NMS_MAX_BOXES / 64 / 64;     // removed-bitmap words per lane (3)
+
+__device__ __forceinline__ u64 uniform_u64(u64 v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int lane /*uniform*/) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(64) k_nms_scan(const u64* mask, const int32_t* n_ptr, int K, int W, int max_boxes,
+                                                 int32_t* keep, int32_t* n_keep) {
+    const int lane = threadIdx.x;
+    const int n = min(*n_ptr, K);
+    u64 removed[NMS_SLOTS];                 // lane l, slot s holds bitmap word s*64 + l
+#pragma unroll
+    for (int s = 0; s < NMS_SLOTS; ++s) removed[s] = 0;
+    int total = 0;
+    const int chunks = (n + 63) / 64;
+    for (int c = 0; c < chunks && total < max_boxes; ++c) {
+        const int base = c * 64;
+        const int i = base + lane;
+        const u64 diag = i < n ? mask[(size_t)i * W + c] : 0ull;     // issued before the resolve
+        u64 rem = 0;
+#pragma unroll
+        for (int s = 0; s < NMS_SLOTS; ++s)
+            if ((c >> 6) == s) rem = readlane_u64(removed[s], c & 63);
+        const int cnt = min(64, n - base);
+        const u64 vmask = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
+        u64 alive = uniform_u64(~rem & vmask);
+        u64 kept = 0;
+        int room = max_boxes - total;
+        while (alive && room > 0) {          // wave-uniform: iterates over KEPT boxes only
+            const int b = __builtin_ctzll(alive);
+            kept |= 1ull << b;
+            --room;
+            alive &= ~(1ull << b);
+            alive &= ~readlane_u64(diag, b);
+            alive = uniform_u64(alive);
+        }
+        if ((kept >> lane) & 1) keep[total + __popcll(kept & ((1ull << lane) - 1))] = i;
+        total += __popcll(kept);
+        if (total >= max_boxes) break;
+        // OR the kept rows into the bitmap for all later chunks; loads are independent
+        u64 k = kept;
+        while (k) {
+            const int b = __builtin_ctzll(k);
+            k &= k - 1;
+            const u64* row = mask + (size_t)(base + b) * W;
+#pragma unroll
+            for (int s = 0; s < NMS_SLOTS; ++s) {
+                const int w = s * 64 + lane;
+                if (w > c && w < W) removed[s] |= row[w];
+            }
+        }
+    }
+    if (lane == 0) *n_keep = total;
+}
+
+__global__ void k_gather_rois(const short4* cand, const int32_t* keep, const int32_t* n_keep, int batch, int out_rows, float4* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= out_rows) return;
+    const int n = *n_keep;
+    float4 o = make_float4(0, 0, 0, 0);
+    if (n > 0) {
+        const int padded = (n + batch - 1) / batch * batch;
+        int src = k < n ? k : (k < padded ? (k / batch) * batch : 0);
+        const short4 b = cand[keep[src]];
+        o = make_float4((float)b.x, (float)b.y, (float)b.z, (float)b.w);
+    }
+    out[k] = o;
+}
+
+template <typename Box4>
+static int nms_launch(const Box4* boxes, const int32_t* n, int K, double thresh, int max_boxes,
+                      int32_t* keep, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream, const char* what) {
+    if (K < 0 || K > FRCNN_NMS_MAX_BOXES) return fail(FRCNN_E_ARG, "%s: K=%d exceeds %d", what, K, FRCNN_NMS_MAX_BOXES);
+    if (max_boxes <= 0 || !n || !keep || !n_keep) return fail(FRCNN_E_ARG, "%s: bad argument", what);
+    hipStream_t s = as_stream(stream);
+    if (K == 0) {
+        if (hipMemsetAsync(n_keep, 0, 4, s) != hipSuccess) return fail(FRCNN_E_HIP, "%s: memset failed", what);
+        return FRCNN_OK;
+    }
+    if (!boxes) return fail(FRCNN_E_ARG, "%s: null boxes", what);
+    if (!workspace || workspace_bytes < frcnn_nms_workspace_bytes(K))
+        return fail(FRCNN_E_WORKSPACE, "%s: workspace needs %zu bytes", what, frcnn_nms_workspace_bytes(K));
+    const int W = (K + 63) / 64;
+    u64* mask = (u64*)workspace;
+    const int tiles = W * (W + 1) / 2;
+    k_nms_mask<Box4><<<tiles, 64, 0, s>>>(boxes, n, K, W, thresh, mask);
+    if (int e = check_launch(what)) return e;
+    k_nms_scan<<<1, 64, 0, s>>>(mask, n, K, W, max_boxes, keep, n_keep);
+    return check_launch(what);
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" {
+
+size_t frcnn_topk_workspace_bytes(int N) { return align_up((size_t)(N > 0 ? N : 1) * 8, 256); }
+
+int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, int32_t* order, int32_t* n_out,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (N < 0 || K <= 0 || !order || !n_out) return fail(FRCNN_E_ARG, "topk_order: bad argument");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(n_out, 0, 4, s) != hipSuccess || hipMemsetAsync(order, 0xFF, (size_t)K * 4, s) != hipSuccess)
+        return fail(FRCNN_E_HIP, "topk_order: memset failed");
+    if (N == 0) return FRCNN_OK;
+    if (!scores) return fail(FRCNN_E_ARG, "topk_order: null scores");
+    if (!workspace || workspace_bytes < frcnn_topk_workspace_bytes(N))
+        return fail(FRCNN_E_WORKSPACE, "topk_order: workspace needs %zu bytes", frcnn_topk_workspace_bytes(N));
+    u64* keys = (u64*)workspace;
+    k_topk_keys<<<(N + 255) / 256, 256, 0, s>>>(scores, valid, N, keys, n_out);
+    if (int e = check_launch("topk_order keys")) return e;
+    const int per_block = TOPK_BLOCK * TOPK_PER_THREAD;
+    k_topk_rank<<<(N + per_block - 1) / per_block, TOPK_BLOCK, 0, s>>>(keys, N, K, order);
+    if (int e = check_launch("topk_order rank")) return e;
+    k_topk_finish<<<1, 64, 0, s>>>(n_out, K);
+    return check_launch("topk_order finish");
+}
+
+int frcnn_gather_candidates(const float* rois, const float* scores, const int32_t* order, const int32_t* n, int K,
+                            int16_t* cand, float* cand_scores, void* stream) {
+    if (K <= 0 || !rois || !scores || !order || !n || !cand) return fail(FRCNN_E_ARG, "gather_candidates: bad argument");
+    k_gather_candidates<<<(K + 255) / 256, 256, 0, as_stream(stream)>>>((const float4*)rois, scores, order, n, K, (short4*)cand, cand_scores);
+    return check_launch("gather_candidates");
+}
+
+size_t frcnn_nms_workspace_bytes(int K) {
+    const size_t W = (size_t)(K + 63) / 64;
+    return align_up((size_t)(K > 0 ? K : 1) * W * 8, 256);
+}
+
+int frcnn_nms_i16(const int16_t* boxes, const int32_t* n, int K, double thresh, int max_boxes,
+                  int32_t* keep, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    return nms_launch<short4>((const short4*)boxes, n, K, thresh, max_boxes, keep, n_keep, workspace, workspace_bytes, stream, "nms_i16");
+}
+
+int frcnn_nms_f64(const double* boxes, const int32_t* n, int K, double thresh, int max_boxes,
+                  int32_t* keep, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    return nms_launch<double4>((const double4*)boxes, n, K, thresh, max_boxes, keep, n_keep, workspace, workspace_bytes, stream, "nms_f64");
+}
+
+int frcnn_gather_rois(const int16_t* cand, const int32_t* keep, const int32_t* n_keep, int batch, int out_rows, float* out, void* stream) {
+    if (batch <= 0 || out_rows <= 0 || !cand || !keep || !n_keep || !out) return fail(FRCNN_E_ARG, "gather_rois: bad argument");
+    k_gather_rois<<<(out_rows + 255) / 256, 256, 0, as_stream(stream)>>>((const short4*)cand, keep, n_keep, batch, out_rows, (float4*)out);
+    return check_launch("gather_rois");
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+"""Device-tensor level wrappers over the C ABI (include/frcnn_hip.h).
+
+torch tensors are only the container type (device memory + the current HIP stream); all
+arithmetic happens inside libfrcnn_hip.so.  Every function takes/returns CUDA(=HIP) tensors
+and is asynchronous on ``torch.cuda.current_stream()``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NMS_MAX_BOXES = 12288
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.FrcnnError("no HIP device visible: the faster_rcnn_amd ops need an MI355X (no CPU fallback)")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device-contiguous tensor required"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _anchor_arg(anchor_hw):
+    a = np.ascontiguousarray(np.asarray(anchor_hw), dtype=np.int32)
+    assert a.ndim == 2 and a.shape[1] == 2
+    return a, a.ctypes.data_as(ctypes.c_void_p), a.shape[0]
+
+
+def _dev(x, dtype):
+    """numpy / tensor -> contiguous device tensor of dtype."""
+    if isinstance(x, torch.Tensor):
+        return x.to(device="cuda", dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device="cuda", dtype=dtype)
+
+
+def _ws(nbytes):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+
+
+# ----------------------------------------------------------------------------- anchors
+def anchors_image(rows, cols, anchor_hw, stride):
+    _require_gpu()
+    keep, ap, A = _anchor_arg(anchor_hw)
+    out = torch.empty((rows * cols * A, 4), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_anchors_image", rows, cols, ap, A, stride, _p(out), _stream())
+    return out
+
+
+def anchors_conv(rows, cols, anchor_hw_conv):
+    _require_gpu()
+    keep, ap, A = _anchor_arg(anchor_hw_conv)
+    out = torch.empty((rows, cols, A, 4), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_anchors_conv", rows, cols, ap, A, _p(out), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- IoU
+def cross_ious(boxes1, boxes2):
+    """boxes1: (M,4) f32 or int16 device tensor; boxes2: (G,4) f32.  -> (M,G) f32."""
+    _require_gpu()
+    M, G = boxes1.shape[0], boxes2.shape[0]
+    out = torch.zeros((M, G), dtype=torch.float32, device="cuda")
+    b2 = boxes2.to(torch.float32).contiguous()
+    if boxes1.dtype == torch.int16:
+        _lib.call("frcnn_cross_ious_i16", _p(boxes1.contiguous()), M, _p(b2), G, _p(out), _stream())
+    else:
+        _lib.call("frcnn_cross_ious_f32", _p(boxes1.to(torch.float32).contiguous()), M, _p(b2), G, _p(out), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- RPN targets
+def rpn_assign(rows, cols, anchor_hw, stride, gt, img_w, img_h):
+    """-> can_use (N,) u8, is_pos (N,) u8, bbreg (N,4) f32, argmax_gt (N,) i32 (device)."""
+    _require_gpu()
+    keep, ap, A = _anchor_arg(anchor_hw)
+    gt = _dev(gt, torch.float32).reshape(-1, 4)
+    G = gt.shape[0]
+    n = rows * cols * A
+    can_use = torch.empty(n, dtype=torch.uint8, device="cuda")
+    is_pos = torch.empty(n, dtype=torch.uint8, device="cuda")
+    bbreg = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    argmax = torch.empty(n, dtype=torch.int32, device="cuda")
+    nbytes = _lib.load().frcnn_rpn_assign_workspace_bytes(rows, cols, A, G)
+    ws = _ws(nbytes)
+    _lib.call("frcnn_rpn_assign", rows, cols, ap, A, stride, _p(gt) if G else ctypes.c_void_p(0), G, int(img_w), int(img_h),
+              _p(can_use), _p(is_pos), _p(bbreg), _p(argmax), _p(ws), ws.numel(), _stream())
+    return can_use, is_pos, bbreg, argmax
+
+
+# ----------------------------------------------------------------------------- proposals
+def decode_proposals(regr, anchor_hw_conv):
+    """regr: (1,R,C,4A) or (R,C,4A) f32 device tensor -> rois (N,4) f32, valid (N,) u8."""
+    _require_gpu()
+    keep, ap, A = _anchor_arg(anchor_hw_conv)
+    regr = regr.reshape(regr.shape[-3], regr.shape[-2], regr.shape[-1]).contiguous()
+    rows, cols = regr.shape[0], regr.shape[1]
+    assert regr.shape[2] == 4 * A
+    n = rows * cols * A
+    rois = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+    _lib.call("frcnn_decode_proposals", _p(regr), rows, cols, ap, A, _p(rois), _p(valid), _stream())
+    return rois, valid
+
+
+def transform_inplace(coords, deltas):
+    _require_gpu()
+    assert coords.dtype == torch.float32 and deltas.dtype == torch.float32
+    _lib.call("frcnn_transform_inplace", _p(coords), _p(deltas.contiguous()), coords.shape[0], _stream())
+    return coords
+
+
+def topk_order(scores, valid, K):
+    """-> order (K,) i32 (entries >= n are -1), n (1,) i32 device."""
+    _require_gpu()
+    N = scores.numel()
+    order = torch.empty(K, dtype=torch.int32, device="cuda")
+    n_out = torch.empty(1, dtype=torch.int32, device="cuda")
+    ws = _ws(_lib.load().frcnn_topk_workspace_bytes(N))
+    _lib.call("frcnn_topk_order", _p(scores.contiguous()), _p(valid), N, K, _p(order), _p(n_out), _p(ws), ws.numel(), _stream())
+    return order, n_out
+
+
+def gather_candidates(rois, scores, order, n, K):
+    _require_gpu()
+    cand = torch.empty((K, 4), dtype=torch.int16, device="cuda")
+    cs = torch.empty(K, dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_gather_candidates", _p(rois), _p(scores.contiguous()), _p(order), _p(n), K, _p(cand), _p(cs), _stream())
+    return cand, cs
+
+
+def nms_sorted(boxes, n, thresh, max_boxes):
+    """boxes: (K,4) int16 or float64, already in descending-score order; n: (1,) i32 device.
+    -> keep (max_boxes,) i32 positions, n_keep (1,) i32."""
+    _require_gpu()
+    K = boxes.shape[0]
+    keep = torch.full((max_boxes,), -1, dtype=torch.int32, device="cuda")
+    n_keep = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = _ws(_lib.load().frcnn_nms_workspace_bytes(K))
+    name = {torch.int16: "frcnn_nms_i16", torch.float64: "frcnn_nms_f64"}[boxes.dtype]
+    _lib.call(name, _p(boxes.contiguous()), _p(n), K, float(thresh), int(max_boxes), _p(keep), _p(n_keep), _p(ws), ws.numel(), _stream())
+    return keep, n_keep
+
+
+def gather_rois(cand, keep, n_keep, batch, out_rows):
+    _require_gpu()
+    out = torch.empty((out_rows, 4), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_gather_rois", _p(cand), _p(keep), _p(n_keep), batch, out_rows, _p(out), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- detector targets
+def roi_targets(rois_i16, gt_f32, gt_f64, gt_cls, bg_idx):
+    _require_gpu()
+    E, G = rois_i16.shape[0], gt_f32.shape[0]
+    elig = torch.zeros(E, dtype=torch.uint8, device="cuda")
+    cls = torch.full((E,), bg_idx, dtype=torch.int32, device="cuda")
+    tg = torch.zeros((E, 4), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_roi_targets", _p(rois_i16.contiguous()), E, _p(gt_f32.contiguous()), _p(gt_f64.contiguous()),
+              _p(gt_cls.contiguous()), G, bg_idx, _p(elig), _p(cls), _p(tg), _stream())
+    return elig, cls, tg
+
+
+# ----------------------------------------------------------------------------- RoI crop/resize
+def roi_crop_resize(feat, rois, pool):
+    """feat: (R,C,Cf) f32 (or (1,R,C,Cf)); rois: (n,4) f32 -> (n,pool,pool,Cf) f32."""
+    _require_gpu()
+    feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
+    rows, cols, C = feat.shape
+    rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
+    n = rois.shape[0]
+    out = torch.empty((n, pool, pool, C), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_roi_crop_resize_fwd", _p(feat), rows, cols, C, _p(rois), n, pool, _p(out), _stream())
+    return out
+
+
+def roi_crop_resize_bwd(dout, rois, rows, cols):
+    _require_gpu()
+    n, pool, _, C = dout.shape
+    dfeat = torch.zeros((rows, cols, C), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_roi_crop_resize_bwd", _p(dout.contiguous()), rows, cols, C, _p(rois.reshape(-1, 4).contiguous()), n, pool, _p(dfeat), _stream())
+    return dfeat

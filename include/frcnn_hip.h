@@ -1,0 +1,145 @@
+/*
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so, the MI355X (gfx950) implementation of the
+ * Faster R-CNN hot path of Kelicious/faster_rcnn.
+ *
+ * The reference has no FFI of its own: its "operator API" for this path is a set of
+ * Python call signatures over numpy arrays and the Keras model duck type
+ * (SURVEY.md 8(b)).  Each entry point below names the reference function it
+ * replaces (paths relative to faster_rcnn/ in the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / HIP types in signatures.
+ *   - Every pointer is a DEVICE pointer unless its name ends in _h (host).
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
+ *     performs no allocation and no host synchronisation (hipGraph-capturable).
+ *     Scratch memory is supplied by the caller: ask frcnn_*_workspace_bytes().
+ *   - Return value: 0 = ok, <0 = error (FRCNN_E_*); frcnn_last_error() gives the text
+ *     of the calling thread's last failure.  No exceptions cross the boundary.
+ *   - Box layout is always [x1, y1, x2, y2]; activations are NHWC f32; flat anchor
+ *     index i = (y*cols + x)*A + a (rpn_util.py:143-156).
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK          0
+#define FRCNN_E_ARG      -1   /* bad argument (null pointer, size out of range) */
+#define FRCNN_E_WORKSPACE -2  /* workspace too small */
+#define FRCNN_E_HIP      -3   /* a HIP runtime call failed */
+#define FRCNN_E_UNSUPPORTED -4
+
+#define FRCNN_MAX_ANCHORS 32
+#define FRCNN_NMS_MAX_BOXES 12288   /* pre-NMS candidates one frcnn_nms_* call accepts */
+
+const char* frcnn_last_error(void);
+int frcnn_version(void);
+/* number of HIP devices visible; does not initialise a context */
+int frcnn_device_count(void);
+
+/* ------------------------------------------------------------------ anchors */
+/* rpn_util._get_all_anchor_coords (rpn_util.py:276-298): all anchors in image pixels.
+ * anchor_hw_h: host [A][2] = {height, width} (util.get_anchors, util.py:242-253).
+ * out: [rows*cols*A][4] f32. */
+int frcnn_anchors_image(int rows, int cols, const int32_t* anchor_hw_h, int A, int stride,
+                        float* out, void* stream);
+
+/* det_util._get_anchor_coords (det_util.py:162-175): anchors in conv-cell units;
+ * anchor_hw_conv_h = anchor dims already floor-divided by the stride (det_util.py:374). */
+int frcnn_anchors_conv(int rows, int cols, const int32_t* anchor_hw_conv_h, int A,
+                       float* out, void* stream);
+
+/* ------------------------------------------------------------------ IoU */
+/* util.cross_ious (util.py:146-177), no "+1" convention, f32 result [M][G].
+ * _f32: boxes1 f32 (rpn_util.py:66).  _i16: boxes1 int16 (det_util.py:314). */
+int frcnn_cross_ious_f32(const float* boxes1, int M, const float* boxes2, int G, float* out, void* stream);
+int frcnn_cross_ious_i16(const int16_t* boxes1, int M, const float* boxes2, int G, float* out, void* stream);
+
+/* ------------------------------------------------------------------ RPN targets */
+/* RpnTrainingManager._process (rpn_util.py:54-103), everything before the host-RNG
+ * sampling step: anchors -> IoU vs gt -> positives / negatives / out-of-bounds ->
+ * regression targets.  gt: [G][4] f32 image pixels.  Outputs (N = rows*cols*A):
+ * can_use[N] u8, is_pos[N] u8, bbreg[N][4] f32, argmax_gt[N] i32 (may be NULL).
+ * G == 0 is allowed (no positives; every in-bounds anchor is a usable negative). */
+size_t frcnn_rpn_assign_workspace_bytes(int rows, int cols, int A, int G);
+int frcnn_rpn_assign(int rows, int cols, const int32_t* anchor_hw_h, int A, int stride,
+                     const float* gt, int G, int img_w, int img_h,
+                     uint8_t* can_use, uint8_t* is_pos, float* bbreg, int32_t* argmax_gt,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ proposals */
+/* det_util._get_rois + _get_valid_box_idxs (det_util.py:370-380, 179-205) with
+ * util.transform_np_inplace (util.py:111-142) inside: regr [rows][cols][4A] f32 ->
+ * rois [N][4] f32 (integer valued, conv-cell units, sanitised), valid[N] u8. */
+int frcnn_decode_proposals(const float* regr, int rows, int cols, const int32_t* anchor_hw_conv_h, int A,
+                           float* rois, uint8_t* valid, void* stream);
+
+/* util.transform_np_inplace (util.py:111-142) on arbitrary boxes: coords [n][4] f32 is
+ * updated in place from deltas [n][4] f32. */
+int frcnn_transform_inplace(float* coords, const float* deltas, int n, void* stream);
+
+/* probs.argsort()[::-1][:K] over the valid entries (det_util.py:68-74, 148-154).
+ * Tie rule (the reference's is unspecified): descending score, ascending index.
+ * order[K] i32 receives the indices (entries >= *n_out are set to -1);
+ * n_out (device i32) = min(K, number of valid entries).  valid may be NULL (all valid). */
+size_t frcnn_topk_workspace_bytes(int N);
+int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K,
+                     int32_t* order, int32_t* n_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* rois[order].astype('int16') (det_util.py:75-76, 154-155) plus the matching scores.
+ * Rows >= *n are zero filled. */
+int frcnn_gather_candidates(const float* rois, const float* scores, const int32_t* order, const int32_t* n, int K,
+                            int16_t* cand, float* cand_scores, void* stream);
+
+/* det_util.nms (det_util.py:209-256) on candidates ALREADY in descending score order.
+ * "+1" pixel convention, keep while overlap <= thresh, stop at max_boxes.
+ * n (device i32) = number of live rows (<= K <= FRCNN_NMS_MAX_BOXES).
+ * keep[max_boxes] i32 receives positions into the candidate list in pick order,
+ * n_keep (device i32) their count.
+ * _i16: int16 boxes (proposal NMS).  _f64: float64 boxes (voc_dets.py:76). */
+size_t frcnn_nms_workspace_bytes(int K);
+int frcnn_nms_i16(const int16_t* boxes, const int32_t* n, int K, double thresh, int max_boxes,
+                  int32_t* keep, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream);
+int frcnn_nms_f64(const double* boxes, const int32_t* n, int K, double thresh, int max_boxes,
+                  int32_t* keep, int32_t* n_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* boxes[pick] for the proposal path, written as the f32 RoI list the detector consumes
+ * (voc_dets.py:31-47): rows [0,*n_keep) = cand[keep[k]]; rows up to the next multiple of
+ * `batch` repeat row (k/batch)*batch (the reference pads its last batch with that batch's
+ * first RoI); any further rows up to out_rows repeat row 0.  out: [out_rows][4] f32. */
+int frcnn_gather_rois(const int16_t* cand, const int32_t* keep, const int32_t* n_keep,
+                      int batch, int out_rows, float* out, void* stream);
+
+/* ------------------------------------------------------------------ detector targets */
+/* det_util._rois_to_truth (det_util.py:310-366) per RoI, before host compaction:
+ * rois [E][4] int16 (conv units); gt_f32 [G][4] = GT/stride rounded to f32 (IoU input,
+ * util.py:229-238); gt_f64 [G][4] = the same boxes in f64 (regression input,
+ * det_util.py:349); gt_cls [G] i32.
+ * eligible[E] u8 (max IoU >= .1), cls[E] i32 (GT class if max IoU >= .5 else bg_idx),
+ * targets[E][4] f32 (already * [10,10,5,5]; zeros for non-positives). */
+int frcnn_roi_targets(const int16_t* rois, int E, const float* gt_f32, const double* gt_f64,
+                      const int32_t* gt_cls, int G, int bg_idx,
+                      uint8_t* eligible, int32_t* cls, float* targets, void* stream);
+
+/* ------------------------------------------------------------------ RoI crop + resize */
+/* custom_layers.RoiResizeConv.call (custom_layers.py:35-56): for each RoI, int32-truncate
+ * the corners, crop feat[y1:y2, x1:x2, :] (x2/y2 exclusive) and resize it to pool x pool
+ * with TF-1.3 bilinear (align_corners=False, no half-pixel offset).
+ * feat [rows][cols][C] f32, rois [n][4] f32, out [n][pool][pool][C] f32.  C % 4 == 0. */
+int frcnn_roi_crop_resize_fwd(const float* feat, int rows, int cols, int C,
+                              const float* rois, int n, int pool, float* out, void* stream);
+/* Gradient of the above w.r.t. feat: dfeat [rows][cols][C] must be zeroed by the caller;
+ * contributions are accumulated with f32 atomics. */
+int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C,
+                              const float* rois, int n, int pool, float* dfeat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */
