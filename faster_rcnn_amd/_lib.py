@@ -42,7 +42,21 @@ SIGNATURES = {
     "frcnn_roi_targets": (I, [P, I, P, P, P, I, I, P, P, P, P]),
     "frcnn_roi_crop_resize_fwd": (I, [P, I, I, I, P, I, I, P, P]),
     "frcnn_roi_crop_resize_bwd": (I, [P, I, I, I, P, I, I, P, P]),
+    "frcnn_conv_packed_k": (I, [I, I, I]),
+    "frcnn_pack_conv_weights": (I, [P, I, I, I, I, P, P]),
+    "frcnn_conv2d_fwd": (I, [P, P, P, P, P, P, P, P]),
+    "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
+    "frcnn_softmax_rows": (I, [P, I, I, I, P, I, P]),
 }
+
+
+
+class ConvDesc(ctypes.Structure):
+    """frcnn_conv_desc (include/frcnn_hip.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in (
+        "n", "h", "w", "cin", "cout", "kh", "kw", "stride", "pad_top", "pad_left", "ho", "wo",
+        "act", "ldy", "ldres", "tile")]
+
 
 _lib = None
 
@@ -56,6 +70,10 @@ def load():
         raise FrcnnError(
             f"{LIB_PATH} is missing: build it with `python -m faster_rcnn_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch bundles its own HIP runtime (same SONAME as /opt/rocm's).  The process must use
+    # ONE runtime -- streams and device pointers are shared with torch -- so make sure
+    # torch's copy is loaded first; ours then binds to it by SONAME.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header/library drift

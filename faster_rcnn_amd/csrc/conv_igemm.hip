@@ -1,0 +1,344 @@
+// Implicit-GEMM NHWC convolution on the CDNA4 matrix cores (gfx950), f32 in / f32 accumulate.
+//
+// Replaces Keras Conv2D (+bias) / BatchNormalization(training=False) / Scale / Activation /
+// add in resnet.py:150-176, 218-247, 408-412, 464-474, 508-533 and vgg.py:96-137, 172-185,
+// 233-247 (Dense = 1x1 conv on a 1x1 map).
+//
+// GEMM view:  Y[m][n] = sum_k A[m][k] * Wt[n][k]
+//   m = (img, ho, wo) output pixel, n = output channel, k = (r*S + s)*Cin + c.
+//   A is never materialised (no im2col): for one 32-wide k-chunk inside a single filter tap
+//   (r,s) the A row of pixel m is the 128 contiguous bytes x[img][ho*st+r-pt][wo*st+s-pl][c0..c0+32)
+//   of the NHWC input, or zeros in the padding halo.
+//   Wt is the filter pre-packed to [Cout][Kpad] (k contiguous), so both operands are
+//   "row-major, k contiguous" and share one LDS image + one fragment-read pattern.
+//
+// Workgroup = 256 threads = 4 wave64 in a 2x2 arrangement; each wave owns TM x TN tiles of
+// 32x32 outputs (v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+// 16 accumulator VGPRs per tile).  One ds_read_b128 per operand tile yields FOUR mfma k-steps
+// (lane half h reads k = 8*kk + 4h .. +3; step j multiplies k=8kk+j (h=0) and 8kk+4+j (h=1)),
+// so a 32-deep chunk costs (TM+TN)*4 LDS reads for TM*TN*16 MFMAs.  LDS rows are padded to 36
+// floats (144 B): the 16-lane ds_read_b128 groups then hit 16 distinct 4-bank slots.
+// Global->LDS staging is register double-buffered: loads for chunk t+1 are issued before
+// the MFMAs of chunk t and written to the other LDS buffer after them; one barrier per chunk.
+// The blockIdx -> tile map is XCD-aware (8 XCDs round-robin on blockIdx): each XCD walks a
+// contiguous run of m-tiles of ONE n-tile so that n-tile's filter slice stays in its 4 MB L2.
+//
+// Epilogue (fused, in registers): v = acc*scale[n] + shift[n] (folded bias+BN(+Scale)),
+// + residual[m][n], activation (none / relu / sigmoid), store NHWC.
+#include "common.h"
+
+namespace frcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float* x; const float* w; const float* scale; const float* shift; const float* residual; float* y;
+    int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
+    int M, K, Kpad, act, ldy, ldres;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = BK + 4;     // floats per LDS row (144 B)
+
+__device__ __forceinline__ float activate(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) return 1.0f / (1.0f + __expf(-v));
+    return v;
+}
+
+// Bijective XCD remap (cdna guide T1): consecutive logical ids land on the same XCD.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int TM, int TN, bool GENERIC_A>
+__global__ void __launch_bounds__(256) k_conv_igemm_f32(const ConvArgs p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int PA = BM / 32, PB = BN / 32;          // float4 rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                   // [2][BM][LDS_STRIDE]
+    float* Bs = smem + 2 * BM * LDS_STRIDE;             // [2][BN][LDS_STRIDE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = logical / p.tiles_m, tile_m = logical - tile_n * p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread staging coordinates
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    int a_h[PA], a_w[PA];
+    size_t a_img[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
+            a_h[i] = ho * p.stride - p.pad_top;
+            a_w[i] = wo * p.stride - p.pad_left;
+            a_img[i] = (size_t)img * p.H * p.W * p.Cin;
+        } else {
+            a_h[i] = -(1 << 28); a_w[i] = 0; a_img[i] = 0;
+        }
+    }
+    const float* b_ptr[PB];
+    bool b_ok[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        b_ok[i] = n < p.Cout;
+        b_ptr[i] = p.w + (size_t)(b_ok[i] ? n : 0) * p.Kpad + lcol;
+    }
+
+    f32x4 ra[PA], rb[PB];
+    int r_tap = 0, s_tap = 0, c0 = 0;                   // filter tap / channel offset of the NEXT chunk to load
+
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            rb[i] = b_ok[i] ? *reinterpret_cast<const f32x4*>(b_ptr[i] + kc * BK) : f32x4{0, 0, 0, 0};
+        if constexpr (!GENERIC_A) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const float* src = p.x + a_img[i] + ((size_t)hi * p.W + wi) * p.Cin + c0 + lcol;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0, 0, 0, 0};
+            }
+            c0 += BK;
+            if (c0 == p.Cin) { c0 = 0; if (++s_tap == p.S) { s_tap = 0; ++r_tap; } }
+        } else {
+            // small-Cin path (stem, Cin=3): decode every k separately
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                f32x4 v = {0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = kc * BK + lcol + e;
+                    if (k < p.K) {
+                        const int c = k % p.Cin, rs = k / p.Cin, s = rs % p.S, r = rs / p.S;
+                        const int hi = a_h[i] + r, wi = a_w[i] + s;
+                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                            v[e] = p.x[a_img[i] + ((size_t)hi * p.W + wi) * p.Cin + c];
+                    }
+                }
+                ra[i] = v;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* a = As + buf * BM * LDS_STRIDE;
+        float* b = Bs + buf * BN * LDS_STRIDE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(a + (lrow + 32 * i) * LDS_STRIDE + lcol) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(b + (lrow + 32 * i) * LDS_STRIDE + lcol) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.Kpad / BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) load_chunk(kc + 1);
+        const float* a = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + li) * LDS_STRIDE + lh * 4;
+        const float* b = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + li) * LDS_STRIDE + lh * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (kc + 1 < nk) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + li;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[n] : 1.0f;
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < p.M) {
+                    float v = acc[i][j][e] * sc + sh;
+                    if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
+                    p.y[(size_t)m * p.ldy + n] = activate(v, p.act);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// filter packing: Keras HWIO [R][S][Cin][Cout] -> [Cout][Kpad], k = (r*S+s)*Cin + c, zero padded
+__global__ void k_pack_hwio(const float* w, int RS, int Cin, int Cout, int Kpad, float* out) {
+    const size_t total = (size_t)Cout * Kpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad), n = (int)(i / Kpad);
+        out[i] = k < RS * Cin ? w[(size_t)k * Cout + n] : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// pooling (NHWC, VALID): MaxPooling2D (resnet.py:412, vgg.py:100-128) / AveragePooling2D (resnet.py:515)
+template <bool IS_MAX>
+__global__ void k_pool(const float4* x, int n_img, int H, int W, int C4, int k, int stride, int Ho, int Wo, float4* y) {
+    const size_t total = (size_t)n_img * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int img = (int)(t / Ho);
+        const float4* base = x + (((size_t)img * H + ho * stride) * W + wo * stride) * C4 + c;
+        float4 acc = IS_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0, 0, 0, 0);
+        for (int r = 0; r < k; ++r)
+            for (int s = 0; s < k; ++s) {
+                const float4 v = base[((size_t)r * W + s) * C4];
+                if (IS_MAX) { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
+                else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            }
+        if (!IS_MAX) { const float inv = (float)(k * k); acc.x /= inv; acc.y /= inv; acc.z /= inv; acc.w /= inv; }
+        y[i] = acc;
+    }
+}
+
+// row softmax over the first `cols` entries of each row (Dense(..., activation='softmax'), resnet.py:522)
+__global__ void k_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, int ldy) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * ldx;
+    float mx = -INFINITY;
+    for (int c = 0; c < cols; ++c) mx = fmaxf(mx, xr[c]);
+    float sum = 0.0f;
+    for (int c = 0; c < cols; ++c) sum += expf(xr[c] - mx);
+    for (int c = 0; c < cols; ++c) y[(size_t)r * ldy + c] = expf(xr[c] - mx) / sum;
+}
+
+template <int TM, int TN, bool G>
+static int launch_conv(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    ConvArgs p = a;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32<TM, TN, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
+        attr_done = true;
+    }
+    k_conv_igemm_f32<TM, TN, G><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    return check_launch("conv2d_fwd");
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" {
+
+int frcnn_conv_packed_k(int kh, int kw, int cin) {
+    const int K = kh * kw * cin;
+    return (K + BK - 1) / BK * BK;
+}
+
+int frcnn_pack_conv_weights(const float* w_hwio, int kh, int kw, int cin, int cout, float* packed, void* stream) {
+    if (!w_hwio || !packed || kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return fail(FRCNN_E_ARG, "pack_conv_weights: bad argument");
+    const int Kpad = frcnn_conv_packed_k(kh, kw, cin);
+    const size_t total = (size_t)cout * Kpad;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    k_pack_hwio<<<grid, 256, 0, as_stream(stream)>>>(w_hwio, kh * kw, cin, cout, Kpad, packed);
+    return check_launch("pack_conv_weights");
+}
+
+int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                     const float* scale, const float* shift, const float* residual, float* y, void* stream) {
+    if (!d || !x || !w_packed || !y) return fail(FRCNN_E_ARG, "conv2d_fwd: null pointer");
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->ho <= 0 || d->wo <= 0)
+        return fail(FRCNN_E_ARG, "conv2d_fwd: bad shape");
+    ConvArgs a;
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
+    a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
+    a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    if (M > 0x7fffffffLL) return fail(FRCNN_E_ARG, "conv2d_fwd: too many output pixels");
+    a.M = (int)M; a.K = d->kh * d->kw * d->cin; a.Kpad = frcnn_conv_packed_k(d->kh, d->kw, d->cin);
+    a.act = d->act; a.ldy = d->ldy > 0 ? d->ldy : d->cout; a.ldres = d->ldres > 0 ? d->ldres : d->cout;
+    a.tiles_m = a.tiles_n = 0;
+    hipStream_t s = as_stream(stream);
+    const bool generic = (d->cin % BK) != 0;
+    // tile choice: fill >= ~2 workgroups per CU where the problem allows, else shrink the tile
+    const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
+    int cfg = d->tile;      // 0 = auto
+    if (cfg == 0) {
+        if (d->cout <= 64) cfg = 3;                 // 128 x 64
+        else if (t128 >= 384) cfg = 1;              // 128 x 128
+        else cfg = 2;                               // 64 x 64
+    }
+    if (generic) {
+        if (cfg == 2) return launch_conv<1, 1, true>(a, s);
+        return launch_conv<2, 1, true>(a, s);
+    }
+    switch (cfg) {
+        case 1: return launch_conv<2, 2, false>(a, s);
+        case 2: return launch_conv<1, 1, false>(a, s);
+        case 3: return launch_conv<2, 1, false>(a, s);
+        case 4: return launch_conv<4, 2, false>(a, s);
+        default: return fail(FRCNN_E_ARG, "conv2d_fwd: unknown tile config %d", cfg);
+    }
+}
+
+int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream) {
+    if (!x || !y || n <= 0 || h < k || w < k || c <= 0 || (c & 3) || k <= 0 || stride <= 0) return fail(FRCNN_E_ARG, "pool2d_fwd: bad argument (C must be a multiple of 4)");
+    const int Ho = (h - k) / stride + 1, Wo = (w - k) / stride + 1;
+    const size_t total = (size_t)n * Ho * Wo * (c / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (is_max) k_pool<true><<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, n, h, w, c / 4, k, stride, Ho, Wo, (float4*)y);
+    else k_pool<false><<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, n, h, w, c / 4, k, stride, Ho, Wo, (float4*)y);
+    return check_launch("pool2d_fwd");
+}
+
+int frcnn_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream) {
+    if (rows < 0 || cols <= 0 || ldx < cols || ldy < cols) return fail(FRCNN_E_ARG, "softmax_rows: bad argument");
+    if (rows == 0) return FRCNN_OK;
+    if (!x || !y) return fail(FRCNN_E_ARG, "softmax_rows: null pointer");
+    k_softmax_rows<<<(rows + 63) / 64, 64, 0, as_stream(stream)>>>(x, rows, cols, ldx, y, ldy);
+    return check_launch("softmax_rows");
+}
+
+}  // extern "C"

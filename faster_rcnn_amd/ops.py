@@ -189,3 +189,73 @@ def roi_crop_resize_bwd(dout, rois, rows, cols):
     dfeat = torch.zeros((rows, cols, C), dtype=torch.float32, device="cuda")
     _lib.call("frcnn_roi_crop_resize_bwd", _p(dout.contiguous()), rows, cols, C, _p(rois.reshape(-1, 4).contiguous()), n, pool, _p(dfeat), _stream())
     return dfeat
+
+
+# ----------------------------------------------------------------------------- conv engine
+ACT = {None: 0, "linear": 0, "none": 0, "relu": 1, "sigmoid": 2}
+
+
+def same_pad(size, k, stride):
+    """TF/Keras padding='same': (out, pad_before)."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2
+
+
+def valid_out(size, k, stride):
+    return (size - k) // stride + 1
+
+
+class PackedConv:
+    """A convolution's device-resident parameters: filter packed to [cout][packed_k], and the
+    per-channel scale/shift the epilogue applies (bias and BatchNorm/Scale folded)."""
+
+    def __init__(self, w_hwio, scale=None, shift=None):
+        _require_gpu()
+        w = _dev(w_hwio, torch.float32)
+        self.kh, self.kw, self.cin, self.cout = (int(v) for v in w.shape)
+        kp = _lib.load().frcnn_conv_packed_k(self.kh, self.kw, self.cin)
+        self.w = torch.empty((self.cout, kp), dtype=torch.float32, device="cuda")
+        _lib.call("frcnn_pack_conv_weights", _p(w), self.kh, self.kw, self.cin, self.cout, _p(self.w), _stream())
+        self.scale = None if scale is None else _dev(scale, torch.float32)
+        self.shift = None if shift is None else _dev(shift, torch.float32)
+
+
+def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0):
+    """x: (n,h,w,cin) f32 NHWC device tensor; pc: PackedConv -> (n,ho,wo,cout)."""
+    _require_gpu()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == pc.cin, (x.shape, pc.cin)
+    n, h, w, _ = x.shape
+    if padding == "same":
+        ho, pt = same_pad(h, pc.kh, stride)
+        wo, pl = same_pad(w, pc.kw, stride)
+    else:
+        ho, wo, pt, pl = valid_out(h, pc.kh, stride), valid_out(w, pc.kw, stride), 0, 0
+    if out is None:
+        out = torch.empty((n, ho, wo, pc.cout), dtype=torch.float32, device="cuda")
+    else:
+        assert out.shape == (n, ho, wo, pc.cout) and out.is_contiguous()
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc.cin, cout=pc.cout, kh=pc.kh, kw=pc.kw, stride=stride, pad_top=pt, pad_left=pl,
+                      ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile)
+    _lib.call("frcnn_conv2d_fwd", ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), _stream())
+    return out
+
+
+def pool2d(x, k, stride, is_max=True):
+    _require_gpu()
+    n, h, w, c = x.shape
+    ho, wo = valid_out(h, k, stride), valid_out(w, k, stride)
+    out = torch.empty((n, ho, wo, c), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_pool2d_fwd", _p(x.contiguous()), n, h, w, c, k, stride, 1 if is_max else 0, _p(out), _stream())
+    return out
+
+
+def softmax_rows(x, cols=None):
+    _require_gpu()
+    rows, ld = x.shape
+    cols = ld if cols is None else cols
+    out = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_softmax_rows", _p(x.contiguous()), rows, cols, ld, _p(out), cols, _stream())
+    return out

@@ -139,6 +139,41 @@ int frcnn_roi_crop_resize_fwd(const float* feat, int rows, int cols, int C,
 int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C,
                               const float* rois, int n, int pool, float* dfeat, void* stream);
 
+/* ------------------------------------------------------------------ conv engine (MFMA) */
+/* One NHWC f32 convolution with a fused epilogue: the unit the Keras graphs of
+ * resnet.py / vgg.py are lowered to.
+ *   Conv2D(+bias) -> BatchNormalization(training=False) [-> Scale] -> [add shortcut] -> Activation
+ *   (resnet.py:150-176 identity_block, :218-247 conv_block, :408-412 stem, :464-474 RPN heads,
+ *    :282-313 / :351-392 TimeDistributed blocks with the RoI axis folded into n;
+ *    vgg.py:96-137; Dense layers = 1x1 conv over an n x 1 x 1 x cin tensor).
+ * y[m][c] = act( conv(x, w)[m][c] * scale[c] + shift[c] + residual[m][c] ),  m = (img, ho, wo).
+ * Keras padding='same' = TF SAME: ho = ceil(h/stride), pad_total = max((ho-1)*stride + kh - h, 0),
+ * pad_top = pad_total / 2 (extra pixel at the end); 'valid': pad 0, ho = (h - kh)/stride + 1. */
+#define FRCNN_ACT_NONE 0
+#define FRCNN_ACT_RELU 1
+#define FRCNN_ACT_SIGMOID 2
+typedef struct frcnn_conv_desc {
+    int32_t n, h, w, cin;          /* input  [n][h][w][cin]                                   */
+    int32_t cout, kh, kw, stride;  /* filter [kh][kw][cin][cout], same stride in h and w      */
+    int32_t pad_top, pad_left;     /* implicit zero padding before the first row / column     */
+    int32_t ho, wo;                /* output [n][ho][wo][cout]                                */
+    int32_t act;                   /* FRCNN_ACT_*                                             */
+    int32_t ldy, ldres;            /* row strides (elements) of y / residual; 0 = cout        */
+    int32_t tile;                  /* 0 = auto; 1: 128x128, 2: 64x64, 3: 128x64, 4: 256x128   */
+} frcnn_conv_desc;
+
+/* k extent of a packed filter row: kh*kw*cin rounded up to the kernel's k-chunk (32). */
+int frcnn_conv_packed_k(int kh, int kw, int cin);
+/* Keras HWIO kernel [kh][kw][cin][cout] -> packed [cout][packed_k] (k = (r*kw+s)*cin + c). */
+int frcnn_pack_conv_weights(const float* w_hwio, int kh, int kw, int cin, int cout, float* packed, void* stream);
+/* scale / shift / residual may be NULL (1, 0, none). */
+int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                     const float* scale, const float* shift, const float* residual, float* y, void* stream);
+/* MaxPooling2D / AveragePooling2D, 'valid' (resnet.py:412, 515; vgg.py:100-128). c % 4 == 0. */
+int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream);
+/* softmax over the first `cols` entries of each row (Dense(activation='softmax'), resnet.py:522). */
+int frcnn_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

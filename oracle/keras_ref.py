@@ -44,3 +44,51 @@ def roi_resize(feat, rois, pool=7):
                 bot = bl + (br - bl) * tx
                 out[r, py, px] = top + (bot - top) * ty
     return out
+
+
+# --------------------------------------------------------------------------- conv / BN / pool
+def _torch():
+    import torch
+    return torch
+
+
+def same_pad(size, k, stride):
+    """Keras padding='same' -> TF SAME [3P]: out = ceil(in/stride); pad_total =
+    max((out-1)*stride + k - in, 0); pad_before = pad_total // 2 (extra pixel at the end)."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2, total - total // 2
+
+
+def conv2d(x, w_hwio, bias=None, stride=1, padding="valid", dtype=None):
+    """Keras Conv2D on NHWC input with HWIO kernel (resnet.py:150, 408; vgg.py:96).
+    x: (n,h,w,cin) tensor/array; returns NHWC torch tensor (CPU)."""
+    torch = _torch()
+    import torch.nn.functional as F
+    dtype = dtype or torch.float32
+    x = torch.as_tensor(np.asarray(x)).to(dtype).permute(0, 3, 1, 2)
+    w = torch.as_tensor(np.asarray(w_hwio)).to(dtype).permute(3, 2, 0, 1)
+    if padding == "same":
+        _, pt, pb = same_pad(x.shape[2], w.shape[2], stride)
+        _, pl, pr = same_pad(x.shape[3], w.shape[3], stride)
+        x = F.pad(x, (pl, pr, pt, pb))
+    b = None if bias is None else torch.as_tensor(np.asarray(bias)).to(dtype)
+    y = F.conv2d(x, w, b, stride=stride)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def batchnorm_inference(x, gamma, beta, mean, var, eps):
+    """BatchNormalization(training=False) [3P tf.nn.batch_normalization]:
+    inv = rsqrt(var+eps)*gamma; y = x*inv + (beta - mean*inv)."""
+    torch = _torch()
+    g, b, m, v = (torch.as_tensor(np.asarray(t)).to(x.dtype) for t in (gamma, beta, mean, var))
+    inv = torch.rsqrt(v + eps) * g
+    return x * inv + (b - m * inv)
+
+
+def pool2d(x, k, stride, is_max=True):
+    torch = _torch()
+    import torch.nn.functional as F
+    xc = x.permute(0, 3, 1, 2)
+    y = F.max_pool2d(xc, k, stride) if is_max else F.avg_pool2d(xc, k, stride)
+    return y.permute(0, 2, 3, 1).contiguous()

@@ -1,0 +1,91 @@
+"""GPU parity of the MFMA implicit-GEMM conv engine vs the torch-CPU restatement.
+fp32 tolerance: |got - want_f64| <= 1e-4 * max(1, |want|)  (north_star: fp32 within 1e-4)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from faster_rcnn_amd import ops as o
+    return o
+
+
+def check(got, want64, tol=1e-4):
+    got = got.cpu().double()
+    err = (got - want64).abs() / want64.abs().clamp(min=1.0)
+    assert err.max().item() <= tol, err.max().item()
+
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, padding, act, residual, tile
+    (1, 20, 31, 64, 64, 1, 1, "valid", "relu", False, 0),
+    (1, 20, 31, 64, 256, 1, 1, "valid", None, True, 0),
+    (1, 21, 33, 64, 64, 3, 1, "same", "relu", False, 0),
+    (1, 37, 50, 256, 128, 1, 2, "valid", "relu", False, 0),       # stride-2 1x1 VALID
+    (1, 15, 22, 128, 128, 3, 1, "same", "relu", False, 1),
+    (1, 15, 22, 128, 128, 3, 1, "same", "relu", False, 2),
+    (1, 15, 22, 128, 96, 3, 1, "same", "relu", False, 3),         # cout not a tile multiple
+    (1, 15, 22, 128, 256, 3, 1, "same", "relu", True, 4),
+    (3, 7, 7, 512, 512, 3, 1, "same", "relu", False, 0),          # head: RoIs as batch
+    (1, 38, 63, 512, 9, 1, 1, "valid", "sigmoid", False, 0),      # rpn_out_cls
+    (1, 38, 63, 512, 36, 1, 1, "valid", None, False, 0),          # rpn_out_bbreg
+    (5, 1, 1, 2048, 101, 1, 1, "valid", None, False, 0),          # dense
+    (1, 61, 83, 3, 64, 7, 2, "same", "relu", False, 0),           # stem (odd size)
+    (1, 60, 80, 3, 64, 7, 2, "same", "relu", False, 0),           # stem (even size: pad 2/3)
+    (1, 24, 30, 3, 64, 3, 1, "same", "relu", False, 0),           # vgg block1_conv1
+    (2, 9, 11, 64, 64, 3, 2, "same", None, False, 0),             # SAME with stride 2
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d(ops, case):
+    from oracle import keras_ref
+    n, h, w, cin, cout, k, stride, padding, act, use_res, tile = case
+    rs = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(cout)).astype(np.float32)
+    shift = (0.1 * rs.randn(cout)).astype(np.float32)
+    want = keras_ref.conv2d(x, wt, None, stride, padding, dtype=torch.float64)
+    want = want * torch.from_numpy(scale).double() + torch.from_numpy(shift).double()
+    res = None
+    if use_res:
+        res = rs.randn(*want.shape).astype(np.float32)
+        want = want + torch.from_numpy(res).double()
+    if act == "relu":
+        want = want.clamp(min=0)
+    elif act == "sigmoid":
+        want = torch.sigmoid(want)
+    pc = ops.PackedConv(wt, scale, shift)
+    got = ops.conv2d(torch.from_numpy(x).cuda(), pc, stride, padding, act,
+                     None if res is None else torch.from_numpy(res).cuda(), tile=tile)
+    assert tuple(got.shape) == tuple(want.shape)
+    check(got, want)
+
+
+def test_conv_identity_asymmetric(ops):
+    """A = I against an ASYMMETRIC filter catches a transposed C write (cdna guide s3)."""
+    cin = cout = 64
+    x = np.zeros((1, 1, 64, cin), np.float32)
+    x[0, 0, np.arange(64), np.arange(64)] = 1.0                # pixel m has a one in channel m
+    wt = (np.arange(cin)[:, None] * 100 + np.arange(cout)[None, :]).astype(np.float32).reshape(1, 1, cin, cout)
+    got = ops.conv2d(torch.from_numpy(x).cuda(), ops.PackedConv(wt)).cpu().numpy()[0, 0]
+    assert np.array_equal(got, wt[0, 0])
+
+
+def test_pool_and_softmax(ops):
+    from oracle import keras_ref
+    rs = np.random.RandomState(1)
+    x = rs.randn(2, 17, 23, 64).astype(np.float32)
+    for k, s, mx in ((3, 2, True), (2, 2, True), (7, 7, False)):
+        want = keras_ref.pool2d(torch.from_numpy(x), k, s, mx)
+        got = ops.pool2d(torch.from_numpy(x).cuda(), k, s, mx).cpu()
+        assert got.shape == want.shape
+        assert torch.allclose(got, want, rtol=0, atol=1e-6 if not mx else 0)
+    z = rs.randn(300, 101).astype(np.float32) * 3
+    got = ops.softmax_rows(torch.from_numpy(z).cuda(), 21).cpu()
+    want = torch.softmax(torch.from_numpy(z[:, :21]).double(), dim=1)
+    assert (got.double() - want).abs().max().item() < 1e-6
