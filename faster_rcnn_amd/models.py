@@ -1,0 +1,116 @@
+"""The Keras-model duck type the reference's callers rely on:
+``predict_on_batch`` (det_util.py:41), ``predict`` (voc_dets.py:49), ``output`` (length test,
+det_util.py:27), ``get_layer(name).get_weights()`` (train_rpn_test.py:41), ``load_weights`` /
+``save_weights``.  numpy in / numpy out at this surface; ``forward_dev`` is the
+device-resident form the fused pipeline uses (no host round trip)."""
+import numpy as np
+import torch
+
+from . import nets
+from .weights import load_npz, save_npz
+
+
+class _Layer:
+    def __init__(self, weights, name):
+        self._w, self.name = weights, name
+
+    def get_weights(self):
+        return [np.array(a) for a in self._w[self.name]]
+
+    def set_weights(self, arrs):
+        self._w[self.name] = [np.asarray(a, dtype=np.float32) for a in arrs]
+
+
+class _Model:
+    def __init__(self, weights):
+        self.weights = weights
+
+    def _modules(self):
+        return []
+
+    def get_layer(self, name):
+        if name not in self.weights:
+            raise ValueError("No such layer: " + name)
+        return _Layer(self.weights, name)
+
+    def invalidate(self):
+        """Re-lower (re-pack / re-fold) after weights changed."""
+        for m in self._modules():
+            for u in m.units():
+                u.pc = None
+
+    def load_weights(self, path, by_name=False):
+        new = load_npz(path)
+        for k, v in new.items():
+            if k in self.weights or not by_name:
+                self.weights[k] = v
+        self.invalidate()
+
+    def save_weights(self, path):
+        save_npz(path, self.weights)
+
+    save = save_weights
+
+
+class BaseModel(_Model):
+    def __init__(self, weights, net, kind, freeze_blocks, weight_regularizer=None, bias_regularizer=None):
+        super().__init__(weights)
+        self.net, self.kind, self.freeze_blocks = net, kind, list(freeze_blocks)
+        self.weight_regularizer, self.bias_regularizer = weight_regularizer, bias_regularizer
+
+    def _modules(self):
+        return [self.net]
+
+    def forward_dev(self, x):
+        return self.net(x)
+
+
+class RpnModel(_Model):
+    """base + RPN heads.  ``output`` has 3 entries when the conv4 map is also returned
+    (include_conv=True), which DetTrainingManager tests with len() (det_util.py:27)."""
+
+    def __init__(self, base, include_conv, anchors_per_loc):
+        super().__init__(base.weights)
+        self.base, self.include_conv, self.anchors_per_loc = base, include_conv, anchors_per_loc
+        self.head = nets.RpnHead(base.weights)
+        self.output = ["rpn_out_cls", "rpn_out_bbreg"] + (["conv_out"] if include_conv else [])
+
+    def _modules(self):
+        return [self.base.net, self.head]
+
+    def forward_dev(self, x):
+        feat = self.base.net(x)
+        cls, reg = self.head(feat)
+        return cls, reg, feat
+
+    def predict_on_batch(self, x):
+        cls, reg, feat = self.forward_dev(nets.to_device_image(x))
+        outs = [cls.cpu().numpy(), reg.cpu().numpy()]
+        if self.include_conv:
+            outs.append(feat.cpu().numpy())
+        return outs
+
+
+class DetModel(_Model):
+    """[image or conv4 map, rois] -> [class probabilities (1,n,C), box regressions (1,n,4(C-1))]."""
+
+    def __init__(self, weights, head, num_rois, num_classes, base=None):
+        super().__init__(weights)
+        self.head, self.num_rois, self.num_classes, self.base = head, num_rois, num_classes, base
+        self.output = ["dense_class_%d" % num_classes, "dense_reg_%d" % num_classes]
+
+    def _modules(self):
+        return ([self.base.net] if self.base is not None else []) + [self.head]
+
+    def forward_dev(self, first, rois):
+        feat = self.base.net(first) if self.base is not None else first
+        return self.head(feat, rois)
+
+    def predict(self, inputs):
+        first, rois = inputs
+        first = nets.to_device_image(first)
+        rois = torch.from_numpy(np.ascontiguousarray(np.asarray(rois, dtype=np.float32))).cuda().reshape(-1, 4)
+        cls, reg = self.forward_dev(first, rois)
+        return [cls.cpu().numpy()[None], reg.cpu().numpy()[None]]
+
+    predict_on_batch = predict

@@ -1,0 +1,210 @@
+"""Lowering of the reference's Keras graphs (resnet.py, vgg.py) onto the HIP conv engine.
+
+Every Keras ``Conv2D -> BatchNormalization(training=False) [-> Scale] [-> add] -> Activation``
+group becomes ONE fused launch (``ConvUnit``): bias, BN and Scale fold into the epilogue's
+per-channel scale/shift, the shortcut add and the activation run in registers.
+``TimeDistributed`` blocks run with the RoI axis as the batch axis of the same kernel.
+No tracing compiler: a forward pass is a fixed sequence of C-ABI calls on one HIP stream,
+which ``InferenceGraph`` (pipeline.py) captures into a hipGraph.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .weights import STAGE_FILTERS, VGG_CONVS, resnet_block_names
+
+BN_EPS_STEM = 1e-3      # Keras BatchNormalization default epsilon (bn_conv1, resnet.py:410)
+BN_EPS_BLOCK = 1e-5     # resnet.py:148, 216, 280, 349
+
+
+class ConvUnit:
+    """One fused conv launch and the Keras layers it stands for."""
+
+    def __init__(self, weights, conv, bn=None, scale=None, eps=BN_EPS_BLOCK, stride=1, padding="valid", act=None, tile=0):
+        self.weights, self.conv, self.bn, self.scale_name, self.eps = weights, conv, bn, scale, eps
+        self.stride, self.padding, self.act, self.tile = stride, padding, act, tile
+        self.pc = None
+
+    def lower(self):
+        w = self.weights[self.conv]
+        kernel = np.asarray(w[0], dtype=np.float32)
+        if kernel.ndim == 2:                               # Dense kernel (in, out) == 1x1 conv
+            kernel = kernel.reshape(1, 1, *kernel.shape)
+        cout = kernel.shape[3]
+        bias = np.asarray(w[1], dtype=np.float64) if len(w) > 1 else np.zeros(cout)
+        scale = np.ones(cout)
+        shift = bias.copy()
+        if self.bn is not None:
+            g, b, m, v = (np.asarray(a, dtype=np.float64) for a in self.weights[self.bn])
+            inv = g / np.sqrt(v + self.eps)
+            scale = inv
+            shift = (bias - m) * inv + b
+        if self.scale_name is not None:
+            g2, b2 = (np.asarray(a, dtype=np.float64) for a in self.weights[self.scale_name])
+            scale = scale * g2
+            shift = shift * g2 + b2
+        self.pc = ops.PackedConv(kernel, scale.astype(np.float32), shift.astype(np.float32))
+        return self
+
+    def __call__(self, x, residual=None, out=None):
+        if self.pc is None:
+            self.lower()
+        return ops.conv2d(x, self.pc, self.stride, self.padding, self.act, residual, out, self.tile)
+
+
+def _block_units(weights, stage, block, has_shortcut, stride, separate_scale):
+    def unit(suffix, **kw):
+        tag = "%d%s_branch%s" % (stage, block, suffix)
+        return ConvUnit(weights, "res" + tag, "bn" + tag, ("scale" + tag) if separate_scale else None, BN_EPS_BLOCK, **kw)
+    u = {"2a": unit("2a", stride=stride, act="relu"),
+         "2b": unit("2b", padding="same", act="relu"),
+         "2c": unit("2c", act="relu")}                      # relu applied after the fused shortcut add
+    if has_shortcut:
+        u["1"] = unit("1", stride=stride)
+    return u
+
+
+def run_block(u, x):
+    """identity_block / conv_block (resnet.py:114-247) and their TimeDistributed twins (:250-392)."""
+    shortcut = u["1"](x) if "1" in u else x
+    t = u["2a"](x)
+    t = u["2b"](t)
+    return u["2c"](t, residual=shortcut)
+
+
+class ResNetBase:
+    """conv1 .. stage 4 (resnet50_base resnet.py:395-448, resnet101_base :551-602)."""
+    stride = 16
+    out_channels = 1024
+
+    def __init__(self, weights, depth):
+        self.weights, self.depth = weights, depth
+        r101 = depth == 101
+        self.stem = ConvUnit(weights, "conv1", "bn_conv1", "scale_conv1" if r101 else None, BN_EPS_STEM,
+                             stride=2, padding="same", act="relu")
+        self.blocks = []
+        for stage, block, is_conv in resnet_block_names(depth):
+            stride = 2 if (is_conv and stage > 2) else 1
+            self.blocks.append(_block_units(weights, stage, block, is_conv, stride, r101))
+
+    def units(self):
+        yield self.stem
+        for b in self.blocks:
+            yield from b.values()
+
+    def __call__(self, x):
+        x = self.stem(x)
+        x = ops.pool2d(x, 3, 2, True)                       # MaxPooling2D((3,3), strides=(2,2)) (resnet.py:412)
+        for b in self.blocks:
+            x = run_block(b, x)
+        return x
+
+
+class VggBase:
+    """13 conv + 4 pools, no pool5 (vgg16_base vgg.py:91-141)."""
+    stride = 16
+    out_channels = 512
+
+    def __init__(self, weights):
+        self.weights = weights
+        self.convs = [(name, ConvUnit(weights, name, padding="same", act="relu")) for name, _, _ in VGG_CONVS]
+
+    def units(self):
+        for _, u in self.convs:
+            yield u
+
+    def __call__(self, x):
+        for name, u in self.convs:
+            x = u(x)
+            if name in ("block1_conv2", "block2_conv2", "block3_conv3", "block4_conv3"):
+                x = ops.pool2d(x, 2, 2, True)
+        return x
+
+
+class RpnHead:
+    """rpn_conv1 3x3+ReLU, rpn_out_cls 1x1 sigmoid, rpn_out_bbreg 1x1 linear (resnet.py:464-474)."""
+
+    def __init__(self, weights):
+        self.conv = ConvUnit(weights, "rpn_conv1", padding="same", act="relu")
+        self.cls = ConvUnit(weights, "rpn_out_cls", act="sigmoid")
+        self.reg = ConvUnit(weights, "rpn_out_bbreg")
+
+    def units(self):
+        return [self.conv, self.cls, self.reg]
+
+    def __call__(self, feat):
+        t = self.conv(feat)
+        return self.cls(t), self.reg(t)
+
+
+class _MergedDense:
+    """dense_class_C (softmax) and dense_reg_C (linear) share their input, so they run as ONE
+    GEMM with the two kernels concatenated along the output axis (resnet.py:522-533)."""
+
+    def __init__(self, weights, num_classes):
+        self.C = num_classes
+        kc, bc = weights["dense_class_%d" % num_classes]
+        kr, br = weights["dense_reg_%d" % num_classes]
+        merged = {"dense": [np.concatenate([kc, kr], axis=1), np.concatenate([bc, br])]}
+        self.unit = ConvUnit(merged, "dense")
+
+    def __call__(self, x2d):
+        n, cin = x2d.shape
+        y = self.unit(x2d.reshape(n, 1, 1, cin)).reshape(n, -1)
+        cls = ops.softmax_rows(y, self.C)
+        reg = y[:, self.C:].contiguous()
+        return cls, reg
+
+
+class ResNetHead:
+    """RoiResizeConv -> stage 5 (TimeDistributed) -> AveragePooling2D(7) -> dense x2
+    (resnet50_classifier resnet.py:489-548, resnet101_classifier :631-686)."""
+    pool = 7
+
+    def __init__(self, weights, depth, num_classes):
+        r101 = depth == 101
+        self.blocks = [_block_units(weights, 5, b, b == "a", 1, r101) for b in "abc"]
+        self.dense = _MergedDense(weights, num_classes)
+
+    def units(self):
+        for b in self.blocks:
+            yield from b.values()
+        yield self.dense.unit
+
+    def __call__(self, feat, rois):
+        x = ops.roi_crop_resize(feat, rois, self.pool)      # (n,7,7,1024)
+        for b in self.blocks:
+            x = run_block(b, x)
+        x = ops.pool2d(x, 7, 7, False)                      # (n,1,1,2048)
+        return self.dense(x.reshape(x.shape[0], -1))
+
+
+class VggHead:
+    """RoiResizeConv -> Flatten (h,w,c order) -> fc1, fc2 (ReLU) -> dense x2 (vgg.py:226-255)."""
+    pool = 7
+
+    def __init__(self, weights, num_classes):
+        self.fc1 = ConvUnit(weights, "fc1", act="relu")
+        self.fc2 = ConvUnit(weights, "fc2", act="relu")
+        self.dense = _MergedDense(weights, num_classes)
+
+    def units(self):
+        return [self.fc1, self.fc2, self.dense.unit]
+
+    def __call__(self, feat, rois):
+        x = ops.roi_crop_resize(feat, rois, self.pool)      # (n,7,7,512)
+        n = x.shape[0]
+        x = self.fc1(x.reshape(n, 1, 1, -1))
+        x = self.fc2(x)
+        return self.dense(x.reshape(n, -1))
+
+
+def to_device_image(x):
+    """(1,H,W,3) or (H,W,3) float array/tensor -> (1,H,W,3) f32 device tensor."""
+    if isinstance(x, torch.Tensor):
+        t = x.to(device="cuda", dtype=torch.float32)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    return t.contiguous()

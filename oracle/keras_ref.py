@@ -92,3 +92,121 @@ def pool2d(x, k, stride, is_max=True):
     xc = x.permute(0, 3, 1, 2)
     y = F.max_pool2d(xc, k, stride) if is_max else F.avg_pool2d(xc, k, stride)
     return y.permute(0, 2, 3, 1).contiguous()
+
+
+# --------------------------------------------------------------------------- Keras graphs
+class KerasGraphs:
+    """Layer-by-layer restatement of the reference's model builders, evaluated with torch on
+    the CPU in ``dtype`` (float32 = "the Keras CPU path"; float64 = tolerance anchor).
+    ``weights`` = {keras_layer_name: [arrays in get_weights() order]}."""
+
+    def __init__(self, weights, dtype=None):
+        torch = _torch()
+        self.w = weights
+        self.dtype = dtype or torch.float32
+
+    # -- layers
+    def conv(self, x, name, stride=1, padding="valid"):
+        w = self.w[name]
+        return conv2d(x, w[0], w[1] if len(w) > 1 else None, stride, padding, self.dtype)
+
+    def bn(self, x, name, eps):
+        return batchnorm_inference(x, *self.w[name], eps=eps)
+
+    def scale(self, x, name):
+        """custom_layers.Scale.call (custom_layers.py:121-129): gamma * x + beta."""
+        torch = _torch()
+        g, b = (torch.as_tensor(np.asarray(t)).to(x.dtype) for t in self.w[name])
+        return g * x + b
+
+    def conv_bn(self, x, stage, block, suffix, stride=1, padding="valid", separate_scale=False):
+        tag = "%d%s_branch%s" % (stage, block, suffix)
+        x = self.conv(x, "res" + tag, stride, padding)
+        x = self.bn(x, "bn" + tag, 1e-5)                                   # eps (resnet.py:148, 216)
+        if separate_scale:
+            x = self.scale(x, "scale" + tag)
+        return x
+
+    # -- blocks (resnet.py:114-176 identity_block, :179-247 conv_block; TD twins :250-392)
+    def identity_block(self, x, stage, block, separate_scale=False):
+        t = self.conv_bn(x, stage, block, "2a", separate_scale=separate_scale).clamp(min=0)
+        t = self.conv_bn(t, stage, block, "2b", padding="same", separate_scale=separate_scale).clamp(min=0)
+        t = self.conv_bn(t, stage, block, "2c", separate_scale=separate_scale)
+        return (t + x).clamp(min=0)
+
+    def conv_block(self, x, stage, block, stride=2, separate_scale=False):
+        t = self.conv_bn(x, stage, block, "2a", stride=stride, separate_scale=separate_scale).clamp(min=0)
+        t = self.conv_bn(t, stage, block, "2b", padding="same", separate_scale=separate_scale).clamp(min=0)
+        t = self.conv_bn(t, stage, block, "2c", separate_scale=separate_scale)
+        s = self.conv_bn(x, stage, block, "1", stride=stride, separate_scale=separate_scale)
+        return (t + s).clamp(min=0)
+
+    # -- bases
+    def resnet_base(self, x, depth=50):
+        """resnet50_base (resnet.py:395-448) / resnet101_base (:551-602). x: (1,H,W,3)."""
+        r101 = depth == 101
+        x = self.conv(x, "conv1", stride=2, padding="same")                 # :408
+        x = self.bn(x, "bn_conv1", 1e-3)                                    # Keras default eps (:410)
+        if r101:
+            x = self.scale(x, "scale_conv1")                                # :567
+        x = pool2d(x.clamp(min=0), 3, 2, True)                              # :411-412
+        if r101:
+            plan = {2: ["a", "b", "c"], 3: ["a", "b1", "b2", "b3"], 4: ["a"] + ["b%d" % i for i in range(1, 23)]}
+        else:
+            plan = {2: list("abc"), 3: list("abcd"), 4: list("abcdef")}
+        for stage in (2, 3, 4):
+            for block in plan[stage]:
+                if block == "a":
+                    x = self.conv_block(x, stage, block, stride=1 if stage == 2 else 2, separate_scale=r101)
+                else:
+                    x = self.identity_block(x, stage, block, separate_scale=r101)
+        return x
+
+    def vgg_base(self, x):
+        """vgg16_base (vgg.py:91-141): 3x3 same + relu, 2x2 pools after blocks 1-4."""
+        for blk, n in ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3)):
+            for i in range(1, n + 1):
+                x = self.conv(x, "block%d_conv%d" % (blk, i), padding="same").clamp(min=0)
+            if blk < 5:
+                x = pool2d(x, 2, 2, True)
+        return x
+
+    # -- heads
+    def rpn(self, feat):
+        """resnet50_rpn (resnet.py:464-474) / vgg16_rpn (vgg.py:171-185)."""
+        torch = _torch()
+        t = self.conv(feat, "rpn_conv1", padding="same").clamp(min=0)
+        cls = torch.sigmoid(self.conv(t, "rpn_out_cls"))
+        reg = self.conv(t, "rpn_out_bbreg")
+        return cls, reg
+
+    def _dense(self, x, name):
+        torch = _torch()
+        k, b = (torch.as_tensor(np.asarray(t)).to(x.dtype) for t in self.w[name])
+        return x @ k + b
+
+    def resnet_classifier(self, feat, rois, num_classes, depth=50):
+        """resnet50_classifier (resnet.py:489-548): RoiResizeConv, stage 5 with strides (1,1)
+        (:508), AveragePooling2D(7), flatten, dense softmax + dense linear."""
+        torch = _torch()
+        r101 = depth == 101
+        crops = roi_resize(np.asarray(feat[0].to(torch.float32)), np.asarray(rois), 7)
+        x = torch.as_tensor(crops).to(self.dtype)                            # RoIs as batch
+        x = self.conv_block(x, 5, "a", stride=1, separate_scale=r101)
+        x = self.identity_block(x, 5, "b", separate_scale=r101)
+        x = self.identity_block(x, 5, "c", separate_scale=r101)
+        x = pool2d(x, 7, 7, False).reshape(x.shape[0], -1)
+        cls = torch.softmax(self._dense(x, "dense_class_%d" % num_classes), dim=1)
+        reg = self._dense(x, "dense_reg_%d" % num_classes)
+        return cls, reg
+
+    def vgg_classifier(self, feat, rois, num_classes):
+        """vgg16_classifier (vgg.py:226-255)."""
+        torch = _torch()
+        crops = roi_resize(np.asarray(feat[0].to(torch.float32)), np.asarray(rois), 7)
+        x = torch.as_tensor(crops).to(self.dtype).reshape(len(crops), -1)
+        x = self._dense(x, "fc1").clamp(min=0)
+        x = self._dense(x, "fc2").clamp(min=0)
+        cls = torch.softmax(self._dense(x, "dense_class_%d" % num_classes), dim=1)
+        reg = self._dense(x, "dense_reg_%d" % num_classes)
+        return cls, reg
