@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s, end-to-end (RPN + detector) Faster R-CNN inference,
+ResNet-50, 600x1000 synthetic image, anchor scales 128/256/512, 300 proposals, 21 classes,
+fp32 (BASELINE.json configs[1]) on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`;
+images shard by rank with NO data-path collective (inference has no exchange step), so the
+scaling is weak: every rank processes its own image stream.
+
+A "step" = one image through the whole device-resident path (backbone convs, RPN heads,
+decode, top-8000 ordering, NMS to 300, RoI crop-resize, stage-5 head, softmax, detection
+post-process), replayed from a hipGraph.  The input is resident in HBM when timing starts.
+
+The JSON line also carries
+  roofline      the MFMA conv kernel: algorithmic FLOP of every conv launch of one image /
+                their summed HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak.
+  cpu_baseline  the oracle's torch-CPU restatement of the reference graph ("port"), timed on
+                this host's cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md, Peak FP32 (matrix)
+HEIGHT, WIDTH = 600, 1000
+SCALES = [128, 256, 512]
+NUM_CLASSES = 21
+PROPOSALS = 300
+
+
+def synth_image(seed):
+    rs = np.random.RandomState(seed)
+    img = rs.randint(0, 256, (HEIGHT, WIDTH, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68])
+    return img[None].astype(np.float32)
+
+
+def build_pipeline():
+    from faster_rcnn_amd import resnet, util
+    from faster_rcnn_amd.pipeline import InferencePipeline
+    from faster_rcnn_amd.weights import synthetic_resnet
+    anchors = util.get_anchors(SCALES)
+    w = synthetic_resnet(50, anchors_per_loc=len(anchors), num_classes=NUM_CLASSES, seed=1)
+    base = resnet.resnet50_base(weights=w)
+    rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=len(anchors))
+    det = resnet.resnet50_classifier(PROPOSALS, NUM_CLASSES, weights=w)
+    return InferencePipeline(rpn, det, anchors, max_proposals=PROPOSALS), w, anchors
+
+
+def conv_roofline(pipe, x, passes=3):
+    """HIP-event timing of every conv launch of one image (eager, same stream)."""
+    from faster_rcnn_amd import ops
+    pipe.forward_dev(x)
+    torch.cuda.synchronize()
+    tot_flops = tot_ms = 0.0
+    n_launch = 0
+    per_shape = {}
+    for _ in range(passes):
+        ops.CONV_PROFILE = []
+        pipe.forward_dev(x)
+        torch.cuda.synchronize()
+        prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        for e0, e1, flops, shape in prof:
+            ms = e0.elapsed_time(e1)
+            tot_flops += flops
+            tot_ms += ms
+            n_launch += 1
+            a = per_shape.setdefault(shape, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += ms; a[2] += 1
+    achieved = tot_flops / (tot_ms * 1e-3) / 1e12
+    heavy = max(per_shape.items(), key=lambda kv: kv[1][1])
+    return {
+        "bound": "mfma", "kernel": "k_conv_igemm_f32 (all %d conv launches of one image)" % (n_launch // passes),
+        "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+        "gflop_per_image": round(tot_flops / passes / 1e9, 2), "conv_ms_per_image": round(tot_ms / passes, 3),
+        "heaviest_shape_MNK": list(heavy[0]),
+        "heaviest_shape_tflops": round(heavy[1][0] / (heavy[1][1] * 1e-3) / 1e12, 2),
+    }, per_shape
+
+
+def cpu_baseline(weights, anchors, budget_s=20.0):
+    """The oracle ("port" of the Keras CPU path) on this host: full path on whole images."""
+    from oracle import np_ref
+    from oracle.keras_ref import KerasGraphs
+    g = KerasGraphs(weights, torch.float32)
+    n, t_total = 0, 0.0
+    with torch.no_grad():
+        while n < 1 or (t_total < budget_s and n < 8):
+            x = synth_image(100 + n)
+            t0 = time.perf_counter()
+            feat = g.resnet_base(x, 50)
+            cls, reg = g.rpn(feat)
+            kept = np_ref.proposals(reg.numpy(), cls.numpy(), anchors, 16, 8000, PROPOSALS)[0]
+            rois = np_ref.pad_rois(kept.astype(np.float32), 64)
+            out_cls, out_reg = g.resnet_classifier(feat, rois, NUM_CLASSES, 50)
+            np_ref.detections(kept, out_cls.numpy(), out_reg.numpy(), NUM_CLASSES - 1, 1.0)
+            t_total += time.perf_counter() - t0
+            n += 1
+    return {"value": round(n / t_total, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d synthetic 600x1000 image(s), full RPN+detector path, torch-CPU fp32 restatement of the Keras graph "
+                      "+ numpy proposal/NMS/post-process (%.1f s)" % (n, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+
+    pipe, weights, anchors = build_pipeline()
+    x = torch.from_numpy(synth_image(rank)).cuda()
+    if not args.no_graph:
+        pipe.capture(HEIGHT, WIDTH)
+        pipe._static_in.copy_(x)
+        step = pipe._graph.replay
+    else:
+        step = lambda: pipe.forward_dev(x)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = pipe._static_out if not args.no_graph else pipe.forward_dev(x)
+    n_rois = int(out["n_rois"].item())
+    n_dets = int(out["n_dets"].item()) if "n_dets" in out else None
+
+    if rank == 0:
+        roof, _ = conv_roofline(pipe, x)
+        line = {
+            "metric": "images/sec end-to-end (RPN+det) ResNet-50 600x1000",
+            "value": round(world * args.steps / elapsed, 3), "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: ResNet-50, 600x1000, anchor_scales 128/256/512, RPN + detector inference, fp32",
+                       "images_per_step_per_gpu": 1, "proposals": PROPOSALS, "classes": NUM_CLASSES,
+                       "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, anchors)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -221,6 +221,11 @@ class PackedConv:
         self.shift = None if shift is None else _dev(shift, torch.float32)
 
 
+# When set to a list, every conv2d launch appends (start_event, end_event, flops, shape) so
+# bench.py can time the MFMA kernel per launch with HIP events on the launch stream.
+CONV_PROFILE = None
+
+
 def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0):
     """x: (n,h,w,cin) f32 NHWC device tensor; pc: PackedConv -> (n,ho,wo,cout)."""
     _require_gpu()
@@ -239,7 +244,14 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
         assert residual.shape == out.shape and residual.is_contiguous()
     d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc.cin, cout=pc.cout, kh=pc.kh, kw=pc.kw, stride=stride, pad_top=pt, pad_left=pl,
                       ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile)
+    if CONV_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("frcnn_conv2d_fwd", ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), _stream())
+    if CONV_PROFILE is not None:
+        e1.record()
+        flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
+        CONV_PROFILE.append((e0, e1, flops, (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin)))
     return out
 
 

@@ -1,0 +1,79 @@
+"""Device-resident end-to-end inference: image -> proposals -> detections on ONE HIP stream.
+
+The reference round-trips through host numpy between the RPN and the detector for every image
+(det_util.py:41, 49-55, 136-158; voc_dets.py:20-88).  Here the same stages run back to back on
+the GPU with fixed shapes (counts live in device memory), so the whole pass can be captured
+into a hipGraph and replayed with one host call per image.
+
+Stages (reference line -> entry point):
+    rpn_model.predict_on_batch   det_util.py:41      conv engine (nets.py)
+    _get_rois + valid            det_util.py:370,196 frcnn_decode_proposals
+    argsort()[::-1][:8000]       det_util.py:151-153 frcnn_topk_order + frcnn_gather_candidates
+    nms(max 300, .7)             det_util.py:156     frcnn_nms_i16 + frcnn_gather_rois
+    detector.predict             voc_dets.py:49      frcnn_roi_crop_resize_fwd + conv engine
+    argmax / decode / per-class nms  voc_dets.py:51-86   frcnn_detections
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+class InferencePipeline:
+    def __init__(self, rpn_model, det_model, anchor_dims, stride=16, pre_nms_top_n=8000, max_proposals=300,
+                 roi_batch=64, pad_to_batch=False, bg_idx=None, det_threshold=0.0):
+        self.rpn, self.det = rpn_model, det_model
+        self.anchor_dims = np.asarray(anchor_dims)
+        self.anchor_conv = self.anchor_dims // stride
+        self.stride, self.pre, self.post = stride, pre_nms_top_n, max_proposals
+        self.roi_batch = roi_batch
+        # strict mode scores the reference's padded duplicates too (voc_dets.py:42-46)
+        self.n_rois = -(-max_proposals // roi_batch) * roi_batch if pad_to_batch else max_proposals
+        self.bg_idx = det_model.num_classes - 1 if bg_idx is None else bg_idx
+        self.det_threshold = det_threshold
+        self._graph = None
+
+    # ------------------------------------------------------------------ stages
+    def proposals_dev(self, cls, reg):
+        """RPN outputs (device) -> (rois (n_rois,4) f32, n_keep (1,) i32, cand, keep)."""
+        rois_all, valid = ops.decode_proposals(reg, self.anchor_conv)
+        scores = cls.reshape(-1)
+        order, n = ops.topk_order(scores, valid, self.pre)
+        cand, cand_scores = ops.gather_candidates(rois_all, scores, order, n, self.pre)
+        keep, n_keep = ops.nms_sorted(cand, n, 0.7, self.post)
+        rois = ops.gather_rois(cand, keep, n_keep, self.roi_batch, self.n_rois)
+        return rois, n_keep, cand, keep
+
+    def forward_dev(self, x, resize_ratio=1.0):
+        """x: (1,H,W,3) f32 device tensor (already preprocessed).  Returns a dict of device tensors."""
+        cls, reg, feat = self.rpn.forward_dev(x)
+        rois, n_keep, cand, keep = self.proposals_dev(cls, reg)
+        out_cls, out_reg = self.det.forward_dev(feat, rois)
+        res = {"rpn_cls": cls, "rpn_reg": reg, "feat": feat, "rois": rois, "n_rois": n_keep,
+               "cls": out_cls, "reg": out_reg}
+        if hasattr(ops, "detections"):
+            res.update(ops.detections(rois, n_keep, out_cls, out_reg, self.roi_batch, self.bg_idx, self.det_threshold,
+                                      float(self.stride), float(resize_ratio)))
+        return res
+
+    # ------------------------------------------------------------------ hipGraph
+    def capture(self, height, width, resize_ratio=1.0, warmup=2):
+        """Capture one full pass for a fixed image size into a hipGraph."""
+        self._static_in = torch.zeros((1, height, width, 3), dtype=torch.float32, device="cuda")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.forward_dev(self._static_in, resize_ratio)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_out = self.forward_dev(self._static_in, resize_ratio)
+        return self
+
+    def replay(self, x=None):
+        if x is not None:
+            self._static_in.copy_(x)
+        self._graph.replay()
+        return self._static_out
