@@ -5,7 +5,7 @@
 // 233-247 (Dense = 1x1 conv on a 1x1 map).
 //
 // GEMM view:  Y[m][n] = sum_k A[m][k] * Wt[n][k]
-//   m = (img, ho, wo) output pixel, n = output channel, k = (r*S + s)*Cin + c.
+//   m = (img, ho, wo) output pixel, n = output channel, k = (channel chunk, filter tap (r,s), channel in chunk).
 //   A is never materialised (no im2col): for one 32-wide k-chunk inside a single filter tap
 //   (r,s) the A row of pixel m is the 128 contiguous bytes x[img][ho*st+r-pt][wo*st+s-pl][c0..c0+32)
 //   of the NHWC input, or zeros in the padding halo.
@@ -52,6 +52,31 @@ __device__ __forceinline__ float activate(float v, int act) {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// fused epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int wm, int wn, int li, int lh) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + li;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[n] : 1.0f;
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < p.M) {
+                    float v = acc[i][j][e] * sc + sh;
+                    if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
+                    p.y[(size_t)m * p.ldy + n] = activate(v, p.act);
+                }
+            }
+        }
+    }
 }
 
 template <int TM, int TN, bool GENERIC_A>
@@ -111,8 +136,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32(const ConvArgs p) {
                 const float* src = p.x + a_img[i] + ((size_t)hi * p.W + wi) * p.Cin + c0 + lcol;
                 ra[i] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0, 0, 0, 0};
             }
-            c0 += BK;
-            if (c0 == p.Cin) { c0 = 0; if (++s_tap == p.S) { s_tap = 0; ++r_tap; } }
+            // k order = [channel chunk][tap][32 channels]: consecutive chunks re-read the SAME 128-byte
+            // channel slice of neighbouring pixels, so the 9 taps of a 3x3 hit L1/L2 instead of streaming
+            // the whole input tile 9 times (measured: 46 % L2 hit rate and ~1 GB fetched per launch before)
+            if (++s_tap == p.S) { s_tap = 0; if (++r_tap == p.R) { r_tap = 0; c0 += BK; } }
         } else {
             // small-Cin path (stem, Cin=3): decode every k separately
 #pragma unroll
@@ -178,36 +205,188 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- fused epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + li;
-        if (n >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[n] : 1.0f;
-        const float sh = p.shift ? p.shift[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < p.M) {
-                    float v = acc[i][j][e] * sc + sh;
-                    if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
-                    p.y[(size_t)m * p.ldy + n] = activate(v, p.act);
-                }
-            }
-        }
-    }
+    epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
 }
 
 // ------------------------------------------------------------------------------------
-// filter packing: Keras HWIO [R][S][Cin][Cout] -> [Cout][Kpad], k = (r*S+s)*Cin + c, zero padded
+// v2 main loop: branch-free and software-pipelined inside ONE wave.
+//   * operands come through buffer loads (SRD + 32-bit offsets): padding halo, m >= M and
+//     n >= Cout rows simply carry an out-of-range offset and read back zeros, so the loop
+//     body is a single basic block the scheduler may interleave freely;
+//   * sched_group_barrier pins the interleave: the next chunk's 8 global loads ride behind
+//     the first MFMAs, each kk-step's fragment reads behind the previous step's MFMAs and
+//     the LDS stores behind the last MFMAs.  A 32x32x2 f32 MFMA occupies the matrix pipe
+//     for 64 cycles but the wave's issue port only briefly, so those VALU/VMEM/DS
+//     instructions issue in the shadow of the wave's own MFMAs instead of in a separate
+//     phase (v1: matrix pipe 79 % busy on a 2-wave SIMD, both waves stalling in lockstep).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_OFFSET = 0x80000000u;     // >= num_records of any tensor we accept (< 2 GiB)
+
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) k_conv_igemm_f32_v2(const ConvArgs p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int PA = BM / 32, PB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDS_STRIDE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = logical / p.tiles_m, tile_m = logical - tile_n * p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)((size_t)p.Cout * p.Kpad * 4), 0x00020000);
+
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    int a_h[PA], a_w[PA], a_off[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
+            a_h[i] = ho * p.stride - p.pad_top;
+            a_w[i] = wo * p.stride - p.pad_left;
+            a_off[i] = (((img * p.H + a_h[i]) * p.W + a_w[i]) * p.Cin + lcol) * 4;     // may be "negative" in the halo
+        } else {
+            a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
+        }
+    }
+    unsigned b_off[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        b_off[i] = n < p.Cout ? (unsigned)((n * p.Kpad + lcol) * 4) : OOB_OFFSET;
+    }
+
+    i32x4 ra[PA], rb[PB];
+    int r_tap = 0, s_tap = 0, c0 = 0;
+    auto load_chunk = [&](int kc) {
+        const int tap_off = ((r_tap * p.W + s_tap) * p.Cin + c0) * 4;          // wave-uniform
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], kc * (BK * 4), 0);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0);
+        }
+        // branch-free tap walk (a scalar branch here would split the loop body into two
+        // scheduling regions and undo the interleave below)
+        const int ws = (s_tap + 1 == p.S);
+        const int wr = ws & (r_tap + 1 == p.R);
+        s_tap = (s_tap + 1) * (1 - ws);
+        r_tap = (r_tap + ws) * (1 - wr);
+        c0 += wr * BK;
+    };
+    auto store_chunk = [&](int buf) {
+        float* a = As + buf * BM * LDS_STRIDE;
+        float* b = Bs + buf * BN * LDS_STRIDE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + 32 * i) * LDS_STRIDE + lcol) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + 32 * i) * LDS_STRIDE + lcol) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // Two-deep operand pipeline: chunk t+2 travels global->registers while chunk t+1 travels
+    // registers->LDS and chunk t feeds the MFMAs.  The loads issued in iteration t are consumed
+    // (ds_write) at the top of iteration t+1, so they have a whole chunk of MFMA time to land and
+    // the compiler cannot sink them next to their use.
+    const int nk = p.Kpad / BK;
+    load_chunk(0);
+    store_chunk(0);
+    load_chunk(nk > 1 ? 1 : 0);
+    __syncthreads();
+
+    constexpr int MF = TM * TN * 4;        // MFMAs per kk-step
+    constexpr int NL = PA + PB;            // global loads == LDS stores per chunk per thread
+    constexpr int NF = TM + TN;            // fragment reads per kk-step
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        store_chunk(buf ^ 1);                                  // chunk kc+1 (harmless duplicate at the tail)
+        load_chunk(kc + 2 < nk ? kc + 2 : nk - 1);             // always in range: keeps the body branch-free
+        const float* a = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + li) * LDS_STRIDE + lh * 4;
+        const float* b = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + li) * LDS_STRIDE + lh * 4;
+        f32x4 fa[BK / 8][TM], fb[BK / 8][TN];
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[kk][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_STRIDE + kk * 8);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i][e], fb[kk][j][e], acc[i][j], 0, 0, 0);
+
+        // ---- pinned interleave (per wave, per chunk): everything that is not an MFMA issues in
+        // the shadow of the wave's own MFMAs
+        SGB(SG_DS_RD, NF);                                       // kk = 0 fragments
+#pragma unroll
+        for (int q = 0; q < MF; ++q) {                           // kk-step 0: LDS stores, then kk=1 fragments
+            SGB(SG_MFMA, 1);
+            if (q < NL) SGB(SG_DS_WR, 1);
+            else if (q - NL < NF) SGB(SG_DS_RD, 1);
+        }
+#pragma unroll
+        for (int q = 0; q < MF; ++q) {                           // kk-step 1: global loads, then kk=2 fragments
+            SGB(SG_MFMA, 1);
+            if (q < NL) { SGB(SG_VALU, 4); SGB(SG_VMEM_RD, 1); }
+            else if (q - NL < NF) SGB(SG_DS_RD, 1);
+        }
+#pragma unroll
+        for (int q = 0; q < MF; ++q) {                           // kk-step 2: kk=3 fragments
+            SGB(SG_MFMA, 1);
+            if (q < NF) SGB(SG_DS_RD, 1);
+        }
+#pragma unroll
+        for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);            // kk-step 3
+        __syncthreads();
+    }
+    epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+}
+
+// ------------------------------------------------------------------------------------
+// filter packing: Keras HWIO [R][S][Cin][Cout] -> [Cout][Kpad].
+//   Cin % 32 == 0 : packed k = ((c/32)*R*S + tap)*32 + c%32   (channel chunk outer, tap inner)
+//   otherwise     : packed k = tap*Cin + c, zero padded to Kpad  (small-Cin path decodes k itself)
 __global__ void k_pack_hwio(const float* w, int RS, int Cin, int Cout, int Kpad, float* out) {
     const size_t total = (size_t)Cout * Kpad;
+    const bool chunked = (Cin % BK) == 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % Kpad), n = (int)(i / Kpad);
-        out[i] = k < RS * Cin ? w[(size_t)k * Cout + n] : 0.0f;
+        float v = 0.0f;
+        if (chunked) {
+            const int j = k % BK, kc = k / BK, tap = kc % RS, cc = kc / RS;
+            v = w[((size_t)tap * Cin + cc * BK + j) * Cout + n];
+        } else if (k < RS * Cin) {
+            v = w[(size_t)k * Cout + n];
+        }
+        out[i] = v;
     }
 }
 
@@ -264,6 +443,23 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return check_launch("conv2d_fwd");
 }
 
+template <int TM, int TN>
+static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    ConvArgs p = a;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_v2<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
+        attr_done = true;
+    }
+    k_conv_igemm_f32_v2<TM, TN><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    return check_launch("conv2d_fwd");
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -305,15 +501,24 @@ int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_pa
     const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
     int cfg = d->tile;      // 0 = auto
     if (cfg == 0) {
-        if (d->cout <= 64) cfg = 3;                 // 128 x 64
-        else if (t128 >= 384) cfg = 1;              // 128 x 128
-        else cfg = 2;                               // 64 x 64
+        // measured on MI355X over every conv shape of the C2 pipeline (scripts/conv_shapes.py):
+        // the 64x64 v2 kernel wins wherever the grid is small or k is short; 128x128 v2 only
+        // pays once there are >= 1.5 tiles per CU slot AND a long k loop to amortise its prologue
+        if (generic) cfg = 2;
+        else if (t128 >= 384 && a.Kpad >= 1024) cfg = 11;
+        else cfg = 12;
     }
     if (generic) {
-        if (cfg == 2) return launch_conv<1, 1, true>(a, s);
+        if (cfg == 2 || cfg == 12) return launch_conv<1, 1, true>(a, s);
         return launch_conv<2, 1, true>(a, s);
     }
+    const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * a.Kpad * 4 < 0x7fffffffull;
+    if (cfg >= 11 && !fits_srd) cfg -= 10;
     switch (cfg) {
+        case 11: return launch_conv_v2<2, 2>(a, s);
+        case 12: return launch_conv_v2<1, 1>(a, s);
+        case 13: return launch_conv_v2<2, 1>(a, s);
+        case 14: return launch_conv_v2<4, 2>(a, s);
         case 1: return launch_conv<2, 2, false>(a, s);
         case 2: return launch_conv<1, 1, false>(a, s);
         case 3: return launch_conv<2, 1, false>(a, s);

@@ -29,6 +29,15 @@ CASES = [
     (1, 15, 22, 128, 128, 3, 1, "same", "relu", False, 2),
     (1, 15, 22, 128, 96, 3, 1, "same", "relu", False, 3),         # cout not a tile multiple
     (1, 15, 22, 128, 256, 3, 1, "same", "relu", True, 4),
+    (1, 15, 22, 128, 128, 3, 1, "same", "relu", False, 11),       # v2 kernels (buffer loads, pinned interleave)
+    (1, 15, 22, 128, 128, 3, 1, "same", "relu", True, 12),
+    (1, 15, 22, 128, 96, 3, 1, "same", "relu", False, 13),
+    (1, 15, 22, 128, 256, 3, 1, "same", "relu", True, 14),
+    (1, 37, 50, 256, 128, 1, 2, "valid", "relu", False, 12),
+    (2, 9, 11, 64, 64, 3, 2, "same", None, False, 13),
+    (3, 7, 7, 512, 512, 3, 1, "same", "relu", False, 11),
+    (1, 20, 31, 32, 64, 1, 1, "valid", "relu", False, 11),        # single k-chunk
+    (1, 20, 31, 64, 64, 1, 1, "valid", "relu", False, 12),        # two k-chunks
     (3, 7, 7, 512, 512, 3, 1, "same", "relu", False, 0),          # head: RoIs as batch
     (1, 38, 63, 512, 9, 1, 1, "valid", "sigmoid", False, 0),      # rpn_out_cls
     (1, 38, 63, 512, 36, 1, 1, "valid", None, False, 0),          # rpn_out_bbreg
