@@ -22,6 +22,7 @@ SOURCES = {
     "boxes.hip": ["-ffp-contract=off"],
     "sort_nms.hip": ["-ffp-contract=off"],
     "roi.hip": ["-ffp-contract=off"],
+    "detect.hip": ["-ffp-contract=off"],
 }
 
 

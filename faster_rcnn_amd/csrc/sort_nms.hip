@@ -32,34 +32,30 @@ __global__ void k_topk_keys(const float* scores, const uint8_t* valid, int N, u6
 }
 
 constexpr int TOPK_BLOCK = 256;
-constexpr int TOPK_PER_THREAD = 4;      // keys ranked per thread: 4 compares per LDS read
 
-__global__ void __launch_bounds__(TOPK_BLOCK) k_topk_rank(const u64* keys, int N, int K, int32_t* order) {
+// 2-D decomposition: block (bi, bj) counts, for its 256 keys i, how many keys of j-slice bj are
+// larger, and adds the partial rank with one atomic per key.  N/256 x SPLIT blocks fill the
+// chip even for N = 21 546 (a 1-D version ran on 22 CUs and took 0.5 ms).
+__global__ void __launch_bounds__(TOPK_BLOCK) k_topk_rank(const u64* keys, int N, int slice, int32_t* rank) {
     __shared__ u64 tile[TOPK_BLOCK];
-    const int base = blockIdx.x * TOPK_BLOCK * TOPK_PER_THREAD;
-    u64 mine[TOPK_PER_THREAD];
-    int rank[TOPK_PER_THREAD];
-#pragma unroll
-    for (int r = 0; r < TOPK_PER_THREAD; ++r) {
-        const int i = base + r * TOPK_BLOCK + threadIdx.x;
-        mine[r] = i < N ? keys[i] : 0ull;
-        rank[r] = 0;
-    }
-    for (int t0 = 0; t0 < N; t0 += TOPK_BLOCK) {
+    const int i = blockIdx.x * TOPK_BLOCK + threadIdx.x;
+    const u64 mine = i < N ? keys[i] : ~0ull;
+    const int j_begin = blockIdx.y * slice, j_end = min(N, j_begin + slice);
+    int cnt = 0;
+    for (int t0 = j_begin; t0 < j_end; t0 += TOPK_BLOCK) {
         const int j = t0 + threadIdx.x;
-        tile[threadIdx.x] = j < N ? keys[j] : 0ull;
+        tile[threadIdx.x] = j < j_end ? keys[j] : 0ull;
         __syncthreads();
-#pragma unroll 8
-        for (int jj = 0; jj < TOPK_BLOCK; ++jj) {
-            const u64 k = tile[jj];                    // LDS broadcast
-#pragma unroll
-            for (int r = 0; r < TOPK_PER_THREAD; ++r) rank[r] += k > mine[r];
-        }
+#pragma unroll 16
+        for (int jj = 0; jj < TOPK_BLOCK; ++jj) cnt += tile[jj] > mine;       // LDS broadcast reads
         __syncthreads();
     }
-#pragma unroll
-    for (int r = 0; r < TOPK_PER_THREAD; ++r)
-        if (mine[r] != 0ull && rank[r] < K) order[rank[r]] = (int32_t)(~(unsigned)mine[r]);
+    if (i < N && mine != 0ull && cnt) atomicAdd(&rank[i], cnt);
+}
+
+__global__ void k_topk_scatter(const u64* keys, const int32_t* rank, int N, int K, int32_t* order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && keys[i] != 0ull && rank[i] < K) order[rank[i]] = i;
 }
 
 __global__ void k_topk_finish(int32_t* n_valid_to_n_out, int K) {
@@ -237,7 +233,10 @@ using namespace frcnn;
 
 extern "C" {
 
-size_t frcnn_topk_workspace_bytes(int N) { return align_up((size_t)(N > 0 ? N : 1) * 8, 256); }
+size_t frcnn_topk_workspace_bytes(int N) {
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    return align_up(n * 8, 256) + align_up(n * 4, 256);
+}
 
 int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, int32_t* order, int32_t* n_out,
                      void* workspace, size_t workspace_bytes, void* stream) {
@@ -250,11 +249,19 @@ int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, in
     if (!workspace || workspace_bytes < frcnn_topk_workspace_bytes(N))
         return fail(FRCNN_E_WORKSPACE, "topk_order: workspace needs %zu bytes", frcnn_topk_workspace_bytes(N));
     u64* keys = (u64*)workspace;
+    int32_t* rank = (int32_t*)((char*)workspace + align_up((size_t)N * 8, 256));
+    if (hipMemsetAsync(rank, 0, (size_t)N * 4, s) != hipSuccess) return fail(FRCNN_E_HIP, "topk_order: memset failed");
     k_topk_keys<<<(N + 255) / 256, 256, 0, s>>>(scores, valid, N, keys, n_out);
     if (int e = check_launch("topk_order keys")) return e;
-    const int per_block = TOPK_BLOCK * TOPK_PER_THREAD;
-    k_topk_rank<<<(N + per_block - 1) / per_block, TOPK_BLOCK, 0, s>>>(keys, N, K, order);
+    const int bi = (N + TOPK_BLOCK - 1) / TOPK_BLOCK;
+    int split = 2048 / bi;
+    split = split < 1 ? 1 : (split > 64 ? 64 : split);
+    int slice = ((N + split - 1) / split + TOPK_BLOCK - 1) / TOPK_BLOCK * TOPK_BLOCK;
+    split = (N + slice - 1) / slice;
+    k_topk_rank<<<dim3(bi, split), TOPK_BLOCK, 0, s>>>(keys, N, slice, rank);
     if (int e = check_launch("topk_order rank")) return e;
+    k_topk_scatter<<<bi, TOPK_BLOCK, 0, s>>>(keys, rank, N, K, order);
+    if (int e = check_launch("topk_order scatter")) return e;
     k_topk_finish<<<1, 64, 0, s>>>(n_out, K);
     return check_launch("topk_order finish");
 }

@@ -1,0 +1,181 @@
+"""Mirror of the reference's det_util.py (det_util.py:7-380): proposals, NMS, detector targets.
+
+Same public surface: ``DetTrainingManager(rpn_model, class_mapping, preprocess_func, num_rois,
+stride, anchor_dims)`` with ``get_training_input`` / ``get_det_inputs`` and the free function
+``nms(boxes, probs, overlap_thresh, max_boxes)``.  Inside, the RPN forward, the decode, the
+score ordering, the NMS and the RoI->truth matching stay on the device between C-ABI calls; only
+the results the reference hands to its callers come back as numpy.  RoI batch sampling uses
+``np.random`` on the host like the reference (det_util.py:260-306).
+"""
+import numpy as np
+import torch
+
+from . import nets, ops
+from .shared_constants import BBREG_MULTIPLIERS, DEFAULT_ANCHORS
+from .util import get_bbox_coords
+
+CLASSIFIER_MIN_OVERLAP = 0.1
+CLASSIFIER_POS_OVERLAP = 0.5
+PROBABLE_THRESHOLD = 0.05
+
+
+class DetTrainingManager:
+    def __init__(self, rpn_model, class_mapping, preprocess_func, num_rois=64, stride=16, anchor_dims=DEFAULT_ANCHORS):
+        self.rpn_model = rpn_model
+        self.class_mapping = class_mapping
+        self.preprocess_func = preprocess_func
+        self.num_rois = num_rois
+        self.stride = stride
+        self.anchor_dims = anchor_dims
+        self._cache = {}
+        self.conv_only = True if len(rpn_model.output) == 3 else False
+
+    def batched_image(self, image):
+        return np.expand_dims(self.preprocess_func(image.data), axis=0)
+
+    # ------------------------------------------------------------------ device path
+    def _proposals_dev(self, image, pre_nms, max_boxes):
+        """RPN forward + decode + valid filter + descending score order + int16 cast + NMS
+        (det_util.py:44-77 / 145-156), all on the device.
+        Returns (rois int16 device (n,4), conv feature map device or None)."""
+        x = nets.to_device_image(self.batched_image(image))
+        cls, reg, feat = self.rpn_model.forward_dev(x)
+        rois_all, valid = ops.decode_proposals(reg, np.asarray(self.anchor_dims) // self.stride)
+        scores = cls.reshape(-1)
+        K = min(pre_nms, ops.NMS_MAX_BOXES)
+        order, n = ops.topk_order(scores, valid, K)
+        cand, _ = ops.gather_candidates(rois_all, scores, order, n, K)
+        keep, n_keep = ops.nms_sorted(cand, n, 0.7, max_boxes)
+        nk = int(n_keep.item())
+        rois = cand[keep[:nk].long()]
+        return rois, (feat if self.conv_only else None)
+
+    def _process(self, image):
+        rois, feat = self._proposals_dev(image, 12000, 2000)
+        filtered_rois, y_class_num, y_transform = _rois_to_truth(rois, image, self.class_mapping, stride=self.stride)
+        cache_obj = {"rois": filtered_rois, "y_class_num": y_class_num, "y_transform": y_transform}
+        if feat is not None:
+            cache_obj["conv_out"] = feat.cpu().numpy()
+        self._cache[image.cache_key] = cache_obj
+
+    def get_training_input(self, image):
+        """det_util.py:90-133."""
+        if image.cache_key not in self._cache:
+            self._process(image)
+        results = self._cache[image.cache_key]
+        if len(results["rois"]) == 0:
+            return None, None, None, None
+        rois, y_class_num, y_transform = results["rois"], results["y_class_num"], results["y_transform"]
+        found_object = y_class_num[:, -1] == 0
+        sampled_idxs = _get_det_samples(found_object, self.num_rois)
+        rois, y_class_num, y_transform = rois[sampled_idxs], y_class_num[sampled_idxs], y_transform[sampled_idxs]
+        first_input = results["conv_out"] if self.conv_only else self.batched_image(image)
+        if self.conv_only:
+            del self._cache[image.cache_key]
+        return first_input, np.expand_dims(rois, axis=0), np.expand_dims(y_class_num, axis=0), np.expand_dims(y_transform, axis=0)
+
+    def get_det_inputs(self, image):
+        """det_util.py:136-158: (conv feature map (1,R,C,Cf) or None, nms_rois (n,4) int16)."""
+        rois, feat = self._proposals_dev(image, 8000, 300)
+        return (feat.cpu().numpy() if feat is not None else None), rois.cpu().numpy()
+
+
+def _get_anchor_coords(conv_rows, conv_cols, anchor_dims, multiplier=1):
+    """det_util.py:162-175."""
+    return ops.anchors_conv(conv_rows, conv_cols, np.asarray(anchor_dims) * multiplier).cpu().numpy()
+
+
+def _sanitize_boxes_inplace(conv_cols, conv_rows, coords):
+    """det_util.py:179-192 (host; the device decode fuses this step, see _get_rois)."""
+    coords[:, 2] = np.maximum(coords[:, 0] + 1, coords[:, 2])
+    coords[:, 3] = np.maximum(coords[:, 1] + 1, coords[:, 3])
+    coords[:, 0] = np.maximum(0, coords[:, 0])
+    coords[:, 1] = np.maximum(0, coords[:, 1])
+    coords[:, 2] = np.minimum(conv_cols - 1, coords[:, 2])
+    coords[:, 3] = np.minimum(conv_rows - 1, coords[:, 3])
+    return coords
+
+
+def _get_valid_box_idxs(boxes):
+    """det_util.py:196-205."""
+    return np.where((boxes[:, 2] > boxes[:, 0]) & (boxes[:, 3] > boxes[:, 1]))[0]
+
+
+def nms(boxes, probs, overlap_thresh=0.7, max_boxes=300):
+    """det_util.nms (det_util.py:209-256).  boxes: int16 or float (n,4); probs (n,).
+    Returns (boxes[pick], probs[pick]) in pick order; ``[]`` for empty input like the reference
+    (:220-221).  Ties in ``probs`` (unspecified in the reference) resolve to the lower index."""
+    if len(boxes) == 0:
+        return []
+    boxes = np.asarray(boxes)
+    probs = np.asarray(probs)
+    if len(boxes) > ops.NMS_MAX_BOXES:
+        raise ValueError("nms: at most %d boxes per call" % ops.NMS_MAX_BOXES)
+    n = len(boxes)
+    order, cnt = ops.topk_order(torch.from_numpy(np.ascontiguousarray(probs, dtype=np.float32)).cuda(), None, n)
+    order_h = order.cpu().numpy()
+    sorted_boxes = boxes[order_h]
+    if sorted_boxes.dtype != np.int16:
+        sorted_boxes = sorted_boxes.astype(np.float64)
+    keep, n_keep = ops.nms_sorted(torch.from_numpy(np.ascontiguousarray(sorted_boxes)).cuda(), cnt, overlap_thresh, max_boxes)
+    pick = order_h[keep.cpu().numpy()[:int(n_keep.item())]]
+    return boxes[pick], probs[pick]
+
+
+def _get_det_samples(is_pos, num_desired_rois):
+    """det_util.py:260-306 (host, np.random)."""
+    desired_pos = num_desired_rois // 4
+    pos_samples = np.where(is_pos)[0]
+    neg_samples = np.where(np.logical_not(is_pos))[0]
+    if len(pos_samples) == 0:
+        selected_pos = []
+    elif len(pos_samples) < desired_pos:
+        selected_pos = pos_samples.tolist()
+    else:
+        selected_pos = np.random.choice(pos_samples, desired_pos, replace=False).tolist()
+    desired_neg = num_desired_rois - len(selected_pos)
+    if len(neg_samples) == 0:
+        selected_neg = []
+    elif len(neg_samples) < desired_neg:
+        selected_neg = np.random.choice(neg_samples, desired_neg, replace=True).tolist()
+    else:
+        selected_neg = np.random.choice(neg_samples, desired_neg, replace=False).tolist()
+    if len(selected_neg) == 0 and len(pos_samples) > 0:
+        num_copies = desired_neg // len(pos_samples) + 1
+        selected_neg = np.tile(pos_samples, num_copies)[:desired_neg].tolist()
+    return selected_pos + selected_neg
+
+
+def _rois_to_truth(rois, image, class_mapping, stride=16):
+    """det_util.py:310-366.  rois: int16 (n,4) numpy or device tensor.
+    Returns (eligible rois (E,4) int16, one-hot classes (E,C) int32, [labels | targets] (E,8(C-1)) f32)."""
+    gt_boxes = [gt_box.resize(1 / stride) for gt_box in image.gt_boxes]
+    C = len(class_mapping)
+    rois_d = rois if isinstance(rois, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(rois, dtype=np.int16)).cuda()
+    rois_h = rois_d.cpu().numpy()
+    if len(gt_boxes) == 0 or len(rois_h) == 0:
+        return rois_h[:0], np.zeros((0, C), np.int32), np.zeros((0, 8 * (C - 1)), np.float32)
+    gt64 = np.array([b.corners for b in gt_boxes], dtype=np.float64)
+    gt32 = get_bbox_coords(gt_boxes)
+    gt_cls = np.array([class_mapping[b.obj_cls] for b in gt_boxes], dtype=np.int32)
+    elig, cls, tg = ops.roi_targets(rois_d, torch.from_numpy(gt32).cuda(), torch.from_numpy(gt64).cuda(),
+                                    torch.from_numpy(gt_cls).cuda(), class_mapping["bg"])
+    elig, cls, tg = elig.cpu().numpy().astype(bool), cls.cpu().numpy()[...], tg.cpu().numpy()
+    e_rois, e_cls, e_tg = rois_h[elig], cls[elig], tg[elig]
+    E = len(e_rois)
+    onehot = np.zeros((E, C), dtype=np.int32)
+    onehot[np.arange(E), e_cls] = 1
+    labels = np.zeros((E, 4 * (C - 1)), dtype=np.float32)
+    targs = np.zeros((E, 4 * (C - 1)), dtype=np.float32)
+    pos = np.nonzero(e_cls != class_mapping["bg"])[0]
+    for k in range(4):
+        labels[pos, 4 * e_cls[pos] + k] = 1
+        targs[pos, 4 * e_cls[pos] + k] = e_tg[pos, k]
+    return e_rois, onehot, np.concatenate([labels, targs], axis=1)
+
+
+def _get_rois(regr_out, anchor_dims, stride):
+    """det_util.py:370-380: RPN regression output (1,R,C,4A) -> sanitised proposals (N,4) f32."""
+    reg = regr_out if isinstance(regr_out, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(regr_out, dtype=np.float32)).cuda()
+    rois, _ = ops.decode_proposals(reg, np.asarray(anchor_dims) // stride)
+    return rois.cpu().numpy()

@@ -271,3 +271,19 @@ def softmax_rows(x, cols=None):
     out = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
     _lib.call("frcnn_softmax_rows", _p(x.contiguous()), rows, cols, ld, _p(out), cols, _stream())
     return out
+
+
+# ----------------------------------------------------------------------------- detections
+def detections(rois, n_rois, out_cls, out_reg, roi_batch, bg_idx, det_threshold, stride, resize_ratio, nms_thresh=0.5):
+    """voc_dets.get_dets post-process on the device -> dict of device tensors."""
+    _require_gpu()
+    rows, C = out_cls.shape
+    det_cls = torch.full((rows,), -1, dtype=torch.int32, device="cuda")
+    det_prob = torch.zeros(rows, dtype=torch.float32, device="cuda")
+    det_bbox = torch.zeros((rows, 4), dtype=torch.int32, device="cuda")
+    det_roi = torch.full((rows,), -1, dtype=torch.int32, device="cuda")
+    n_dets = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.call("frcnn_detections", _p(rois), _p(n_rois), rows, _p(out_cls.contiguous()), _p(out_reg.contiguous()), C, int(bg_idx),
+              float(det_threshold), float(stride), float(resize_ratio), float(nms_thresh),
+              _p(det_cls), _p(det_prob), _p(det_bbox), _p(det_roi), _p(n_dets), _stream())
+    return {"det_cls": det_cls, "det_prob": det_prob, "det_bbox": det_bbox, "det_roi": det_roi, "n_dets": n_dets}

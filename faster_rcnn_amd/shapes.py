@@ -1,0 +1,137 @@
+"""Host data model the reference's managers consume (shapes.py:5-408), OpenCV-free.
+
+Only what the hot path touches: ``Image`` (metadata view: width/height/gt_boxes/cache_key,
+``resize_within_bounds``, ``horizontal_flip``), ``InMemoryImage``, ``Metadata``,
+``GroundTruthBox`` and ``Box`` with the reference's arithmetic (float coordinates after a
+resize, ``x -> width - x`` flip without -1, shapes.py:298).  Pixel decode (cv2.imread +
+INTER_CUBIC, shapes.py:19-29) is an f2 "next" row: ``Image.data`` here uses PIL when a file is
+given and is NOT bit-identical to OpenCV's resampler; synthetic configs use InMemoryImage.
+"""
+import numpy as np
+
+
+class Box:
+    def __init__(self, x1, y1, x2, y2):
+        self.x1, self.y1, self.x2, self.y2 = x1, y1, x2, y2
+
+    @staticmethod
+    def from_center_dims_int(x_center, y_center, width, height):
+        x1 = x_center - width // 2
+        y1 = y_center - height // 2
+        return Box(x1, y1, x1 + width, y1 + height)
+
+    @staticmethod
+    def from_corners(coords):
+        return Box(*coords)
+
+    width = property(lambda s: s.x2 - s.x1)
+    height = property(lambda s: s.y2 - s.y1)
+    x_center = property(lambda s: (s.x2 + s.x1) / 2)
+    y_center = property(lambda s: (s.y1 + s.y2) / 2)
+    corners = property(lambda s: np.array([s.x1, s.y1, s.x2, s.y2]))
+    corner_dims = property(lambda s: np.array([s.x1, s.y1, s.width, s.height]))
+    center_dims = property(lambda s: np.array([s.x_center, s.y_center, s.width, s.height]))
+
+    def resize(self, scale_ratio):
+        return Box(self.x1 * scale_ratio, self.y1 * scale_ratio, self.x2 * scale_ratio, self.y2 * scale_ratio)
+
+    def __repr__(self):
+        return "<image.Box x1: {}, y1: {}, x2: {}, y2: {}>".format(self.x1, self.y1, self.x2, self.y2)
+
+
+class GroundTruthBox:
+    def __init__(self, obj_cls, difficult, box):
+        self.obj_cls, self.difficult, self.box = obj_cls, difficult, box
+
+    def __getattr__(self, name):               # x1, y1, x2, y2, width, height, corners, ... forward to the box
+        if name in ("x1", "y1", "x2", "y2", "width", "height", "x_center", "y_center", "corners", "corner_dims", "center_dims"):
+            return getattr(self.box, name)
+        raise AttributeError(name)
+
+    def resize(self, scale_ratio):
+        return GroundTruthBox(self.obj_cls, self.difficult, self.box.resize(scale_ratio))
+
+    def horizontal_flip(self, width):
+        return GroundTruthBox(self.obj_cls, self.difficult, Box(width - self.x2, self.y1, width - self.x1, self.y2))
+
+    def __repr__(self):
+        return "<shapes.GroundTruthBox obj_cls: {}, difficult: {}, box: {}>".format(self.obj_cls, self.difficult, self.box)
+
+
+class Metadata:
+    def __init__(self, name, width, height, gt_boxes, image_path, flipped=False):
+        self.name, self.width, self.height = name, width, height
+        self.gt_boxes, self.image_path, self.flipped = gt_boxes, image_path, flipped
+
+    def horizontal_flip(self):
+        return Metadata(self.name, self.width, self.height, [b.horizontal_flip(self.width) for b in self.gt_boxes],
+                        self.image_path, flipped=not self.flipped)
+
+
+def _bounds_ratio(width, height, min_size, max_size):
+    short_dim, long_dim = min(width, height), max(width, height)
+    min_ratio = min_size / short_dim
+    return max_size / long_dim if min_ratio * long_dim > max_size else min_ratio
+
+
+class Image:
+    def __init__(self, metadata, pixels=None):
+        self.metadata = metadata
+        self._pixels = pixels               # optional in-memory BGR uint8 array (synthetic data)
+
+    width = property(lambda s: s.metadata.width)
+    height = property(lambda s: s.metadata.height)
+    flipped = property(lambda s: s.metadata.flipped)
+    gt_boxes = property(lambda s: s.metadata.gt_boxes)
+    num_gt_boxes = property(lambda s: len(s.metadata.gt_boxes))
+    name = property(lambda s: s.metadata.name)
+    cache_key = property(lambda s: s.metadata.name + str(s.metadata.flipped))
+    _image_path = property(lambda s: s.metadata.image_path)
+
+    @property
+    def data(self):
+        """BGR uint8 (height, width, 3) at the metadata's size, flipped if requested."""
+        if self._pixels is not None:
+            img = self._pixels
+            if img.shape[0] != self.height or img.shape[1] != self.width:
+                img = _resize(img, self.width, self.height)
+        else:
+            from PIL import Image as PilImage
+            img = np.asarray(PilImage.open(self._image_path).convert("RGB"))[:, :, ::-1]
+            img = _resize(img, self.width, self.height)
+        return img[:, ::-1].copy() if self.flipped else img
+
+    def resize(self, scale_ratio):
+        w, h = int(round(scale_ratio * self.width)), int(round(scale_ratio * self.height))
+        md = Metadata(self.name, w, h, [b.resize(scale_ratio) for b in self.gt_boxes], self._image_path, flipped=self.flipped)
+        return Image(md, self._pixels)
+
+    def resize_within_bounds(self, min_size, max_size):
+        ratio = _bounds_ratio(self.width, self.height, min_size, max_size)
+        return self.resize(ratio), ratio
+
+    def horizontal_flip(self):
+        return Image(self.metadata.horizontal_flip(), self._pixels)
+
+
+class InMemoryImage:
+    def __init__(self, data, width, height):
+        self._data, self.width, self.height = data, width, height
+
+    @property
+    def data(self):
+        return _resize(self._data, self.width, self.height)
+
+    def resize(self, scale_ratio):
+        return InMemoryImage(self._data, int(round(scale_ratio * self.width)), int(round(scale_ratio * self.height)))
+
+    def resize_within_bounds(self, min_size, max_size):
+        ratio = _bounds_ratio(self.width, self.height, min_size, max_size)
+        return self.resize(ratio), ratio
+
+
+def _resize(img, width, height):
+    if img.shape[0] == height and img.shape[1] == width:
+        return img
+    from PIL import Image as PilImage
+    return np.asarray(PilImage.fromarray(np.ascontiguousarray(img)).resize((width, height), PilImage.BICUBIC))

@@ -1,0 +1,83 @@
+"""Mirror of the reference's voc_dets.py inference entry points (voc_dets.py:17-129).
+
+``get_dets(training_manager, detector, image, resize_ratio, num_rois, stride, det_threshold)``
+returns the same list of ``{'bbox': int array [x1,y1,x2,y2], 'cls_name', 'prob'}`` dicts in the
+same order.  The detector runs once over all (padded) RoIs and the arg-max / decode /
+per-class NMS / rescale tail runs in one device kernel (frcnn_detections) instead of the
+reference's Python loops.
+"""
+import os
+import timeit
+
+import numpy as np
+import torch
+
+from . import nets, ops
+from .det_util import DetTrainingManager, nms  # noqa: F401  (re-exported like the reference module)
+
+DEFAULT_DET_THRESHOLD = 0.0
+
+
+def _pad_rois(rois, num_rois):
+    """voc_dets.py:31-47: the last batch is padded with copies of ITS first RoI."""
+    n = rois.shape[0]
+    if n % num_rois == 0:
+        return rois
+    last = (n // num_rois) * num_rois
+    extra = np.tile(rois[last], (num_rois - (n - last), 1))
+    return np.concatenate([rois, extra])
+
+
+def get_dets(training_manager, detector, image, resize_ratio, num_rois=64, stride=16,
+             det_threshold=DEFAULT_DET_THRESHOLD):
+    conv_out, rois = training_manager.get_det_inputs(image)
+    class_mapping = training_manager.class_mapping
+    rev_class_mapping = dict((v, k) for k, v in class_mapping.items())
+    num_boxes = rois.shape[0]
+    print("num rois: {}".format(num_boxes))
+    if num_boxes == 0:
+        return []
+    padded = _pad_rois(np.asarray(rois, dtype=np.float32), num_rois)
+    rois_d = torch.from_numpy(np.ascontiguousarray(padded)).cuda()
+    if hasattr(detector, "forward_dev"):
+        out_cls, out_reg = detector.forward_dev(nets.to_device_image(conv_out), rois_d)
+    else:                                   # any other object with the Keras predict() contract
+        cls_parts, reg_parts = [], []
+        for b in range(0, len(padded), num_rois):
+            c, r = detector.predict([conv_out, padded[None, b:b + num_rois]])
+            cls_parts.append(np.asarray(c)[0])
+            reg_parts.append(np.asarray(r)[0])
+        out_cls = torch.from_numpy(np.concatenate(cls_parts).astype(np.float32)).cuda()
+        out_reg = torch.from_numpy(np.concatenate(reg_parts).astype(np.float32)).cuda()
+    n_rows = torch.tensor([len(padded)], dtype=torch.int32, device="cuda")
+    res = ops.detections(rois_d, n_rows, out_cls, out_reg, num_rois, class_mapping["bg"], det_threshold, stride, resize_ratio)
+    nd = int(res["n_dets"].item())
+    det_cls = res["det_cls"].cpu().numpy()[:nd]
+    det_prob = res["det_prob"].cpu().numpy()[:nd]
+    det_bbox = res["det_bbox"].cpu().numpy()[:nd]
+    return [{"bbox": det_bbox[i].astype(np.int64), "cls_name": rev_class_mapping[int(det_cls[i])], "prob": det_prob[i]}
+            for i in range(nd)]
+
+
+def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=16, det_threshold=DEFAULT_DET_THRESHOLD):
+    """voc_dets.py:91-111."""
+    dets_by_cls = {}
+    for image, resized_ratio in zip(images, resized_ratios):
+        start_time = timeit.default_timer()
+        dets = get_dets(training_manager, detector, image, resized_ratio, stride=stride, det_threshold=det_threshold)
+        for det in dets:
+            dets_by_cls.setdefault(det["cls_name"], {}).setdefault(image.name, []).append(det)
+        print("image {} ran in {} seconds".format(image.name, timeit.default_timer() - start_time))
+    return dets_by_cls
+
+
+def write_dets(dets, out_dir):
+    """voc_dets.py:114-129: comp3_det_test_<cls>.txt, 'name prob x1 y1 x2 y2' with +1 coords."""
+    os.makedirs(out_dir, exist_ok=True)
+    for cls_name in dets:
+        file_path = os.path.join(out_dir, "comp3_det_test_{}.txt".format(cls_name))
+        with open(file_path, "w") as outfile:
+            for image_name in dets[cls_name]:
+                for det in dets[cls_name][image_name]:
+                    x1, y1, x2, y2 = det["bbox"] + 1
+                    outfile.write("{} {} {} {} {} {}\n".format(image_name, det["prob"], x1, y1, x2, y2))

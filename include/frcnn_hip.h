@@ -175,6 +175,21 @@ int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stri
 /* softmax over the first `cols` entries of each row (Dense(activation='softmax'), resnet.py:522). */
 int frcnn_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream);
 
+/* ------------------------------------------------------------------ detections */
+/* voc_dets.get_dets, everything after detector.predict (voc_dets.py:51-88): per scored RoI
+ * arg-max class and confidence, skip background / confidence < det_threshold, decode the class's
+ * regression with util.transform (util.py:55-74) x stride, per-class det_util.nms(thresh, 2000)
+ * on the float boxes, divide by resize_ratio and round half-to-even.
+ * rois [max_rows][4] f32 (conv units), *n_rois live rows (<= max_rows <= 512),
+ * out_cls [max_rows][C] f32, out_reg [max_rows][4(C-1)] f32.
+ * Outputs, in the reference's emission order (classes in first-seen order, NMS pick order
+ * inside a class): det_cls[max_rows] i32, det_prob[max_rows] f32, det_bbox[max_rows][4] i32,
+ * det_roi[max_rows] i32 (source RoI row), *n_dets.  The reference's padded duplicate RoIs
+ * (voc_dets.py:42-46) are suppressed by its own NMS (IoU 1), so only live rows are scored. */
+int frcnn_detections(const float* rois, const int32_t* n_rois, int max_rows, const float* out_cls, const float* out_reg,
+                     int num_classes, int bg_idx, float det_threshold, double stride, double resize_ratio, double nms_thresh,
+                     int32_t* det_cls, float* det_prob, int32_t* det_bbox, int32_t* det_roi, int32_t* n_dets, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,25 +375,42 @@ def transform_f64(anchor, reg):
     return x, y, x + w, y + h
 
 
+def transform_legacy(roi_f32, t_f32):
+    """util.transform (util.py:55-74) as voc_dets.py:63-65 evaluates it -- np.float32 scalars for
+    the RoI and the deltas -- under the reference's pinned numpy 1.13 (legacy value-based scalar
+    promotion): f32+f32 stays f32, f32/int and python-float*f32 become f64.  Written with explicit
+    casts so the result does not depend on the numpy version running the oracle."""
+    x1, y1, x2, y2 = (np.float32(v) for v in roi_f32)
+    tx, ty, tw, th = (np.float32(v) for v in t_f32)
+    cxa, cya = np.float64(np.float32(x1 + x2)) / 2, np.float64(np.float32(y1 + y2)) / 2
+    wa, ha = np.float32(x2 - x1), np.float32(y2 - y1)
+    cx = np.float64(np.float32(tx * wa)) + cxa
+    cy = np.float64(np.float32(ty * ha)) + cya
+    w = math.exp(float(tw)) * np.float64(wa)
+    h = math.exp(float(th)) * np.float64(ha)
+    x, y = cx - w / 2, cy - h / 2
+    return x, y, x + w, y + h
+
+
 def detections(rois, out_cls, out_reg, bg_idx, resize_ratio, stride=16, det_threshold=0.0,
                num_rois=64, nms_thresh=0.5):
     """voc_dets.py:20-88 given the detector outputs for every scored RoI row.
 
     rois: (n,4) kept proposals.  out_cls (n_pad, C) / out_reg (n_pad, 4(C-1)): detector
     outputs for the padded RoI list (each last batch padded with copies of its first RoI,
-    voc_dets.py:42-46) -- ``pad_rois`` builds that list.
+    voc_dets.py:42-46) -- ``pad_rois`` builds that list; unpadded outputs (n rows) are accepted
+    too (the padding rows only ever produce duplicates that the NMS removes).
     Returns a list of (cls_idx, prob f32, bbox int64[4]) in the reference's emission
     order: classes in first-seen order, boxes in NMS pick order."""
-    padded = pad_rois(rois, num_rois)
+    padded = pad_rois(rois, num_rois)[:len(out_cls)].astype(np.float32)
     by_cls = {}
     for r in range(len(padded)):
         c = int(np.argmax(out_cls[r]))
         conf = out_cls[r, c]
-        if c == bg_idx or conf < det_threshold:
+        if c == bg_idx or conf < np.float32(det_threshold):
             continue
-        x1, y1, x2, y2 = padded[r]
         t = out_reg[r, 4 * c:4 * c + 4] / BBREG_MULTIPLIERS
-        p = transform_f64([x1, y1, x2, y2], t)
+        p = transform_legacy(padded[r], t)
         by_cls.setdefault(c, ([], []))
         by_cls[c][0].append([stride * p[0], stride * p[1], stride * p[2], stride * p[3]])
         by_cls[c][1].append(conf)

@@ -259,3 +259,27 @@ def test_roi_crop_resize(ops):
     lhs = float((dout.astype(np.float64) * want.astype(np.float64)).sum())
     rhs = float((dfeat.astype(np.float64) * feat.astype(np.float64)).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_detections_device(ops):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dets_legacy.npz"))
+    rois = g["rois"].astype(np.float32)
+    n = len(rois)
+    for tag in ("t0", "t5", "t0r"):
+        thr, ratio = g[tag + "_args"]
+        for rows in (n, 320):                 # unpadded (fast path) and with the reference's padded duplicates
+            r = np.zeros((rows, 4), np.float32)
+            r[:n] = rois
+            if rows > n:
+                r[n:] = rois[256]
+            out = ops.detections(dev(r), dev(np.array([rows], np.int32)), dev(g["out_cls"][:rows]), dev(g["out_reg"][:rows]),
+                                 64, 20, float(thr), 16.0, float(ratio))
+            nd = int(out["n_dets"].item())
+            assert nd == len(g[tag + "_cls"])
+            assert np.array_equal(out["det_cls"].cpu().numpy()[:nd], g[tag + "_cls"])
+            assert np.array_equal(out["det_prob"].cpu().numpy()[:nd], g[tag + "_prob"])
+            assert np.array_equal(out["det_bbox"].cpu().numpy()[:nd], g[tag + "_bbox"])
+    # nothing above threshold
+    out = ops.detections(dev(rois), dev(np.array([n], np.int32)), dev(g["out_cls"][:n]), dev(g["out_reg"][:n]), 64, 20, 2.0, 16.0, 1.0)
+    assert int(out["n_dets"].item()) == 0

@@ -127,3 +127,18 @@ def test_scalar_kats(golden):
     assert np.array_equal(got, golden["kat_transform_np"])
     assert np.array_equal(np_ref.get_rois(np.zeros((1, 2, 3, 36), dtype=np.float32), golden["anchors9"], 16),
                           golden["kat_rois_zero"])
+
+
+@pytest.mark.parametrize("mode", ["legacy", "nep50"])
+def test_detections_golden(mode):
+    """voc_dets.get_dets post-process vs goldens captured under numpy 1.26 (legacy promotion, the
+    reference's pinned semantics) and numpy 2.2 (NEP 50)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dets_%s.npz" % mode))
+    for tag in ("t0", "t5", "t0r"):
+        thr, ratio = g[tag + "_args"]
+        dets = np_ref.detections(g["rois"], g["out_cls"], g["out_reg"], 20, float(ratio), det_threshold=float(thr))
+        assert len(dets) == len(g[tag + "_cls"])
+        assert [d[0] for d in dets] == list(g[tag + "_cls"])
+        assert np.array_equal(np.array([d[1] for d in dets], dtype=np.float32), g[tag + "_prob"])
+        assert np.array_equal(np.array([d[2] for d in dets]), g[tag + "_bbox"])
