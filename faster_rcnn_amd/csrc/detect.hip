@@ -18,6 +18,13 @@ constexpr int DET_MAX = 512;
 constexpr int DET_WORDS = DET_MAX / 64;
 constexpr int DET_MAX_CLASSES = 128;
 
+// readfirstlane returns a SIGNED int: go through unsigned or the low word sign-extends into the high one
+__device__ __forceinline__ u64 det_uniform(u64 v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
 __device__ __forceinline__ bool det_suppresses(const double4 a, const double4 b, double thresh) {
     const double area_a = (a.z - a.x + 1.0) * (a.w - a.y + 1.0);
     const double area_b = (b.z - b.x + 1.0) * (b.w - b.y + 1.0);
@@ -115,7 +122,7 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
             const int cnt = min(64, nv - base);
             const u64 vmask = cnt == 64 ? ~0ull : ((1ull << cnt) - 1);
             u64 alive = ~(((u64)rh << 32) | rl) & vmask;
-            alive = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(alive >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)alive);
+            alive = det_uniform(alive);
             u64 kept = 0;
             while (alive) {
                 const int b = __builtin_ctzll(alive);
@@ -123,7 +130,7 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
                 alive &= ~(1ull << b);
                 const unsigned dl = __builtin_amdgcn_readlane((unsigned)diag, b), dh = __builtin_amdgcn_readlane((unsigned)(diag >> 32), b);
                 alive &= ~(((u64)dh << 32) | dl);
-                alive = ((u64)__builtin_amdgcn_readfirstlane((unsigned)(alive >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)alive);
+                alive = det_uniform(alive);
             }
             if (r == 0) s_kept[c] = kept;
             u64 k = kept;
