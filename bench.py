@@ -8,7 +8,8 @@ N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-
 images shard by rank with NO data-path collective (inference has no exchange step), so the
 scaling is weak: every rank processes its own image stream.
 
-A "step" = one image through the whole device-resident path (backbone convs, RPN heads,
+A "step" = S images (--streams, default 4: one hipGraph + HIP stream per image in flight)
+through the whole device-resident path (backbone convs, RPN heads,
 decode, top-8000 ordering, NMS to 300, RoI crop-resize, stage-5 head, softmax, detection
 post-process), replayed from a hipGraph.  The input is resident in HBM when timing starts.
 
@@ -56,35 +57,50 @@ def build_pipeline():
 
 
 def conv_roofline(pipe, x, passes=3):
-    """HIP-event timing of every conv launch of one image (eager, same stream)."""
+    """HIP-event timing (torch events on the launch stream) of every conv launch of one image,
+    single stream, eager.  Returns the roofline object for the DOMINANT kernel instantiation
+    (most summed time) plus the aggregate over all conv launches."""
     from faster_rcnn_amd import ops
     pipe.forward_dev(x)
     torch.cuda.synchronize()
+    per_kernel, per_shape = {}, {}
     tot_flops = tot_ms = 0.0
-    n_launch = 0
-    per_shape = {}
     for _ in range(passes):
         ops.CONV_PROFILE = []
         pipe.forward_dev(x)
         torch.cuda.synchronize()
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        for e0, e1, flops, shape in prof:
+        for e0, e1, flops, shape, kname in prof:
             ms = e0.elapsed_time(e1)
             tot_flops += flops
             tot_ms += ms
-            n_launch += 1
-            a = per_shape.setdefault(shape, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += ms; a[2] += 1
-    achieved = tot_flops / (tot_ms * 1e-3) / 1e12
-    heavy = max(per_shape.items(), key=lambda kv: kv[1][1])
-    return {
-        "bound": "mfma", "kernel": "k_conv_igemm_f32 (all %d conv launches of one image)" % (n_launch // passes),
+            for table, key in ((per_kernel, kname), (per_shape, (kname,) + shape)):
+                a = table.setdefault(key, [0.0, 0.0, 0])
+                a[0] += flops; a[1] += ms; a[2] += 1
+    dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1][1])
+    achieved = dom[0] / (dom[1] * 1e-3) / 1e12
+    heavy = max(((k, v) for k, v in per_shape.items() if k[0] == dom_name), key=lambda kv: kv[1][1])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC passes (rocprofv3 --pmc), committed
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+    roof = {
+        "bound": "mfma", "kernel": dom_name,
         "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
-        "gflop_per_image": round(tot_flops / passes / 1e9, 2), "conv_ms_per_image": round(tot_ms / passes, 3),
-        "heaviest_shape_MNK": list(heavy[0]),
+        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+        "launches_per_image": dom[2] // passes, "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
+        "gflop_per_launch_avg": round(dom[0] / dom[2] / 1e9, 3),
+        "share_of_conv_time": round(dom[1] / tot_ms, 3),
+        "heaviest_shape_MNK": list(heavy[0][1:]),
         "heaviest_shape_tflops": round(heavy[1][0] / (heavy[1][1] * 1e-3) / 1e12, 2),
-    }, per_shape
+        "all_conv_launches": {"launches_per_image": sum(v[2] for v in per_kernel.values()) // passes,
+                              "gflop_per_image": round(tot_flops / passes / 1e9, 2),
+                              "ms_per_image": round(tot_ms / passes, 3),
+                              "achieved": round(tot_flops / (tot_ms * 1e-3) / 1e12, 2),
+                              "frac": round(tot_flops / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)},
+        "method": "HIP events around each launch on the launch stream, single stream, eager, %d passes" % passes,
+    }
+    return roof, per_shape
 
 
 def cpu_baseline(weights, anchors, budget_s=20.0):
@@ -117,7 +133,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--streams", type=int, default=1, help="images in flight per GPU (one hipGraph + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=4, help="images in flight per GPU (one hipGraph + HIP stream each)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,6 +206,8 @@ def main():
                        "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world},
             "roofline": roof,
         }
+        # algorithmic conv FLOP actually retired per second by the whole job (all images in flight)
+        line["roofline"]["end_to_end_conv_tflops"] = round(roof["all_conv_launches"]["gflop_per_image"] * line["value"] / world / 1e3, 2)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, anchors)
         print(json.dumps(line), flush=True)

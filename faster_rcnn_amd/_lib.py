@@ -45,6 +45,7 @@ SIGNATURES = {
     "frcnn_conv_packed_k": (I, [I, I, I]),
     "frcnn_pack_conv_weights": (I, [P, I, I, I, I, P, P]),
     "frcnn_conv2d_fwd": (I, [P, P, P, P, P, P, P, P]),
+    "frcnn_conv2d_config": (I, [P]),
     "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
     "frcnn_softmax_rows": (I, [P, I, I, I, P, I, P]),
     "frcnn_detections": (I, [P, P, I, P, P, I, I, ctypes.c_float, c_double, c_double, c_double, P, P, P, P, P, P]),

@@ -464,6 +464,27 @@ static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
 
 using namespace frcnn;
 
+// tile / main-loop selection shared by frcnn_conv2d_fwd and frcnn_conv2d_config
+static int choose_config(const frcnn_conv_desc* d) {
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const int Kpad = (d->kh * d->kw * d->cin + BK - 1) / BK * BK;
+    const bool generic = (d->cin % BK) != 0;
+    const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
+    int cfg = d->tile;      // 0 = auto
+    if (cfg == 0) {
+        // measured on MI355X over every conv shape of the C2 pipeline (scripts/conv_shapes.py):
+        // the 64x64 v2 kernel wins wherever the grid is small or k is short; 128x128 v2 only
+        // pays once there are >= 1.5 tiles per CU slot AND a long k loop to amortise its prologue
+        if (generic) cfg = 2;
+        else if (t128 >= 384 && Kpad >= 1024) cfg = 11;
+        else cfg = 12;
+    }
+    const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * Kpad * 4 < 0x7fffffffull;
+    if (cfg >= 11 && (!fits_srd || generic)) cfg -= 10;
+    if (generic) cfg = (cfg == 2) ? 2 : 3;
+    return cfg;
+}
+
 extern "C" {
 
 int frcnn_conv_packed_k(int kh, int kw, int cin) {
@@ -497,23 +518,11 @@ int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_pa
     a.tiles_m = a.tiles_n = 0;
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
-    // tile choice: fill >= ~2 workgroups per CU where the problem allows, else shrink the tile
-    const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
-    int cfg = d->tile;      // 0 = auto
-    if (cfg == 0) {
-        // measured on MI355X over every conv shape of the C2 pipeline (scripts/conv_shapes.py):
-        // the 64x64 v2 kernel wins wherever the grid is small or k is short; 128x128 v2 only
-        // pays once there are >= 1.5 tiles per CU slot AND a long k loop to amortise its prologue
-        if (generic) cfg = 2;
-        else if (t128 >= 384 && a.Kpad >= 1024) cfg = 11;
-        else cfg = 12;
-    }
+    const int cfg = choose_config(d);
     if (generic) {
-        if (cfg == 2 || cfg == 12) return launch_conv<1, 1, true>(a, s);
+        if (cfg == 2) return launch_conv<1, 1, true>(a, s);
         return launch_conv<2, 1, true>(a, s);
     }
-    const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * a.Kpad * 4 < 0x7fffffffull;
-    if (cfg >= 11 && !fits_srd) cfg -= 10;
     switch (cfg) {
         case 11: return launch_conv_v2<2, 2>(a, s);
         case 12: return launch_conv_v2<1, 1>(a, s);
@@ -525,6 +534,11 @@ int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_pa
         case 4: return launch_conv<4, 2, false>(a, s);
         default: return fail(FRCNN_E_ARG, "conv2d_fwd: unknown tile config %d", cfg);
     }
+}
+
+int frcnn_conv2d_config(const frcnn_conv_desc* d) {
+    if (!d) return fail(FRCNN_E_ARG, "conv2d_config: null descriptor");
+    return choose_config(d);
 }
 
 int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream) {

@@ -224,6 +224,9 @@ class PackedConv:
 # When set to a list, every conv2d launch appends (start_event, end_event, flops, shape) so
 # bench.py can time the MFMA kernel per launch with HIP events on the launch stream.
 CONV_PROFILE = None
+CONV_KERNEL_NAMES = {1: "k_conv_igemm_f32<2,2,false>", 2: "k_conv_igemm_f32<1,1,*>", 3: "k_conv_igemm_f32<2,1,*>",
+                     4: "k_conv_igemm_f32<4,2,false>", 11: "k_conv_igemm_f32_v2<2,2>", 12: "k_conv_igemm_f32_v2<1,1>",
+                     13: "k_conv_igemm_f32_v2<2,1>", 14: "k_conv_igemm_f32_v2<4,2>"}
 
 
 def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0):
@@ -251,7 +254,8 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
     if CONV_PROFILE is not None:
         e1.record()
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
-        CONV_PROFILE.append((e0, e1, flops, (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin)))
+        CONV_PROFILE.append((e0, e1, flops, (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin),
+                             CONV_KERNEL_NAMES.get(_lib.load().frcnn_conv2d_config(ctypes.byref(d)), "?")))
     return out
 
 

@@ -170,6 +170,9 @@ int frcnn_pack_conv_weights(const float* w_hwio, int kh, int kw, int cin, int co
 /* scale / shift / residual may be NULL (1, 0, none). */
 int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                      const float* scale, const float* shift, const float* residual, float* y, void* stream);
+/* The tile code (see frcnn_conv_desc.tile) frcnn_conv2d_fwd will run for this descriptor:
+ * lets a profiler attribute a launch to its kernel instantiation. */
+int frcnn_conv2d_config(const frcnn_conv_desc* d);
 /* MaxPooling2D / AveragePooling2D, 'valid' (resnet.py:412, 515; vgg.py:100-128). c % 4 == 0. */
 int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream);
 /* softmax over the first `cols` entries of each row (Dense(activation='softmax'), resnet.py:522). */

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condense a profile_round.sh output directory into the text summary committed under profiles/."""
+import collections, csv, glob, json, os, sys
+root = sys.argv[1]
+print("== bench lines")
+for f in ("bench_default.json", "bench_streams1.json"):
+    p = os.path.join(root, f)
+    if os.path.exists(p):
+        print(f, open(p).read().strip())
+for tag in ("trace_streams1", "trace_default"):
+    fs = glob.glob(os.path.join(root, tag, "**", "*kernel_stats.csv"), recursive=True)
+    if not fs:
+        continue
+    print("\n== rocprofv3 --kernel-trace --stats:", tag)
+    print("%-78s %7s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+    for r in csv.DictReader(open(fs[0])):
+        if float(r["Percentage"]) < 0.05:
+            continue
+        print("%-78s %7s %12.1f %10.2f %6.2f" % (r["Name"][:78], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "conv_igemm" in k or "nms" in k or "topk_rank" in k or "roi_fwd" in k:
+            acc[k.split("(")[0][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+traffic = {}
+if acc:
+    print("\n== PMC means per dispatch (rocprofv3 --pmc, separate passes, eager single stream)")
+for k in sorted(acc):
+    c = {n: sum(v) / len(v) for n, v in acc[k].items()}
+    print(k, "dispatches/pass:", len(next(iter(acc[k].values()))))
+    for n in sorted(c):
+        print("    %-34s %.4g" % (n, c[n]))
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM)
+        hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        name = "k_conv_igemm_f32_v2<2,2>" if "v2ILi2ELi2" in k or "v2<2, 2>" in k else ("k_conv_igemm_f32_v2<1,1>" if "v2<1, 1>" in k else k)
+        traffic[name] = {"hbm_bytes_per_launch": round(hbm), "fetch_kb_raw": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"]}
+        print("    -> HBM-side bytes per launch (2*FETCH+WRITE)*1024 = %.3g" % hbm)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        print("    -> matrix pipe busy = MFMA_BUSY/1024 SIMDs / (GUI_ACTIVE/8 XCDs) = %.3f" % (c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8)))
+    if "TCC_HIT_sum" in c:
+        print("    -> L2 hit rate = %.3f" % (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
+json.dump(traffic, open(os.path.join(root, "traffic.json"), "w"), indent=1)
