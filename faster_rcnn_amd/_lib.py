@@ -46,6 +46,10 @@ SIGNATURES = {
     "frcnn_pack_conv_weights": (I, [P, I, I, I, I, P, P]),
     "frcnn_conv2d_fwd": (I, [P, P, P, P, P, P, P, P]),
     "frcnn_conv2d_config": (I, [P]),
+    "frcnn_conv2d_fwd_masked": (I, [P, P, P, P, P, P, P, P, P]),
+    "frcnn_pack_conv_weights_dgrad": (I, [P, P, I, I, I, I, P, P]),
+    "frcnn_conv2d_wgrad_workspace_bytes": (c_size_t, [P]),
+    "frcnn_conv2d_wgrad": (I, [P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
     "frcnn_softmax_rows": (I, [P, I, I, I, P, I, P]),
     "frcnn_detections": (I, [P, P, I, P, P, I, I, ctypes.c_float, c_double, c_double, c_double, P, P, P, P, P, P]),

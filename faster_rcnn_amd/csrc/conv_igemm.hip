@@ -34,6 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const float* x; const float* w; const float* scale; const float* shift; const float* residual; float* y;
+    const float* mask;      // optional [M][Cout]: output is zeroed where mask <= 0 (ReLU backward fused into dgrad)
     int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
     int M, K, Kpad, act, ldy, ldres;
     int tiles_m, tiles_n;
@@ -72,6 +73,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& 
                 if (m < p.M) {
                     float v = acc[i][j][e] * sc + sh;
                     if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
+                    if (p.mask && !(p.mask[(size_t)m * p.Cout + n] > 0.0f)) v = 0.0f;
                     p.y[(size_t)m * p.ldy + n] = activate(v, p.act);
                 }
             }
@@ -391,6 +393,149 @@ __global__ void k_pack_hwio(const float* w, int RS, int Cin, int Cout, int Kpad,
 }
 
 // ------------------------------------------------------------------------------------
+// Backward of a stride-1 convolution w.r.t. its input = a forward convolution of the output
+// gradient with the filter transposed (Cin <-> Cout) and flipped in both taps.  The per-channel
+// epilogue scale s[co] of the forward layer (folded BatchNorm) multiplies the incoming gradient,
+// which is the same as scaling the transposed filter's INPUT channel co, so it is folded here and
+// the dgrad launch is an ordinary frcnn_conv2d_fwd on these weights.
+//   w'[r'][s'][co][ci] = w[R-1-r'][S-1-s'][ci][co] * s[co]      (conv' has Cin' = Cout, Cout' = Cin)
+__global__ void k_pack_dgrad(const float* w, const float* scale, int R, int S, int Cin, int Cout, int Kpad, float* out) {
+    const int RS = R * S;
+    const size_t total = (size_t)Cin * Kpad;               // rows = Cout' = Cin, k over (co chunk, tap', co)
+    const bool chunked = (Cout % BK) == 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad), ci = (int)(i / Kpad);
+        int tap, co;
+        bool ok = true;
+        if (chunked) { const int j = k % BK, kc = k / BK; tap = kc % RS; co = (kc / RS) * BK + j; }
+        else { ok = k < RS * Cout; tap = k / Cout; co = k % Cout; }
+        float v = 0.0f;
+        if (ok) {
+            const int r = R - 1 - tap / S, sx = S - 1 - tap % S;
+            v = w[((size_t)(r * S + sx) * Cin + ci) * Cout + co] * (scale ? scale[co] : 1.0f);
+        }
+        out[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Weight gradient on the matrix cores:  dW[tap][ci][co] = s[co] * sum_m A[m][(tap,ci)] * G[m][co]
+// (A = implicit im2col of the layer input x, G = gradient w.r.t. the layer's pre-activation
+// output, m = output pixel).  The reduction index is the PIXEL, so both operands are staged
+// [pixel][channel] exactly as they lie in HBM (NHWC) and the 32x32x2 MFMA reads them with
+// conflict-free ds_read_b32 (lane = channel).  Workgroup = 4 waves = 64 (ci) x 64 (co) outputs of
+// one filter tap; grid.z splits the pixel range, each slice writes its own partial slab and a
+// second kernel reduces the slabs in a fixed order (bitwise reproducible; no float atomics).
+struct WgradArgs {
+    const float* x; const float* g; float* partial;
+    int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo, M;
+    int m_per_slice;
+};
+
+constexpr int WG_MC = 32;                 // pixels per staged chunk
+constexpr int WG_LD = 64 + 4;             // LDS row stride in floats (272 B keeps 16-B alignment for the b128 stores)
+
+__global__ void __launch_bounds__(256) k_conv_wgrad_f32(const WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][WG_MC][WG_LD];
+    __shared__ __attribute__((aligned(16))) float Gs[2][WG_MC][WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int ci_tiles = (p.Cin + 63) / 64;
+    const int tap = blockIdx.x / ci_tiles, ci0 = (blockIdx.x % ci_tiles) * 64;
+    const int r_tap = tap / p.S, s_tap = tap % p.S;
+    const int co0 = blockIdx.y * 64;
+    const int m_begin = blockIdx.z * p.m_per_slice, m_end = min(p.M, m_begin + p.m_per_slice);
+
+    // staging: 256 threads move 32 pixels x 64 channels (16 float4 per pixel) per operand per chunk
+    const int srow = tid >> 4, scol = (tid & 15) * 4;      // rows srow and srow+16
+    f32x4 rx[2], rg[2];
+    auto load = [&](int mc) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = mc + srow + 16 * q;
+            f32x4 vx = {0, 0, 0, 0}, vg = {0, 0, 0, 0};
+            if (m < m_end) {
+                const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
+                const int hi = ho * p.stride - p.pad_top + r_tap, wi = wo * p.stride - p.pad_left + s_tap;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+                    const float* src = p.x + (((size_t)img * p.H + hi) * p.W + wi) * p.Cin + ci0 + scol;
+                    if (ci0 + scol + 3 < p.Cin) vx = *reinterpret_cast<const f32x4*>(src);
+                    else for (int e = 0; e < 4; ++e) if (ci0 + scol + e < p.Cin) vx[e] = src[e];
+                }
+                const float* gs = p.g + (size_t)m * p.Cout + co0 + scol;
+                if (co0 + scol + 3 < p.Cout && (p.Cout & 3) == 0) vg = *reinterpret_cast<const f32x4*>(gs);
+                else for (int e = 0; e < 4; ++e) if (co0 + scol + e < p.Cout) vg[e] = gs[e];
+            }
+            rx[q] = vx; rg[q] = vg;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<f32x4*>(&Xs[buf][srow + 16 * q][scol]) = rx[q];
+            *reinterpret_cast<f32x4*>(&Gs[buf][srow + 16 * q][scol]) = rg[q];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+
+    const int n_chunks = (m_end - m_begin + WG_MC - 1) / WG_MC;
+    if (n_chunks > 0) {
+        load(m_begin);
+        store(0);
+        __syncthreads();
+        for (int c = 0; c < n_chunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < n_chunks) load(m_begin + (c + 1) * WG_MC);
+#pragma unroll
+            for (int st = 0; st < WG_MC / 2; ++st) {
+                const float a = Xs[buf][2 * st + lh][wk * 32 + li];
+                const float b = Gs[buf][2 * st + lh][wn * 32 + li];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            if (c + 1 < n_chunks) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial slab layout = HWIO: [slice][tap][ci][co]
+    const int co = co0 + wn * 32 + li;
+    if (co < p.Cout) {
+        float* dst = p.partial + ((size_t)blockIdx.z * p.R * p.S + tap) * p.Cin * p.Cout;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ci = ci0 + wk * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+            if (ci < p.Cin) dst[(size_t)ci * p.Cout + co] = acc[e];
+        }
+    }
+}
+
+// dW = s[co] * sum over slices (fixed order); dbias[co] handled by k_colsum
+__global__ void k_wgrad_reduce(const float* partial, int slices, size_t elems, int Cout, const float* scale, float* dw) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        for (int sidx = 0; sidx < slices; ++sidx) v += partial[(size_t)sidx * elems + i];
+        dw[i] = scale ? v * scale[i % Cout] : v;
+    }
+}
+
+// dbias[co] = s[co] * sum_m G[m][co]: one workgroup per 64 columns, rows strided over 4 waves, fixed-order tree
+__global__ void __launch_bounds__(256) k_colsum(const float* g, int M, int Cout, const float* scale, float* out) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = blockIdx.x * 64 + lane;
+    float v = 0.0f;
+    if (co < Cout) for (int m = wave; m < M; m += 4) v += g[(size_t)m * Cout + co];
+    part[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0 && co < Cout) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        out[co] = scale ? t * scale[co] : t;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // pooling (NHWC, VALID): MaxPooling2D (resnet.py:412, vgg.py:100-128) / AveragePooling2D (resnet.py:515)
 template <bool IS_MAX>
 __global__ void k_pool(const float4* x, int n_img, int H, int W, int C4, int k, int stride, int Ho, int Wo, float4* y) {
@@ -504,11 +649,16 @@ int frcnn_pack_conv_weights(const float* w_hwio, int kh, int kw, int cin, int co
 
 int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                      const float* scale, const float* shift, const float* residual, float* y, void* stream) {
+    return frcnn_conv2d_fwd_masked(d, x, w_packed, scale, shift, residual, nullptr, y, stream);
+}
+
+int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                            const float* scale, const float* shift, const float* residual, const float* mask, float* y, void* stream) {
     if (!d || !x || !w_packed || !y) return fail(FRCNN_E_ARG, "conv2d_fwd: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->ho <= 0 || d->wo <= 0)
         return fail(FRCNN_E_ARG, "conv2d_fwd: bad shape");
     ConvArgs a;
-    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y;
+    a.x = x; a.w = w_packed; a.scale = scale; a.shift = shift; a.residual = residual; a.y = y; a.mask = mask;
     a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
     a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
     const long long M = (long long)d->n * d->ho * d->wo;
@@ -534,6 +684,61 @@ int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_pa
         case 4: return launch_conv<4, 2, false>(a, s);
         default: return fail(FRCNN_E_ARG, "conv2d_fwd: unknown tile config %d", cfg);
     }
+}
+
+int frcnn_pack_conv_weights_dgrad(const float* w_hwio, const float* scale, int kh, int kw, int cin, int cout, float* packed, void* stream) {
+    if (!w_hwio || !packed || kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return fail(FRCNN_E_ARG, "pack_conv_weights_dgrad: bad argument");
+    const int Kpad = frcnn_conv_packed_k(kh, kw, cout);
+    const size_t total = (size_t)cin * Kpad;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    k_pack_dgrad<<<grid, 256, 0, as_stream(stream)>>>(w_hwio, scale, kh, kw, cin, cout, Kpad, packed);
+    return check_launch("pack_conv_weights_dgrad");
+}
+
+static int wgrad_slices(const frcnn_conv_desc* d) {
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long tiles = (long long)d->kh * d->kw * ((d->cin + 63) / 64) * ((d->cout + 63) / 64);
+    long long s = (2048 + tiles - 1) / tiles;                 // aim at ~2048 workgroups
+    const long long max_s = (M + 4 * WG_MC - 1) / (4 * WG_MC); // at least 4 chunks per slice
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d) {
+    if (!d) return 0;
+    return align_up((size_t)wgrad_slices(d) * d->kh * d->kw * d->cin * d->cout * sizeof(float), 256);
+}
+
+int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g, const float* scale,
+                       float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !x || !g || !dw_hwio) return fail(FRCNN_E_ARG, "conv2d_wgrad: null pointer");
+    if ((d->cin & 3) && d->cin >= 4) return fail(FRCNN_E_UNSUPPORTED, "conv2d_wgrad: cin must be a multiple of 4 (or < 4)");
+    if (!workspace || workspace_bytes < frcnn_conv2d_wgrad_workspace_bytes(d))
+        return fail(FRCNN_E_WORKSPACE, "conv2d_wgrad: workspace needs %zu bytes", frcnn_conv2d_wgrad_workspace_bytes(d));
+    WgradArgs a;
+    a.x = x; a.g = g; a.partial = (float*)workspace;
+    a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
+    a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
+    a.M = d->n * d->ho * d->wo;
+    const int slices = wgrad_slices(d);
+    a.m_per_slice = ((a.M + slices - 1) / slices + WG_MC - 1) / WG_MC * WG_MC;
+    hipStream_t s = as_stream(stream);
+    dim3 grid(d->kh * d->kw * ((d->cin + 63) / 64), (d->cout + 63) / 64, slices);
+    k_conv_wgrad_f32<<<grid, 256, 0, s>>>(a);
+    if (int e = check_launch("conv2d_wgrad")) return e;
+    const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
+    int rgrid = (int)((elems + 255) / 256);
+    if (rgrid > 4096) rgrid = 4096;
+    k_wgrad_reduce<<<rgrid, 256, 0, s>>>((const float*)workspace, slices, elems, d->cout, scale, dw_hwio);
+    if (int e = check_launch("conv2d_wgrad reduce")) return e;
+    if (dbias) {
+        k_colsum<<<(d->cout + 63) / 64, 256, 0, s>>>(g, a.M, d->cout, scale, dbias);
+        if (int e = check_launch("conv2d_wgrad bias")) return e;
+    }
+    return FRCNN_OK;
 }
 
 int frcnn_conv2d_config(const frcnn_conv_desc* d) {

@@ -291,3 +291,65 @@ def detections(rois, n_rois, out_cls, out_reg, roi_batch, bg_idx, det_threshold,
               float(det_threshold), float(stride), float(resize_ratio), float(nms_thresh),
               _p(det_cls), _p(det_prob), _p(det_bbox), _p(det_roi), _p(n_dets), _stream())
     return {"det_cls": det_cls, "det_prob": det_prob, "det_bbox": det_bbox, "det_roi": det_roi, "n_dets": n_dets}
+
+
+# ----------------------------------------------------------------------------- conv backward
+def _conv_desc(x_shape, kh, kw, cout, stride, padding, act=0):
+    n, h, w, cin = x_shape
+    if padding == "same":
+        ho, pt = same_pad(h, kh, stride)
+        wo, pl = same_pad(w, kw, stride)
+    else:
+        ho, wo, pt, pl = valid_out(h, kh, stride), valid_out(w, kw, stride), 0, 0
+    return _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride, pad_top=pt, pad_left=pl,
+                         ho=ho, wo=wo, act=act, ldy=0, ldres=0, tile=0)
+
+
+class PackedDgrad:
+    """Filter of the input-gradient convolution of a stride-1 layer (transposed, flipped, with the
+    forward epilogue scale folded in).  w_hwio: device or host (kh,kw,cin,cout); scale: (cout,) or None."""
+
+    def __init__(self, w_hwio, scale=None):
+        _require_gpu()
+        w = _dev(w_hwio, torch.float32)
+        self.kh, self.kw, cin, cout = (int(v) for v in w.shape)
+        self.cin, self.cout = cout, cin                      # geometry of the dgrad convolution
+        kp = _lib.load().frcnn_conv_packed_k(self.kh, self.kw, cout)
+        self.w = torch.empty((cin, kp), dtype=torch.float32, device="cuda")
+        sc = None if scale is None else _dev(scale, torch.float32)
+        _lib.call("frcnn_pack_conv_weights_dgrad", _p(w), _p(sc), self.kh, self.kw, cin, cout, _p(self.w), _stream())
+        self.scale = self.shift = None
+
+
+def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
+    """Gradient w.r.t. the input of a stride-1 conv.  gy: (n,ho,wo,cout_fwd) gradient w.r.t. the layer's
+    post-BN pre-activation output; residual: gradient arriving over an identity shortcut; mask: forward
+    activation (n,h,w,cin_fwd) whose ReLU sits in front of this layer's input (None = no ReLU)."""
+    _require_gpu()
+    n, ho, wo, _ = gy.shape
+    # forward 'same' (stride 1, odd kernel) pads (k-1)/2 on both sides -> so does the transposed conv
+    pt = (pd.kh - 1) // 2 if padding == "same" else 0
+    pl = (pd.kw - 1) // 2 if padding == "same" else 0
+    assert padding == "same" or (pd.kh == 1 and pd.kw == 1), "dgrad supports 1x1 valid and odd 'same' kernels"
+    if out is None:
+        out = torch.empty((n, ho, wo, pd.cout), dtype=torch.float32, device="cuda")
+    d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=pd.cin, cout=pd.cout, kh=pd.kh, kw=pd.kw, stride=1, pad_top=pt, pad_left=pl,
+                      ho=ho, wo=wo, act=0, ldy=0, ldres=0, tile=0)
+    _lib.call("frcnn_conv2d_fwd_masked", ctypes.byref(d), _p(gy.contiguous()), _p(pd.w), None, None, _p(residual), _p(mask), _p(out), _stream())
+    return out
+
+
+def conv2d_wgrad(x, g, kh, kw, stride=1, padding="valid", scale=None, dw=None, dbias=None, want_bias=True):
+    """-> (dw (kh,kw,cin,cout), dbias (cout,) or None); g: (n,ho,wo,cout)."""
+    _require_gpu()
+    cout = g.shape[-1]
+    d = _conv_desc(tuple(x.shape), kh, kw, cout, stride, padding)
+    assert (d.ho, d.wo) == (g.shape[1], g.shape[2])
+    if dw is None:
+        dw = torch.empty((kh, kw, x.shape[-1], cout), dtype=torch.float32, device="cuda")
+    if dbias is None and want_bias:
+        dbias = torch.empty(cout, dtype=torch.float32, device="cuda")
+    ws = _ws(_lib.load().frcnn_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+    _lib.call("frcnn_conv2d_wgrad", ctypes.byref(d), _p(x.contiguous()), _p(g.contiguous()), _p(scale), _p(dw), _p(dbias if want_bias else None),
+              _p(ws), ws.numel(), _stream())
+    return dw, (dbias if want_bias else None)

@@ -170,6 +170,26 @@ int frcnn_pack_conv_weights(const float* w_hwio, int kh, int kw, int cin, int co
 /* scale / shift / residual may be NULL (1, 0, none). */
 int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                      const float* scale, const float* shift, const float* residual, float* y, void* stream);
+/* Same as frcnn_conv2d_fwd with an extra mask [M][cout]: outputs are zeroed where mask <= 0.  Used
+ * as the INPUT-GRADIENT pass of a stride-1 convolution: x := gradient w.r.t. the layer output,
+ * w_packed := frcnn_pack_conv_weights_dgrad(...), residual := gradient arriving over the identity
+ * shortcut, mask := the forward activation feeding this layer (fused ReLU backward).  This is what
+ * Keras' train_on_batch derives for every Conv2D/ReLU/add group (train_util.py:54, 118). */
+int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                            const float* scale, const float* shift, const float* residual, const float* mask,
+                            float* y, void* stream);
+/* Filter of the input-gradient convolution: transposed (cin <-> cout), flipped in both taps, input
+ * channel co scaled by scale[co] (the forward epilogue scale = folded BatchNorm; NULL = 1).
+ * packed: [cin][frcnn_conv_packed_k(kh, kw, cout)]. */
+int frcnn_pack_conv_weights_dgrad(const float* w_hwio, const float* scale, int kh, int kw, int cin, int cout,
+                                  float* packed, void* stream);
+/* Weight / bias gradient of the convolution described by d (forward geometry):
+ *   dw[kh][kw][cin][cout] = scale[co] * sum_m im2col(x)[m][(tap,ci)] * g[m][co],  dbias[co] = scale[co] * sum_m g[m][co]
+ * g [M][cout] = gradient w.r.t. the layer's post-BatchNorm, pre-activation output.  Deterministic
+ * (slice partials reduced in a fixed order).  dbias may be NULL. */
+size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d);
+int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g, const float* scale,
+                       float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 /* The tile code (see frcnn_conv_desc.tile) frcnn_conv2d_fwd will run for this descriptor:
  * lets a profiler attribute a launch to its kernel instantiation. */
 int frcnn_conv2d_config(const frcnn_conv_desc* d);

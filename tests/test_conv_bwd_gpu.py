@@ -1,0 +1,61 @@
+"""GPU parity of conv backward (input gradient via the transposed conv, MFMA weight gradient) vs
+torch autograd in float64."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+
+def ref_conv(x, w, stride, padding):
+    from oracle import keras_ref
+    xc = x.permute(0, 3, 1, 2)
+    wc = w.permute(3, 2, 0, 1)
+    if padding == "same":
+        _, pt, pb = keras_ref.same_pad(xc.shape[2], wc.shape[2], stride)
+        _, pl, pr = keras_ref.same_pad(xc.shape[3], wc.shape[3], stride)
+        xc = F.pad(xc, (pl, pr, pt, pb))
+    return F.conv2d(xc, wc, stride=stride).permute(0, 2, 3, 1)
+
+
+CASES = [  # n,h,w,cin,cout,k,stride,padding
+    (1, 13, 17, 64, 64, 1, 1, "valid"),
+    (1, 13, 17, 64, 128, 3, 1, "same"),
+    (2, 7, 7, 128, 256, 3, 1, "same"),
+    (1, 19, 23, 256, 36, 1, 1, "valid"),       # rpn_out_bbreg: cout not a multiple of 32
+    (1, 19, 23, 128, 9, 1, 1, "valid"),        # rpn_out_cls
+    (1, 21, 30, 128, 64, 1, 2, "valid"),       # stride-2 1x1 (wgrad only: res4a_branch2a / branch1)
+    (5, 1, 1, 256, 101, 1, 1, "valid"),        # dense
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_backward(case):
+    from faster_rcnn_amd import ops
+    n, h, w, cin, cout, k, stride, padding = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = torch.from_numpy(rs.randn(n, h, w, cin)).double().requires_grad_(True)
+    wt = torch.from_numpy(rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).double().requires_grad_(True)
+    scale = torch.from_numpy(1 + 0.1 * rs.randn(cout)).double()
+    xr = torch.relu(x)                                   # a ReLU in front of the layer (fused mask)
+    y = ref_conv(xr, wt, stride, padding) * scale
+    gy = torch.from_numpy(rs.randn(*y.shape)).double()
+    res = torch.from_numpy(rs.randn(n, h, w, cin)).double()
+    (y * gy).sum().backward()
+    dev = lambda t: t.detach().float().cuda().contiguous()
+    # weight / bias gradient
+    dw, db = ops.conv2d_wgrad(dev(xr), dev(gy), k, k, stride, padding, scale=dev(scale))
+    err = ((dw.cpu().double() - wt.grad).abs() / wt.grad.abs().clamp(min=1.0)).max().item()
+    assert err < 1e-4, err
+    want_db = (gy * scale).sum(dim=(0, 1, 2))
+    assert ((db.cpu().double() - want_db).abs() / want_db.abs().clamp(min=1.0)).max().item() < 1e-4
+    # determinism: bitwise equal on a second run
+    dw2, _ = ops.conv2d_wgrad(dev(xr), dev(gy), k, k, stride, padding, scale=dev(scale))
+    assert torch.equal(dw, dw2)
+    if stride == 1:
+        pd = ops.PackedDgrad(dev(wt), dev(scale))
+        dx = ops.conv2d_dgrad(dev(gy), pd, padding, residual=dev(res), mask=dev(x))
+        want = x.grad + res * (x.detach() > 0)           # (convT(gy*scale) + residual) masked by the ReLU
+        err = ((dx.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
+        assert err < 1e-4, err
