@@ -52,6 +52,16 @@ SIGNATURES = {
     "frcnn_conv2d_wgrad": (I, [P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
     "frcnn_softmax_rows": (I, [P, I, I, I, P, I, P]),
+    "frcnn_loss_rpn_cls": (I, [P, P, I, I, P, P, P]),
+    "frcnn_loss_rpn_reg": (I, [P, P, I, I, P, P, P]),
+    "frcnn_loss_det_cls": (I, [P, P, I, I, P, P, I, P]),
+    "frcnn_loss_det_reg": (I, [P, P, I, I, P, P, I, P]),
+    "frcnn_relu_bwd_inplace": (I, [P, P, c_size_t, P]),
+    "frcnn_avgpool_bwd_masked": (I, [P, P, I, I, I, P, P]),
+    "frcnn_sgd_momentum": (I, [P, P, P, c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, P]),
+    "frcnn_adam": (I, [P, P, P, P, c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, I, ctypes.c_float, ctypes.c_float, P]),
+    "frcnn_sumsq": (I, [P, c_size_t, P, P]),
+    "frcnn_fold_bias": (I, [P, P, P, P, I, P]),
     "frcnn_detections": (I, [P, P, I, P, P, I, I, ctypes.c_float, c_double, c_double, c_double, P, P, P, P, P, P]),
 }
 

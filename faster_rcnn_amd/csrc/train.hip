@@ -1,0 +1,249 @@
+// Training-side kernels for gfx950: the four reference losses (value + gradient), the small
+// elementwise backward pieces around the conv engine, SGD-momentum / Adam and the L2 penalty.
+// All HBM / latency bound.  Loss reductions run in ONE workgroup with f64 accumulation so that
+// loss values and gradients are bitwise reproducible run to run (no float atomics).
+//
+// Loss semantics = loss_functions.py:15-76 evaluated by Keras 2.0.8 on the TF backend
+// (SURVEY Appendix A.7), including the reference's quirks:
+//   * N_CLS = 256 and N_REG = 2400 are constants, not the actual sample counts (:8-9);
+//   * bbreg_loss_rpn multiplies the mask OUTSIDE K.sum (:44): the result is a tensor that Keras
+//     then averages, i.e. loss = mean(mask) * 10 * S / 2400 with S summed over ALL anchors;
+//   * bbreg_loss_det divides by sum(1e-4 + mask) (:65); cls_loss_det uses batch element 0 (:76).
+// Keras clips probabilities to [1e-7, 1 - 1e-7] before the logarithm: a clipped probability has
+// zero gradient.
+#include "common.h"
+
+namespace frcnn {
+
+constexpr int LB = 1024;
+constexpr float KERAS_EPS = 1e-7f;
+
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += scratch[w];      // fixed order
+    return t;
+}
+
+__device__ __forceinline__ float smooth_l1(float d) { const float a = fabsf(d); return a <= 1.0f ? 0.5f * a * a : a - 0.5f; }
+__device__ __forceinline__ float smooth_l1_grad(float d) { return fabsf(d) <= 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f); }
+
+// cls_loss_rpn (loss_functions.py:15-28).  y_true [cells][2A] = [can_use | is_pos], p [cells][A] sigmoid
+// outputs.  loss = sum(sel * BCE(is_pos, p)) / 256; g_logit = sel * (p - z) / 256 (0 where p was clipped).
+__global__ void __launch_bounds__(LB) k_loss_rpn_cls(const float* y_true, const float* p, int cells, int A, float* loss, float* g_logit) {
+    __shared__ double scratch[LB / 64];
+    double acc = 0.0;
+    const int n = cells * A;
+    for (int i = threadIdx.x; i < n; i += LB) {
+        const int cell = i / A, a = i % A;
+        const float sel = y_true[(size_t)cell * 2 * A + a], z = y_true[(size_t)cell * 2 * A + A + a];
+        const float pr = p[i];
+        const float pc = fminf(fmaxf(pr, KERAS_EPS), 1.0f - KERAS_EPS);
+        const float x = logf(pc / (1.0f - pc));                       // Keras goes back to logits
+        const float bce = fmaxf(x, 0.0f) - x * z + log1pf(expf(-fabsf(x)));
+        acc += (double)(sel * bce);
+        const bool clipped = pr < KERAS_EPS || pr > 1.0f - KERAS_EPS;
+        if (g_logit) g_logit[i] = clipped ? 0.0f : sel * (pc - z) / 256.0f;
+    }
+    const double t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) *loss = (float)(t / 256.0);
+}
+
+// bbreg_loss_rpn (loss_functions.py:31-48).  y_true [cells][8A] = [mask(4A) | target(4A)], pred [cells][4A].
+__global__ void __launch_bounds__(LB) k_loss_rpn_reg(const float* y_true, const float* pred, int cells, int A4, float* loss, float* g_pred) {
+    __shared__ double scratch[LB / 64];
+    double s = 0.0, msum = 0.0;
+    const int n = cells * A4;
+    for (int i = threadIdx.x; i < n; i += LB) {
+        const int cell = i / A4, k = i % A4;
+        msum += (double)y_true[(size_t)cell * 2 * A4 + k];
+        s += (double)smooth_l1(y_true[(size_t)cell * 2 * A4 + A4 + k] - pred[i]);
+    }
+    const double S = block_sum(s, scratch);
+    const double Msum = block_sum(msum, scratch);
+    const double mean_mask = Msum / (double)n;
+    if (threadIdx.x == 0) *loss = (float)(mean_mask * 10.0 * S / 2400.0);
+    if (g_pred) {
+        const float coef = (float)(mean_mask * 10.0 / 2400.0);
+        for (int i = threadIdx.x; i < n; i += LB) {
+            const int cell = i / A4, k = i % A4;
+            g_pred[i] = -coef * smooth_l1_grad(y_true[(size_t)cell * 2 * A4 + A4 + k] - pred[i]);
+        }
+    }
+}
+
+// cls_loss_det (loss_functions.py:70-76): mean over RoIs of -sum_c y*log(clip(p/sum p)).  g w.r.t. the
+// pre-softmax logits = (p - y)/n (the renormalisation is the identity on a softmax output).
+__global__ void __launch_bounds__(LB) k_loss_det_cls(const float* y_true, const float* p, int n_rois, int C, float* loss, float* g_logit, int ldg) {
+    __shared__ double scratch[LB / 64];
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < n_rois; r += LB) {
+        float sum = 0.0f;
+        for (int c = 0; c < C; ++c) sum += p[(size_t)r * C + c];
+        double l = 0.0;
+        bool true_clipped = false;
+        for (int c = 0; c < C; ++c) {
+            const float y = y_true[(size_t)r * C + c];
+            if (y != 0.0f) {
+                const float q = p[(size_t)r * C + c] / sum;
+                true_clipped |= q < KERAS_EPS || q > 1.0f - KERAS_EPS;
+                l -= (double)(y * logf(fminf(fmaxf(q, KERAS_EPS), 1.0f - KERAS_EPS)));
+            }
+        }
+        acc += l;
+        if (g_logit)
+            for (int c = 0; c < C; ++c)
+                g_logit[(size_t)r * ldg + c] = true_clipped ? 0.0f : (p[(size_t)r * C + c] - y_true[(size_t)r * C + c]) / (float)n_rois;
+    }
+    const double t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) *loss = (float)(t / (double)n_rois);
+}
+
+// bbreg_loss_det (loss_functions.py:51-67).  y_true [n][8K] = [mask(4K) | target(4K)], pred [n][4K].
+__global__ void __launch_bounds__(LB) k_loss_det_reg(const float* y_true, const float* pred, int n_rois, int K4, float* loss, float* g_pred, int ldg) {
+    __shared__ double scratch[LB / 64];
+    double num = 0.0, den = 0.0;
+    const int n = n_rois * K4;
+    for (int i = threadIdx.x; i < n; i += LB) {
+        const int r = i / K4, k = i % K4;
+        const float m = y_true[(size_t)r * 2 * K4 + k];
+        num += (double)(m * smooth_l1(y_true[(size_t)r * 2 * K4 + K4 + k] - pred[i]));
+        den += (double)(1e-4f + m);
+    }
+    const double Num = block_sum(num, scratch);
+    const double Den = block_sum(den, scratch);
+    if (threadIdx.x == 0) *loss = (float)(Num / Den);
+    if (g_pred) {
+        const float inv = (float)(1.0 / Den);
+        for (int i = threadIdx.x; i < n; i += LB) {
+            const int r = i / K4, k = i % K4;
+            const float m = y_true[(size_t)r * 2 * K4 + k];
+            g_pred[(size_t)r * ldg + k] = -m * inv * smooth_l1_grad(y_true[(size_t)r * 2 * K4 + K4 + k] - pred[i]);
+        }
+    }
+}
+
+// g *= (y > 0)   (ReLU backward where no conv epilogue can fuse it, e.g. after the RoI-crop scatter)
+__global__ void k_relu_bwd(float4* g, const float4* y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = g[i]; const float4 b = y[i];
+        a.x = b.x > 0.0f ? a.x : 0.0f; a.y = b.y > 0.0f ? a.y : 0.0f; a.z = b.z > 0.0f ? a.z : 0.0f; a.w = b.w > 0.0f ? a.w : 0.0f;
+        g[i] = a;
+    }
+}
+
+// AveragePooling2D(k) over a k x k map followed by nothing: gx[n][h][w][c] = (y[n][h][w][c] > 0) * gp[n][c] / k^2
+__global__ void k_avgpool_bwd_masked(const float4* gp, const float4* y, int hw, int C4, size_t total4, float inv, float4* gx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const size_t n = i / ((size_t)hw * C4);
+        const float4 g = gp[n * C4 + c], b = y[i];
+        gx[i] = make_float4(b.x > 0.0f ? g.x * inv : 0.0f, b.y > 0.0f ? g.y * inv : 0.0f, b.z > 0.0f ? g.z * inv : 0.0f, b.w > 0.0f ? g.w * inv : 0.0f);
+    }
+}
+
+// Keras SGD(momentum, nesterov=False):  g += 2*l2*w;  v = momentum*v - lr*g;  w += v
+__global__ void k_sgd_momentum(float* w, const float* g, float* v, size_t n, float lr, float momentum, float l2, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale + 2.0f * l2 * w[i];
+        const float vi = momentum * v[i] - lr * gi;
+        v[i] = vi;
+        w[i] += vi;
+    }
+}
+
+// Keras Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m/(sqrt(v)+eps)
+__global__ void k_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, float l2, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale + 2.0f * l2 * w[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// out = sum(w^2) (one workgroup, f64 accumulate): the L2 penalty value l2 * sum(w^2) of Keras' regularizers
+__global__ void __launch_bounds__(LB) k_sumsq(const float* w, size_t n, float* out) {
+    __shared__ double scratch[LB / 64];
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += LB) acc += (double)w[i] * (double)w[i];
+    const double t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) *out = (float)t;
+}
+
+// shift[n] = bias[n]*scale[n] + shift_const[n]: re-fold a TRAINABLE conv bias into the frozen BatchNorm epilogue
+__global__ void k_fold_bias(const float* bias, const float* scale, const float* shift_const, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bias ? bias[i] : 0.0f) * (scale ? scale[i] : 1.0f) + (shift_const ? shift_const[i] : 0.0f);
+}
+
+static inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" {
+
+int frcnn_loss_rpn_cls(const float* y_true, const float* y_pred, int cells, int A, float* loss, float* grad_logit, void* stream) {
+    if (!y_true || !y_pred || !loss || cells <= 0 || A <= 0) return fail(FRCNN_E_ARG, "loss_rpn_cls: bad argument");
+    k_loss_rpn_cls<<<1, LB, 0, as_stream(stream)>>>(y_true, y_pred, cells, A, loss, grad_logit);
+    return check_launch("loss_rpn_cls");
+}
+int frcnn_loss_rpn_reg(const float* y_true, const float* y_pred, int cells, int A, float* loss, float* grad_pred, void* stream) {
+    if (!y_true || !y_pred || !loss || cells <= 0 || A <= 0) return fail(FRCNN_E_ARG, "loss_rpn_reg: bad argument");
+    k_loss_rpn_reg<<<1, LB, 0, as_stream(stream)>>>(y_true, y_pred, cells, 4 * A, loss, grad_pred);
+    return check_launch("loss_rpn_reg");
+}
+int frcnn_loss_det_cls(const float* y_true, const float* y_pred, int n_rois, int C, float* loss, float* grad_logit, int ldg, void* stream) {
+    if (!y_true || !y_pred || !loss || n_rois <= 0 || C <= 1 || (grad_logit && ldg < C)) return fail(FRCNN_E_ARG, "loss_det_cls: bad argument");
+    k_loss_det_cls<<<1, LB, 0, as_stream(stream)>>>(y_true, y_pred, n_rois, C, loss, grad_logit, ldg);
+    return check_launch("loss_det_cls");
+}
+int frcnn_loss_det_reg(const float* y_true, const float* y_pred, int n_rois, int num_classes_excl_bg, float* loss, float* grad_pred, int ldg, void* stream) {
+    if (!y_true || !y_pred || !loss || n_rois <= 0 || num_classes_excl_bg <= 0 || (grad_pred && ldg < 4 * num_classes_excl_bg)) return fail(FRCNN_E_ARG, "loss_det_reg: bad argument");
+    k_loss_det_reg<<<1, LB, 0, as_stream(stream)>>>(y_true, y_pred, n_rois, 4 * num_classes_excl_bg, loss, grad_pred, ldg);
+    return check_launch("loss_det_reg");
+}
+int frcnn_relu_bwd_inplace(float* g, const float* y, size_t n, void* stream) {
+    if (!g || !y || (n & 3)) return fail(FRCNN_E_ARG, "relu_bwd_inplace: bad argument (n must be a multiple of 4)");
+    if (n == 0) return FRCNN_OK;
+    k_relu_bwd<<<ew_grid(n / 4), 256, 0, as_stream(stream)>>>((float4*)g, (const float4*)y, n / 4);
+    return check_launch("relu_bwd_inplace");
+}
+int frcnn_avgpool_bwd_masked(const float* g_pooled, const float* y, int n, int k, int c, float* gx, void* stream) {
+    if (!g_pooled || !y || !gx || n <= 0 || k <= 0 || c <= 0 || (c & 3)) return fail(FRCNN_E_ARG, "avgpool_bwd_masked: bad argument");
+    const size_t total4 = (size_t)n * k * k * (c / 4);
+    k_avgpool_bwd_masked<<<ew_grid(total4), 256, 0, as_stream(stream)>>>((const float4*)g_pooled, (const float4*)y, k * k, c / 4, total4, 1.0f / (float)(k * k), (float4*)gx);
+    return check_launch("avgpool_bwd_masked");
+}
+int frcnn_sgd_momentum(float* w, const float* g, float* v, size_t n, float lr, float momentum, float l2, float grad_scale, void* stream) {
+    if (!w || !g || !v) return fail(FRCNN_E_ARG, "sgd_momentum: null pointer");
+    if (n == 0) return FRCNN_OK;
+    k_sgd_momentum<<<ew_grid(n), 256, 0, as_stream(stream)>>>(w, g, v, n, lr, momentum, l2, grad_scale);
+    return check_launch("sgd_momentum");
+}
+int frcnn_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int t, float l2, float grad_scale, void* stream) {
+    if (!w || !g || !m || !v || t < 1) return fail(FRCNN_E_ARG, "adam: bad argument");
+    if (n == 0) return FRCNN_OK;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+    k_adam<<<ew_grid(n), 256, 0, as_stream(stream)>>>(w, g, m, v, n, (float)lr_t, beta1, beta2, eps, l2, grad_scale);
+    return check_launch("adam");
+}
+int frcnn_fold_bias(const float* bias, const float* scale, const float* shift_const, float* out, int n, void* stream) {
+    if (!out || n <= 0) return fail(FRCNN_E_ARG, "fold_bias: bad argument");
+    k_fold_bias<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(bias, scale, shift_const, out, n);
+    return check_launch("fold_bias");
+}
+int frcnn_sumsq(const float* w, size_t n, float* out, void* stream) {
+    if (!w || !out) return fail(FRCNN_E_ARG, "sumsq: null pointer");
+    k_sumsq<<<1, LB, 0, as_stream(stream)>>>(w, n, out);
+    return check_launch("sumsq");
+}
+
+}  // extern "C"

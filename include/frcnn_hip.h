@@ -213,6 +213,36 @@ int frcnn_detections(const float* rois, const int32_t* n_rois, int max_rows, con
                      int num_classes, int bg_idx, float det_threshold, double stride, double resize_ratio, double nms_thresh,
                      int32_t* det_cls, float* det_prob, int32_t* det_bbox, int32_t* det_roi, int32_t* n_dets, void* stream);
 
+/* ------------------------------------------------------------------ training: losses, optimisers */
+/* The reference's four Keras loss functions (loss_functions.py:15-76) as Keras 2.0.8 evaluates them
+ * inside train_on_batch (train_util.py:54, 118): value into *loss (device f32) and, when the grad
+ * pointer is not NULL, the gradient of that loss w.r.t. the network output it is fed with.
+ *   rpn_cls: y_true [cells][2A] f32 = [can_use | is_pos], y_pred [cells][A] sigmoid outputs;
+ *            grad is w.r.t. the PRE-sigmoid logits.  loss = sum(sel*BCE)/256 (:24).
+ *   rpn_reg: y_true [cells][8A] = [mask | targets], y_pred [cells][4A];
+ *            loss = mean(mask)*10*S/2400 with S over ALL anchors (the reference's quirk, :44).
+ *   det_cls: y_true/y_pred [n][C]; grad w.r.t. the PRE-softmax logits, written with row stride ldg (:76).
+ *   det_reg: y_true [n][8K] = [mask | targets], y_pred [n][4K], K = classes excl. background (:65). */
+int frcnn_loss_rpn_cls(const float* y_true, const float* y_pred, int cells, int A, float* loss, float* grad_logit, void* stream);
+int frcnn_loss_rpn_reg(const float* y_true, const float* y_pred, int cells, int A, float* loss, float* grad_pred, void* stream);
+int frcnn_loss_det_cls(const float* y_true, const float* y_pred, int n_rois, int C, float* loss, float* grad_logit, int ldg, void* stream);
+int frcnn_loss_det_reg(const float* y_true, const float* y_pred, int n_rois, int num_classes_excl_bg, float* loss, float* grad_pred, int ldg, void* stream);
+/* g *= (y > 0): ReLU backward where no conv epilogue can carry it.  n % 4 == 0. */
+int frcnn_relu_bwd_inplace(float* g, const float* y, size_t n, void* stream);
+/* Backward of AveragePooling2D(k) on a k x k map (resnet.py:515) fused with the ReLU in front of it:
+ * gx[n][k][k][c] = (y > 0) * g_pooled[n][c] / k^2. */
+int frcnn_avgpool_bwd_masked(const float* g_pooled, const float* y, int n, int k, int c, float* gx, void* stream);
+/* Keras optimisers (args_util.py:48-59) over a flat parameter buffer; l2 = the regulariser factor of
+ * resnet.py:26-27 (its gradient 2*l2*w is added here), grad_scale = 1/world_size after an all-reduce sum. */
+int frcnn_sgd_momentum(float* w, const float* g, float* v, size_t n, float lr, float momentum, float l2, float grad_scale, void* stream);
+int frcnn_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int t,
+               float l2, float grad_scale, void* stream);
+/* Epilogue shift of a layer whose conv bias trains while its BatchNorm is frozen (resnet.py:150-153):
+ * out[c] = bias[c]*scale[c] + shift_const[c] (NULL bias = 0, NULL scale = 1, NULL shift_const = 0). */
+int frcnn_fold_bias(const float* bias, const float* scale, const float* shift_const, float* out, int n, void* stream);
+/* *out = sum(w^2): the value of the l2 regularisation term is l2 * that. */
+int frcnn_sumsq(const float* w, size_t n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

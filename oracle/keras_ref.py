@@ -46,10 +46,40 @@ def roi_resize(feat, rois, pool=7):
     return out
 
 
+def roi_resize_torch(feat, rois, pool=7):
+    """roi_resize on a torch tensor (R,C,Cf), differentiable w.r.t. feat; same tap/lerp arithmetic."""
+    torch = _torch()
+    outs = []
+    for roi in np.asarray(rois):
+        x1, y1, x2, y2 = (int(v) for v in roi)
+        crop = feat[y1:y2, x1:x2, :]
+        h, w = crop.shape[:2]
+        sy, sx = f32(h) / f32(pool), f32(w) / f32(pool)
+        ys = [f32(i) * sy for i in range(pool)]
+        xs = [f32(i) * sx for i in range(pool)]
+        ylo = [int(v) for v in ys]; xlo = [int(v) for v in xs]
+        yhi = [min(v + 1, h - 1) for v in ylo]; xhi = [min(v + 1, w - 1) for v in xlo]
+        ty = torch.tensor([float(f32(a - f32(b))) for a, b in zip(ys, ylo)], dtype=feat.dtype).view(pool, 1, 1)
+        tx = torch.tensor([float(f32(a - f32(b))) for a, b in zip(xs, xlo)], dtype=feat.dtype).view(1, pool, 1)
+        tl = crop[ylo][:, xlo]; tr = crop[ylo][:, xhi]; bl = crop[yhi][:, xlo]; br = crop[yhi][:, xhi]
+        top = tl + (tr - tl) * tx
+        bot = bl + (br - bl) * tx
+        outs.append(top + (bot - top) * ty)
+    return torch.stack(outs)
+
+
 # --------------------------------------------------------------------------- conv / BN / pool
 def _torch():
     import torch
     return torch
+
+
+def _t(a, dtype):
+    """array or tensor -> tensor of dtype (tensors keep their autograd history)."""
+    torch = _torch()
+    if isinstance(a, torch.Tensor):
+        return a.to(dtype)
+    return torch.as_tensor(np.asarray(a)).to(dtype)
 
 
 def same_pad(size, k, stride):
@@ -66,13 +96,13 @@ def conv2d(x, w_hwio, bias=None, stride=1, padding="valid", dtype=None):
     torch = _torch()
     import torch.nn.functional as F
     dtype = dtype or torch.float32
-    x = torch.as_tensor(np.asarray(x)).to(dtype).permute(0, 3, 1, 2)
-    w = torch.as_tensor(np.asarray(w_hwio)).to(dtype).permute(3, 2, 0, 1)
+    x = _t(x, dtype).permute(0, 3, 1, 2)
+    w = _t(w_hwio, dtype).permute(3, 2, 0, 1)
     if padding == "same":
         _, pt, pb = same_pad(x.shape[2], w.shape[2], stride)
         _, pl, pr = same_pad(x.shape[3], w.shape[3], stride)
         x = F.pad(x, (pl, pr, pt, pb))
-    b = None if bias is None else torch.as_tensor(np.asarray(bias)).to(dtype)
+    b = None if bias is None else _t(bias, dtype)
     y = F.conv2d(x, w, b, stride=stride)
     return y.permute(0, 2, 3, 1).contiguous()
 
@@ -81,7 +111,7 @@ def batchnorm_inference(x, gamma, beta, mean, var, eps):
     """BatchNormalization(training=False) [3P tf.nn.batch_normalization]:
     inv = rsqrt(var+eps)*gamma; y = x*inv + (beta - mean*inv)."""
     torch = _torch()
-    g, b, m, v = (torch.as_tensor(np.asarray(t)).to(x.dtype) for t in (gamma, beta, mean, var))
+    g, b, m, v = (_t(t, x.dtype) for t in (gamma, beta, mean, var))
     inv = torch.rsqrt(v + eps) * g
     return x * inv + (b - m * inv)
 
@@ -116,7 +146,7 @@ class KerasGraphs:
     def scale(self, x, name):
         """custom_layers.Scale.call (custom_layers.py:121-129): gamma * x + beta."""
         torch = _torch()
-        g, b = (torch.as_tensor(np.asarray(t)).to(x.dtype) for t in self.w[name])
+        g, b = (_t(t, x.dtype) for t in self.w[name])
         return g * x + b
 
     def conv_bn(self, x, stage, block, suffix, stride=1, padding="valid", separate_scale=False):
@@ -182,8 +212,21 @@ class KerasGraphs:
 
     def _dense(self, x, name):
         torch = _torch()
-        k, b = (torch.as_tensor(np.asarray(t)).to(x.dtype) for t in self.w[name])
+        k, b = (_t(t, x.dtype) for t in self.w[name])
         return x @ k + b
+
+    def resnet_classifier_logits(self, feat, rois, num_classes, depth=50):
+        """Differentiable form of resnet_classifier (torch RoI resize): returns (softmax probs, reg)."""
+        torch = _torch()
+        r101 = depth == 101
+        x = roi_resize_torch(feat[0], rois, 7)
+        x = self.conv_block(x, 5, "a", stride=1, separate_scale=r101)
+        x = self.identity_block(x, 5, "b", separate_scale=r101)
+        x = self.identity_block(x, 5, "c", separate_scale=r101)
+        x = pool2d(x, 7, 7, False).reshape(x.shape[0], -1)
+        cls = torch.softmax(self._dense(x, "dense_class_%d" % num_classes), dim=1)
+        reg = self._dense(x, "dense_reg_%d" % num_classes)
+        return cls, reg
 
     def resnet_classifier(self, feat, rois, num_classes, depth=50):
         """resnet50_classifier (resnet.py:489-548): RoiResizeConv, stage 5 with strides (1,1)

@@ -1,0 +1,110 @@
+"""GPU parity of one/two training steps (RPN step 1, detector step 2) vs the torch-autograd
+restatement of Keras' compile + train_on_batch.  Weight UPDATES (new - old) are compared, scaled
+by the largest update of the tensor: <= 2e-3 (f32 gradient sums over thousands of pixels vs f64)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def image(h, w, seed=0):
+    rs = np.random.RandomState(seed)
+    return (rs.randint(0, 256, (h, w, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]
+
+
+def check_updates(old, got, want, names, tol=2e-3):
+    worst = 0.0
+    for n in names:
+        for o, g, w in zip(old[n], got[n], want[n]):
+            dg, dw = np.asarray(g, np.float64) - o, np.asarray(w, np.float64) - o
+            scale = max(np.abs(dw).max(), 1e-12)
+            worst = max(worst, np.abs(dg - dw).max() / scale)
+            assert np.abs(dw).max() > 0, n
+    assert worst < tol, worst
+    return worst
+
+
+def rpn_targets(rows, cols, A, seed=1):
+    rs = np.random.RandomState(seed)
+    can_use = rs.rand(1, rows, cols, A) < 0.25
+    is_pos = rs.rand(1, rows, cols, A) < 0.15
+    y_class = np.concatenate([can_use, is_pos], axis=3)
+    sel = np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32)
+    tg = (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)
+    return y_class, np.concatenate([sel, tg], axis=3)
+
+
+@pytest.mark.parametrize("opt_kind", ["sgd", "adam"])
+def test_rpn_train_steps(opt_kind):
+    from faster_rcnn_amd import resnet, train
+    from faster_rcnn_amd.weights import synthetic_resnet
+    from oracle import keras_train_ref as kt
+    A = 9
+    w0 = synthetic_resnet(50, anchors_per_loc=A, seed=7)
+    old = {k: [np.array(a, dtype=np.float64) for a in v] for k, v in w0.items()}
+    x = image(112, 144)
+    rows, cols = resnet.get_conv_rows_cols(112, 144)
+    y_class, y_bbreg = rpn_targets(rows, cols, A)
+    base = resnet.resnet50_base(weights={k: [a.copy() for a in v] for k, v in w0.items()},
+                                weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
+    rpn = resnet.resnet50_rpn(base, anchors_per_loc=A)
+    tr = train.RpnTrainer(rpn, l2=1e-4)
+    lr = 1e-3
+    opt = train.SGD(lr=lr, momentum=0.9) if opt_kind == "sgd" else train.Adam(lr=lr)
+    tr.compile(opt)
+    ref_opt = kt.Optim(opt_kind, lr)
+    ref_w = w0
+    names = kt.conv_layer_names(50, [4]) + ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"]
+    for step in range(2):                      # the second step exercises momentum / Adam slots and the re-packing
+        losses = tr.train_on_batch(x, [y_class, y_bbreg])
+        ref_w, ref_losses, _ = kt.rpn_train_step(ref_w, x, y_class, y_bbreg, A, ref_opt, l2=1e-4)
+        for a, b in zip(losses, ref_losses):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (step, losses, ref_losses)
+    tr.sync_weights()
+    check_updates(old, rpn.weights, ref_w, names)
+    # frozen layers untouched
+    assert np.array_equal(rpn.weights["res3a_branch2a"][0], w0["res3a_branch2a"][0])
+    # the model's inference path now runs on the trained weights
+    cls, reg = rpn.predict_on_batch(x)[:2]
+    from oracle.keras_ref import KerasGraphs
+    g = KerasGraphs(ref_w, torch.float64)
+    c64, r64 = g.rpn(g.resnet_base(x, 50))
+    assert float((torch.as_tensor(reg).double() - r64).abs().max()) < 1e-3
+
+
+def test_det_train_step():
+    from faster_rcnn_amd import resnet, train
+    from faster_rcnn_amd.weights import synthetic_resnet
+    from oracle import keras_train_ref as kt
+    C = 21
+    w0 = synthetic_resnet(50, num_classes=C, seed=9)
+    old = {k: [np.array(a, dtype=np.float64) for a in v] for k, v in w0.items()}
+    x = image(112, 144, seed=2)
+    rows, cols = resnet.get_conv_rows_cols(112, 144)
+    rs = np.random.RandomState(4)
+    n = 16
+    x1 = rs.randint(0, cols - 2, n); y1 = rs.randint(0, rows - 2, n)
+    rois = np.stack([x1, y1, np.minimum(cols - 1, x1 + 1 + rs.randint(0, 6, n)), np.minimum(rows - 1, y1 + 1 + rs.randint(0, 5, n))], axis=1).astype(np.float32)[None]
+    cls_idx = rs.randint(0, C, n)
+    y_class = np.zeros((1, n, C), np.int32); y_class[0, np.arange(n), cls_idx] = 1
+    labels = np.zeros((n, 4 * (C - 1)), np.float32); targs = np.zeros((n, 4 * (C - 1)), np.float32)
+    for i, c in enumerate(cls_idx):
+        if c < C - 1:
+            labels[i, 4 * c:4 * c + 4] = 1
+            targs[i, 4 * c:4 * c + 4] = rs.randn(4) * 2
+    y_bbreg = np.concatenate([labels, targs], axis=1)[None]
+    base = resnet.resnet50_base(weights={k: [a.copy() for a in v] for k, v in w0.items()})
+    det = resnet.resnet50_classifier(n, C, base_model=base)
+    tr = train.DetTrainer(det, l2=1e-4)
+    tr.compile(train.SGD(lr=1e-3, momentum=0.9))
+    ref_opt = kt.Optim("sgd", 1e-3)
+    ref_w = w0
+    for step in range(2):
+        losses = tr.train_on_batch([x, rois], [y_class, y_bbreg])
+        ref_w, ref_losses, _ = kt.det_train_step(ref_w, x, rois, y_class, y_bbreg, C, ref_opt, l2=1e-4)
+        for a, b in zip(losses, ref_losses):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (step, losses, ref_losses)
+    tr.sync_weights()
+    names = kt.conv_layer_names(50, [4, 5]) + ["dense_class_%d" % C, "dense_reg_%d" % C]
+    check_updates(old, det.weights, ref_w, names)
