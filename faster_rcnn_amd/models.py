@@ -83,7 +83,31 @@ class RpnModel(_Model):
         cls, reg = self.head(feat)
         return cls, reg, feat
 
+    # ---- training (train_util.py:31-54)
+    def compile(self, optimizer, loss=None):
+        from .train import RpnTrainer
+        reg = self.base.weight_regularizer
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = RpnTrainer(self, l2=reg.l2 if reg is not None else 0.0)
+        self._trainer.compile(optimizer, loss)
+
+    def train_on_batch(self, x, y, skip=False):
+        self._dirty = True
+        return self._trainer.train_on_batch(x, y, skip=skip)
+
+    def _flush_trainer(self):
+        if getattr(self, "_trainer", None) is not None and getattr(self, "_dirty", False):
+            self._trainer.sync_weights()
+            self._dirty = False
+
+    def save_weights(self, path):
+        self._flush_trainer()
+        super().save_weights(path)
+
+    save = save_weights
+
     def predict_on_batch(self, x):
+        self._flush_trainer()
         cls, reg, feat = self.forward_dev(nets.to_device_image(x))
         outs = [cls.cpu().numpy(), reg.cpu().numpy()]
         if self.include_conv:
@@ -105,6 +129,24 @@ class DetModel(_Model):
     def forward_dev(self, first, rois):
         feat = self.base.net(first) if self.base is not None else first
         return self.head(feat, rois)
+
+    # ---- training (train_util.py:95-118)
+    def compile(self, optimizer, loss=None):
+        from .train import DetTrainer
+        reg = self.base.weight_regularizer if self.base is not None else None
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = DetTrainer(self, l2=reg.l2 if reg is not None else 0.0)
+        self._trainer.compile(optimizer, loss)
+
+    def train_on_batch(self, x, y, skip=False):
+        return self._trainer.train_on_batch(x, y, skip=skip)
+
+    def save_weights(self, path):
+        if getattr(self, "_trainer", None) is not None:
+            self._trainer.sync_weights()
+        super().save_weights(path)
+
+    save = save_weights
 
     def predict(self, inputs):
         first, rois = inputs

@@ -201,11 +201,8 @@ class TBlock:
 
 def _sync_grads(params):
     """Data-parallel exchange: ONE all-reduce (sum) of the flat gradient buffer over RCCL."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(params.g, op=dist.ReduceOp.SUM)
-        return 1.0 / dist.get_world_size()
-    return 1.0
+    from . import dp
+    return dp.allreduce_sum_(params.g)
 
 
 def _l2_of(weights, names):
