@@ -149,6 +149,7 @@ def test_training_loops_through_reference_surface(tmp_path):
     # step 2: detector on proposals from the (now frozen) step-1 RPN
     rpn_frozen = resnet.resnet50_rpn(resnet.resnet50_base(weights=saved), anchors_per_loc=9)
     dw = synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=12)
+    dw_before = dw["res5a_branch2a"][0].copy()
     det_base = resnet.resnet50_base(weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, weights=dw)
     det = resnet.resnet50_classifier(64, 21, det_base)
     dmgr = det_util.DetTrainingManager(rpn_frozen, VOC_CLASS_MAPPING, resnet.preprocess, anchor_dims=anchors)
@@ -156,4 +157,4 @@ def test_training_loops_through_reference_surface(tmp_path):
     train_util.train_detector_step2(det, imgs, dmgr, train.optimizer_from_str("sgd"), phases=[[3, 1e-3]], save_frequency=2, save_weights_dest=ddest)
     dsaved = load_npz(ddest)
     assert "dense_class_21" in dsaved and dsaved["dense_class_21"][0].shape == (2048, 21)
-    assert not np.array_equal(dsaved["res5a_branch2a"][0], dw["res5a_branch2a"][0])
+    assert not np.array_equal(dsaved["res5a_branch2a"][0], dw_before)
