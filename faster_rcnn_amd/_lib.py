@@ -60,7 +60,8 @@ SIGNATURES = {
     "frcnn_avgpool_bwd_masked": (I, [P, P, I, I, I, P, P]),
     "frcnn_sgd_momentum": (I, [P, P, P, c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, P]),
     "frcnn_adam": (I, [P, P, P, P, c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, I, ctypes.c_float, ctypes.c_float, P]),
-    "frcnn_sumsq": (I, [P, c_size_t, P, P]),
+    "frcnn_sumsq_workspace_bytes": (c_size_t, []),
+    "frcnn_sumsq": (I, [P, c_size_t, P, P, c_size_t, P]),
     "frcnn_fold_bias": (I, [P, P, P, P, I, P]),
     "frcnn_detections": (I, [P, P, I, P, P, I, I, ctypes.c_float, c_double, c_double, c_double, P, P, P, P, P, P]),
 }

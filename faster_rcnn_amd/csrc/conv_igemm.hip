@@ -520,19 +520,26 @@ __global__ void k_wgrad_reduce(const float* partial, int slices, size_t elems, i
     }
 }
 
-// dbias[co] = s[co] * sum_m G[m][co]: one workgroup per 64 columns, rows strided over 4 waves, fixed-order tree
-__global__ void __launch_bounds__(256) k_colsum(const float* g, int M, int Cout, const float* scale, float* out) {
+// dbias[co] = s[co] * sum_m G[m][co], two stages: (64 columns x 1 row slice) per workgroup into a
+// partial table, then a fixed-order sum over the slices (reproducible).
+constexpr int COLSUM_SLICES = 64;
+__global__ void __launch_bounds__(256) k_colsum_partial(const float* g, int M, int Cout, int rows_per_slice, float* partial) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int co = blockIdx.x * 64 + lane;
+    const int m0 = blockIdx.y * rows_per_slice, m1 = min(M, m0 + rows_per_slice);
     float v = 0.0f;
-    if (co < Cout) for (int m = wave; m < M; m += 4) v += g[(size_t)m * Cout + co];
+    if (co < Cout) for (int m = m0 + wave; m < m1; m += 4) v += g[(size_t)m * Cout + co];
     part[wave][lane] = v;
     __syncthreads();
-    if (wave == 0 && co < Cout) {
-        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        out[co] = scale ? t * scale[co] : t;
-    }
+    if (wave == 0 && co < Cout) partial[(size_t)blockIdx.y * Cout + co] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+__global__ void k_colsum_final(const float* partial, int slices, int Cout, const float* scale, float* out) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= Cout) return;
+    float t = 0.0f;
+    for (int sidx = 0; sidx < slices; ++sidx) t += partial[(size_t)sidx * Cout + co];
+    out[co] = scale ? t * scale[co] : t;
 }
 
 // ------------------------------------------------------------------------------------
@@ -709,7 +716,9 @@ static int wgrad_slices(const frcnn_conv_desc* d) {
 
 size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d) {
     if (!d) return 0;
-    return align_up((size_t)wgrad_slices(d) * d->kh * d->kw * d->cin * d->cout * sizeof(float), 256);
+    const size_t dw = (size_t)wgrad_slices(d) * d->kh * d->kw * d->cin * d->cout * sizeof(float);
+    const size_t db = (size_t)COLSUM_SLICES * d->cout * sizeof(float);
+    return align_up(dw > db ? dw : db, 256);
 }
 
 int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g, const float* scale,
@@ -734,8 +743,14 @@ int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g,
     if (rgrid > 4096) rgrid = 4096;
     k_wgrad_reduce<<<rgrid, 256, 0, s>>>((const float*)workspace, slices, elems, d->cout, scale, dw_hwio);
     if (int e = check_launch("conv2d_wgrad reduce")) return e;
-    if (dbias) {
-        k_colsum<<<(d->cout + 63) / 64, 256, 0, s>>>(g, a.M, d->cout, scale, dbias);
+    if (dbias) {                                   // the slab workspace is free again after the reduce (stream order)
+        int cs = (a.M + 63) / 64;
+        if (cs > COLSUM_SLICES) cs = COLSUM_SLICES;
+        if (cs < 1) cs = 1;
+        const int rows_per_slice = (a.M + cs - 1) / cs;
+        k_colsum_partial<<<dim3((d->cout + 63) / 64, cs), 256, 0, s>>>(g, a.M, d->cout, rows_per_slice, (float*)workspace);
+        if (int e = check_launch("conv2d_wgrad bias")) return e;
+        k_colsum_final<<<(d->cout + 255) / 256, 256, 0, s>>>((const float*)workspace, cs, d->cout, scale, dbias);
         if (int e = check_launch("conv2d_wgrad bias")) return e;
     }
     return FRCNN_OK;

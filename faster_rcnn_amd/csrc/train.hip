@@ -167,13 +167,21 @@ __global__ void k_adam(float* w, const float* g, float* m, float* v, size_t n, f
     }
 }
 
-// out = sum(w^2) (one workgroup, f64 accumulate): the L2 penalty value l2 * sum(w^2) of Keras' regularizers
-__global__ void __launch_bounds__(LB) k_sumsq(const float* w, size_t n, float* out) {
-    __shared__ double scratch[LB / 64];
+// out = sum(w^2): 256 workgroups write f64 partials, one wave adds them in a fixed order (reproducible).
+// The L2 penalty value l2 * sum(w^2) of Keras' regularizers.
+constexpr int SUMSQ_BLOCKS = 256;
+__global__ void __launch_bounds__(256) k_sumsq_partial(const float* w, size_t n, double* partial) {
+    __shared__ double scratch[4];
     double acc = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += LB) acc += (double)w[i] * (double)w[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)SUMSQ_BLOCKS * 256) acc += (double)w[i] * (double)w[i];
     const double t = block_sum(acc, scratch);
-    if (threadIdx.x == 0) *out = (float)t;
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(64) k_sumsq_final(const double* partial, float* out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < SUMSQ_BLOCKS; i += 64) acc += partial[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (threadIdx.x == 0) *out = (float)acc;
 }
 
 // shift[n] = bias[n]*scale[n] + shift_const[n]: re-fold a TRAINABLE conv bias into the frozen BatchNorm epilogue
@@ -240,9 +248,13 @@ int frcnn_fold_bias(const float* bias, const float* scale, const float* shift_co
     k_fold_bias<<<(n + 255) / 256, 256, 0, as_stream(stream)>>>(bias, scale, shift_const, out, n);
     return check_launch("fold_bias");
 }
-int frcnn_sumsq(const float* w, size_t n, float* out, void* stream) {
+size_t frcnn_sumsq_workspace_bytes(void) { return SUMSQ_BLOCKS * sizeof(double); }
+int frcnn_sumsq(const float* w, size_t n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!w || !out) return fail(FRCNN_E_ARG, "sumsq: null pointer");
-    k_sumsq<<<1, LB, 0, as_stream(stream)>>>(w, n, out);
+    if (!workspace || workspace_bytes < frcnn_sumsq_workspace_bytes()) return fail(FRCNN_E_WORKSPACE, "sumsq: workspace needs %zu bytes", frcnn_sumsq_workspace_bytes());
+    k_sumsq_partial<<<SUMSQ_BLOCKS, 256, 0, as_stream(stream)>>>(w, n, (double*)workspace);
+    if (int e = check_launch("sumsq")) return e;
+    k_sumsq_final<<<1, 64, 0, as_stream(stream)>>>((const double*)workspace, out);
     return check_launch("sumsq");
 }
 

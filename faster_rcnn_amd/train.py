@@ -77,7 +77,8 @@ class ParamSet:
 
     def sumsq(self):
         out = torch.empty(1, dtype=torch.float32, device="cuda")
-        _lib.call("frcnn_sumsq", _p(self.w), self.total, _p(out), _stream())
+        ws = ops._ws(_lib.load().frcnn_sumsq_workspace_bytes())
+        _lib.call("frcnn_sumsq", _p(self.w), self.total, _p(out), _p(ws), ws.numel(), _stream())
         return out
 
     def export(self, weights):

@@ -241,7 +241,8 @@ int frcnn_adam(float* w, const float* g, float* m, float* v, size_t n, float lr,
  * out[c] = bias[c]*scale[c] + shift_const[c] (NULL bias = 0, NULL scale = 1, NULL shift_const = 0). */
 int frcnn_fold_bias(const float* bias, const float* scale, const float* shift_const, float* out, int n, void* stream);
 /* *out = sum(w^2): the value of the l2 regularisation term is l2 * that. */
-int frcnn_sumsq(const float* w, size_t n, float* out, void* stream);
+size_t frcnn_sumsq_workspace_bytes(void);
+int frcnn_sumsq(const float* w, size_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
