@@ -63,6 +63,12 @@ SIGNATURES = {
     "frcnn_sumsq_workspace_bytes": (c_size_t, []),
     "frcnn_sumsq": (I, [P, c_size_t, P, P, c_size_t, P]),
     "frcnn_fold_bias": (I, [P, P, P, P, I, P]),
+    "frcnn_conv_packed_k_bf16": (I, [I, I, I]),
+    "frcnn_pack_conv_weights_bf16": (I, [P, I, I, I, I, P, P]),
+    "frcnn_conv2d_fwd_bf16": (I, [P, P, P, P, P, P, P, I, P]),
+    "frcnn_cast_f32_to_bf16": (I, [P, c_size_t, P, P]),
+    "frcnn_avgpool_bf16_to_f32": (I, [P, I, I, I, P, P]),
+    "frcnn_roi_crop_resize_fwd_bf16": (I, [P, I, I, I, P, I, I, P, P]),
     "frcnn_detections": (I, [P, P, I, P, P, I, I, ctypes.c_float, c_double, c_double, c_double, P, P, P, P, P, P]),
 }
 

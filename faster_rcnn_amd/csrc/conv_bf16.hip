@@ -1,0 +1,332 @@
+// bf16 convolution path (BASELINE configs[3]: ResNet-101, 600x1500, "bf16 conv + fp32 NMS") for gfx950.
+//
+// Same implicit-GEMM structure as conv_igemm.hip's v2 kernel -- NHWC activations, filters packed
+// [Cout][Kpad] with k = [channel chunk][tap][channel], SRD buffer loads with out-of-range -> 0 for the
+// halo and the tile tails, two-deep global->register->LDS operand pipeline, XCD-aware tile map, fused
+// scale/shift/residual/activation epilogue -- with bf16 operands on v_mfma_f32_32x32x16_bf16 (f32
+// accumulate, 16x the f32-input MFMA rate):
+//   * a k-chunk is 64 channels = 128 B per row, so the 16-byte staging pattern (8 lanes per row, 32 rows
+//     per pass) and the 144-byte padded LDS rows are IDENTICAL to the f32 kernel;
+//   * lane (i, h) feeds MFMA k-step s with the 8 bf16 at byte offset 32*s + 16*h of row i
+//     (A[i][8h+j], B[8h+j][i], cdna guide s3) -- one ds_read_b128 per operand tile per MFMA;
+//   * activations stay bf16 in HBM between layers (half the bytes); the epilogue rounds once (RNE,
+//     v_cvt_pk_bf16_f32) after the f32 scale/shift/residual/activation.
+// At these shapes the kernel is operand-bandwidth bound, not MFMA bound: a 128x128x64 step needs
+// 32 KB of operands for 16 MFMAs (512 cycles) per wave.
+#include "common.h"
+
+namespace frcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgsBf16 {
+    const __bf16* x; const __bf16* w; const float* scale; const float* shift; const __bf16* residual; void* y;
+    int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
+    int M, Kpad, act, out_f32;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BKH = 64;                 // channels per k-chunk (128 B)
+constexpr int LDS_STRIDE_B = 144;       // bytes per LDS row
+constexpr unsigned OOB_OFFSET_B = 0x80000000u;
+
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+
+__device__ __forceinline__ int xcd_remap_b(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+__device__ __forceinline__ float activate_b(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) return 1.0f / (1.0f + __expf(-v));
+    return v;
+}
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int PA = BM / 32, PB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    char* As = smem_b;                                   // [2][BM][144 B]
+    char* Bs = smem_b + 2 * BM * LDS_STRIDE_B;           // [2][BN][144 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap_b(blockIdx.x, nwg);
+    const int tile_n = logical / p.tiles_m, tile_m = logical - tile_n * p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(p.w), 0, (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000);
+
+    const int lrow = tid >> 3, lcolb = (tid & 7) * 16;         // byte column inside the 128-B chunk row
+    int a_h[PA], a_w[PA], a_off[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
+            a_h[i] = ho * p.stride - p.pad_top;
+            a_w[i] = wo * p.stride - p.pad_left;
+            a_off[i] = (((img * p.H + a_h[i]) * p.W + a_w[i]) * p.Cin) * 2 + lcolb;
+        } else {
+            a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
+        }
+    }
+    unsigned b_off[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        b_off[i] = n < p.Cout ? (unsigned)(n * p.Kpad * 2 + lcolb) : OOB_OFFSET_B;
+    }
+
+    i32x4 ra[PA], rb[PB];
+    int r_tap = 0, s_tap = 0, c0 = 0;
+    auto load_chunk = [&](int kc) {
+        const int tap_off = ((r_tap * p.W + s_tap) * p.Cin + c0) * 2;
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], kc * (BKH * 2), 0);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET_B, 0, 0);
+        }
+        const int ws = (s_tap + 1 == p.S);
+        const int wr = ws & (r_tap + 1 == p.R);
+        s_tap = (s_tap + 1) * (1 - ws);
+        r_tap = (r_tap + ws) * (1 - wr);
+        c0 += wr * BKH;
+    };
+    auto store_chunk = [&](int buf) {
+        char* a = As + buf * BM * LDS_STRIDE_B;
+        char* b = Bs + buf * BN * LDS_STRIDE_B;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + 32 * i) * LDS_STRIDE_B + lcolb) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + 32 * i) * LDS_STRIDE_B + lcolb) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.Kpad / BKH;
+    load_chunk(0);
+    store_chunk(0);
+    load_chunk(nk > 1 ? 1 : 0);
+    __syncthreads();
+
+    constexpr int MF = TM * TN;            // MFMAs per k-step (k = 16)
+    constexpr int NL = PA + PB;
+    constexpr int NF = TM + TN;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        store_chunk(buf ^ 1);
+        load_chunk(kc + 2 < nk ? kc + 2 : nk - 1);
+        const char* a = As + buf * BM * LDS_STRIDE_B + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
+        const char* b = Bs + buf * BN * LDS_STRIDE_B + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
+        bf16x8 fa[4][TM], fb[4][TN];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_STRIDE_B + s * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_STRIDE_B + s * 32);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+        // interleave: fragments for step s+1 and the staging traffic ride behind step s's MFMAs
+        SGB(SG_DS_RD, NF);
+#pragma unroll
+        for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_DS_WR, (NL + MF - 1) / MF); if (q < NF) SGB(SG_DS_RD, 1); }
+#pragma unroll
+        for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_VALU, 6); SGB(SG_VMEM_RD, (NL + MF - 1) / MF); if (q < NF) SGB(SG_DS_RD, 1); }
+#pragma unroll
+        for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); if (q < NF) SGB(SG_DS_RD, 1); }
+#pragma unroll
+        for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D map col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + li;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[n] : 1.0f;
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < p.M) {
+                    float v = acc[i][j][e] * sc + sh;
+                    if (p.residual) v += (float)p.residual[(size_t)m * p.Cout + n];
+                    v = activate_b(v, p.act);
+                    if (p.out_f32) reinterpret_cast<float*>(p.y)[(size_t)m * p.Cout + n] = v;
+                    else reinterpret_cast<__bf16*>(p.y)[(size_t)m * p.Cout + n] = (__bf16)v;
+                }
+            }
+        }
+    }
+}
+
+// f32 HWIO [R][S][Cin][Cout] -> bf16 packed [Cout][Kpad], k = ((c/64)*R*S + tap)*64 + c%64 (Cin % 64 == 0)
+__global__ void k_pack_hwio_bf16(const float* w, int RS, int Cin, int Cout, int Kpad, __bf16* out) {
+    const size_t total = (size_t)Cout * Kpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad), n = (int)(i / Kpad);
+        const int j = k % BKH, kc = k / BKH, tap = kc % RS, cc = kc / RS;
+        out[i] = (__bf16)w[((size_t)tap * Cin + cc * BKH + j) * Cout + n];
+    }
+}
+
+__global__ void k_cast_f32_bf16(const float4* x, size_t n4, __bf16* y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        __bf16* o = y + 4 * i;
+        o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    }
+}
+
+// AveragePooling2D(k) over a k x k bf16 map -> f32 [n][C] (f32 accumulate)
+__global__ void k_avgpool_bf16_f32(const __bf16* x, int n, int hw, int C, float* y) {
+    const size_t total = (size_t)n * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t img = i / C;
+        float acc = 0.0f;
+        for (int q = 0; q < hw; ++q) acc += (float)x[(img * hw + q) * C + c];
+        y[i] = acc / (float)hw;
+    }
+}
+
+// RoiResizeConv on a bf16 feature map (custom_layers.py:35-56): f32 lerp, bf16 output
+__global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int rows, int cols, int C, const float4* rois, int pool, __bf16* out) {
+    const int pix = blockIdx.x;
+    const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    const float4 roi = rois[r];
+    const int x1 = (int)roi.x, y1 = (int)roi.y, x2 = (int)roi.z, y2 = (int)roi.w;
+    const int h = y2 - y1, w = x2 - x1;
+    __bf16* o = out + (size_t)pix * C;
+    const bool ok = h > 0 && w > 0 && x1 >= 0 && y1 >= 0 && x2 <= cols && y2 <= rows;
+    if (!ok) { for (int c = threadIdx.x; c < C; c += blockDim.x) o[c] = (__bf16)0.0f; return; }
+    const float sy = (float)h / (float)pool, sx = (float)w / (float)pool;
+    const float fy = (float)py * sy, fx = (float)px * sx;
+    const int ly = (int)fy, lx = (int)fx;
+    const float ty = fy - (float)ly, tx = fx - (float)lx;
+    const int ylo = y1 + ly, yhi = y1 + min(ly + 1, h - 1), xlo = x1 + lx, xhi = x1 + min(lx + 1, w - 1);
+    const __bf16* tl = feat + ((size_t)ylo * cols + xlo) * C;
+    const __bf16* tr = feat + ((size_t)ylo * cols + xhi) * C;
+    const __bf16* bl = feat + ((size_t)yhi * cols + xlo) * C;
+    const __bf16* br = feat + ((size_t)yhi * cols + xhi) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float a = (float)tl[c], b = (float)tr[c], d = (float)bl[c], e = (float)br[c];
+        const float top = a + (b - a) * tx, bot = d + (e - d) * tx;
+        o[c] = (__bf16)(top + (bot - top) * ty);
+    }
+}
+
+template <int TM, int TN>
+static int launch_bf16(const ConvArgsBf16& a, hipStream_t s) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    ConvArgsBf16 p = a;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE_B;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS to %zu", lds);
+        attr_done = true;
+    }
+    k_conv_igemm_bf16<TM, TN><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    return check_launch("conv2d_fwd_bf16");
+}
+
+static inline int ew_grid_b(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" {
+
+int frcnn_conv_packed_k_bf16(int kh, int kw, int cin) { return kh * kw * cin; }
+
+int frcnn_pack_conv_weights_bf16(const float* w_hwio, int kh, int kw, int cin, int cout, void* packed_bf16, void* stream) {
+    if (!w_hwio || !packed_bf16 || kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return fail(FRCNN_E_ARG, "pack_conv_weights_bf16: bad argument");
+    if (cin % BKH) return fail(FRCNN_E_UNSUPPORTED, "pack_conv_weights_bf16: cin must be a multiple of 64");
+    const size_t total = (size_t)cout * kh * kw * cin;
+    k_pack_hwio_bf16<<<ew_grid_b(total), 256, 0, as_stream(stream)>>>(w_hwio, kh * kw, cin, cout, kh * kw * cin, (__bf16*)packed_bf16);
+    return check_launch("pack_conv_weights_bf16");
+}
+
+int frcnn_conv2d_fwd_bf16(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
+                          const float* scale, const float* shift, const void* residual_bf16, void* y, int y_is_f32, void* stream) {
+    if (!d || !x_bf16 || !w_packed_bf16 || !y) return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: null pointer");
+    if (d->cin % BKH) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_bf16: cin must be a multiple of 64");
+    if ((size_t)d->n * d->h * d->w * d->cin * 2 >= 0x7fffffffull || (size_t)d->cout * d->kh * d->kw * d->cin * 2 >= 0x7fffffffull)
+        return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_bf16: tensor exceeds the 2 GiB buffer-descriptor range");
+    ConvArgsBf16 a;
+    a.x = (const __bf16*)x_bf16; a.w = (const __bf16*)w_packed_bf16; a.scale = scale; a.shift = shift;
+    a.residual = (const __bf16*)residual_bf16; a.y = y;
+    a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
+    a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
+    a.M = d->n * d->ho * d->wo; a.Kpad = d->kh * d->kw * d->cin; a.act = d->act; a.out_f32 = y_is_f32;
+    a.tiles_m = a.tiles_n = 0;
+    hipStream_t s = as_stream(stream);
+    const long long t128 = ((long long)(a.M + 127) / 128) * ((d->cout + 127) / 128);
+    int cfg = d->tile;
+    if (cfg == 0) cfg = t128 >= 256 ? 1 : 2;
+    switch (cfg) {
+        case 1: case 11: return launch_bf16<2, 2>(a, s);
+        case 2: case 12: return launch_bf16<1, 1>(a, s);
+        case 3: case 13: return launch_bf16<2, 1>(a, s);
+        default: return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: unknown tile config %d", cfg);
+    }
+}
+
+int frcnn_cast_f32_to_bf16(const float* x, size_t n, void* y_bf16, void* stream) {
+    if (!x || !y_bf16 || (n & 3)) return fail(FRCNN_E_ARG, "cast_f32_to_bf16: bad argument (n must be a multiple of 4)");
+    if (n == 0) return FRCNN_OK;
+    k_cast_f32_bf16<<<ew_grid_b(n / 4), 256, 0, as_stream(stream)>>>((const float4*)x, n / 4, (__bf16*)y_bf16);
+    return check_launch("cast_f32_to_bf16");
+}
+
+int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y, void* stream) {
+    if (!x_bf16 || !y || n <= 0 || k <= 0 || c <= 0) return fail(FRCNN_E_ARG, "avgpool_bf16_to_f32: bad argument");
+    k_avgpool_bf16_f32<<<ew_grid_b((size_t)n * c), 256, 0, as_stream(stream)>>>((const __bf16*)x_bf16, n, k * k, c, y);
+    return check_launch("avgpool_bf16_to_f32");
+}
+
+int frcnn_roi_crop_resize_fwd_bf16(const void* feat_bf16, int rows, int cols, int C, const float* rois, int n, int pool, void* out_bf16, void* stream) {
+    if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16: bad shape");
+    if (n == 0) return FRCNN_OK;
+    if (!feat_bf16 || !rois || !out_bf16) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16: null pointer");
+    k_roi_fwd_bf16<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const __bf16*)feat_bf16, rows, cols, C, (const float4*)rois, pool, (__bf16*)out_bf16);
+    return check_launch("roi_crop_resize_fwd_bf16");
+}
+
+}  // extern "C"

@@ -72,7 +72,7 @@ class RpnModel(_Model):
     def __init__(self, base, include_conv, anchors_per_loc):
         super().__init__(base.weights)
         self.base, self.include_conv, self.anchors_per_loc = base, include_conv, anchors_per_loc
-        self.head = nets.RpnHead(base.weights)
+        self.head = nets.RpnHead(base.weights, getattr(base.net, "dtype", "f32"))
         self.output = ["rpn_out_cls", "rpn_out_bbreg"] + (["conv_out"] if include_conv else [])
 
     def _modules(self):
@@ -111,7 +111,7 @@ class RpnModel(_Model):
         cls, reg, feat = self.forward_dev(nets.to_device_image(x))
         outs = [cls.cpu().numpy(), reg.cpu().numpy()]
         if self.include_conv:
-            outs.append(feat.cpu().numpy())
+            outs.append(feat.float().cpu().numpy())
         return outs
 
 

@@ -20,9 +20,11 @@ BN_EPS_BLOCK = 1e-5     # resnet.py:148, 216, 280, 349
 class ConvUnit:
     """One fused conv launch and the Keras layers it stands for."""
 
-    def __init__(self, weights, conv, bn=None, scale=None, eps=BN_EPS_BLOCK, stride=1, padding="valid", act=None, tile=0):
+    def __init__(self, weights, conv, bn=None, scale=None, eps=BN_EPS_BLOCK, stride=1, padding="valid", act=None, tile=0,
+                 dtype="f32", out_f32=False):
         self.weights, self.conv, self.bn, self.scale_name, self.eps = weights, conv, bn, scale, eps
         self.stride, self.padding, self.act, self.tile = stride, padding, act, tile
+        self.dtype, self.out_f32 = dtype, out_f32           # "bf16": bf16 operands / activations (configs[3])
         self.pc = None
 
     def lower(self):
@@ -43,19 +45,22 @@ class ConvUnit:
             g2, b2 = (np.asarray(a, dtype=np.float64) for a in self.weights[self.scale_name])
             scale = scale * g2
             shift = shift * g2 + b2
-        self.pc = ops.PackedConv(kernel, scale.astype(np.float32), shift.astype(np.float32))
+        packer = ops.PackedConvBf16 if self.dtype == "bf16" else ops.PackedConv
+        self.pc = packer(kernel, scale.astype(np.float32), shift.astype(np.float32))
         return self
 
     def __call__(self, x, residual=None, out=None):
         if self.pc is None:
             self.lower()
+        if self.dtype == "bf16":
+            return ops.conv2d_bf16(x, self.pc, self.stride, self.padding, self.act, residual, self.out_f32, self.tile)
         return ops.conv2d(x, self.pc, self.stride, self.padding, self.act, residual, out, self.tile)
 
 
-def _block_units(weights, stage, block, has_shortcut, stride, separate_scale):
+def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dtype="f32"):
     def unit(suffix, **kw):
         tag = "%d%s_branch%s" % (stage, block, suffix)
-        return ConvUnit(weights, "res" + tag, "bn" + tag, ("scale" + tag) if separate_scale else None, BN_EPS_BLOCK, **kw)
+        return ConvUnit(weights, "res" + tag, "bn" + tag, ("scale" + tag) if separate_scale else None, BN_EPS_BLOCK, dtype=dtype, **kw)
     u = {"2a": unit("2a", stride=stride, act="relu"),
          "2b": unit("2b", padding="same", act="relu"),
          "2c": unit("2c", act="relu")}                      # relu applied after the fused shortcut add
@@ -77,15 +82,15 @@ class ResNetBase:
     stride = 16
     out_channels = 1024
 
-    def __init__(self, weights, depth):
-        self.weights, self.depth = weights, depth
+    def __init__(self, weights, depth, dtype="f32"):
+        self.weights, self.depth, self.dtype = weights, depth, dtype
         r101 = depth == 101
         self.stem = ConvUnit(weights, "conv1", "bn_conv1", "scale_conv1" if r101 else None, BN_EPS_STEM,
                              stride=2, padding="same", act="relu")
         self.blocks = []
         for stage, block, is_conv in resnet_block_names(depth):
             stride = 2 if (is_conv and stage > 2) else 1
-            self.blocks.append(_block_units(weights, stage, block, is_conv, stride, r101))
+            self.blocks.append(_block_units(weights, stage, block, is_conv, stride, r101, dtype))
 
     def units(self):
         yield self.stem
@@ -95,6 +100,8 @@ class ResNetBase:
     def __call__(self, x):
         x = self.stem(x)
         x = ops.pool2d(x, 3, 2, True)                       # MaxPooling2D((3,3), strides=(2,2)) (resnet.py:412)
+        if self.dtype == "bf16":                            # the 3-channel stem and its pool stay f32
+            x = ops.cast_bf16(x)
         for b in self.blocks:
             x = run_block(b, x)
         return x
@@ -124,10 +131,10 @@ class VggBase:
 class RpnHead:
     """rpn_conv1 3x3+ReLU, rpn_out_cls 1x1 sigmoid, rpn_out_bbreg 1x1 linear (resnet.py:464-474)."""
 
-    def __init__(self, weights):
-        self.conv = ConvUnit(weights, "rpn_conv1", padding="same", act="relu")
-        self.cls = ConvUnit(weights, "rpn_out_cls", act="sigmoid")
-        self.reg = ConvUnit(weights, "rpn_out_bbreg")
+    def __init__(self, weights, dtype="f32"):
+        self.conv = ConvUnit(weights, "rpn_conv1", padding="same", act="relu", dtype=dtype)
+        self.cls = ConvUnit(weights, "rpn_out_cls", act="sigmoid", dtype=dtype, out_f32=True)      # scores / deltas leave in f32
+        self.reg = ConvUnit(weights, "rpn_out_bbreg", dtype=dtype, out_f32=True)
 
     def units(self):
         return [self.conv, self.cls, self.reg]
@@ -161,9 +168,10 @@ class ResNetHead:
     (resnet50_classifier resnet.py:489-548, resnet101_classifier :631-686)."""
     pool = 7
 
-    def __init__(self, weights, depth, num_classes):
+    def __init__(self, weights, depth, num_classes, dtype="f32"):
         r101 = depth == 101
-        self.blocks = [_block_units(weights, 5, b, b == "a", 1, r101) for b in "abc"]
+        self.dtype = dtype
+        self.blocks = [_block_units(weights, 5, b, b == "a", 1, r101, dtype) for b in "abc"]
         self.dense = _MergedDense(weights, num_classes)
 
     def units(self):
@@ -172,6 +180,11 @@ class ResNetHead:
         yield self.dense.unit
 
     def __call__(self, feat, rois):
+        if self.dtype == "bf16":
+            x = ops.roi_crop_resize_bf16(feat, rois, self.pool)
+            for b in self.blocks:
+                x = run_block(b, x)
+            return self.dense(ops.avgpool_bf16(x, 7))      # pooled features and the dense layers stay f32
         x = ops.roi_crop_resize(feat, rois, self.pool)      # (n,7,7,1024)
         for b in self.blocks:
             x = run_block(b, x)

@@ -353,3 +353,63 @@ def conv2d_wgrad(x, g, kh, kw, stride=1, padding="valid", scale=None, dw=None, d
     _lib.call("frcnn_conv2d_wgrad", ctypes.byref(d), _p(x.contiguous()), _p(g.contiguous()), _p(scale), _p(dw), _p(dbias if want_bias else None),
               _p(ws), ws.numel(), _stream())
     return dw, (dbias if want_bias else None)
+
+
+# ----------------------------------------------------------------------------- bf16 conv path
+class PackedConvBf16:
+    """bf16-packed filter + f32 epilogue scale/shift (configs[3]: bf16 conv)."""
+
+    def __init__(self, w_hwio, scale=None, shift=None):
+        _require_gpu()
+        w = _dev(w_hwio, torch.float32)
+        self.kh, self.kw, self.cin, self.cout = (int(v) for v in w.shape)
+        self.w = torch.empty((self.cout, self.kh * self.kw * self.cin), dtype=torch.bfloat16, device="cuda")
+        _lib.call("frcnn_pack_conv_weights_bf16", _p(w), self.kh, self.kw, self.cin, self.cout, _p(self.w), _stream())
+        self.scale = None if scale is None else _dev(scale, torch.float32)
+        self.shift = None if shift is None else _dev(shift, torch.float32)
+
+
+def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f32=False, tile=0):
+    """x: (n,h,w,cin) bf16 NHWC -> (n,ho,wo,cout) bf16 (or f32 when out_f32)."""
+    _require_gpu()
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == pc.cin
+    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act])
+    d.tile = tile
+    out = torch.empty((x.shape[0], d.ho, d.wo, pc.cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape == out.shape and residual.is_contiguous()
+    if CONV_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("frcnn_conv2d_fwd_bf16", ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), 1 if out_f32 else 0, _stream())
+    if CONV_PROFILE is not None:
+        e1.record()
+        flops = 2.0 * x.shape[0] * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin
+        CONV_PROFILE.append((e0, e1, flops, (x.shape[0] * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin), "k_conv_igemm_bf16"))
+    return out
+
+
+def cast_bf16(x):
+    _require_gpu()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
+    _lib.call("frcnn_cast_f32_to_bf16", _p(x.contiguous()), x.numel(), _p(out), _stream())
+    return out
+
+
+def avgpool_bf16(x, k):
+    """(n,k,k,c) bf16 -> (n,c) f32."""
+    _require_gpu()
+    n, _, _, c = x.shape
+    out = torch.empty((n, c), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_avgpool_bf16_to_f32", _p(x.contiguous()), n, k, c, _p(out), _stream())
+    return out
+
+
+def roi_crop_resize_bf16(feat, rois, pool):
+    _require_gpu()
+    feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
+    rows, cols, C = feat.shape
+    rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
+    out = torch.empty((rois.shape[0], pool, pool, C), dtype=torch.bfloat16, device="cuda")
+    _lib.call("frcnn_roi_crop_resize_fwd_bf16", _p(feat), rows, cols, C, _p(rois), rois.shape[0], pool, _p(out), _stream())
+    return out

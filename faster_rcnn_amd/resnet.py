@@ -45,17 +45,18 @@ def get_conv_rows_cols(height, width):
     return dims
 
 
-def _base(depth, freeze_blocks, weight_regularizer, bias_regularizer, weights):
+def _base(depth, freeze_blocks, weight_regularizer, bias_regularizer, weights, dtype="f32"):
     weights = weights if weights is not None else synthetic_resnet(depth)
-    return BaseModel(weights, nets.ResNetBase(weights, depth), "resnet%d" % depth, freeze_blocks, weight_regularizer, bias_regularizer)
+    return BaseModel(weights, nets.ResNetBase(weights, depth, dtype), "resnet%d" % depth, freeze_blocks, weight_regularizer, bias_regularizer)
 
 
-def resnet50_base(freeze_blocks=[1, 2, 3], weight_regularizer=None, bias_regularizer=None, weights=None):
-    return _base(50, freeze_blocks, weight_regularizer, bias_regularizer, weights)
+def resnet50_base(freeze_blocks=[1, 2, 3], weight_regularizer=None, bias_regularizer=None, weights=None, dtype="f32"):
+    """dtype="bf16" selects the bf16 conv path (BASELINE configs[3]); the reference has no such knob."""
+    return _base(50, freeze_blocks, weight_regularizer, bias_regularizer, weights, dtype)
 
 
-def resnet101_base(freeze_blocks=[1, 2, 3], weight_regularizer=None, bias_regularizer=None, weights=None):
-    return _base(101, freeze_blocks, weight_regularizer, bias_regularizer, weights)
+def resnet101_base(freeze_blocks=[1, 2, 3], weight_regularizer=None, bias_regularizer=None, weights=None, dtype="f32"):
+    return _base(101, freeze_blocks, weight_regularizer, bias_regularizer, weights, dtype)
 
 
 def resnet50_rpn(base_model, weight_regularizer=None, bias_regularizer=None, include_conv=False,
@@ -67,21 +68,22 @@ def resnet50_rpn(base_model, weight_regularizer=None, bias_regularizer=None, inc
 resnet101_rpn = resnet50_rpn
 
 
-def _classifier(depth, num_rois, num_classes, base_model, weights):
+def _classifier(depth, num_rois, num_classes, base_model, weights, dtype="f32"):
     if base_model is not None:
         weights = base_model.weights
+        dtype = getattr(base_model.net, "dtype", dtype)
     elif weights is None:
         weights = synthetic_resnet(depth, num_classes=num_classes)
     assert "dense_class_%d" % num_classes in weights, "weights were drawn for a different class count"
-    return DetModel(weights, nets.ResNetHead(weights, depth, num_classes), num_rois, num_classes, base_model)
+    return DetModel(weights, nets.ResNetHead(weights, depth, num_classes, dtype), num_rois, num_classes, base_model)
 
 
-def resnet50_classifier(num_rois, num_classes, base_model=None, weight_regularizer=None, bias_regularizer=None, weights=None):
-    return _classifier(50, num_rois, num_classes, base_model, weights)
+def resnet50_classifier(num_rois, num_classes, base_model=None, weight_regularizer=None, bias_regularizer=None, weights=None, dtype="f32"):
+    return _classifier(50, num_rois, num_classes, base_model, weights, dtype)
 
 
-def resnet101_classifier(num_rois, num_classes, base_model=None, weight_regularizer=None, bias_regularizer=None, weights=None):
-    return _classifier(101, num_rois, num_classes, base_model, weights)
+def resnet101_classifier(num_rois, num_classes, base_model=None, weight_regularizer=None, bias_regularizer=None, weights=None, dtype="f32"):
+    return _classifier(101, num_rois, num_classes, base_model, weights, dtype)
 
 
 def rpn_from_h5(h5_path, anchors_per_loc=DEFAULT_ANCHORS_PER_LOC, depth=50):

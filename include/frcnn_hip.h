@@ -244,6 +244,23 @@ int frcnn_fold_bias(const float* bias, const float* scale, const float* shift_co
 size_t frcnn_sumsq_workspace_bytes(void);
 int frcnn_sumsq(const float* w, size_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------ bf16 conv path */
+/* BASELINE configs[3] ("bf16 conv + fp32 NMS"): the same implicit-GEMM convolution with bf16
+ * activations/filters on v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 scale/shift, one RNE rounding
+ * at the store.  cin % 64 == 0 (the 3-channel stem stays on the f32 kernel).  Layouts as the f32 path;
+ * packed filter row length = kh*kw*cin, k = ((c/64)*kh*kw + tap)*64 + c%64. */
+int frcnn_conv_packed_k_bf16(int kh, int kw, int cin);
+int frcnn_pack_conv_weights_bf16(const float* w_hwio, int kh, int kw, int cin, int cout, void* packed_bf16, void* stream);
+/* y is bf16 [M][cout], or f32 when y_is_f32 != 0 (network outputs: RPN scores/regressions). */
+int frcnn_conv2d_fwd_bf16(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
+                          const float* scale, const float* shift, const void* residual_bf16, void* y, int y_is_f32, void* stream);
+int frcnn_cast_f32_to_bf16(const float* x, size_t n, void* y_bf16, void* stream);
+/* AveragePooling2D(k) of a k x k bf16 map -> f32 [n][c] (resnet.py:515). */
+int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y, void* stream);
+/* frcnn_roi_crop_resize_fwd on a bf16 feature map (f32 interpolation, bf16 result). */
+int frcnn_roi_crop_resize_fwd_bf16(const void* feat_bf16, int rows, int cols, int C, const float* rois, int n, int pool,
+                                   void* out_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
