@@ -32,10 +32,22 @@ import numpy as np
 import torch
 
 PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_BF16_TFLOPS = 2500.0             # dense bf16 MFMA peak (spec)
 HEIGHT, WIDTH = 600, 1000
 SCALES = [128, 256, 512]
 NUM_CLASSES = 21
 PROPOSALS = 300
+DEPTH, DTYPE = 50, "f32"
+WORKLOAD = "configs[1]: ResNet-50, 600x1000, anchor_scales 128/256/512, RPN + detector inference, fp32"
+
+
+def select_config(name):
+    """c2 (default) = BASELINE configs[1], the headline.  c4 = configs[3] (ResNet-101, KITTI 600x1500,
+    6 anchor scales, 10 classes, bf16 conv + fp32 NMS): a parity-test config, measurable on request."""
+    global HEIGHT, WIDTH, SCALES, NUM_CLASSES, DEPTH, DTYPE, WORKLOAD
+    if name == "c4":
+        HEIGHT, WIDTH, SCALES, NUM_CLASSES, DEPTH, DTYPE = 600, 1500, [16, 32, 64, 128, 256, 512], 10, 101, "bf16"
+        WORKLOAD = "configs[3]: ResNet-101, KITTI 600x1500, anchor_scales 16-512, RPN + detector inference, bf16 conv + fp32 NMS"
 
 
 def synth_image(seed):
@@ -49,37 +61,51 @@ def build_pipeline():
     from faster_rcnn_amd.pipeline import InferencePipeline
     from faster_rcnn_amd.weights import synthetic_resnet
     anchors = util.get_anchors(SCALES)
-    w = synthetic_resnet(50, anchors_per_loc=len(anchors), num_classes=NUM_CLASSES, seed=1)
-    base = resnet.resnet50_base(weights=w)
+    w = synthetic_resnet(DEPTH, anchors_per_loc=len(anchors), num_classes=NUM_CLASSES, seed=1)
+    base = (resnet.resnet50_base if DEPTH == 50 else resnet.resnet101_base)(weights=w, dtype=DTYPE)
     rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=len(anchors))
-    det = resnet.resnet50_classifier(PROPOSALS, NUM_CLASSES, weights=w)
+    det = (resnet.resnet50_classifier if DEPTH == 50 else resnet.resnet101_classifier)(PROPOSALS, NUM_CLASSES, weights=w, dtype=DTYPE)
     return InferencePipeline(rpn, det, anchors, max_proposals=PROPOSALS), w, anchors
 
 
-def conv_roofline(pipe, x, passes=3):
-    """HIP-event timing (torch events on the launch stream) of every conv launch of one image,
-    single stream, eager.  Returns the roofline object for the DOMINANT kernel instantiation
-    (most summed time) plus the aggregate over all conv launches."""
+def conv_roofline(pipe, x, reps=10):
+    """Per-launch duration of every conv launch of one image, measured with HIP events on the launch
+    stream.  An event pair around ONE short kernel also measures the event packets themselves
+    (tens of microseconds on this stack), so each distinct launch (kernel instantiation x shape) is
+    re-issued `reps` times back to back between one pair, with the host pre-enqueued behind a spin
+    kernel; its average is the launch duration.  Returns the roofline object for the DOMINANT kernel
+    instantiation (largest summed duration per image) plus the aggregate over all conv launches."""
     from faster_rcnn_amd import ops
     pipe.forward_dev(x)
     torch.cuda.synchronize()
-    per_kernel, per_shape = {}, {}
+    ops.CONV_PROFILE = []
+    pipe.forward_dev(x)
+    torch.cuda.synchronize()
+    prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+    groups = {}
+    for rec in prof:
+        g = groups.setdefault((rec["kernel"],) + rec["shape"], {"count": 0, "rec": rec})
+        g["count"] += 1
+    per_kernel = {}
     tot_flops = tot_ms = 0.0
-    for _ in range(passes):
-        ops.CONV_PROFILE = []
-        pipe.forward_dev(x)
+    for key, g in groups.items():
+        rec = g["rec"]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(5_000_000)
+        rec["relaunch"]()
+        e0.record()
+        for _ in range(reps):
+            rec["relaunch"]()
+        e1.record()
         torch.cuda.synchronize()
-        prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        for e0, e1, flops, shape, kname in prof:
-            ms = e0.elapsed_time(e1)
-            tot_flops += flops
-            tot_ms += ms
-            for table, key in ((per_kernel, kname), (per_shape, (kname,) + shape)):
-                a = table.setdefault(key, [0.0, 0.0, 0])
-                a[0] += flops; a[1] += ms; a[2] += 1
+        g["ms"] = e0.elapsed_time(e1) / reps
+        a = per_kernel.setdefault(rec["kernel"], [0.0, 0.0, 0])
+        a[0] += rec["flops"] * g["count"]; a[1] += g["ms"] * g["count"]; a[2] += g["count"]
+        tot_flops += rec["flops"] * g["count"]
+        tot_ms += g["ms"] * g["count"]
     dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1][1])
     achieved = dom[0] / (dom[1] * 1e-3) / 1e12
-    heavy = max(((k, v) for k, v in per_shape.items() if k[0] == dom_name), key=lambda kv: kv[1][1])
+    heavy_key, heavy = max(((k, v) for k, v in groups.items() if k[0] == dom_name), key=lambda kv: kv[1]["ms"] * kv[1]["count"])
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC passes (rocprofv3 --pmc), committed
     if os.path.exists(tpath):
@@ -88,19 +114,19 @@ def conv_roofline(pipe, x, passes=3):
         "bound": "mfma", "kernel": dom_name,
         "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
-        "launches_per_image": dom[2] // passes, "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
+        "launches_per_image": dom[2], "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
         "gflop_per_launch_avg": round(dom[0] / dom[2] / 1e9, 3),
         "share_of_conv_time": round(dom[1] / tot_ms, 3),
-        "heaviest_shape_MNK": list(heavy[0][1:]),
-        "heaviest_shape_tflops": round(heavy[1][0] / (heavy[1][1] * 1e-3) / 1e12, 2),
-        "all_conv_launches": {"launches_per_image": sum(v[2] for v in per_kernel.values()) // passes,
-                              "gflop_per_image": round(tot_flops / passes / 1e9, 2),
-                              "ms_per_image": round(tot_ms / passes, 3),
+        "heaviest_shape_MNK": list(heavy_key[1:4]),
+        "heaviest_shape_tflops": round(heavy["rec"]["flops"] / (heavy["ms"] * 1e-3) / 1e12, 2),
+        "all_conv_launches": {"launches_per_image": sum(v[2] for v in per_kernel.values()),
+                              "gflop_per_image": round(tot_flops / 1e9, 2),
+                              "ms_per_image": round(tot_ms, 3),
                               "achieved": round(tot_flops / (tot_ms * 1e-3) / 1e12, 2),
                               "frac": round(tot_flops / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)},
-        "method": "HIP events around each launch on the launch stream, single stream, eager, %d passes" % passes,
+        "method": "HIP events on the launch stream; each distinct launch re-issued %d x back to back between one event pair" % reps,
     }
-    return roof, per_shape
+    return roof, groups
 
 
 def cpu_baseline(weights, anchors, budget_s=20.0):
@@ -133,8 +159,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--config", choices=("c2", "c4"), default="c2", help="c2 = BASELINE configs[1] (headline); c4 = configs[3]")
     ap.add_argument("--streams", type=int, default=4, help="images in flight per GPU (one hipGraph + HIP stream each)")
     args = ap.parse_args()
+    select_config(args.config)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -194,13 +222,13 @@ def main():
     if rank == 0:
         roof, _ = conv_roofline(pipe, x)
         line = {
-            "metric": "images/sec end-to-end (RPN+det) ResNet-50 600x1000",
+            "metric": "images/sec end-to-end (RPN+det) ResNet-%d %dx%d" % (DEPTH, HEIGHT, WIDTH),
             "value": round(world * S * args.steps / elapsed, 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: ResNet-50, 600x1000, anchor_scales 128/256/512, RPN + detector inference, fp32",
+            "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": WORKLOAD,
                        "images_per_step_per_gpu": S, "proposals": PROPOSALS, "classes": NUM_CLASSES,
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay",
                        "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world},
@@ -208,7 +236,12 @@ def main():
         }
         # algorithmic conv FLOP actually retired per second by the whole job (all images in flight)
         line["roofline"]["end_to_end_conv_tflops"] = round(roof["all_conv_launches"]["gflop_per_image"] * line["value"] / world / 1e3, 2)
-        if world == 1 and not args.no_cpu_baseline:
+        if DTYPE == "bf16":
+            for k in ("peak",):
+                roof[k] = PEAK_BF16_TFLOPS
+            roof["frac"] = round(roof["achieved"] / PEAK_BF16_TFLOPS, 4)
+            roof["all_conv_launches"]["frac"] = round(roof["all_conv_launches"]["achieved"] / PEAK_BF16_TFLOPS, 4)
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             line["cpu_baseline"] = cpu_baseline(weights, anchors)
         print(json.dumps(line), flush=True)
     if dist is not None:

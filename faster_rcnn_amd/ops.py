@@ -221,8 +221,8 @@ class PackedConv:
         self.shift = None if shift is None else _dev(shift, torch.float32)
 
 
-# When set to a list, every conv2d launch appends (start_event, end_event, flops, shape) so
-# bench.py can time the MFMA kernel per launch with HIP events on the launch stream.
+# When set to a list, every conv2d launch appends {kernel, flops, shape, relaunch()} so bench.py can
+# re-issue each distinct launch back to back between one HIP-event pair on the launch stream.
 CONV_PROFILE = None
 CONV_KERNEL_NAMES = {1: "k_conv_igemm_f32<2,2,false>", 2: "k_conv_igemm_f32<1,1,*>", 3: "k_conv_igemm_f32<2,1,*>",
                      4: "k_conv_igemm_f32<4,2,false>", 11: "k_conv_igemm_f32_v2<2,2>", 12: "k_conv_igemm_f32_v2<1,1>",
@@ -247,15 +247,14 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
         assert residual.shape == out.shape and residual.is_contiguous()
     d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc.cin, cout=pc.cout, kh=pc.kh, kw=pc.kw, stride=stride, pad_top=pt, pad_left=pl,
                       ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile)
-    if CONV_PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     _lib.call("frcnn_conv2d_fwd", ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), _stream())
     if CONV_PROFILE is not None:
-        e1.record()
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
-        CONV_PROFILE.append((e0, e1, flops, (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin),
-                             CONV_KERNEL_NAMES.get(_lib.load().frcnn_conv2d_config(ctypes.byref(d)), "?")))
+        kname = CONV_KERNEL_NAMES.get(_lib.load().frcnn_conv2d_config(ctypes.byref(d)), "?")
+        args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out))
+        keep = (d, x, pc, residual, out)
+        CONV_PROFILE.append({"kernel": kname, "flops": flops, "shape": (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
+                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd", *args, _stream())})
     return out
 
 
@@ -378,14 +377,13 @@ def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f
     out = torch.empty((x.shape[0], d.ho, d.wo, pc.cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
     if residual is not None:
         assert residual.dtype == torch.bfloat16 and residual.shape == out.shape and residual.is_contiguous()
-    if CONV_PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     _lib.call("frcnn_conv2d_fwd_bf16", ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), 1 if out_f32 else 0, _stream())
     if CONV_PROFILE is not None:
-        e1.record()
         flops = 2.0 * x.shape[0] * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin
-        CONV_PROFILE.append((e0, e1, flops, (x.shape[0] * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin), "k_conv_igemm_bf16"))
+        args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), 1 if out_f32 else 0)
+        keep = (d, x, pc, residual, out)
+        CONV_PROFILE.append({"kernel": "k_conv_igemm_bf16", "flops": flops, "shape": (x.shape[0] * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
+                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_bf16", *args, _stream())})
     return out
 
 

