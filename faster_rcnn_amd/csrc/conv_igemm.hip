@@ -26,6 +26,7 @@
 // Epilogue (fused, in registers): v = acc*scale[n] + shift[n] (folded bias+BN(+Scale)),
 // + residual[m][n], activation (none / relu / sigmoid), store NHWC.
 #include "common.h"
+#include <stdlib.h>
 
 namespace frcnn {
 
@@ -227,7 +228,7 @@ constexpr unsigned OOB_OFFSET = 0x80000000u;     // >= num_records of any tensor
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
 
-template <int TM, int TN>
+template <int TM, int TN, int VARIANT = 0>
 __global__ void __launch_bounds__(256) k_conv_igemm_f32_v2(const ConvArgs p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int PA = BM / 32, PB = BN / 32;
@@ -323,8 +324,10 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32_v2(const ConvArgs p) {
     constexpr int NF = TM + TN;            // fragment reads per kk-step
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        store_chunk(buf ^ 1);                                  // chunk kc+1 (harmless duplicate at the tail)
-        load_chunk(kc + 2 < nk ? kc + 2 : nk - 1);             // always in range: keeps the body branch-free
+        if constexpr (VARIANT == 0) {
+            store_chunk(buf ^ 1);                              // chunk kc+1 (harmless duplicate at the tail)
+            load_chunk(kc + 2 < nk ? kc + 2 : nk - 1);         // always in range: keeps the body branch-free
+        }
         const float* a = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + li) * LDS_STRIDE + lh * 4;
         const float* b = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + li) * LDS_STRIDE + lh * 4;
         f32x4 fa[BK / 8][TM], fb[BK / 8][TN];
@@ -345,28 +348,52 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32_v2(const ConvArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i][e], fb[kk][j][e], acc[i][j], 0, 0, 0);
 
-        // ---- pinned interleave (per wave, per chunk): everything that is not an MFMA issues in
-        // the shadow of the wave's own MFMAs
-        SGB(SG_DS_RD, NF);                                       // kk = 0 fragments
+        if constexpr (VARIANT == 0) {
+            // ---- pinned interleave (per wave, per chunk): everything that is not an MFMA issues in
+            // the shadow of the wave's own MFMAs
+            SGB(SG_DS_RD, NF);                                       // kk = 0 fragments
 #pragma unroll
-        for (int q = 0; q < MF; ++q) {                           // kk-step 0: LDS stores, then kk=1 fragments
-            SGB(SG_MFMA, 1);
-            if (q < NL) SGB(SG_DS_WR, 1);
-            else if (q - NL < NF) SGB(SG_DS_RD, 1);
+            for (int q = 0; q < MF; ++q) {                           // kk-step 0: LDS stores, then kk=1 fragments
+                SGB(SG_MFMA, 1);
+                if (q < NL) SGB(SG_DS_WR, 1);
+                else if (q - NL < NF) SGB(SG_DS_RD, 1);
+            }
+#pragma unroll
+            for (int q = 0; q < MF; ++q) {                           // kk-step 1: global loads, then kk=2 fragments
+                SGB(SG_MFMA, 1);
+                if (q < NL) { SGB(SG_VALU, 4); SGB(SG_VMEM_RD, 1); }
+                else if (q - NL < NF) SGB(SG_DS_RD, 1);
+            }
+#pragma unroll
+            for (int q = 0; q < MF; ++q) {                           // kk-step 2: kk=3 fragments
+                SGB(SG_MFMA, 1);
+                if (q < NF) SGB(SG_DS_RD, 1);
+            }
+#pragma unroll
+            for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);            // kk-step 3
+        } else {
+            // VARIANT 1: the LDS stores come AFTER all fragment reads in program order (the compiler keeps
+            // may-alias LDS accesses ordered), so they can ride behind the last MFMAs instead of sitting in
+            // front of the first one; the next loads follow the stores (register reuse) at the tail.
+            store_chunk(buf ^ 1);
+            load_chunk(kc + 2 < nk ? kc + 2 : nk - 1);
+            SGB(SG_DS_RD, NF);
+#pragma unroll
+            for (int kk = 0; kk < BK / 8 - 1; ++kk) {
+#pragma unroll
+                for (int q = 0; q < MF; ++q) {
+                    SGB(SG_MFMA, 1);
+                    if (q < NF) SGB(SG_DS_RD, 1);
+                    else if (kk == BK / 8 - 2 && q - NF < NL) SGB(SG_DS_WR, 1);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < MF; ++q) {
+                SGB(SG_MFMA, 1);
+                if (MF - NF < NL && q < NL - (MF - NF)) SGB(SG_DS_WR, 1);
+                else if (q < NL + (MF - NF < NL ? NL - (MF - NF) : 0)) { SGB(SG_VALU, 4); SGB(SG_VMEM_RD, 1); }
+            }
         }
-#pragma unroll
-        for (int q = 0; q < MF; ++q) {                           // kk-step 1: global loads, then kk=2 fragments
-            SGB(SG_MFMA, 1);
-            if (q < NL) { SGB(SG_VALU, 4); SGB(SG_VMEM_RD, 1); }
-            else if (q - NL < NF) SGB(SG_DS_RD, 1);
-        }
-#pragma unroll
-        for (int q = 0; q < MF; ++q) {                           // kk-step 2: kk=3 fragments
-            SGB(SG_MFMA, 1);
-            if (q < NF) SGB(SG_DS_RD, 1);
-        }
-#pragma unroll
-        for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);            // kk-step 3
         __syncthreads();
     }
     epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
@@ -595,7 +622,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return check_launch("conv2d_fwd");
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int VARIANT = 0>
 static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     ConvArgs p = a;
@@ -604,11 +631,11 @@ static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_v2<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_v2<TM, TN, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
         attr_done = true;
     }
-    k_conv_igemm_f32_v2<TM, TN><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    k_conv_igemm_f32_v2<TM, TN, VARIANT><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
     return check_launch("conv2d_fwd");
 }
 
@@ -623,15 +650,18 @@ static int choose_config(const frcnn_conv_desc* d) {
     const bool generic = (d->cin % BK) != 0;
     const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
     int cfg = d->tile;      // 0 = auto
+    static const int forced = getenv("FRCNN_FORCE_TILE") ? atoi(getenv("FRCNN_FORCE_TILE")) : 0;   // dev knob
+    if (cfg == 0 && forced && !generic) cfg = forced;
     if (cfg == 0) {
         // measured on MI355X over every conv shape of the C2 pipeline (scripts/conv_shapes.py):
         // the 64x64 v2 kernel wins wherever the grid is small or k is short; 128x128 v2 only
         // pays once there are >= 1.5 tiles per CU slot AND a long k loop to amortise its prologue
         if (generic) cfg = 2;
-        else if (t128 >= 384 && Kpad >= 1024) cfg = 11;
-        else cfg = 12;
+        else if (t128 >= 384 && Kpad >= 1024) cfg = 21;
+        else cfg = 22;
     }
     const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * Kpad * 4 < 0x7fffffffull;
+    if (cfg >= 21 && (!fits_srd || generic)) cfg -= 20;
     if (cfg >= 11 && (!fits_srd || generic)) cfg -= 10;
     if (generic) cfg = (cfg == 2) ? 2 : 3;
     return cfg;
@@ -681,6 +711,8 @@ int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const floa
         return launch_conv<2, 1, true>(a, s);
     }
     switch (cfg) {
+        case 21: return launch_conv_v2<2, 2, 1>(a, s);
+        case 22: return launch_conv_v2<1, 1, 1>(a, s);
         case 11: return launch_conv_v2<2, 2>(a, s);
         case 12: return launch_conv_v2<1, 1>(a, s);
         case 13: return launch_conv_v2<2, 1>(a, s);

@@ -226,7 +226,8 @@ class PackedConv:
 CONV_PROFILE = None
 CONV_KERNEL_NAMES = {1: "k_conv_igemm_f32<2,2,false>", 2: "k_conv_igemm_f32<1,1,*>", 3: "k_conv_igemm_f32<2,1,*>",
                      4: "k_conv_igemm_f32<4,2,false>", 11: "k_conv_igemm_f32_v2<2,2>", 12: "k_conv_igemm_f32_v2<1,1>",
-                     13: "k_conv_igemm_f32_v2<2,1>", 14: "k_conv_igemm_f32_v2<4,2>"}
+                     13: "k_conv_igemm_f32_v2<2,1>", 14: "k_conv_igemm_f32_v2<4,2>",
+                     21: "k_conv_igemm_f32_v2<2,2,1>", 22: "k_conv_igemm_f32_v2<1,1,1>"}
 
 
 def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0):

@@ -160,7 +160,8 @@ typedef struct frcnn_conv_desc {
     int32_t act;                   /* FRCNN_ACT_*                                             */
     int32_t ldy, ldres;            /* row strides (elements) of y / residual; 0 = cout        */
     int32_t tile;                  /* 0 = auto; 1: 128x128, 2: 64x64, 3: 128x64, 4: 256x128;
-                                      11..14: the same tiles with the pipelined v2 main loop   */
+                                      11..14: the same tiles with the pipelined v2 main loop;
+                                      21, 22: 128x128 / 64x64 v2 with the late-LDS-store schedule */
 } frcnn_conv_desc;
 
 /* k extent of a packed filter row: kh*kw*cin rounded up to the kernel's k-chunk (32). */
