@@ -58,6 +58,7 @@ SIGNATURES = {
     "frcnn_loss_det_reg": (I, [P, P, I, I, P, P, I, P]),
     "frcnn_relu_bwd_inplace": (I, [P, P, c_size_t, P]),
     "frcnn_avgpool_bwd_masked": (I, [P, P, I, I, I, P, P]),
+    "frcnn_maxpool_bwd": (I, [P, P, P, I, I, I, I, I, P, P]),
     "frcnn_sgd_momentum": (I, [P, P, P, c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, P]),
     "frcnn_adam": (I, [P, P, P, P, c_size_t, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, I, ctypes.c_float, ctypes.c_float, P]),
     "frcnn_sumsq_workspace_bytes": (c_size_t, []),

@@ -146,6 +146,36 @@ __global__ void k_avgpool_bwd_masked(const float4* gp, const float4* y, int hw, 
     }
 }
 
+// MaxPooling2D(k, stride=k) backward (vgg.py:100-128; TF MaxPoolGrad routes each window's gradient to its
+// FIRST maximum in scan order).  One thread per input element; windows do not overlap (k == stride).
+__global__ void k_maxpool_bwd(const float* x, const float* y, const float* gy, int n, int H, int W, int C, int k, float* gx) {
+    const int Ho = H / k, Wo = W / k;
+    const size_t total = (size_t)n * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t t = i / C;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int img = (int)(t / H);
+        const int ho = h / k, wo = w / k;
+        float g = 0.0f;
+        if (ho < Ho && wo < Wo) {
+            const size_t oi = (((size_t)img * Ho + ho) * Wo + wo) * C + c;
+            const float m = y[oi], v = x[i];
+            if (v == m) {
+                bool first = true;                       // is there an earlier element of the window equal to the max?
+                for (int r = ho * k; r <= h && first; ++r)
+                    for (int q = wo * k; q < wo * k + k; ++q) {
+                        if (r == h && q >= w) break;
+                        if (x[(((size_t)img * H + r) * W + q) * C + c] == m) { first = false; break; }
+                    }
+                if (first) g = gy[oi];
+            }
+        }
+        gx[i] = g;
+    }
+}
+
 // Keras SGD(momentum, nesterov=False):  g += 2*l2*w;  v = momentum*v - lr*g;  w += v
 __global__ void k_sgd_momentum(float* w, const float* g, float* v, size_t n, float lr, float momentum, float l2, float gscale) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -229,6 +259,11 @@ int frcnn_avgpool_bwd_masked(const float* g_pooled, const float* y, int n, int k
     const size_t total4 = (size_t)n * k * k * (c / 4);
     k_avgpool_bwd_masked<<<ew_grid(total4), 256, 0, as_stream(stream)>>>((const float4*)g_pooled, (const float4*)y, k * k, c / 4, total4, 1.0f / (float)(k * k), (float4*)gx);
     return check_launch("avgpool_bwd_masked");
+}
+int frcnn_maxpool_bwd(const float* x, const float* y, const float* gy, int n, int h, int w, int c, int k, float* gx, void* stream) {
+    if (!x || !y || !gy || !gx || n <= 0 || h < k || w < k || c <= 0 || k <= 0) return fail(FRCNN_E_ARG, "maxpool_bwd: bad argument");
+    k_maxpool_bwd<<<ew_grid((size_t)n * h * w * c), 256, 0, as_stream(stream)>>>(x, y, gy, n, h, w, c, k, gx);
+    return check_launch("maxpool_bwd");
 }
 int frcnn_sgd_momentum(float* w, const float* g, float* v, size_t n, float lr, float momentum, float l2, float grad_scale, void* stream) {
     if (!w || !g || !v) return fail(FRCNN_E_ARG, "sgd_momentum: null pointer");

@@ -86,7 +86,7 @@ class RpnModel(_Model):
     # ---- training (train_util.py:31-54)
     def compile(self, optimizer, loss=None):
         from .train import RpnTrainer
-        reg = self.base.weight_regularizer
+        reg = getattr(self, "weight_regularizer", None) or self.base.weight_regularizer
         if getattr(self, "_trainer", None) is None:
             self._trainer = RpnTrainer(self, l2=reg.l2 if reg is not None else 0.0)
         self._trainer.compile(optimizer, loss)
@@ -133,7 +133,7 @@ class DetModel(_Model):
     # ---- training (train_util.py:95-118)
     def compile(self, optimizer, loss=None):
         from .train import DetTrainer
-        reg = self.base.weight_regularizer if self.base is not None else None
+        reg = self.base.weight_regularizer if self.base is not None else getattr(self, "weight_regularizer", None)
         if getattr(self, "_trainer", None) is None:
             self._trainer = DetTrainer(self, l2=reg.l2 if reg is not None else 0.0)
         self._trainer.compile(optimizer, loss)

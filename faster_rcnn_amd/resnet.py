@@ -62,7 +62,9 @@ def resnet101_base(freeze_blocks=[1, 2, 3], weight_regularizer=None, bias_regula
 def resnet50_rpn(base_model, weight_regularizer=None, bias_regularizer=None, include_conv=False,
                  anchors_per_loc=DEFAULT_ANCHORS_PER_LOC):
     assert base_model.weights["rpn_out_cls"][0].shape[-1] == anchors_per_loc, "weights were drawn for a different anchor count"
-    return RpnModel(base_model, include_conv, anchors_per_loc)
+    m = RpnModel(base_model, include_conv, anchors_per_loc)
+    m.weight_regularizer = weight_regularizer            # the heads' own regulariser (step 3 regularises only them)
+    return m
 
 
 resnet101_rpn = resnet50_rpn
@@ -79,11 +81,15 @@ def _classifier(depth, num_rois, num_classes, base_model, weights, dtype="f32"):
 
 
 def resnet50_classifier(num_rois, num_classes, base_model=None, weight_regularizer=None, bias_regularizer=None, weights=None, dtype="f32"):
-    return _classifier(50, num_rois, num_classes, base_model, weights, dtype)
+    m = _classifier(50, num_rois, num_classes, base_model, weights, dtype)
+    m.weight_regularizer = weight_regularizer
+    return m
 
 
 def resnet101_classifier(num_rois, num_classes, base_model=None, weight_regularizer=None, bias_regularizer=None, weights=None, dtype="f32"):
-    return _classifier(101, num_rois, num_classes, base_model, weights, dtype)
+    m = _classifier(101, num_rois, num_classes, base_model, weights, dtype)
+    m.weight_regularizer = weight_regularizer
+    return m
 
 
 def rpn_from_h5(h5_path, anchors_per_loc=DEFAULT_ANCHORS_PER_LOC, depth=50):

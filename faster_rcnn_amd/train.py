@@ -215,41 +215,149 @@ def _regularised_conv_names(weights):
     return [n for n in weights if n.startswith(("conv1", "res", "rpn_", "dense_", "fc", "block")) and not n.startswith("bn")]
 
 
-# ----------------------------------------------------------------------------- RPN step 1
-class RpnTrainer:
-    """rpn_model.compile(...) + rpn_model.train_on_batch(x, [y_class, y_bbreg]) (train_util.py:31-54)
-    for a ResNet-50/101 RPN: forward conv1..res4f + heads, the two RPN losses (+ L2), backward through
-    stage 4 and the heads, optimiser step.  Returns [total, cls_loss, reg_loss] like Keras."""
+# ----------------------------------------------------------------------------- trainable base networks
+class ResNetBaseTrain:
+    """conv1..stage 4 with the stages outside freeze_blocks trainable (resnet.py:395-448)."""
 
-    def __init__(self, rpn_model, l2=0.0):
-        base = rpn_model.base.net
-        assert isinstance(base, nets.ResNetBase), "training is implemented for the ResNet graphs"
+    def __init__(self, base_model, params):
+        from .weights import resnet_block_names
+        net = base_model.net
+        freeze = set(base_model.freeze_blocks)
+        self.stem, self.frozen_blocks, self.blocks = net.stem, [], []
+        first = True
+        for (stage, block, _), units in zip(resnet_block_names(net.depth), net.blocks):
+            if stage in freeze:
+                assert first, "a frozen stage after a trainable one is not supported"
+                self.frozen_blocks.append(units)
+            else:
+                self.blocks.append(TBlock(units, params, needs_input_grad=not first))
+                first = False
+
+    @staticmethod
+    def trainable_names(base_model):
+        from .weights import resnet_block_names
+        net, freeze = base_model.net, set(base_model.freeze_blocks)
+        names = []
+        for (stage, block, _), units in zip(resnet_block_names(net.depth), net.blocks):
+            if stage not in freeze:
+                names += [u.conv for u in units.values()]
+        return names
+
+    def convs(self):
+        return [c for b in self.blocks for c in b.convs()]
+
+    def forward(self, x):
+        t = ops.pool2d(self.stem(x), 3, 2, True)
+        for units in self.frozen_blocks:
+            t = nets.run_block(units, t)
+        for b in self.blocks:
+            t = b.forward(t)
+        return t
+
+    def backward(self, g):
+        """g: gradient w.r.t. the pre-ReLU value of the feature map (already masked)."""
+        for b in reversed(self.blocks):
+            g = b.backward(g)
+
+
+class VggBaseTrain:
+    """vgg16_base (vgg.py:91-141): 3x3 conv + ReLU chain with 2x2 pools; blocks outside freeze_blocks train."""
+    POOL_AFTER = ("block1_conv2", "block2_conv2", "block3_conv3", "block4_conv3")
+
+    def __init__(self, base_model, params):
+        net = base_model.net
+        train = set(self.trainable_names(base_model))
+        self.layers = []                       # (name, unit-or-TConv, trainable)
+        seen_trainable = False
+        for name, u in net.convs:
+            if name in train:
+                self.layers.append((name, TConv(u, params, needs_dgrad=seen_trainable), True))
+                seen_trainable = True
+            else:
+                assert not seen_trainable, "a frozen block after a trainable one is not supported"
+                self.layers.append((name, u, False))
+
+    @staticmethod
+    def trainable_names(base_model):
+        freeze = set(base_model.freeze_blocks)
+        return [name for name, _ in base_model.net.convs if int(name[5]) not in freeze]
+
+    def convs(self):
+        return [l for _, l, t in self.layers if t]
+
+    def forward(self, x):
+        self.pools = {}
+        for name, layer, trainable in self.layers:
+            x = layer.forward(x) if trainable else layer(x)
+            if name in self.POOL_AFTER:
+                y = ops.pool2d(x, 2, 2, True)
+                self.pools[name] = (x, y)
+                x = y
+        return x
+
+    def backward(self, g):
+        for name, layer, trainable in reversed(self.layers):
+            if not trainable:
+                return
+            if name in self.POOL_AFTER:                 # g arrives w.r.t. the pool output: route it, then ReLU-mask
+                x, y = self.pools[name]
+                gx = torch.empty_like(x)
+                _lib.call("frcnn_maxpool_bwd", _p(x), _p(y), _p(g.contiguous()), x.shape[0], x.shape[1], x.shape[2], x.shape[3], 2, _p(gx), _stream())
+                _lib.call("frcnn_relu_bwd_inplace", _p(gx), _p(x), gx.numel(), _stream())
+                g = gx
+            layer.wgrad(g)
+            if not layer.needs_dgrad:
+                return
+            src = layer.x                                   # this conv's input = previous layer's ReLU output (or a pool output)
+            prev_pooled = any(src is py for (_, py) in self.pools.values())
+            g = layer.dgrad(g, mask=None if prev_pooled else src)
+
+
+def _make_base_train(base_model, params):
+    return (ResNetBaseTrain if isinstance(base_model.net, nets.ResNetBase) else VggBaseTrain)(base_model, params)
+
+
+def _base_trainable_names(base_model):
+    return (ResNetBaseTrain if isinstance(base_model.net, nets.ResNetBase) else VggBaseTrain).trainable_names(base_model)
+
+
+def _reg_sumsq_frozen(weights, model_layer_names, train_names, l2):
+    """sum(w^2) over the model's regularised layers that do NOT train (a constant of the run)."""
+    if not l2:
+        return 0.0
+    return _l2_of(weights, [n for n in model_layer_names if n not in train_names])
+
+
+def _base_layer_names(base_model):
+    return [u.conv for u in base_model.net.units()]
+
+
+# ----------------------------------------------------------------------------- RPN steps 1 and 3
+class RpnTrainer:
+    """rpn_model.compile(...) + rpn_model.train_on_batch(x, [y_class, y_bbreg]) (train_util.py:31-54):
+    forward base + heads, the two RPN losses (+ L2), backward through the heads and whatever part of the
+    base trains (step 1: ResNet stage 4 / VGG blocks 3-5; step 3: nothing -- freeze_blocks covers the
+    whole base, train_rpn_step3.py:59-76), optimiser step.  Returns [total, cls_loss, reg_loss]."""
+
+    def __init__(self, rpn_model, l2=0.0, l2_base=None):
         self.model, self.l2 = rpn_model, l2
         w = rpn_model.weights
         self.A = rpn_model.anchors_per_loc
-        freeze = set(rpn_model.base.freeze_blocks)
-        from .weights import resnet_block_names
-        names = resnet_block_names(base.depth)
-        train_names = []
-        for (stage, block, _), units in zip(names, base.blocks):
-            if stage not in freeze:
-                train_names += [u.conv for u in units.values()]
-        train_names += ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"]
+        head_names = ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"]
+        train_names = _base_trainable_names(rpn_model.base) + head_names
         self.params = ParamSet(w, train_names)
-        self.frozen_blocks, self.blocks = [], []
-        first_trainable = True
-        for (stage, block, _), units in zip(names, base.blocks):
-            if stage in freeze:
-                self.frozen_blocks.append(units)
-            else:
-                self.blocks.append(TBlock(units, self.params, needs_input_grad=not first_trainable))
-                first_trainable = False
-        self.stem = base.stem
-        self.rpn_conv = TConv(rpn_model.head.conv, self.params, needs_dgrad=True)
+        self.base = _make_base_train(rpn_model.base, self.params)
+        self.base_trains = len(self.base.convs()) > 0
+        self.rpn_conv = TConv(rpn_model.head.conv, self.params, needs_dgrad=self.base_trains)
         self.rpn_cls = TConv(rpn_model.head.cls, self.params, needs_dgrad=True)
         self.rpn_reg = TConv(rpn_model.head.reg, self.params, needs_dgrad=True)
-        reg_names = [n for n in _regularised_conv_names(w) if n in w and not n.startswith(("dense_", "fc")) and not n.startswith("res5")]
-        self.frozen_sumsq = _l2_of(w, [n for n in reg_names if n not in train_names]) if l2 else 0.0
+        # Keras sums the regulariser of every layer that was GIVEN one: the heads always (when l2 != 0), the
+        # base only if it was built with regularisers (step 1 yes, step 3 no: train_rpn_step3.py:70)
+        base_reg = rpn_model.base.weight_regularizer is not None if l2_base is None else bool(l2_base)
+        reg_layers = head_names + (_base_layer_names(rpn_model.base) if base_reg else [])
+        self.frozen_sumsq = _reg_sumsq_frozen(w, reg_layers, train_names, l2)
+        self.l2_mask_base = base_reg
+        assert base_reg or not self.base_trains or not l2, "a trainable base without regularisers next to regularised heads is not supported"
         self.optimizer = None
 
     def compile(self, optimizer, loss=None):
@@ -257,20 +365,11 @@ class RpnTrainer:
         self.params.reset_optimizer()
 
     def _tconvs(self):
-        out = []
-        for b in self.blocks:
-            out += b.convs()
-        return out + [self.rpn_conv, self.rpn_cls, self.rpn_reg]
+        return self.base.convs() + [self.rpn_conv, self.rpn_cls, self.rpn_reg]
 
     def forward(self, x):
-        t = self.stem(x)
-        t = ops.pool2d(t, 3, 2, True)
-        for units in self.frozen_blocks:
-            t = nets.run_block(units, t)
-        for b in self.blocks:
-            t = b.forward(t)
-        self.feat = t
-        h = self.rpn_conv.forward(t)
+        self.feat = self.base.forward(x)
+        h = self.rpn_conv.forward(self.feat)
         return self.rpn_cls.forward(h), self.rpn_reg.forward(h), h
 
     def train_on_batch(self, x, y, skip=False):
@@ -297,9 +396,8 @@ class RpnTrainer:
             tmp = self.rpn_cls.dgrad(g_cls)
             gh = self.rpn_reg.dgrad(g_reg, residual=tmp, mask=h)
             self.rpn_conv.wgrad(gh)
-            g = self.rpn_conv.dgrad(gh, mask=self.feat)
-            for b in reversed(self.blocks):
-                g = b.backward(g)
+            if self.base_trains:
+                self.base.backward(self.rpn_conv.dgrad(gh, mask=self.feat))
         sq = p.sumsq() if self.l2 else None
         scale = _sync_grads(p)
         p.step(self.optimizer, self.l2, scale)
@@ -315,47 +413,90 @@ class RpnTrainer:
         self.model.invalidate()
 
 
-# ----------------------------------------------------------------------------- detector step 2
+# ----------------------------------------------------------------------------- detector steps 2 and 4
+class _ResNetHeadTrain:
+    def __init__(self, head, params):
+        self.blocks = [TBlock(units, params, needs_input_grad=True, input_is_relu=(i > 0)) for i, units in enumerate(head.blocks)]
+
+    @staticmethod
+    def names(head):
+        return [u.conv for units in head.blocks for u in units.values()]
+
+    def convs(self):
+        return [c for b in self.blocks for c in b.convs()]
+
+    def forward(self, crop):
+        c = crop
+        for b in self.blocks:
+            c = b.forward(c)
+        self.h5 = c
+        return ops.pool2d(c, 7, 7, False)                       # (n,1,1,2048)
+
+    def backward(self, g_pooled):
+        """g_pooled (n,1,1,C) -> gradient w.r.t. the RoI crops (n,7,7,Cf)."""
+        n = self.h5.shape[0]
+        gx = torch.empty_like(self.h5)
+        _lib.call("frcnn_avgpool_bwd_masked", _p(g_pooled.contiguous()), _p(self.h5), n, 7, self.h5.shape[-1], _p(gx), _stream())
+        for b in reversed(self.blocks):
+            gx = b.backward(gx)
+        return gx
+
+
+class _VggHeadTrain:
+    def __init__(self, head, params):
+        self.fc1 = TConv(head.fc1, params, needs_dgrad=True)
+        self.fc2 = TConv(head.fc2, params, needs_dgrad=True)
+
+    @staticmethod
+    def names(head):
+        return ["fc1", "fc2"]
+
+    def convs(self):
+        return [self.fc1, self.fc2]
+
+    def forward(self, crop):
+        self.crop_shape = crop.shape
+        n = crop.shape[0]
+        return self.fc2.forward(self.fc1.forward(crop.reshape(n, 1, 1, -1)))      # (n,1,1,4096)
+
+    def backward(self, g):
+        """g: gradient w.r.t. fc2's ReLU output."""
+        g = g.contiguous()
+        _lib.call("frcnn_relu_bwd_inplace", _p(g), _p(self.fc2.y), g.numel(), _stream())
+        self.fc2.wgrad(g)
+        g1 = self.fc2.dgrad(g, mask=self.fc1.y)
+        self.fc1.wgrad(g1)
+        return self.fc1.dgrad(g1).reshape(self.crop_shape)
+
+
 class DetTrainer:
-    """detector.compile + detector.train_on_batch([image, rois], [y_cls, y_reg]) (train_util.py:95-118):
-    base forward (stage 4 trainable), RoiResizeConv, stage 5, average pool, dense x2, the two detector
-    losses (+ L2), backward through the head, the RoI crop (atomic scatter) and stage 4."""
+    """detector.compile + detector.train_on_batch([image or conv features, rois], [y_cls, y_reg])
+    (train_util.py:95-118, 159-182): [base forward,] RoiResizeConv, head, the two detector losses (+ L2),
+    backward through the head, the RoI crop (atomic scatter) and the trainable part of the base.
+    Step 2 feeds images through the detector's own base; step 4 feeds cached conv features (no base)."""
 
     def __init__(self, det_model, l2=0.0):
-        assert det_model.base is not None and isinstance(det_model.base.net, nets.ResNetBase)
         self.model, self.l2 = det_model, l2
         w = det_model.weights
-        base = det_model.base.net
         self.C = det_model.num_classes
-        freeze = set(det_model.base.freeze_blocks)
-        from .weights import resnet_block_names
-        names = resnet_block_names(base.depth)
+        is_resnet = isinstance(det_model.head, nets.ResNetHead)
+        head_cls = _ResNetHeadTrain if is_resnet else _VggHeadTrain
         # dense_class / dense_reg train as ONE merged GEMM; keep a merged master entry
         kc, bc = w["dense_class_%d" % self.C]
         kr, br = w["dense_reg_%d" % self.C]
         self.merged = {"dense": [np.concatenate([kc, kr], axis=1), np.concatenate([bc, br])]}
-        train_names = []
-        for (stage, block, _), units in zip(names, base.blocks):
-            if stage not in freeze:
-                train_names += [u.conv for u in units.values()]
-        for units in det_model.head.blocks:
-            train_names += [u.conv for u in units.values()]
+        base_names = _base_trainable_names(det_model.base) if det_model.base is not None else []
+        head_names = head_cls.names(det_model.head)
+        train_names = base_names + head_names
         all_w = dict(w)
         all_w.update(self.merged)
         self.params = ParamSet(all_w, train_names + ["dense"])
-        self.stem, self.frozen_blocks, self.blocks = base.stem, [], []
-        first = True
-        for (stage, block, _), units in zip(names, base.blocks):
-            if stage in freeze:
-                self.frozen_blocks.append(units)
-            else:
-                self.blocks.append(TBlock(units, self.params, needs_input_grad=not first))
-                first = False
-        self.head_blocks = [TBlock(units, self.params, needs_input_grad=True, input_is_relu=(i > 0))
-                            for i, units in enumerate(det_model.head.blocks)]
+        self.base = _make_base_train(det_model.base, self.params) if det_model.base is not None else None
+        self.base_trains = self.base is not None and len(self.base.convs()) > 0
+        self.head = head_cls(det_model.head, self.params)
         self.dense = TConv(nets.ConvUnit(all_w, "dense"), self.params, needs_dgrad=True)
-        reg_names = [n for n in _regularised_conv_names(w) if not n.startswith("rpn_")]
-        self.frozen_sumsq = _l2_of(w, [n for n in reg_names if n not in train_names and not n.startswith("dense_")]) if l2 else 0.0
+        reg_layers = head_names + (_base_layer_names(det_model.base) if det_model.base is not None and det_model.base.weight_regularizer is not None else [])
+        self.frozen_sumsq = _reg_sumsq_frozen(w, reg_layers, train_names, l2)
         self.optimizer = None
 
     def compile(self, optimizer, loss=None):
@@ -363,31 +504,18 @@ class DetTrainer:
         self.params.reset_optimizer()
 
     def _tconvs(self):
-        out = []
-        for b in self.blocks + self.head_blocks:
-            out += b.convs()
-        return out + [self.dense]
+        return (self.base.convs() if self.base is not None else []) + self.head.convs() + [self.dense]
 
     def forward(self, x, rois):
-        t = self.stem(x)
-        t = ops.pool2d(t, 3, 2, True)
-        for units in self.frozen_blocks:
-            t = nets.run_block(units, t)
-        for b in self.blocks:
-            t = b.forward(t)
-        self.feat = t
-        c = ops.roi_crop_resize(t, rois, 7)
-        for b in self.head_blocks:
-            c = b.forward(c)
-        self.h5 = c
-        pooled = ops.pool2d(c, 7, 7, False)
-        y = self.dense.forward(pooled)                         # (n,1,1,C+4(C-1))
-        n = y.shape[0]
-        y2 = y.reshape(n, -1)
+        self.feat = self.base.forward(x) if self.base is not None else x
+        crop = ops.roi_crop_resize(self.feat, rois, 7)
+        self.pooled = self.head.forward(crop)
+        y = self.dense.forward(self.pooled)                    # (n,1,1,C+4(C-1))
+        y2 = y.reshape(y.shape[0], -1)
         return ops.softmax_rows(y2, self.C), y2[:, self.C:].contiguous(), y2
 
     def train_on_batch(self, x, y, skip=False):
-        """x = [image (1,H,W,3), rois (1,n,4)]; y = [y_class (1,n,C), y_bbreg (1,n,8(C-1))]."""
+        """x = [image (1,H,W,3) or conv features (1,R,C,Cf), rois (1,n,4)]; y = [y_class (1,n,C), y_bbreg (1,n,8(C-1))]."""
         assert self.optimizer is not None, "call compile() first"
         p = self.params
         loss1 = torch.zeros(1, dtype=torch.float32, device="cuda")
@@ -406,16 +534,11 @@ class DetTrainer:
             _lib.call("frcnn_loss_det_reg", _p(yr), _p(reg), n, C - 1, _p(loss2), ctypes.c_void_p(g.data_ptr() + 4 * C), C + K4, _stream())
             g4 = g.reshape(n, 1, 1, C + K4)
             self.dense.wgrad(g4)
-            gp = self.dense.dgrad(g4)                                           # (n,1,1,2048)
-            gx = torch.empty_like(self.h5)
-            _lib.call("frcnn_avgpool_bwd_masked", _p(gp), _p(self.h5), n, 7, self.h5.shape[-1], _p(gx), _stream())
-            for b in reversed(self.head_blocks):
-                gx = b.backward(gx)
-            gfeat = ops.roi_crop_resize_bwd(gx, rois, self.feat.shape[1], self.feat.shape[2])
-            _lib.call("frcnn_relu_bwd_inplace", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
-            gb = gfeat.reshape(self.feat.shape)
-            for b in reversed(self.blocks):
-                gb = b.backward(gb)
+            gcrop = self.head.backward(self.dense.dgrad(g4))
+            if self.base_trains:
+                gfeat = ops.roi_crop_resize_bwd(gcrop, rois, self.feat.shape[1], self.feat.shape[2])
+                _lib.call("frcnn_relu_bwd_inplace", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
+                self.base.backward(gfeat.reshape(self.feat.shape))
         sq = p.sumsq() if self.l2 else None
         scale = _sync_grads(p)
         p.step(self.optimizer, self.l2, scale)
@@ -427,7 +550,7 @@ class DetTrainer:
 
     def sync_weights(self):
         w = self.model.weights
-        self.params.export(self.merged if False else w)          # per-layer entries
+        self.params.export(w)                                    # per-layer entries (+ the merged "dense")
         dense = w.pop("dense")
         C = self.C
         w["dense_class_%d" % C] = [dense[0][:, :C].copy(), dense[1][:C].copy()]

@@ -32,7 +32,9 @@ def vgg16_base(freeze_blocks=[1, 2], weight_regularizer=None, bias_regularizer=N
 def vgg16_rpn(base_model, include_conv=False, weight_regularizer=None, bias_regularizer=None,
               anchors_per_loc=DEFAULT_ANCHORS_PER_LOC):
     assert base_model.weights["rpn_out_cls"][0].shape[-1] == anchors_per_loc
-    return RpnModel(base_model, include_conv, anchors_per_loc)
+    m = RpnModel(base_model, include_conv, anchors_per_loc)
+    m.weight_regularizer = weight_regularizer
+    return m
 
 
 def vgg16_classifier(num_rois, num_classes, base_model=None, weight_regularizer=None, bias_regularizer=None, weights=None):
@@ -40,7 +42,9 @@ def vgg16_classifier(num_rois, num_classes, base_model=None, weight_regularizer=
         weights = base_model.weights
     elif weights is None:
         weights = synthetic_vgg16(num_classes=num_classes)
-    return DetModel(weights, nets.VggHead(weights, num_classes), num_rois, num_classes, base_model)
+    m = DetModel(weights, nets.VggHead(weights, num_classes), num_rois, num_classes, base_model)
+    m.weight_regularizer = weight_regularizer
+    return m
 
 
 def rpn_from_h5(h5_path, anchors_per_loc=DEFAULT_ANCHORS_PER_LOC):

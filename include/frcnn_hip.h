@@ -233,6 +233,9 @@ int frcnn_relu_bwd_inplace(float* g, const float* y, size_t n, void* stream);
 /* Backward of AveragePooling2D(k) on a k x k map (resnet.py:515) fused with the ReLU in front of it:
  * gx[n][k][k][c] = (y > 0) * g_pooled[n][c] / k^2. */
 int frcnn_avgpool_bwd_masked(const float* g_pooled, const float* y, int n, int k, int c, float* gx, void* stream);
+/* Backward of MaxPooling2D((k,k), strides=(k,k)) (vgg.py:100-128): x [n][h][w][c] the pool input, y its
+ * output [n][h/k][w/k][c], gy the gradient w.r.t. y; the gradient goes to the first maximum of each window. */
+int frcnn_maxpool_bwd(const float* x, const float* y, const float* gy, int n, int h, int w, int c, int k, float* gx, void* stream);
 /* Keras optimisers (args_util.py:48-59) over a flat parameter buffer; l2 = the regulariser factor of
  * resnet.py:26-27 (its gradient 2*l2*w is added here), grad_scale = 1/world_size after an all-reduce sum. */
 int frcnn_sgd_momentum(float* w, const float* g, float* v, size_t n, float lr, float momentum, float l2, float grad_scale, void* stream);

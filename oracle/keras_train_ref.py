@@ -120,37 +120,72 @@ def _finish(weights, w, params, total, optim):
     return out, grads
 
 
-def rpn_train_step(weights, x, y_class, y_bbreg, A, optim, depth=50, freeze_blocks=(1, 2, 3), l2=0.0, dtype=torch.float64):
-    """Returns (new_weights, [total, l1, l2], grads)."""
-    stages = [s for s in (2, 3, 4) if s not in freeze_blocks]
-    trainable = set(conv_layer_names(depth, stages)) | {"rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"}
-    w, params = _prepare(weights, trainable, dtype)
+VGG_BLOCK_CONVS = {1: 2, 2: 2, 3: 3, 4: 3, 5: 3}
+
+
+def vgg_conv_names(blocks):
+    return ["block%d_conv%d" % (b, i) for b in blocks for i in range(1, VGG_BLOCK_CONVS[b] + 1)]
+
+
+def rpn_train_step(weights, x, y_class, y_bbreg, A, optim, depth=50, freeze_blocks=(1, 2, 3), l2=0.0, dtype=torch.float64,
+                   arch="resnet", l2_base=True):
+    """One compile()d train_on_batch of an RPN model (train_rpn_step1.py:59-90; step 3 = every base block
+    frozen and only the heads regularised, train_rpn_step3.py:59-76).  Returns (new_weights, [total, l1, l2], grads)."""
+    heads = ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"]
+    if arch == "resnet":
+        base_train = conv_layer_names(depth, [s for s in (2, 3, 4) if s not in freeze_blocks])
+        base_all = ["conv1"] + conv_layer_names(depth, (2, 3, 4))
+    else:
+        base_train = vgg_conv_names([b for b in (1, 2, 3, 4, 5) if b not in freeze_blocks])
+        base_all = vgg_conv_names((1, 2, 3, 4, 5))
+    w, params = _prepare(weights, set(base_train) | set(heads), dtype)
     g = KerasGraphs(w, dtype)
-    feat = g.resnet_base(x, depth)
+    feat = g.resnet_base(x, depth) if arch == "resnet" else g.vgg_base(x)
     cls, reg = g.rpn(feat)
     yc = torch.tensor(np.asarray(y_class, dtype=np.float64), dtype=dtype)
     yr = torch.tensor(np.asarray(y_bbreg, dtype=np.float64), dtype=dtype)
     l1 = cls_loss_rpn(yc, cls, A)
     l2v = bbreg_loss_rpn(yr, reg, A)
-    reg_names = ["conv1"] + conv_layer_names(depth, (2, 3, 4)) + ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"]
+    reg_names = (base_all if l2_base else []) + heads
     total = l1 + l2v + (_l2_penalty(w, reg_names, l2) if l2 else 0.0)
     new, grads = _finish(weights, w, params, total, optim)
-    return new, [float(total), float(l1), float(l2v)], grads
+    return new, [float(total.detach()), float(l1.detach()), float(l2v.detach())], grads
 
 
-def det_train_step(weights, x, rois, y_class, y_bbreg, C, optim, depth=50, freeze_blocks=(1, 2, 3), l2=0.0, dtype=torch.float64):
-    stages = [s for s in (2, 3, 4) if s not in freeze_blocks]
+def det_train_step(weights, x, rois, y_class, y_bbreg, C, optim, depth=50, freeze_blocks=(1, 2, 3), l2=0.0, dtype=torch.float64,
+                   arch="resnet", with_base=True):
+    """One train_on_batch of a detector model.  with_base=True: step 2 (image in, own base; train_det_step2.py:78-87);
+    with_base=False: step 4 (x = conv features, only the head trains and is regularised; train_det_step4.py:67-95)."""
     dn = ["dense_class_%d" % C, "dense_reg_%d" % C]
-    trainable = set(conv_layer_names(depth, stages + [5])) | set(dn)
-    w, params = _prepare(weights, trainable, dtype)
+    if arch == "resnet":
+        base_train = conv_layer_names(depth, [s for s in (2, 3, 4) if s not in freeze_blocks]) if with_base else []
+        base_all = ["conv1"] + conv_layer_names(depth, (2, 3, 4))
+        head = conv_layer_names(depth, [5])
+    else:
+        base_train = vgg_conv_names([b for b in (1, 2, 3, 4, 5) if b not in freeze_blocks]) if with_base else []
+        base_all = vgg_conv_names((1, 2, 3, 4, 5))
+        head = ["fc1", "fc2"]
+    w, params = _prepare(weights, set(base_train) | set(head) | set(dn), dtype)
     g = KerasGraphs(w, dtype)
-    feat = g.resnet_base(x, depth)
-    cls, reg = g.resnet_classifier_logits(feat, np.asarray(rois).reshape(-1, 4), C, depth)
+    if with_base:
+        feat = g.resnet_base(x, depth) if arch == "resnet" else g.vgg_base(x)
+    else:
+        feat = torch.tensor(np.asarray(x), dtype=dtype)
+    rr = np.asarray(rois).reshape(-1, 4)
+    if arch == "resnet":
+        cls, reg = g.resnet_classifier_logits(feat, rr, C, depth)
+    else:
+        from .keras_ref import roi_resize_torch
+        t = roi_resize_torch(feat[0], rr, 7).reshape(len(rr), -1)
+        t = g._dense(t, "fc1").clamp(min=0)
+        t = g._dense(t, "fc2").clamp(min=0)
+        cls = torch.softmax(g._dense(t, dn[0]), dim=1)
+        reg = g._dense(t, dn[1])
     yc = torch.tensor(np.asarray(y_class, dtype=np.float64), dtype=dtype)[0]
     yr = torch.tensor(np.asarray(y_bbreg, dtype=np.float64), dtype=dtype)[0]
     l1 = cls_loss_det(yc, cls)
     l2v = bbreg_loss_det(yr, reg, C - 1)
-    reg_names = ["conv1"] + conv_layer_names(depth, (2, 3, 4, 5)) + dn
+    reg_names = (base_all if with_base else []) + head + dn
     total = l1 + l2v + (_l2_penalty(w, reg_names, l2) if l2 else 0.0)
     new, grads = _finish(weights, w, params, total, optim)
-    return new, [float(total), float(l1), float(l2v)], grads
+    return new, [float(total.detach()), float(l1.detach()), float(l2v.detach())], grads

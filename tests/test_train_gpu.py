@@ -158,3 +158,110 @@ def test_training_loops_through_reference_surface(tmp_path):
     dsaved = load_npz(ddest)
     assert "dense_class_21" in dsaved and dsaved["dense_class_21"][0].shape == (2048, 21)
     assert not np.array_equal(dsaved["res5a_branch2a"][0], dw_before)
+
+
+# ------------------------------------------------------------------ the reference's own test flow (VGG16, Adam, 1 step)
+def _voc_image():
+    import os
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+    return extract_img_data(os.path.join(os.path.dirname(__file__), "golden", "VOC_test"), "000005")
+
+
+def test_vgg16_rpn_one_adam_step_like_train_rpn_test():
+    """Mirror of the reference's train_rpn_test.py:21-46: VGG16 RPN, seeds 1337/1, ONE Adam step (lr 1e-5) on
+    image 000005 (un-resized, 500x375), compare the block5_conv3 kernel.  The reference compares to a golden
+    .h5 that is absent from its checkout; here the comparand is the autograd restatement (parity unpinned)."""
+    import random
+    from faster_rcnn_amd import rpn_util, train, train_util, util, vgg
+    from faster_rcnn_amd.weights import synthetic_vgg16
+    from oracle import keras_train_ref as kt
+    np.random.seed(1337); random.seed(1)
+    image = _voc_image()
+    assert (image.width, image.height, image.num_gt_boxes) == (500, 375, 5)
+    anchors = util.get_anchors([128, 256, 512])
+    w0 = synthetic_vgg16(seed=21, with_classifier=False)
+    old = {k: [np.array(a, dtype=np.float64) for a in v] for k, v in w0.items()}
+    base = vgg.vgg16_base(weights={k: [a.copy() for a in v] for k, v in w0.items()})
+    rpn = vgg.vgg16_rpn(base, anchors_per_loc=9)
+    mgr = rpn_util.RpnTrainingManager(vgg.get_conv_rows_cols, vgg.STRIDE, vgg.preprocess, anchors)
+    x = mgr.batched_image(image)
+    y_class, y_bbreg = mgr.rpn_y_true(image)
+    assert y_class.shape == (1, 23, 31, 18) and y_class[0, :, :, :9].sum() <= 256
+    rpn.compile(train.Adam(lr=1e-5))
+    losses = rpn.train_on_batch(x, [y_class, y_bbreg])
+    ref_w, ref_losses, _ = kt.rpn_train_step(w0, x, y_class, y_bbreg, 9, kt.Optim("adam", 1e-5), freeze_blocks=(1, 2), arch="vgg")
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (losses, ref_losses)
+    rpn.save_weights("/tmp/_vgg_rpn_step.npz")
+    got = rpn.get_layer("block5_conv3").get_weights()[0]
+    # Adam's first step moves every weight by lr*g/(|g|+1e-8) ~ +-lr: compare the step direction element-wise
+    dg, dw = got.astype(np.float64) - old["block5_conv3"][0], ref_w["block5_conv3"][0] - old["block5_conv3"][0]
+    assert np.abs(dw).max() > 5e-6
+    agree = (np.sign(dg) == np.sign(dw)) | (np.abs(dw) < 2e-6)
+    assert agree.mean() > 0.999, agree.mean()
+    assert np.array_equal(rpn.get_layer("block2_conv2").get_weights()[0], w0["block2_conv2"][0])       # frozen blocks 1-2
+
+
+def test_vgg16_det_step2_and_resnet_steps_3_4():
+    from faster_rcnn_amd import resnet, train, vgg
+    from faster_rcnn_amd.weights import synthetic_resnet, synthetic_vgg16
+    from oracle import keras_train_ref as kt
+    rs = np.random.RandomState(8)
+    x = image(96, 128, seed=5)
+    n, C = 8, 21
+
+    def det_targets(rows, cols):
+        x1 = rs.randint(0, cols - 2, n); y1 = rs.randint(0, rows - 2, n)
+        rois = np.stack([x1, y1, np.minimum(cols - 1, x1 + 1 + rs.randint(0, 5, n)), np.minimum(rows - 1, y1 + 1 + rs.randint(0, 4, n))], axis=1).astype(np.float32)[None]
+        ci = rs.randint(0, C, n)
+        yc = np.zeros((1, n, C), np.int32); yc[0, np.arange(n), ci] = 1
+        lab = np.zeros((n, 4 * (C - 1)), np.float32); tg = np.zeros((n, 4 * (C - 1)), np.float32)
+        for i, c in enumerate(ci):
+            if c < C - 1:
+                lab[i, 4 * c:4 * c + 4] = 1; tg[i, 4 * c:4 * c + 4] = rs.randn(4)
+        return rois, yc, np.concatenate([lab, tg], axis=1)[None]
+
+    # ---- VGG16 detector step 2 (own base, blocks 3-5 + fc + dense train; train_det_test.py:28-60 flow)
+    w0 = synthetic_vgg16(seed=22)
+    old = {k: [np.array(a, dtype=np.float64) for a in v] for k, v in w0.items()}
+    base = vgg.vgg16_base(weights={k: [a.copy() for a in v] for k, v in w0.items()})
+    det = vgg.vgg16_classifier(n, C, base_model=base)
+    rois, yc, yb = det_targets(6, 8)
+    det.compile(train.SGD(1e-3, 0.9))
+    losses = det.train_on_batch([x, rois], [yc, yb])
+    ref_w, ref_losses, _ = kt.det_train_step(w0, x, rois, yc, yb, C, kt.Optim("sgd", 1e-3), freeze_blocks=(1, 2), arch="vgg")
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (losses, ref_losses)
+    det._trainer.sync_weights()
+    check_updates(old, det.weights, ref_w, kt.vgg_conv_names((3, 4, 5)) + ["fc1", "fc2", "dense_class_21", "dense_reg_21"])
+
+    # ---- ResNet-50 step 3: whole base frozen, only the (regularised) RPN heads train
+    w0 = synthetic_resnet(50, seed=23)
+    old = {k: [np.array(a, dtype=np.float64) for a in v] for k, v in w0.items()}
+    base = resnet.resnet50_base(freeze_blocks=[1, 2, 3, 4], weights={k: [a.copy() for a in v] for k, v in w0.items()})
+    rpn = resnet.resnet50_rpn(base, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, anchors_per_loc=9)
+    rows, cols = resnet.get_conv_rows_cols(96, 128)
+    y_class, y_bbreg = rpn_targets(rows, cols, 9)
+    rpn.compile(train.SGD(1e-3, 0.9))
+    losses = rpn.train_on_batch(x, [y_class, y_bbreg])
+    ref_w, ref_losses, _ = kt.rpn_train_step(w0, x, y_class, y_bbreg, 9, kt.Optim("sgd", 1e-3), freeze_blocks=(1, 2, 3, 4), l2=1e-4, l2_base=False)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (losses, ref_losses)
+    rpn._trainer.sync_weights()
+    check_updates(old, rpn.weights, ref_w, ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"])
+    assert np.array_equal(rpn.weights["res4f_branch2c"][0], w0["res4f_branch2c"][0])
+
+    # ---- ResNet-50 step 4: detector WITHOUT a base, fed with conv features
+    w0 = synthetic_resnet(50, seed=24)
+    old = {k: [np.array(a, dtype=np.float64) for a in v] for k, v in w0.items()}
+    feat = np.maximum(rs.randn(1, rows, cols, 1024), 0).astype(np.float32)
+    det = resnet.resnet50_classifier(n, C, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER,
+                                     weights={k: [a.copy() for a in v] for k, v in w0.items()})
+    rois, yc, yb = det_targets(rows, cols)
+    det.compile(train.SGD(1e-3, 0.9))
+    losses = det.train_on_batch([feat, rois], [yc, yb])
+    ref_w, ref_losses, _ = kt.det_train_step(w0, feat, rois, yc, yb, C, kt.Optim("sgd", 1e-3), l2=1e-4, with_base=False)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (losses, ref_losses)
+    det._trainer.sync_weights()
+    check_updates(old, det.weights, ref_w, kt.conv_layer_names(50, [5]) + ["dense_class_21", "dense_reg_21"])
