@@ -1,0 +1,18 @@
+"""Mirror of the reference's eval_dets.voc_ap (eval_dets.py:8-36): VOC07 11-point / area-under-curve AP.
+Host metric code; pinned by the golden `ap_val` captured from the imported reference."""
+import numpy as np
+
+
+def voc_ap(rec, prec, use_07_metric=True):
+    if use_07_metric:
+        ap = 0.0
+        for t in np.arange(0.0, 1.1, 0.1):
+            p = 0 if np.sum(rec >= t) == 0 else np.max(prec[rec >= t])
+            ap = ap + p / 11.0
+        return ap
+    mrec = np.concatenate(([0.0], rec, [1.0]))
+    mpre = np.concatenate(([0.0], prec, [0.0]))
+    for i in range(mpre.size - 1, 0, -1):
+        mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
+    i = np.where(mrec[1:] != mrec[:-1])[0]
+    return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])

@@ -90,6 +90,7 @@ def train_detector_step2(detector, images, training_manager, optimizer, phases=[
 
 def train_detector_step4(detector, images, training_manager, optimizer, phases=[[DEFAULT_NUM_ITERATIONS, DEFAULT_LEARN_RATE]],
                          save_frequency=None, save_weights_dest=None, save_model_dest=None):
-    """train_util.train_detector_step4 (train_util.py:133-193): same loop, the manager hands conv features
-    (needs a base-less DetTrainer, not built yet)."""
-    raise NotImplementedError("step-4 training (detector on cached conv features) is a 'next' row (SURVEY 8(f) f4)")
+    """train_util.train_detector_step4 (train_util.py:133-193): same loop; the manager (conv_only: its RPN
+    model has three outputs, det_util.py:27) hands the cached conv features instead of the image and the
+    base-less detector trains its head only."""
+    return _train_detector(detector, images, training_manager, optimizer, phases, save_frequency, save_weights_dest, save_model_dest)

@@ -27,6 +27,8 @@ CASES = [  # n,h,w,cin,cout,k,stride,padding
     (1, 19, 23, 128, 9, 1, 1, "valid"),        # rpn_out_cls
     (1, 21, 30, 128, 64, 1, 2, "valid"),       # stride-2 1x1 (wgrad only: res4a_branch2a / branch1)
     (5, 1, 1, 256, 101, 1, 1, "valid"),        # dense
+    (1, 12, 16, 512, 512, 3, 1, "same"),       # vgg block4 (long k: 144 chunks)
+    (1, 6, 8, 512, 512, 3, 1, "same"),         # vgg block5
 ]
 
 

@@ -142,3 +142,8 @@ def test_detections_golden(mode):
         assert [d[0] for d in dets] == list(g[tag + "_cls"])
         assert np.array_equal(np.array([d[1] for d in dets], dtype=np.float32), g[tag + "_prob"])
         assert np.array_equal(np.array([d[2] for d in dets]), g[tag + "_bbox"])
+
+
+def test_voc_ap_mirror(golden):
+    from faster_rcnn_amd import eval_dets
+    assert abs(eval_dets.voc_ap(golden["ap_rec"], golden["ap_prec"]) - golden["ap_val"][0]) < 1e-12
