@@ -3,7 +3,7 @@ Host metric code; pinned by the golden `ap_val` captured from t
 import numpy as np
 
 
-def voc_ap(rec, prec, use_07_metric=True):
+def voc_ap(rec, prec, use_07_metric=False):
     if use_07_metric:
         ap = 0.0
         for t in np.arange(0.0, 1.1, 0.1):
