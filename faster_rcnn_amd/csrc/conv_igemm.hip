@@ -228,16 +228,22 @@ constexpr unsigned OOB_OFFSET = 0x80000000u;     // >= num_records of any tensor
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
 
-template <int TM, int TN, int VARIANT = 0>
-__global__ void __launch_bounds__(256) k_conv_igemm_f32_v2(const ConvArgs p) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int PA = BM / 32, PB = BN / 32;
+template <int TM, int TN, int VARIANT = 0, int WM = 2, int WN = 2>
+__global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvArgs p) {
+    // WM x WN waves, each owning TM x TN 32x32 tiles.  2x2 waves (256 threads) is the base shape; 4x2 waves
+    // (512 threads) on the same 128x128 tile halves the registers per wave so FOUR waves share a SIMD
+    // instead of two and a wave's barrier / LDS-latency gaps are covered by three partners.
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int RPP = NT / 8;                          // tile rows staged per pass (8 lanes x 16 B per row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * BM * LDS_STRIDE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     const int nwg = p.tiles_m * p.tiles_n;
@@ -254,7 +260,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32_v2(const ConvArgs p) {
     int a_h[PA], a_w[PA], a_off[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RPP * i;
         if (m < p.M) {
             const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
             a_h[i] = ho * p.stride - p.pad_top;
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32_v2(const ConvArgs p) {
     unsigned b_off[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int n = n0 + lrow + 32 * i;
+        const int n = n0 + lrow + RPP * i;
         b_off[i] = n < p.Cout ? (unsigned)((n * p.Kpad + lcol) * 4) : OOB_OFFSET;
     }
 
@@ -296,9 +302,9 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32_v2(const ConvArgs p) {
         float* a = As + buf * BM * LDS_STRIDE;
         float* b = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + 32 * i) * LDS_STRIDE + lcol) = ra[i];
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + RPP * i) * LDS_STRIDE + lcol) = ra[i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + 32 * i) * LDS_STRIDE + lcol) = rb[i];
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + RPP * i) * LDS_STRIDE + lcol) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -622,20 +628,20 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return check_launch("conv2d_fwd");
 }
 
-template <int TM, int TN, int VARIANT = 0>
+template <int TM, int TN, int VARIANT = 0, int WM = 2, int WN = 2>
 static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgs p = a;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_v2<TM, TN, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
         attr_done = true;
     }
-    k_conv_igemm_f32_v2<TM, TN, VARIANT><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
     return check_launch("conv2d_fwd");
 }
 
@@ -661,6 +667,7 @@ static int choose_config(const frcnn_conv_desc* d) {
         else cfg = 22;
     }
     const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * Kpad * 4 < 0x7fffffffull;
+    if (cfg >= 41 && (!fits_srd || generic)) cfg = 2;
     if (cfg >= 21 && (!fits_srd || generic)) cfg -= 20;
     if (cfg >= 11 && (!fits_srd || generic)) cfg -= 10;
     if (generic) cfg = (cfg == 2) ? 2 : 3;
@@ -711,6 +718,9 @@ int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const floa
         return launch_conv<2, 1, true>(a, s);
     }
     switch (cfg) {
+        case 41: return launch_conv_v2<1, 2, 1, 4, 2>(a, s);     // 128x128, 8 waves
+        case 42: return launch_conv_v2<2, 1, 1, 2, 4>(a, s);     // 128x128, 8 waves (2x4)
+        case 43: return launch_conv_v2<1, 1, 1, 4, 2>(a, s);     // 128x64, 8 waves
         case 21: return launch_conv_v2<2, 2, 1>(a, s);
         case 22: return launch_conv_v2<1, 1, 1>(a, s);
         case 11: return launch_conv_v2<2, 2>(a, s);

@@ -40,6 +40,10 @@ CASES = [
     (1, 15, 22, 128, 96, 3, 1, "same", "relu", False, 22),
     (1, 20, 31, 32, 64, 1, 1, "valid", "relu", False, 21),
     (1, 20, 31, 64, 64, 1, 1, "valid", "relu", False, 22),
+    (1, 15, 22, 128, 128, 3, 1, "same", "relu", True, 41),        # 8-wave 128x128 variants
+    (1, 15, 22, 128, 200, 3, 1, "same", "relu", False, 42),
+    (2, 9, 11, 64, 64, 3, 2, "same", None, False, 43),
+    (3, 7, 7, 512, 512, 3, 1, "same", "relu", False, 41),
     (1, 20, 31, 32, 64, 1, 1, "valid", "relu", False, 11),        # single k-chunk
     (1, 20, 31, 64, 64, 1, 1, "valid", "relu", False, 12),        # two k-chunks
     (3, 7, 7, 512, 512, 3, 1, "same", "relu", False, 0),          # head: RoIs as batch
