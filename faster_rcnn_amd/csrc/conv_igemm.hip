@@ -39,6 +39,9 @@ struct ConvArgs {
     int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
     int M, K, Kpad, act, ldy, ldres;
     int tiles_m, tiles_n;
+    int splits;             // split-K: K-slices per output tile (1 = none)
+    float* slabs;           // [tile][slice][BM*BN] f32 partial tiles
+    unsigned* tickets;      // [tile] arrival counters: zero on entry, left zero on exit
 };
 
 constexpr int BK = 32;
@@ -228,7 +231,13 @@ constexpr unsigned OOB_OFFSET = 0x80000000u;     // >= num_records of any tensor
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
 
-template <int TM, int TN, int VARIANT = 0, int WM = 2, int WN = 2>
+//
+// SPLITK: small grids (stage 4, the RPN heads, the dense layers: <= 152 tiles for 256 CUs and a long k loop)
+// cut K into `splits` slices, one workgroup each.  Every slice writes its f32 partial tile to a slab, publishes
+// it with ONE agent-scope release and draws a ticket; the workgroup that draws the last ticket acquires, sums
+// the slabs in slice order (fixed order: two runs are bitwise equal) and runs the fused epilogue.  One launch,
+// no atomics on data (cdna guide s5 "in-launch split-K reduction").
+template <int TM, int TN, int VARIANT = 0, int WM = 2, int WN = 2, bool SPLITK = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvArgs p) {
     // WM x WN waves, each owning TM x TN 32x32 tiles.  2x2 waves (256 threads) is the base shape; 4x2 waves
     // (512 threads) on the same 128x128 tile halves the registers per wave so FOUR waves share a SIMD
@@ -246,9 +255,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int splits = SPLITK ? p.splits : 1;
+    const int nwg = p.tiles_m * p.tiles_n * splits;
     const int logical = xcd_remap(blockIdx.x, nwg);
-    const int tile_n = logical / p.tiles_m, tile_m = logical - tile_n * p.tiles_m;
+    const int tile = SPLITK ? logical / splits : logical;          // a tile's slices are neighbours on one XCD
+    const int slice = SPLITK ? logical - tile * splits : 0;
+    const int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -277,8 +289,17 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
         b_off[i] = n < p.Cout ? (unsigned)((n * p.Kpad + lcol) * 4) : OOB_OFFSET;
     }
 
+    // this workgroup's chunk range [kb, ke) of the packed k axis (chunk = tap-major inside a 32-channel group)
+    const int nk_all = p.Kpad / BK;
+    const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
+    const int ke = SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all;
+
     i32x4 ra[PA], rb[PB];
     int r_tap = 0, s_tap = 0, c0 = 0;
+    if (SPLITK) {
+        const int RS = p.R * p.S, tap = kb % RS;
+        r_tap = tap / p.S; s_tap = tap - r_tap * p.S; c0 = (kb / RS) * BK;
+    }
     auto load_chunk = [&](int kc) {
         const int tap_off = ((r_tap * p.W + s_tap) * p.Cin + c0) * 4;          // wave-uniform
 #pragma unroll
@@ -319,20 +340,19 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
     // registers->LDS and chunk t feeds the MFMAs.  The loads issued in iteration t are consumed
     // (ds_write) at the top of iteration t+1, so they have a whole chunk of MFMA time to land and
     // the compiler cannot sink them next to their use.
-    const int nk = p.Kpad / BK;
-    load_chunk(0);
+    load_chunk(kb);
     store_chunk(0);
-    load_chunk(nk > 1 ? 1 : 0);
+    load_chunk(kb + 1 < ke ? kb + 1 : kb);
     __syncthreads();
 
     constexpr int MF = TM * TN * 4;        // MFMAs per kk-step
     constexpr int NL = PA + PB;            // global loads == LDS stores per chunk per thread
     constexpr int NF = TM + TN;            // fragment reads per kk-step
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
+    for (int kc = kb; kc < ke; ++kc) {
+        const int buf = (kc - kb) & 1;
         if constexpr (VARIANT == 0) {
             store_chunk(buf ^ 1);                              // chunk kc+1 (harmless duplicate at the tail)
-            load_chunk(kc + 2 < nk ? kc + 2 : nk - 1);         // always in range: keeps the body branch-free
+            load_chunk(kc + 2 < ke ? kc + 2 : ke - 1);         // always in range: keeps the body branch-free
         }
         const float* a = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + li) * LDS_STRIDE + lh * 4;
         const float* b = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + li) * LDS_STRIDE + lh * 4;
@@ -382,7 +402,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
             // may-alias LDS accesses ordered), so they can ride behind the last MFMAs instead of sitting in
             // front of the first one; the next loads follow the stores (register reuse) at the tail.
             store_chunk(buf ^ 1);
-            load_chunk(kc + 2 < nk ? kc + 2 : nk - 1);
+            load_chunk(kc + 2 < ke ? kc + 2 : ke - 1);
             SGB(SG_DS_RD, NF);
 #pragma unroll
             for (int kk = 0; kk < BK / 8 - 1; ++kk) {
@@ -401,6 +421,57 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
             }
         }
         __syncthreads();
+    }
+    if constexpr (SPLITK) {
+        // publish this slice's partial tile WRITE-THROUGH (sc1 stores need no release fence: cdna guide G16 R1);
+        // thread-major 16-B rows, so the stores and the reducer's loads coalesce
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.slabs, 0, (int)((size_t)p.tiles_m * p.tiles_n * splits * (BM * BN) * 4), 0x00020000);
+        const unsigned slab_off = (unsigned)((tile * splits + slice) * (BM * BN) * 4 + tid * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), srsrc,
+                                                           slab_off + ((i * TN + j) * 4 + q) * (NT * 16), 0, 16 /* sc1 */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains ...
+        __syncthreads();                                       // ... before ONE lane draws the ticket
+        int* last = reinterpret_cast<int*>(smem);              // the main loop is done with the (one) LDS array
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = (t == (unsigned)(splits - 1));
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // drop this CU's stale L1 lines
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            *last = is_last;
+        }
+        __syncthreads();
+        if (!*last) return;
+        const float4* base = reinterpret_cast<const float4*>(p.slabs + (size_t)tile * splits * (BM * BN));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        for (int sl = 0; sl < splits; ++sl) {
+            const float4* sp = base + (size_t)sl * (BM * BN / 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = sp[((i * TN + j) * 4 + q) * NT + tid];
+                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                    }
+        }
     }
     epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
 }
@@ -645,6 +716,25 @@ static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
     return check_launch("conv2d_fwd");
 }
 
+constexpr size_t SPLITK_TICKET_BYTES = 16384;      // head of the workspace: one u32 per output tile (<= 4096 tiles)
+
+template <int TM, int TN, int VARIANT = 0, int WM = 2, int WN = 2>
+static int launch_conv_v2_splitk(const ConvArgs& a, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    ConvArgs p = a;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
+        attr_done = true;
+    }
+    k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN, true><<<p.tiles_m * p.tiles_n * p.splits, 64 * WM * WN, lds, s>>>(p);
+    return check_launch("conv2d_fwd (split-K)");
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -666,12 +756,35 @@ static int choose_config(const frcnn_conv_desc* d) {
         else if (t128 >= 384 && Kpad >= 1024) cfg = 21;
         else cfg = 22;
     }
+    cfg %= 100;             // hundreds digit(s) = forced split-K factor (choose_splits)
     const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * Kpad * 4 < 0x7fffffffull;
     if (cfg >= 41 && (!fits_srd || generic)) cfg = 2;
     if (cfg >= 21 && (!fits_srd || generic)) cfg -= 20;
     if (cfg >= 11 && (!fits_srd || generic)) cfg -= 10;
     if (generic) cfg = (cfg == 2) ? 2 : 3;
     return cfg;
+}
+
+// K-slices per output tile for the 64x64 kernel (1 = plain launch).  desc.tile / 100 forces a value (dev knob).
+static int choose_splits(const frcnn_conv_desc* d, int cfg) {
+    if (cfg != 22) return 1;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long tiles = ((M + 63) / 64) * ((d->cout + 63) / 64);
+    const int nk = (d->kh * d->kw * d->cin + BK - 1) / BK;
+    if (tiles * sizeof(unsigned) > SPLITK_TICKET_BYTES) return 1;
+    int s = d->tile / 100;
+    if (s <= 0) {
+        // measured on MI355X (scripts/conv_shapes.py, C2 shapes): grids under 1.5 tiles per CU with >= 16 chunks
+        // gain from 3 slices (stage 3/4 3x3 and 1x1-reduce, rpn_conv1: -10..-37 %); tiny grids (RPN heads, dense)
+        // take enough slices for ~2 workgroups per CU, at least 4 chunks each; shorter k loops lose to the combine
+        if (tiles >= 384 || nk < 16) return 1;
+        s = tiles >= 100 ? 3 : (int)((456 + tiles - 1) / tiles);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 16) s = 16;
+    }
+    if (s > nk) s = nk;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : s;
 }
 
 extern "C" {
@@ -698,6 +811,21 @@ int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_pa
 
 int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                             const float* scale, const float* shift, const float* residual, const float* mask, float* y, void* stream) {
+    return frcnn_conv2d_fwd_ws(d, x, w_packed, scale, shift, residual, mask, y, nullptr, 0, stream);
+}
+
+size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d) {
+    if (!d || d->cin <= 0 || (d->cin % BK) != 0) return 0;
+    const int splits = choose_splits(d, choose_config(d));
+    if (splits <= 1) return 0;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const size_t tiles = (size_t)((M + 63) / 64) * ((d->cout + 63) / 64);
+    return SPLITK_TICKET_BYTES + tiles * splits * 64 * 64 * sizeof(float);
+}
+
+int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                        const float* scale, const float* shift, const float* residual, const float* mask, float* y,
+                        void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !x || !w_packed || !y) return fail(FRCNN_E_ARG, "conv2d_fwd: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->ho <= 0 || d->wo <= 0)
         return fail(FRCNN_E_ARG, "conv2d_fwd: bad shape");
@@ -710,9 +838,20 @@ int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const floa
     a.M = (int)M; a.K = d->kh * d->kw * d->cin; a.Kpad = frcnn_conv_packed_k(d->kh, d->kw, d->cin);
     a.act = d->act; a.ldy = d->ldy > 0 ? d->ldy : d->cout; a.ldres = d->ldres > 0 ? d->ldres : d->cout;
     a.tiles_m = a.tiles_n = 0;
+    a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
     const int cfg = choose_config(d);
+    if (!generic && workspace) {
+        const size_t need = frcnn_conv2d_workspace_bytes(d);
+        if (need) {
+            if (workspace_bytes < need) return fail(FRCNN_E_WORKSPACE, "conv2d_fwd: workspace needs %zu bytes", need);
+            a.splits = choose_splits(d, cfg);
+            a.tickets = (unsigned*)workspace;
+            a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
+            return launch_conv_v2_splitk<1, 1, 1>(a, s);
+        }
+    }
     if (generic) {
         if (cfg == 2) return launch_conv<1, 1, true>(a, s);
         return launch_conv<2, 1, true>(a, s);

@@ -227,7 +227,63 @@ CONV_PROFILE = None
 CONV_KERNEL_NAMES = {1: "k_conv_igemm_f32<2,2,false>", 2: "k_conv_igemm_f32<1,1,*>", 3: "k_conv_igemm_f32<2,1,*>",
                      4: "k_conv_igemm_f32<4,2,false>", 11: "k_conv_igemm_f32_v2<2,2>", 12: "k_conv_igemm_f32_v2<1,1>",
                      13: "k_conv_igemm_f32_v2<2,1>", 14: "k_conv_igemm_f32_v2<4,2>",
-                     21: "k_conv_igemm_f32_v2<2,2,1>", 22: "k_conv_igemm_f32_v2<1,1,1>"}
+                     21: "k_conv_igemm_f32_v2<2,2,1>", 22: "k_conv_igemm_f32_v2<1,1,1>",
+                     41: "k_conv_igemm_f32_v2<1,2,1,4,2>", 42: "k_conv_igemm_f32_v2<2,1,1,2,4>", 43: "k_conv_igemm_f32_v2<1,1,1,4,2>"}
+
+
+class ConvWorkspace:
+    """Split-K workspace (arrival tickets + f32 partial tiles) of frcnn_conv2d_fwd_ws.
+
+    The C ABI wants the ticket words zero on entry and leaves them zero, so one buffer zeroed at
+    allocation serves every conv launched on ONE stream (or replayed from ONE hipGraph).  Streams or
+    graphs that may run concurrently need one ``ConvWorkspace`` each (pipeline.py owns one per graph).
+    """
+
+    def __init__(self, nbytes=0):
+        self.buf = None
+        if nbytes:
+            self.get(nbytes)
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.zeros(int(nbytes), dtype=torch.uint8, device="cuda")
+        return self.buf
+
+
+_CONV_WS = None             # the workspace conv launches use right now (None: per-stream default)
+_STREAM_WS = {}             # eager launches: HIP stream handle -> ConvWorkspace (same-stream launches serialise)
+
+
+class conv_workspace:
+    """``with conv_workspace(ws):`` routes the split-K launches inside to ``ws``."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __enter__(self):
+        global _CONV_WS
+        self.prev, _CONV_WS = _CONV_WS, self.ws
+        return self.ws
+
+    def __exit__(self, *exc):
+        global _CONV_WS
+        _CONV_WS = self.prev
+
+
+def _conv_launch(d, x, w, scale, shift, residual, mask, out):
+    """frcnn_conv2d_fwd_ws with the right workspace; returns the ctypes argument tuple for re-launches."""
+    need = _lib.load().frcnn_conv2d_workspace_bytes(ctypes.byref(d))
+    ws = None
+    if need:
+        holder = _CONV_WS
+        if holder is None and not torch.cuda.is_current_stream_capturing():
+            # a capture without an explicit workspace takes the plain launch: graphs replay concurrently
+            holder = _STREAM_WS.setdefault(torch.cuda.current_stream().cuda_stream, ConvWorkspace())
+        if holder is not None:
+            ws = holder.get(need)
+    args = (ctypes.byref(d), _p(x), _p(w), _p(scale), _p(shift), _p(residual), _p(mask), _p(out), _p(ws), ws.numel() if ws is not None else 0)
+    _lib.call("frcnn_conv2d_fwd_ws", *args, _stream())
+    return args, ws
 
 
 def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0):
@@ -248,14 +304,13 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
         assert residual.shape == out.shape and residual.is_contiguous()
     d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc.cin, cout=pc.cout, kh=pc.kh, kw=pc.kw, stride=stride, pad_top=pt, pad_left=pl,
                       ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile)
-    _lib.call("frcnn_conv2d_fwd", ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), _stream())
+    args, ws = _conv_launch(d, x, pc.w, pc.scale, pc.shift, residual, None, out)
     if CONV_PROFILE is not None:
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
-        kname = CONV_KERNEL_NAMES.get(_lib.load().frcnn_conv2d_config(ctypes.byref(d)), "?")
-        args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out))
-        keep = (d, x, pc, residual, out)
+        kname = CONV_KERNEL_NAMES.get(_lib.load().frcnn_conv2d_config(ctypes.byref(d)), "?") + (" split-K" if ws is not None else "")
+        keep = (d, x, pc, residual, out, ws)
         CONV_PROFILE.append({"kernel": kname, "flops": flops, "shape": (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
-                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd", *args, _stream())})
+                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_ws", *args, _stream())})
     return out
 
 
@@ -335,7 +390,7 @@ def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
         out = torch.empty((n, ho, wo, pd.cout), dtype=torch.float32, device="cuda")
     d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=pd.cin, cout=pd.cout, kh=pd.kh, kw=pd.kw, stride=1, pad_top=pt, pad_left=pl,
                       ho=ho, wo=wo, act=0, ldy=0, ldres=0, tile=0)
-    _lib.call("frcnn_conv2d_fwd_masked", ctypes.byref(d), _p(gy.contiguous()), _p(pd.w), None, None, _p(residual), _p(mask), _p(out), _stream())
+    _conv_launch(d, gy.contiguous(), pd.w, None, None, residual, mask, out)
     return out
 
 

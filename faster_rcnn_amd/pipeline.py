@@ -60,15 +60,18 @@ class InferencePipeline:
     def capture(self, height, width, resize_ratio=1.0, warmup=2):
         """Capture one full pass for a fixed image size into a hipGraph."""
         self._static_in = torch.zeros((1, height, width, 3), dtype=torch.float32, device="cuda")
+        # the graph owns its split-K workspace: graphs of several pipelines replay concurrently.  The warm-up
+        # passes size it, so the capture itself allocates (and re-zeroes) nothing.
+        self._conv_ws = ops.ConvWorkspace()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws):
             for _ in range(warmup):
                 self.forward_dev(self._static_in, resize_ratio)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph), ops.conv_workspace(self._conv_ws):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
 

@@ -179,6 +179,18 @@ int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_pa
 int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                             const float* scale, const float* shift, const float* residual, const float* mask,
                             float* y, void* stream);
+/* Split-K form of the same launch for small grids (ResNet stage 4, the RPN heads, the dense layers):
+ * K is cut into slices, one workgroup each; the workgroup that arrives last sums the slices' f32
+ * partial tiles in slice order (deterministic) and runs the fused epilogue -- still ONE launch.
+ * frcnn_conv2d_workspace_bytes returns 0 when the shape does not split.  Workspace contract: its
+ * first 16 KiB (arrival tickets) must be ZERO on entry and are left zero on exit, so a buffer zeroed
+ * once after allocation serves any sequence of calls on ONE stream; concurrent streams / hipGraphs
+ * need one workspace each.  workspace == NULL selects the plain launch.  desc.tile / 100, when
+ * non-zero, forces the number of slices (100 = never split); desc.tile % 100 is the tile code. */
+size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d);
+int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                        const float* scale, const float* shift, const float* residual, const float* mask,
+                        float* y, void* workspace, size_t workspace_bytes, void* stream);
 /* Filter of the input-gradient convolution: transposed (cin <-> cout), flipped in both taps, input
  * channel co scaled by scale[co] (the forward epilogue scale = folded BatchNorm; NULL = 1).
  * packed: [cin][frcnn_conv_packed_k(kh, kw, cout)]. */

@@ -44,6 +44,14 @@ CASES = [
     (1, 15, 22, 128, 200, 3, 1, "same", "relu", False, 42),
     (2, 9, 11, 64, 64, 3, 2, "same", None, False, 43),
     (3, 7, 7, 512, 512, 3, 1, "same", "relu", False, 41),
+    (1, 15, 22, 128, 96, 3, 1, "same", "relu", True, 322),        # split-K, 3 slices: slices start mid-filter (36 chunks)
+    (1, 15, 22, 128, 128, 3, 1, "same", None, False, 722),        # 7 slices of 36 chunks: uneven slice lengths
+    (2, 9, 11, 64, 64, 3, 2, "same", "relu", False, 1822),        # as many slices as chunks (18): one chunk each
+    (1, 38, 63, 512, 9, 1, 1, "valid", "sigmoid", False, 422),    # rpn_out_cls, 4 slices
+    (5, 1, 1, 2048, 101, 1, 1, "valid", None, False, 1622),       # dense, 16 slices, 5 valid rows of 64
+    (1, 38, 63, 256, 256, 3, 1, "same", "relu", True, 0),         # stage-4 3x3 at full size: auto picks split-K
+    (1, 38, 63, 1024, 256, 1, 1, "valid", "relu", False, 0),      # stage-4 1x1 reduce
+    (1, 38, 63, 256, 256, 3, 1, "same", "relu", True, 122),       # same shape, split-K forced off
     (1, 20, 31, 32, 64, 1, 1, "valid", "relu", False, 11),        # single k-chunk
     (1, 20, 31, 64, 64, 1, 1, "valid", "relu", False, 12),        # two k-chunks
     (3, 7, 7, 512, 512, 3, 1, "same", "relu", False, 0),          # head: RoIs as batch
@@ -106,3 +114,27 @@ def test_pool_and_softmax(ops):
     got = ops.softmax_rows(torch.from_numpy(z).cuda(), 21).cpu()
     want = torch.softmax(torch.from_numpy(z[:, :21]).double(), dim=1)
     assert (got.double() - want).abs().max().item() < 1e-6
+
+
+def test_split_k_workspace_reuse_and_determinism(ops):
+    """One workspace serves launch after launch (tickets return to zero), results do not depend on what
+    the slabs held before, and the fixed slice order makes two runs bitwise equal."""
+    rs = np.random.RandomState(7)
+    pcs, xs = [], []
+    for cin, cout, k in [(256, 256, 3), (1024, 256, 1), (512, 36, 1)]:
+        wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+        pcs.append(ops.PackedConv(wt, np.ones(cout, np.float32), np.zeros(cout, np.float32)))
+        xs.append(torch.from_numpy(rs.randn(1, 38, 63, cin).astype(np.float32)).cuda())
+    ws = ops.ConvWorkspace()
+    with ops.conv_workspace(ws):
+        first = [ops.conv2d(x, pc, 1, "same", "relu").clone() for x, pc in zip(xs, pcs)]
+        assert ws.buf is not None, "these shapes must take the split-K launch"
+        for _ in range(20):
+            again = [ops.conv2d(x, pc, 1, "same", "relu") for x, pc in zip(xs, pcs)]
+        torch.cuda.synchronize()
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+        assert int(ws.buf[:16384].sum().item()) == 0            # tickets left zero
+    for x, pc, a in zip(xs, pcs, first):                          # vs the plain launch (different summation order)
+        plain = ops.conv2d(x, pc, 1, "same", "relu", tile=122)
+        assert (plain - a).abs().max().item() <= 2e-5 * max(1.0, plain.abs().max().item())
