@@ -52,6 +52,8 @@ SIGNATURES = {
     "frcnn_pack_conv_weights_dgrad": (I, [P, P, I, I, I, I, P, P]),
     "frcnn_conv2d_wgrad_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_wgrad": (I, [P, P, P, P, P, P, P, c_size_t, P]),
+    "frcnn_refresh_packed": (I, [P, I, P]),
+    "frcnn_colsum_batch": (I, [P, I, P]),
     "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
     "frcnn_softmax_rows": (I, [P, I, I, I, P, I, P]),
     "frcnn_loss_rpn_cls": (I, [P, P, I, I, P, P, P]),
@@ -82,6 +84,17 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in (
         "n", "h", "w", "cin", "cout", "kh", "kw", "stride", "pad_top", "pad_left", "ho", "wo",
         "act", "ldy", "ldres", "tile")]
+
+
+class PackJob(ctypes.Structure):
+    """frcnn_pack_job (include/frcnn_hip.h)."""
+    _fields_ = [(k, c_void_p) for k in ("w_hwio", "packed", "packed_dgrad", "bias", "scale", "shift_const", "shift")] + \
+               [(k, ctypes.c_int32) for k in ("kh", "kw", "cin", "cout")]
+
+
+class ColsumJob(ctypes.Structure):
+    """frcnn_colsum_job (include/frcnn_hip.h)."""
+    _fields_ = [(k, c_void_p) for k in ("g", "scale", "out")] + [(k, ctypes.c_int32) for k in ("m", "cout")]
 
 
 _lib = None

@@ -480,20 +480,18 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
 // filter packing: Keras HWIO [R][S][Cin][Cout] -> [Cout][Kpad].
 //   Cin % 32 == 0 : packed k = ((c/32)*R*S + tap)*32 + c%32   (channel chunk outer, tap inner)
 //   otherwise     : packed k = tap*Cin + c, zero padded to Kpad  (small-Cin path decodes k itself)
+__device__ __forceinline__ float pack_hwio_elem(const float* w, int RS, int Cin, int Cout, int Kpad, size_t i) {
+    const int k = (int)(i % Kpad), n = (int)(i / Kpad);
+    if ((Cin % BK) == 0) {
+        const int j = k % BK, kc = k / BK, tap = kc % RS, cc = kc / RS;
+        return w[((size_t)tap * Cin + cc * BK + j) * Cout + n];
+    }
+    return k < RS * Cin ? w[(size_t)k * Cout + n] : 0.0f;
+}
 __global__ void k_pack_hwio(const float* w, int RS, int Cin, int Cout, int Kpad, float* out) {
     const size_t total = (size_t)Cout * Kpad;
-    const bool chunked = (Cin % BK) == 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % Kpad), n = (int)(i / Kpad);
-        float v = 0.0f;
-        if (chunked) {
-            const int j = k % BK, kc = k / BK, tap = kc % RS, cc = kc / RS;
-            v = w[((size_t)tap * Cin + cc * BK + j) * Cout + n];
-        } else if (k < RS * Cin) {
-            v = w[(size_t)k * Cout + n];
-        }
-        out[i] = v;
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = pack_hwio_elem(w, RS, Cin, Cout, Kpad, i);
 }
 
 // ------------------------------------------------------------------------------------
@@ -503,22 +501,74 @@ __global__ void k_pack_hwio(const float* w, int RS, int Cin, int Cout, int Kpad,
 // which is the same as scaling the transposed filter's INPUT channel co, so it is folded here and
 // the dgrad launch is an ordinary frcnn_conv2d_fwd on these weights.
 //   w'[r'][s'][co][ci] = w[R-1-r'][S-1-s'][ci][co] * s[co]      (conv' has Cin' = Cout, Cout' = Cin)
+__device__ __forceinline__ float pack_dgrad_elem(const float* w, const float* scale, int R, int S, int Cin, int Cout, int Kpad, size_t i) {
+    const int RS = R * S;                                   // rows = Cout' = Cin, k over (co chunk, tap', co)
+    const int k = (int)(i % Kpad), ci = (int)(i / Kpad);
+    int tap, co;
+    if ((Cout % BK) == 0) { const int j = k % BK, kc = k / BK; tap = kc % RS; co = (kc / RS) * BK + j; }
+    else { if (k >= RS * Cout) return 0.0f; tap = k / Cout; co = k % Cout; }
+    const int r = R - 1 - tap / S, sx = S - 1 - tap % S;
+    return w[((size_t)(r * S + sx) * Cin + ci) * Cout + co] * (scale ? scale[co] : 1.0f);
+}
 __global__ void k_pack_dgrad(const float* w, const float* scale, int R, int S, int Cin, int Cout, int Kpad, float* out) {
-    const int RS = R * S;
-    const size_t total = (size_t)Cin * Kpad;               // rows = Cout' = Cin, k over (co chunk, tap', co)
-    const bool chunked = (Cout % BK) == 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % Kpad), ci = (int)(i / Kpad);
-        int tap, co;
-        bool ok = true;
-        if (chunked) { const int j = k % BK, kc = k / BK; tap = kc % RS; co = (kc / RS) * BK + j; }
-        else { ok = k < RS * Cout; tap = k / Cout; co = k % Cout; }
-        float v = 0.0f;
-        if (ok) {
-            const int r = R - 1 - tap / S, sx = S - 1 - tap % S;
-            v = w[((size_t)(r * S + sx) * Cin + ci) * Cout + co] * (scale ? scale[co] : 1.0f);
+    const size_t total = (size_t)Cin * Kpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = pack_dgrad_elem(w, scale, R, S, Cin, Cout, Kpad, i);
+}
+
+// One launch re-derives EVERY trainable layer's device-side forms from the fp32 master weights after an
+// optimiser step: forward pack, input-gradient pack and the folded epilogue shift.  The job table rides in
+// the kernel arguments (no table upload); blockIdx.y = job.
+constexpr int REFRESH_JOBS = 32;
+struct RefreshTable { frcnn_pack_job job[REFRESH_JOBS]; };
+__global__ void __launch_bounds__(256) k_refresh_packed(const RefreshTable t) {
+    const frcnn_pack_job& j = t.job[blockIdx.y];
+    const int RS = j.kh * j.kw;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j.packed) {
+        const int Kpad = (RS * j.cin + BK - 1) / BK * BK;
+        const size_t total = (size_t)j.cout * Kpad;
+        for (size_t i = first; i < total; i += stride) j.packed[i] = pack_hwio_elem(j.w_hwio, RS, j.cin, j.cout, Kpad, i);
+    }
+    if (j.packed_dgrad) {
+        const int Kpad = (RS * j.cout + BK - 1) / BK * BK;
+        const size_t total = (size_t)j.cin * Kpad;
+        for (size_t i = first; i < total; i += stride) j.packed_dgrad[i] = pack_dgrad_elem(j.w_hwio, j.scale, j.kh, j.kw, j.cin, j.cout, Kpad, i);
+    }
+    if (j.shift)
+        for (size_t i = first; i < (size_t)j.cout; i += stride)
+            j.shift[i] = (j.bias ? j.bias[i] : 0.0f) * (j.scale ? j.scale[i] : 1.0f) + (j.shift_const ? j.shift_const[i] : 0.0f);
+}
+
+// Bias gradients of many layers in ONE launch: out[co] = scale[co] * sum_m g[m][co].  A 1024-thread workgroup
+// owns 64 columns of one job; its 16 waves stride over the rows (256-B coalesced reads) and are summed in a
+// fixed order, so the result is reproducible.  blockIdx.x walks the (job, column group) pairs.
+constexpr int COLSUM_JOBS = 64;
+struct ColsumTable { frcnn_colsum_job job[COLSUM_JOBS]; int first_block[COLSUM_JOBS + 1]; int n; };
+__global__ void __launch_bounds__(1024) k_colsum_batch(const ColsumTable t) {
+    __shared__ float part[16][64];
+    int ji = 0;
+    while (ji + 1 < t.n && (int)blockIdx.x >= t.first_block[ji + 1]) ++ji;
+    const frcnn_colsum_job& j = t.job[ji];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = ((int)blockIdx.x - t.first_block[ji]) * 64 + lane;
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+    if (co < j.cout) {
+        const float* g = j.g + co;
+        int m = wave;
+        for (; m + 48 < j.m; m += 64) {
+            v0 += g[(size_t)m * j.cout]; v1 += g[(size_t)(m + 16) * j.cout];
+            v2 += g[(size_t)(m + 32) * j.cout]; v3 += g[(size_t)(m + 48) * j.cout];
         }
-        out[i] = v;
+        for (; m < j.m; m += 16) v0 += g[(size_t)m * j.cout];
+    }
+    part[wave][lane] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (wave == 0 && co < j.cout) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += part[w][lane];
+        j.out[co] = j.scale ? s * j.scale[co] : s;
     }
 }
 
@@ -933,6 +983,39 @@ int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g,
         if (int e = check_launch("conv2d_wgrad bias")) return e;
         k_colsum_final<<<(d->cout + 255) / 256, 256, 0, s>>>((const float*)workspace, cs, d->cout, scale, dbias);
         if (int e = check_launch("conv2d_wgrad bias")) return e;
+    }
+    return FRCNN_OK;
+}
+
+int frcnn_refresh_packed(const frcnn_pack_job* jobs, int n_jobs, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(FRCNN_E_ARG, "refresh_packed: bad argument");
+    for (int i = 0; i < n_jobs; ++i)
+        if (!jobs[i].w_hwio || jobs[i].kh <= 0 || jobs[i].kw <= 0 || jobs[i].cin <= 0 || jobs[i].cout <= 0)
+            return fail(FRCNN_E_ARG, "refresh_packed: job %d is malformed", i);
+    for (int b = 0; b < n_jobs; b += REFRESH_JOBS) {
+        RefreshTable t;
+        const int n = n_jobs - b < REFRESH_JOBS ? n_jobs - b : REFRESH_JOBS;
+        for (int i = 0; i < n; ++i) t.job[i] = jobs[b + i];
+        for (int i = n; i < REFRESH_JOBS; ++i) t.job[i] = jobs[b];        // never indexed (grid.y == n)
+        k_refresh_packed<<<dim3(96, n), 256, 0, as_stream(stream)>>>(t);
+        if (int e = check_launch("refresh_packed")) return e;
+    }
+    return FRCNN_OK;
+}
+
+int frcnn_colsum_batch(const frcnn_colsum_job* jobs, int n_jobs, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(FRCNN_E_ARG, "colsum_batch: bad argument");
+    for (int i = 0; i < n_jobs; ++i)
+        if (!jobs[i].g || !jobs[i].out || jobs[i].m <= 0 || jobs[i].cout <= 0) return fail(FRCNN_E_ARG, "colsum_batch: job %d is malformed", i);
+    for (int b = 0; b < n_jobs; b += COLSUM_JOBS) {
+        ColsumTable t;
+        t.n = n_jobs - b < COLSUM_JOBS ? n_jobs - b : COLSUM_JOBS;
+        int blocks = 0;
+        for (int i = 0; i < t.n; ++i) { t.job[i] = jobs[b + i]; t.first_block[i] = blocks; blocks += (jobs[b + i].cout + 63) / 64; }
+        for (int i = t.n; i < COLSUM_JOBS; ++i) { t.job[i] = jobs[b]; t.first_block[i] = blocks; }
+        t.first_block[COLSUM_JOBS] = blocks;
+        k_colsum_batch<<<blocks, 1024, 0, as_stream(stream)>>>(t);
+        if (int e = check_launch("colsum_batch")) return e;
     }
     return FRCNN_OK;
 }

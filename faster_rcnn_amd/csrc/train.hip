@@ -199,11 +199,17 @@ __global__ void k_adam(float* w, const float* g, float* m, float* v, size_t n, f
 
 // out = sum(w^2): 256 workgroups write f64 partials, one wave adds them in a fixed order (reproducible).
 // The L2 penalty value l2 * sum(w^2) of Keras' regularizers.
-constexpr int SUMSQ_BLOCKS = 256;
+constexpr int SUMSQ_BLOCKS = 1024;
 __global__ void __launch_bounds__(256) k_sumsq_partial(const float* w, size_t n, double* partial) {
     __shared__ double scratch[4];
     double acc = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)SUMSQ_BLOCKS * 256) acc += (double)w[i] * (double)w[i];
+    const size_t n4 = n / 4;                                 // 16-byte loads (the flat parameter buffer is 256-B aligned)
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)SUMSQ_BLOCKS * 256) {
+        const float4 v = w4[i];
+        acc += ((double)v.x * (double)v.x + (double)v.y * (double)v.y) + ((double)v.z * (double)v.z + (double)v.w * (double)v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) { const double v = (double)w[4 * n4 + threadIdx.x]; acc += v * v; }
     const double t = block_sum(acc, scratch);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
@@ -287,6 +293,7 @@ size_t frcnn_sumsq_workspace_bytes(void) { return SUMSQ_BLOCKS * sizeof(double);
 int frcnn_sumsq(const float* w, size_t n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!w || !out) return fail(FRCNN_E_ARG, "sumsq: null pointer");
     if (!workspace || workspace_bytes < frcnn_sumsq_workspace_bytes()) return fail(FRCNN_E_WORKSPACE, "sumsq: workspace needs %zu bytes", frcnn_sumsq_workspace_bytes());
+    if ((uintptr_t)w & 15) return fail(FRCNN_E_ARG, "sumsq: w must be 16-byte aligned");
     k_sumsq_partial<<<SUMSQ_BLOCKS, 256, 0, as_stream(stream)>>>(w, n, (double*)workspace);
     if (int e = check_launch("sumsq")) return e;
     k_sumsq_final<<<1, 64, 0, as_stream(stream)>>>((const double*)workspace, out);

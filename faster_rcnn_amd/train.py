@@ -139,12 +139,14 @@ class TConv:
 
     def refresh(self):
         """Re-pack from the master weights (after an optimiser step)."""
-        if not self.trainable:
-            return
-        _lib.call("frcnn_pack_conv_weights", _p(self.k4), self.kh, self.kw, self.cin, self.cout, _p(self.pc.w), _stream())
-        _lib.call("frcnn_fold_bias", _p(self.bv), _p(self.scale), _p(self.const), _p(self.pc.shift), self.cout, _stream())
-        if self.needs_dgrad:
-            _lib.call("frcnn_pack_conv_weights_dgrad", _p(self.k4), _p(self.scale), self.kh, self.kw, self.cin, self.cout, _p(self.pd.w), _stream())
+        if self.trainable:
+            refresh_packed(make_refresh_jobs([self]))
+
+    def pack_job(self):
+        ptr = lambda t: None if t is None else t.data_ptr()
+        return _lib.PackJob(w_hwio=ptr(self.k4), packed=ptr(self.pc.w), packed_dgrad=ptr(self.pd.w) if self.needs_dgrad else None,
+                            bias=ptr(self.bv), scale=ptr(self.scale), shift_const=ptr(self.const), shift=ptr(self.pc.shift),
+                            kh=self.kh, kw=self.kw, cin=self.cin, cout=self.cout)
 
     def forward(self, x, residual=None):
         self.x = x
@@ -155,10 +157,39 @@ class TConv:
         """g: gradient w.r.t. this layer's post-BN pre-activation output."""
         if self.trainable:
             ops.conv2d_wgrad(self.x, g, self.kh, self.kw, self.u.stride, self.u.padding, scale=self.scale,
-                             dw=self.gk4, dbias=self.gb, want_bias=self.gb is not None)
+                             dw=self.gk4, want_bias=False)
+            if self.gb is not None:            # bias gradients of the whole step leave in ONE launch (flush_bias_grads)
+                _PENDING_BIAS.append((g if g.is_contiguous() else g.contiguous(), self.scale, self.gb))
 
     def dgrad(self, g, residual=None, mask=None):
         return ops.conv2d_dgrad(g, self.pd, self.u.padding, residual=residual, mask=mask)
+
+
+_PENDING_BIAS = []          # (g, scale, dbias) of this step's trainable convs; g is kept alive until the flush
+
+
+def flush_bias_grads():
+    """dbias[co] = scale[co] * sum_m g[m][co] for every conv that ran wgrad since the last flush."""
+    if not _PENDING_BIAS:
+        return
+    jobs = (_lib.ColsumJob * len(_PENDING_BIAS))()
+    for j, (g, scale, out) in zip(jobs, _PENDING_BIAS):
+        j.g, j.scale, j.out = g.data_ptr(), (None if scale is None else scale.data_ptr()), out.data_ptr()
+        j.cout = g.shape[-1]
+        j.m = g.numel() // g.shape[-1]
+    _lib.call("frcnn_colsum_batch", jobs, len(_PENDING_BIAS), _stream())
+    _PENDING_BIAS.clear()
+
+
+def make_refresh_jobs(tconvs):
+    """ctypes job table of frcnn_refresh_packed for the trainable convs (pointers are fixed for a trainer's life)."""
+    jobs = [c.pack_job() for c in tconvs if c.trainable]
+    return (_lib.PackJob * len(jobs))(*jobs)
+
+
+def refresh_packed(jobs):
+    if len(jobs):
+        _lib.call("frcnn_refresh_packed", jobs, len(jobs), _stream())
 
 
 class TBlock:
@@ -359,6 +390,7 @@ class RpnTrainer:
         self.l2_mask_base = base_reg
         assert base_reg or not self.base_trains or not l2, "a trainable base without regularisers next to regularised heads is not supported"
         self.optimizer = None
+        self._refresh_jobs = None
 
     def compile(self, optimizer, loss=None):
         self.optimizer = optimizer
@@ -398,11 +430,13 @@ class RpnTrainer:
             self.rpn_conv.wgrad(gh)
             if self.base_trains:
                 self.base.backward(self.rpn_conv.dgrad(gh, mask=self.feat))
+        flush_bias_grads()
         sq = p.sumsq() if self.l2 else None
         scale = _sync_grads(p)
         p.step(self.optimizer, self.l2, scale)
-        for c in self._tconvs():
-            c.refresh()
+        if self._refresh_jobs is None:
+            self._refresh_jobs = make_refresh_jobs(self._tconvs())
+        refresh_packed(self._refresh_jobs)
         l1, l2v = float(loss1.item()), float(loss2.item())
         reg_term = self.l2 * (float(sq.item()) + self.frozen_sumsq) if self.l2 else 0.0
         return [l1 + l2v + reg_term, l1, l2v]
@@ -498,6 +532,7 @@ class DetTrainer:
         reg_layers = head_names + (_base_layer_names(det_model.base) if det_model.base is not None and det_model.base.weight_regularizer is not None else [])
         self.frozen_sumsq = _reg_sumsq_frozen(w, reg_layers, train_names, l2)
         self.optimizer = None
+        self._refresh_jobs = None
 
     def compile(self, optimizer, loss=None):
         self.optimizer = optimizer
@@ -539,11 +574,13 @@ class DetTrainer:
                 gfeat = ops.roi_crop_resize_bwd(gcrop, rois, self.feat.shape[1], self.feat.shape[2])
                 _lib.call("frcnn_relu_bwd_inplace", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
                 self.base.backward(gfeat.reshape(self.feat.shape))
+        flush_bias_grads()
         sq = p.sumsq() if self.l2 else None
         scale = _sync_grads(p)
         p.step(self.optimizer, self.l2, scale)
-        for c in self._tconvs():
-            c.refresh()
+        if self._refresh_jobs is None:
+            self._refresh_jobs = make_refresh_jobs(self._tconvs())
+        refresh_packed(self._refresh_jobs)
         l1, l2v = float(loss1.item()), float(loss2.item())
         reg_term = self.l2 * (float(sq.item()) + self.frozen_sumsq) if self.l2 else 0.0
         return [l1 + l2v + reg_term, l1, l2v]

@@ -161,7 +161,9 @@ typedef struct frcnn_conv_desc {
     int32_t ldy, ldres;            /* row strides (elements) of y / residual; 0 = cout        */
     int32_t tile;                  /* 0 = auto; 1: 128x128, 2: 64x64, 3: 128x64, 4: 256x128;
                                       11..14: the same tiles with the pipelined v2 main loop;
-                                      21, 22: 128x128 / 64x64 v2 with the late-LDS-store schedule */
+                                      21, 22: 128x128 / 64x64 v2 with the late-LDS-store schedule;
+                                      41..43: 128x128 (4x2 / 2x4 waves) and 128x64 with 8 waves;
+                                      + 100*s: force s split-K slices (frcnn_conv2d_fwd_ws)       */
 } frcnn_conv_desc;
 
 /* k extent of a packed filter row: kh*kw*cin rounded up to the kernel's k-chunk (32). */
@@ -196,6 +198,32 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
  * packed: [cin][frcnn_conv_packed_k(kh, kw, cout)]. */
 int frcnn_pack_conv_weights_dgrad(const float* w_hwio, const float* scale, int kh, int kw, int cin, int cout,
                                   float* packed, void* stream);
+/* After an optimiser step: re-derive the device forms of MANY trainable layers from their fp32
+ * master weights in ONE launch (Keras keeps one variable per layer and needs no such step; here
+ * the conv engine reads packed filters).  `jobs` is a HOST array (it rides in the kernel arguments).
+ * Per job: packed := frcnn_pack_conv_weights(w_hwio), packed_dgrad := frcnn_pack_conv_weights_dgrad
+ * (w_hwio, scale), shift[n] := bias[n]*scale[n] + shift_const[n]; NULL outputs are skipped, NULL
+ * bias / scale / shift_const read as 0 / 1 / 0. */
+typedef struct frcnn_pack_job {
+    const float* w_hwio;
+    float* packed;
+    float* packed_dgrad;
+    const float* bias;
+    const float* scale;
+    const float* shift_const;
+    float* shift;
+    int32_t kh, kw, cin, cout;
+} frcnn_pack_job;
+int frcnn_refresh_packed(const frcnn_pack_job* jobs, int n_jobs, void* stream);
+/* Bias gradients of many layers in one launch: out[co] = scale[co] * sum_m g[m][co] (g [m][cout],
+ * scale may be NULL).  `jobs` is a HOST array.  Fixed summation order (reproducible). */
+typedef struct frcnn_colsum_job {
+    const float* g;
+    const float* scale;
+    float* out;
+    int32_t m, cout;
+} frcnn_colsum_job;
+int frcnn_colsum_batch(const frcnn_colsum_job* jobs, int n_jobs, void* stream);
 /* Weight / bias gradient of the convolution described by d (forward geometry):
  *   dw[kh][kw][cin][cout] = scale[co] * sum_m im2col(x)[m][(tap,ci)] * g[m][co],  dbias[co] = scale[co] * sum_m g[m][co]
  * g [M][cout] = gradient w.r.t. the layer's post-BatchNorm, pre-activation output.  Deterministic

@@ -61,3 +61,51 @@ def test_conv_backward(case):
         want = x.grad + res * (x.detach() > 0)           # (convT(gy*scale) + residual) masked by the ReLU
         err = ((dx.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
         assert err < 1e-4, err
+
+
+def test_refresh_packed_matches_single_packs():
+    """The batched post-step refresh writes bit-for-bit what the three per-layer calls write."""
+    import ctypes
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(3)
+    shapes = [(3, 3, 64, 96), (1, 1, 256, 36), (1, 1, 128, 9), (3, 3, 128, 128), (1, 1, 2048, 101)] * 8     # 40 jobs: two launches
+    keep, jobs = [], []
+    for kh, kw, cin, cout in shapes:
+        w = torch.from_numpy(rs.randn(kh, kw, cin, cout).astype(np.float32)).cuda()
+        bias, scale, const = (torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda() for _ in range(3))
+        kp = _lib.load().frcnn_conv_packed_k(kh, kw, cin)
+        kpd = _lib.load().frcnn_conv_packed_k(kh, kw, cout)
+        packed = torch.full((cout, kp), float("nan"), device="cuda")
+        pdg = torch.full((cin, kpd), float("nan"), device="cuda")
+        shift = torch.full((cout,), float("nan"), device="cuda")
+        keep.append((w, bias, scale, const, packed, pdg, shift))
+        jobs.append(_lib.PackJob(w_hwio=w.data_ptr(), packed=packed.data_ptr(), packed_dgrad=pdg.data_ptr(), bias=bias.data_ptr(),
+                                 scale=scale.data_ptr(), shift_const=const.data_ptr(), shift=shift.data_ptr(), kh=kh, kw=kw, cin=cin, cout=cout))
+    arr = (_lib.PackJob * len(jobs))(*jobs)
+    _lib.call("frcnn_refresh_packed", arr, len(jobs), ops._stream())
+    for (kh, kw, cin, cout), (w, bias, scale, const, packed, pdg, shift) in zip(shapes, keep):
+        want = ops.PackedConv(w, scale, None).w
+        assert torch.equal(packed, want)
+        assert torch.equal(pdg, ops.PackedDgrad(w, scale).w)
+        assert torch.allclose(shift, bias * scale + const, rtol=1e-6, atol=1e-6)      # fma vs mul+add
+
+
+def test_colsum_batch():
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(4)
+    keep, jobs = [], []
+    for m, cout, use_scale in [(2394, 256, True), (2394, 1024, True), (3136, 2048, False), (2394, 9, False), (2394, 36, True), (64, 101, False), (5, 64, True)] * 10:
+        g = torch.from_numpy(rs.randn(m, cout).astype(np.float32)).cuda()
+        scale = torch.from_numpy(rs.rand(cout).astype(np.float32) + 0.5).cuda() if use_scale else None
+        out = torch.full((cout,), float("nan"), device="cuda")
+        keep.append((g, scale, out))
+        jobs.append(_lib.ColsumJob(g=g.data_ptr(), scale=None if scale is None else scale.data_ptr(), out=out.data_ptr(), m=m, cout=cout))
+    arr = (_lib.ColsumJob * len(jobs))(*jobs)
+    _lib.call("frcnn_colsum_batch", arr, len(jobs), ops._stream())
+    first = [o.clone() for _, _, o in keep]
+    _lib.call("frcnn_colsum_batch", arr, len(jobs), ops._stream())
+    for (g, scale, out), f in zip(keep, first):
+        want = g.double().sum(0) * (scale.double() if scale is not None else 1.0)
+        err = (out.double() - want).abs().max().item()
+        assert err <= 1e-5 * max(1.0, want.abs().max().item()) * 10, err
+        assert torch.equal(out, f)                              # fixed summation order
