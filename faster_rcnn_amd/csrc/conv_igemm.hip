@@ -525,7 +525,30 @@ __global__ void __launch_bounds__(256) k_refresh_packed(const RefreshTable t) {
     const frcnn_pack_job& j = t.job[blockIdx.y];
     const int RS = j.kh * j.kw;
     const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j.packed) {
+    if (j.packed && (j.cin % BK) == 0) {
+        // HWIO has cout fastest, the packed rows have the 32 channels of a chunk fastest: transpose 32 x 64
+        // (channel x cout) tiles through LDS so both the reads (256 B) and the writes (128 B) are whole segments
+        __shared__ float tile[BK][65];
+        const int Kpad = RS * j.cin, nblk = (j.cout + 63) / 64, ntiles = RS * (j.cin / BK) * nblk;
+        const int lane = threadIdx.x & 63, jr = threadIdx.x >> 6, wn = threadIdx.x >> 3, j4 = (threadIdx.x & 7) * 4;
+        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+            const int nb = tl % nblk, kc = tl / nblk, tap = kc % RS, cc = kc / RS, n0 = nb * 64;
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                const int c = jr + 4 * pp;
+                tile[c][lane] = n0 + lane < j.cout ? j.w_hwio[((size_t)tap * j.cin + cc * BK + c) * j.cout + n0 + lane] : 0.0f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int n = wn + 32 * pass;
+                if (n0 + n < j.cout)
+                    *reinterpret_cast<float4*>(j.packed + (size_t)(n0 + n) * Kpad + kc * BK + j4) =
+                        make_float4(tile[j4][n], tile[j4 + 1][n], tile[j4 + 2][n], tile[j4 + 3][n]);
+            }
+            __syncthreads();
+        }
+    } else if (j.packed) {
         const int Kpad = (RS * j.cin + BK - 1) / BK * BK;
         const size_t total = (size_t)j.cout * Kpad;
         for (size_t i = first; i < total; i += stride) j.packed[i] = pack_hwio_elem(j.w_hwio, RS, j.cin, j.cout, Kpad, i);
