@@ -68,7 +68,7 @@ def build_pipeline():
     return InferencePipeline(rpn, det, anchors, max_proposals=PROPOSALS), w, anchors
 
 
-def conv_roofline(pipe, x, reps=10):
+def conv_roofline(pipe, x, reps=10, split_k=True):
     """Per-launch duration of every conv launch of one image, measured with HIP events on the launch
     stream.  An event pair around ONE short kernel also measures the event packets themselves
     (tens of microseconds on this stack), so each distinct launch (kernel instantiation x shape) is
@@ -76,11 +76,12 @@ def conv_roofline(pipe, x, reps=10):
     kernel; its average is the launch duration.  Returns the roofline object for the DOMINANT kernel
     instantiation (largest summed duration per image) plus the aggregate over all conv launches."""
     from faster_rcnn_amd import ops
-    pipe.forward_dev(x)
-    torch.cuda.synchronize()
-    ops.CONV_PROFILE = []
-    pipe.forward_dev(x)
-    torch.cuda.synchronize()
+    with ops.conv_workspace(None if split_k else ops.NO_SPLIT_K):     # the same launch forms the timed graphs hold
+        pipe.forward_dev(x)
+        torch.cuda.synchronize()
+        ops.CONV_PROFILE = []
+        pipe.forward_dev(x)
+        torch.cuda.synchronize()
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
     groups = {}
     for rec in prof:
@@ -92,7 +93,8 @@ def conv_roofline(pipe, x, reps=10):
         rec = g["rec"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(5_000_000)
-        rec["relaunch"]()
+        for _ in range(3):                      # the shader clock settles over the first launches of a shape
+            rec["relaunch"]()
         e0.record()
         for _ in range(reps):
             rec["relaunch"]()
@@ -160,6 +162,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--config", choices=("c2", "c4"), default="c2", help="c2 = BASELINE configs[1] (headline); c4 = configs[3]")
+    ap.add_argument("--split-k", choices=("auto", "on", "off"), default="auto", help="split-K conv launches for small grids")
     ap.add_argument("--streams", type=int, default=4, help="images in flight per GPU (one hipGraph + HIP stream each)")
     args = ap.parse_args()
     select_config(args.config)
@@ -178,12 +181,15 @@ def main():
     pipe, weights, anchors = build_pipeline()
     x = torch.from_numpy(synth_image(rank)).cuda()
     S = max(1, args.streams)
+    # split-K is a latency tool: measured on MI355X it gains 6-9 % with one image in flight and nothing (f32) or
+    # -4 % (bf16) with four, where concurrency already fills the small grids
+    split_k = args.split_k == "on" or (args.split_k == "auto" and (S == 1 or DTYPE == "f32"))
     if not args.no_graph:
         from faster_rcnn_amd.pipeline import InferencePipeline
         pipes = [pipe] + [InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS) for _ in range(S - 1)]
         streams = [torch.cuda.Stream() for _ in range(S)]
         for i, (pl, st) in enumerate(zip(pipes, streams)):
-            pl.capture(HEIGHT, WIDTH)
+            pl.capture(HEIGHT, WIDTH, split_k=split_k)
             pl._static_in.copy_(torch.from_numpy(synth_image(rank * S + i)).cuda())
         torch.cuda.synchronize()
 
@@ -220,7 +226,7 @@ def main():
     n_dets = int(out["n_dets"].item()) if "n_dets" in out else None
 
     if rank == 0:
-        roof, _ = conv_roofline(pipe, x)
+        roof, _ = conv_roofline(pipe, x, split_k=split_k)
         line = {
             "metric": "images/sec end-to-end (RPN+det) ResNet-%d %dx%d" % (DEPTH, HEIGHT, WIDTH),
             "value": round(world * S * args.steps / elapsed, 3), "unit": "img/s",
@@ -230,7 +236,7 @@ def main():
             "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": WORKLOAD,
                        "images_per_step_per_gpu": S, "proposals": PROPOSALS, "classes": NUM_CLASSES,
-                       "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
                        "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world},
             "roofline": roof,
         }
@@ -245,6 +251,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(weights, anchors)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()                  # rank 0 is still measuring the roofline: leave the group together
         dist.destroy_process_group()
 
 

@@ -71,6 +71,8 @@ SIGNATURES = {
     "frcnn_conv_packed_k_bf16": (I, [I, I, I]),
     "frcnn_pack_conv_weights_bf16": (I, [P, I, I, I, I, P, P]),
     "frcnn_conv2d_fwd_bf16": (I, [P, P, P, P, P, P, P, I, P]),
+    "frcnn_conv2d_workspace_bytes_bf16": (c_size_t, [P]),
+    "frcnn_conv2d_fwd_bf16_ws": (I, [P, P, P, P, P, P, P, I, P, c_size_t, P]),
     "frcnn_cast_f32_to_bf16": (I, [P, c_size_t, P, P]),
     "frcnn_avgpool_bf16_to_f32": (I, [P, I, I, I, P, P]),
     "frcnn_roi_crop_resize_fwd_bf16": (I, [P, I, I, I, P, I, I, P, P]),

@@ -20,12 +20,16 @@ namespace frcnn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgsBf16 {
     const __bf16* x; const __bf16* w; const float* scale; const float* shift; const __bf16* residual; void* y;
     int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
     int M, Kpad, act, out_f32;
     int tiles_m, tiles_n;
+    int splits;             // split-K (see conv_igemm.hip): K-slices per tile, f32 partial slabs, arrival tickets
+    float* slabs;
+    unsigned* tickets;
 };
 
 constexpr int BKH = 64;                 // channels per k-chunk (128 B)
@@ -45,9 +49,9 @@ __device__ __forceinline__ float activate_b(float v, int act) {
     return v;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool SPLITK = false>
 __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256;
     constexpr int PA = BM / 32, PB = BN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char* As = smem_b;                                   // [2][BM][144 B]
@@ -57,9 +61,12 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int splits = SPLITK ? p.splits : 1;
+    const int nwg = p.tiles_m * p.tiles_n * splits;
     const int logical = xcd_remap_b(blockIdx.x, nwg);
-    const int tile_n = logical / p.tiles_m, tile_m = logical - tile_n * p.tiles_m;
+    const int tile = SPLITK ? logical / splits : logical;
+    const int slice = SPLITK ? logical - tile * splits : 0;
+    const int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -88,8 +95,16 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
         b_off[i] = n < p.Cout ? (unsigned)(n * p.Kpad * 2 + lcolb) : OOB_OFFSET_B;
     }
 
+    const int nk_all = p.Kpad / BKH;
+    const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
+    const int ke = SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all;
+
     i32x4 ra[PA], rb[PB];
     int r_tap = 0, s_tap = 0, c0 = 0;
+    if (SPLITK) {
+        const int RS = p.R * p.S, tap = kb % RS;
+        r_tap = tap / p.S; s_tap = tap - r_tap * p.S; c0 = (kb / RS) * BKH;
+    }
     auto load_chunk = [&](int kc) {
         const int tap_off = ((r_tap * p.W + s_tap) * p.Cin + c0) * 2;
 #pragma unroll
@@ -124,19 +139,18 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    const int nk = p.Kpad / BKH;
-    load_chunk(0);
+    load_chunk(kb);
     store_chunk(0);
-    load_chunk(nk > 1 ? 1 : 0);
+    load_chunk(kb + 1 < ke ? kb + 1 : kb);
     __syncthreads();
 
     constexpr int MF = TM * TN;            // MFMAs per k-step (k = 16)
     constexpr int NL = PA + PB;
     constexpr int NF = TM + TN;
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
+    for (int kc = kb; kc < ke; ++kc) {
+        const int buf = (kc - kb) & 1;
         store_chunk(buf ^ 1);
-        load_chunk(kc + 2 < nk ? kc + 2 : nk - 1);
+        load_chunk(kc + 2 < ke ? kc + 2 : ke - 1);
         const char* a = As + buf * BM * LDS_STRIDE_B + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
         const char* b = Bs + buf * BN * LDS_STRIDE_B + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
         bf16x8 fa[4][TM], fb[4][TN];
@@ -165,6 +179,57 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
 #pragma unroll
         for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);
         __syncthreads();
+    }
+
+    if constexpr (SPLITK) {
+        // write-through partial tile -> ticket -> the last arriver sums the slices in order (conv_igemm.hip)
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.slabs, 0, (int)((size_t)p.tiles_m * p.tiles_n * splits * (BM * BN) * 4), 0x00020000);
+        const unsigned slab_off = (unsigned)((tile * splits + slice) * (BM * BN) * 4 + tid * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), srsrc,
+                                                           slab_off + ((i * TN + j) * 4 + q) * (NT * 16), 0, 16 /* sc1 */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* last = reinterpret_cast<int*>(smem_b);
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = (t == (unsigned)(splits - 1));
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *last = is_last;
+        }
+        __syncthreads();
+        if (!*last) return;
+        const float4* base = reinterpret_cast<const float4*>(p.slabs + (size_t)tile * splits * (BM * BN));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        for (int sl = 0; sl < splits; ++sl) {
+            const float4* sp = base + (size_t)sl * (BM * BN / 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = sp[((i * TN + j) * 4 + q) * NT + tid];
+                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                    }
+        }
     }
 
     // epilogue: C/D map col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -265,6 +330,44 @@ static int launch_bf16(const ConvArgsBf16& a, hipStream_t s) {
     return check_launch("conv2d_fwd_bf16");
 }
 
+constexpr size_t SPLITK_TICKET_BYTES_B = 16384;     // same workspace layout as frcnn_conv2d_fwd_ws
+
+static int launch_bf16_splitk(const ConvArgsBf16& a, hipStream_t s) {
+    ConvArgsBf16 p = a;
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_n = (p.Cout + 63) / 64;
+    const size_t lds = (size_t)2 * (64 + 64) * LDS_STRIDE_B;
+    k_conv_igemm_bf16<1, 1, true><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
+    return check_launch("conv2d_fwd_bf16 (split-K)");
+}
+
+// K-slices per tile for the 64x64 bf16 kernel: same policy as the f32 engine (conv_igemm.hip choose_splits)
+static int choose_splits_bf16(const frcnn_conv_desc* d, int cfg) {
+    if (cfg != 2 && cfg != 12) return 1;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long tiles = ((M + 63) / 64) * ((d->cout + 63) / 64);
+    const int nk = d->kh * d->kw * d->cin / BKH;
+    if (tiles * sizeof(unsigned) > SPLITK_TICKET_BYTES_B) return 1;
+    int s = d->tile / 100;
+    if (s <= 0) {
+        if (tiles >= 384 || nk < 8) return 1;
+        s = tiles >= 100 ? 3 : (int)((456 + tiles - 1) / tiles);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 16) s = 16;
+    }
+    if (s > nk) s = nk;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : s;
+}
+
+static int choose_config_bf16(const frcnn_conv_desc* d) {
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
+    int cfg = d->tile % 100;
+    if (cfg == 0) cfg = t128 >= 256 ? 1 : 2;
+    return cfg;
+}
+
 static inline int ew_grid_b(size_t n) { size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
 }  // namespace frcnn
@@ -285,6 +388,21 @@ int frcnn_pack_conv_weights_bf16(const float* w_hwio, int kh, int kw, int cin, i
 
 int frcnn_conv2d_fwd_bf16(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
                           const float* scale, const float* shift, const void* residual_bf16, void* y, int y_is_f32, void* stream) {
+    return frcnn_conv2d_fwd_bf16_ws(d, x_bf16, w_packed_bf16, scale, shift, residual_bf16, y, y_is_f32, nullptr, 0, stream);
+}
+
+size_t frcnn_conv2d_workspace_bytes_bf16(const frcnn_conv_desc* d) {
+    if (!d || d->cin <= 0 || (d->cin % BKH) != 0) return 0;
+    const int splits = choose_splits_bf16(d, choose_config_bf16(d));
+    if (splits <= 1) return 0;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const size_t tiles = (size_t)((M + 63) / 64) * ((d->cout + 63) / 64);
+    return SPLITK_TICKET_BYTES_B + tiles * splits * 64 * 64 * sizeof(float);
+}
+
+int frcnn_conv2d_fwd_bf16_ws(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
+                             const float* scale, const float* shift, const void* residual_bf16, void* y, int y_is_f32,
+                             void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !x_bf16 || !w_packed_bf16 || !y) return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: null pointer");
     if (d->cin % BKH) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_bf16: cin must be a multiple of 64");
     if ((size_t)d->n * d->h * d->w * d->cin * 2 >= 0x7fffffffull || (size_t)d->cout * d->kh * d->kw * d->cin * 2 >= 0x7fffffffull)
@@ -296,10 +414,26 @@ int frcnn_conv2d_fwd_bf16(const frcnn_conv_desc* d, const void* x_bf16, const vo
     a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
     a.M = d->n * d->ho * d->wo; a.Kpad = d->kh * d->kw * d->cin; a.act = d->act; a.out_f32 = y_is_f32;
     a.tiles_m = a.tiles_n = 0;
+    a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
     hipStream_t s = as_stream(stream);
-    const long long t128 = ((long long)(a.M + 127) / 128) * ((d->cout + 127) / 128);
-    int cfg = d->tile;
-    if (cfg == 0) cfg = t128 >= 256 ? 1 : 2;
+    const int cfg = choose_config_bf16(d);
+    static bool attr_done = false;
+    if (workspace) {
+        const size_t need = frcnn_conv2d_workspace_bytes_bf16(d);
+        if (need) {
+            if (workspace_bytes < need) return fail(FRCNN_E_WORKSPACE, "conv2d_fwd_bf16: workspace needs %zu bytes", need);
+            if (!attr_done) {
+                if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(2 * 128 * LDS_STRIDE_B)) != hipSuccess)
+                    return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS");
+                attr_done = true;
+            }
+            a.splits = choose_splits_bf16(d, cfg);
+            a.tickets = (unsigned*)workspace;
+            a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES_B);
+            return launch_bf16_splitk(a, s);
+        }
+    }
     switch (cfg) {
         case 1: case 11: return launch_bf16<2, 2>(a, s);
         case 2: case 12: return launch_bf16<1, 1>(a, s);

@@ -250,6 +250,7 @@ class ConvWorkspace:
         return self.buf
 
 
+NO_SPLIT_K = object()       # ``with conv_workspace(NO_SPLIT_K):`` = plain launches only
 _CONV_WS = None             # the workspace conv launches use right now (None: per-stream default)
 _STREAM_WS = {}             # eager launches: HIP stream handle -> ConvWorkspace (same-stream launches serialise)
 
@@ -270,17 +271,20 @@ class conv_workspace:
         _CONV_WS = self.prev
 
 
+def _split_k_ws(need):
+    """The split-K workspace tensor a launch needing `need` bytes should use right now, or None (plain launch)."""
+    if not need or _CONV_WS is NO_SPLIT_K:
+        return None
+    holder = _CONV_WS
+    if holder is None and not torch.cuda.is_current_stream_capturing():
+        # a capture without an explicit workspace takes the plain launch: graphs replay concurrently
+        holder = _STREAM_WS.setdefault(torch.cuda.current_stream().cuda_stream, ConvWorkspace())
+    return None if holder is None else holder.get(need)
+
+
 def _conv_launch(d, x, w, scale, shift, residual, mask, out):
     """frcnn_conv2d_fwd_ws with the right workspace; returns the ctypes argument tuple for re-launches."""
-    need = _lib.load().frcnn_conv2d_workspace_bytes(ctypes.byref(d))
-    ws = None
-    if need:
-        holder = _CONV_WS
-        if holder is None and not torch.cuda.is_current_stream_capturing():
-            # a capture without an explicit workspace takes the plain launch: graphs replay concurrently
-            holder = _STREAM_WS.setdefault(torch.cuda.current_stream().cuda_stream, ConvWorkspace())
-        if holder is not None:
-            ws = holder.get(need)
+    ws = _split_k_ws(_lib.load().frcnn_conv2d_workspace_bytes(ctypes.byref(d)))
     args = (ctypes.byref(d), _p(x), _p(w), _p(scale), _p(shift), _p(residual), _p(mask), _p(out), _p(ws), ws.numel() if ws is not None else 0)
     _lib.call("frcnn_conv2d_fwd_ws", *args, _stream())
     return args, ws
@@ -433,13 +437,15 @@ def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f
     out = torch.empty((x.shape[0], d.ho, d.wo, pc.cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
     if residual is not None:
         assert residual.dtype == torch.bfloat16 and residual.shape == out.shape and residual.is_contiguous()
-    _lib.call("frcnn_conv2d_fwd_bf16", ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), 1 if out_f32 else 0, _stream())
+    ws = _split_k_ws(_lib.load().frcnn_conv2d_workspace_bytes_bf16(ctypes.byref(d)))
+    args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), 1 if out_f32 else 0,
+            _p(ws), ws.numel() if ws is not None else 0)
+    _lib.call("frcnn_conv2d_fwd_bf16_ws", *args, _stream())
     if CONV_PROFILE is not None:
         flops = 2.0 * x.shape[0] * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin
-        args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), 1 if out_f32 else 0)
-        keep = (d, x, pc, residual, out)
+        keep = (d, x, pc, residual, out, ws)
         CONV_PROFILE.append({"kernel": "k_conv_igemm_bf16", "flops": flops, "shape": (x.shape[0] * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
-                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_bf16", *args, _stream())})
+                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_bf16_ws", *args, _stream())})
     return out
 
 

@@ -57,12 +57,16 @@ class InferencePipeline:
         return res
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, height, width, resize_ratio=1.0, warmup=2):
-        """Capture one full pass for a fixed image size into a hipGraph."""
+    def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=True):
+        """Capture one full pass for a fixed image size into a hipGraph.
+
+        ``split_k``: let small-grid convs cut K over several workgroups.  It shortens ONE image's pass (the
+        stage-4 / RPN layers fill 60 % of the CUs otherwise); with several graphs replaying concurrently the
+        chip is already full and the plain launches do less total work, so throughput set-ups pass False."""
         self._static_in = torch.zeros((1, height, width, 3), dtype=torch.float32, device="cuda")
         # the graph owns its split-K workspace: graphs of several pipelines replay concurrently.  The warm-up
         # passes size it, so the capture itself allocates (and re-zeroes) nothing.
-        self._conv_ws = ops.ConvWorkspace()
+        self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws):

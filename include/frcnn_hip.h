@@ -298,6 +298,11 @@ int frcnn_pack_conv_weights_bf16(const float* w_hwio, int kh, int kw, int cin, i
 /* y is bf16 [M][cout], or f32 when y_is_f32 != 0 (network outputs: RPN scores/regressions). */
 int frcnn_conv2d_fwd_bf16(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
                           const float* scale, const float* shift, const void* residual_bf16, void* y, int y_is_f32, void* stream);
+/* Split-K form (same workspace contract as frcnn_conv2d_fwd_ws; 0 bytes = the shape does not split). */
+size_t frcnn_conv2d_workspace_bytes_bf16(const frcnn_conv_desc* d);
+int frcnn_conv2d_fwd_bf16_ws(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
+                             const float* scale, const float* shift, const void* residual_bf16, void* y, int y_is_f32,
+                             void* workspace, size_t workspace_bytes, void* stream);
 int frcnn_cast_f32_to_bf16(const float* x, size_t n, void* y_bf16, void* stream);
 /* AveragePooling2D(k) of a k x k bf16 map -> f32 [n][c] (resnet.py:515). */
 int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y, void* stream);
