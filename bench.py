@@ -72,9 +72,9 @@ def conv_roofline(pipe, x, reps=10, split_k=True):
     """Per-launch duration of every conv launch of one image, measured with HIP events on the launch
     stream.  An event pair around ONE short kernel also measures the event packets themselves
     (tens of microseconds on this stack), so each distinct launch (kernel instantiation x shape) is
-    re-issued `reps` times back to back between one pair, with the host pre-enqueued behind a spin
-    kernel; its average is the launch duration.  Returns the roofline object for the DOMINANT kernel
-    instantiation (largest summed duration per image) plus the aggregate over all conv launches."""
+    captured `reps` times back to back into a hipGraph -- the way the timed pipeline issues it -- and one
+    event pair brackets a replay; its average is the launch duration.  Returns the roofline object for the
+    DOMINANT kernel instantiation (largest summed duration per image) plus the aggregate over all conv launches."""
     from faster_rcnn_amd import ops
     with ops.conv_workspace(None if split_k else ops.NO_SPLIT_K):     # the same launch forms the timed graphs hold
         pipe.forward_dev(x)
@@ -92,12 +92,13 @@ def conv_roofline(pipe, x, reps=10, split_k=True):
     for key, g in groups.items():
         rec = g["rec"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda._sleep(5_000_000)
-        for _ in range(3):                      # the shader clock settles over the first launches of a shape
-            rec["relaunch"]()
+        graph = torch.cuda.CUDAGraph()          # the product path replays hipGraphs: time the launch the same way
+        with torch.cuda.graph(graph):
+            for _ in range(reps):
+                rec["relaunch"]()
+        graph.replay()                          # the shader clock settles over the first launches of a shape
         e0.record()
-        for _ in range(reps):
-            rec["relaunch"]()
+        graph.replay()
         e1.record()
         torch.cuda.synchronize()
         g["ms"] = e0.elapsed_time(e1) / reps
@@ -126,7 +127,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True):
                               "ms_per_image": round(tot_ms, 3),
                               "achieved": round(tot_flops / (tot_ms * 1e-3) / 1e12, 2),
                               "frac": round(tot_flops / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)},
-        "method": "HIP events on the launch stream; each distinct launch re-issued %d x back to back between one event pair" % reps,
+        "method": "HIP events on the launch stream around a hipGraph that holds each distinct launch %d x back to back" % reps,
     }
     return roof, groups
 

@@ -1,7 +1,23 @@
 #!/usr/bin/env python3
 """Condense a profile_round.sh output directory into the text summary committed under profiles/."""
 import collections, csv, glob, json, os, sys
+import re
 root = sys.argv[1]
+
+
+def bench_kernel_name(k):
+    """rocprof kernel name -> the name bench.py / ops.CONV_KERNEL_NAMES use for the same instantiation."""
+    m = re.search(r"k_conv_igemm_f32_v2<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", k)
+    if m:
+        tm, tn, var, wm, wn, sk = m.groups()
+        args = [tm, tn] + ([var] if var != "0" or (wm, wn) != ("2", "2") else []) + ([wm, wn] if (wm, wn) != ("2", "2") else [])
+        return "k_conv_igemm_f32_v2<%s>" % ",".join(args) + (" split-K" if sk == "true" else "")
+    m = re.search(r"k_conv_igemm_bf16<", k)
+    if m:
+        return "k_conv_igemm_bf16"
+    return k
+
+
 print("== bench lines")
 for f in ("bench_default.json", "bench_streams1.json"):
     p = os.path.join(root, f)
@@ -34,7 +50,7 @@ for k in sorted(acc):
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM)
         hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
-        name = "k_conv_igemm_f32_v2<2,2>" if "v2ILi2ELi2" in k or "v2<2, 2>" in k else ("k_conv_igemm_f32_v2<1,1>" if "v2<1, 1>" in k else k)
+        name = bench_kernel_name(k)
         traffic[name] = {"hbm_bytes_per_launch": round(hbm), "fetch_kb_raw": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"]}
         print("    -> HBM-side bytes per launch (2*FETCH+WRITE)*1024 = %.3g" % hbm)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
