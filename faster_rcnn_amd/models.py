@@ -40,6 +40,7 @@ class _Model:
                 u.pc = None
 
     def load_weights(self, path, by_name=False):
+        """Keras ``load_weights``: ``path`` is a Keras 2.0.x .h5 (weights or full model) or this package's .npz."""
         new = load_npz(path)
         for k, v in new.items():
             if k in self.weights or not by_name:

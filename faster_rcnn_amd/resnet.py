@@ -93,9 +93,9 @@ def resnet101_classifier(num_rois, num_classes, base_model=None, weight_regulari
 
 
 def rpn_from_h5(h5_path, anchors_per_loc=DEFAULT_ANCHORS_PER_LOC, depth=50):
-    """resnet.rpn_from_h5 (resnet.py:32-44) for weight files written by ``save_weights``
-    (.npz; Keras .h5 needs the offline converter).  Step-4 RPN models carry the
-    conv4 map as third output (train_det_step4.py:80)."""
+    """resnet.rpn_from_h5 (resnet.py:32-44): a Keras 2.0.x ``.h5`` (read in-process, h5lite.py) or the
+    ``.npz`` this package's ``save_weights`` writes.  Step-4 RPN models carry the conv4 map as third
+    output (train_det_step4.py:80)."""
     w = load_npz(h5_path)
     base = _base(depth, [1, 2, 3], None, None, w)
     return RpnModel(base, True, anchors_per_loc)

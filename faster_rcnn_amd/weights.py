@@ -125,7 +125,20 @@ def save_npz(path, weights):
     np.savez(path, **flat)
 
 
+def load_weights_file(path):
+    """{layer_name: [arrays in get_weights() order]} from either a Keras 2.0.x ``.h5`` (save_weights or a full
+    model.save file, read in-process by h5lite) or the ``.npz`` this package's save_weights writes."""
+    from . import h5lite
+    if h5lite.is_hdf5(path):
+        return h5lite.read_keras_weights(path)
+    return _load_npz(path)
+
+
 def load_npz(path):
+    return load_weights_file(path)
+
+
+def _load_npz(path):
     z = np.load(path)
     out = {}
     for key in z.files:
