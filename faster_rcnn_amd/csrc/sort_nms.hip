@@ -1,9 +1,9 @@
 // Score ordering (top-K) and greedy NMS for gfx950.
 //
 // top-K: rank-by-counting over packed 64-bit keys (score bits | ~index) -- every key is
-//        unique, so ranks are a permutation and the result is deterministic.  N <= 64 K
-//        anchors, so the N^2 compare sweep is a few tens of microseconds spread over the
-//        whole chip and needs no multi-pass radix machinery.
+//        unique, so ranks are a permutation and the result is deterministic.  A 16-bit
+//        histogram first finds the bin of the K-th key, so only the ~K candidates at or above
+//        it are ranked against each other (C^2 compares, not N^2).
 // NMS:   (1) all-pairs suppression bit matrix, upper triangle only, one 64x64 tile per
 //        wave64 (a lane's 64 pair tests become one 64-bit word = one coalesced store);
 //        (2) a single-wave sequential scan that keeps the `removed` bitmap in registers,
@@ -23,24 +23,83 @@ __device__ __forceinline__ unsigned mono_f32(float f) {      // order-preserving
 }
 
 // ------------------------------------------------------------------------------------ top-K
-__global__ void k_topk_keys(const float* scores, const uint8_t* valid, int N, u64* keys, int32_t* n_valid) {
+// Exact top-K in four small passes: (1) histogram of the keys' top 16 bits (sign, exponent, 7 mantissa bits of the
+// score), (2) one workgroup finds the bin b holding the K-th largest key, (3) keys in bins >= b are compacted
+// into a candidate list (K <= C, typically C - K = one bin's population), (4) rank-by-counting among the
+// candidates only: every non-candidate is smaller than every candidate, so a candidate's rank among the
+// candidates IS its global rank.  C^2 compares instead of N^2 (64 296 anchors, K = 8000: 64x fewer); a
+// degenerate score distribution (everything in one bin) degrades to the N^2 sweep, never to a wrong answer.
+constexpr int TOPK_BINS = 65536;
+constexpr int TOPK_BLOCK = 256;
+struct TopkCtrl { int32_t n_cand; int32_t thr_bin; int32_t pad[62]; };
+
+__device__ __forceinline__ u64 topk_key(float score, int i) { return (((u64)mono_f32(score)) << 32) | (unsigned)(~(unsigned)i); }
+
+__global__ void k_topk_hist(const float* scores, const uint8_t* valid, int N, unsigned* hist, int32_t* n_valid) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool v = i < N && (!valid || valid[i]);
-    if (i < N) keys[i] = v ? (((u64)mono_f32(scores[i])) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+    if (v) atomicAdd(&hist[mono_f32(scores[i]) >> 16], 1u);
     const u64 b = __ballot(v);
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, __popcll(b));
 }
 
-constexpr int TOPK_BLOCK = 256;
+// thread t owns the 64 bins [65536 - 64(t+1), 65536 - 64t): bins are walked from the largest key down
+__global__ void __launch_bounds__(1024) k_topk_threshold(const unsigned* hist, const int32_t* n_valid, int K, TopkCtrl* ctrl) {
+    __shared__ unsigned tot[1024];
+    const int t = threadIdx.x;
+    const unsigned* mine = hist + (TOPK_BINS - 64 * (t + 1));
+    unsigned sum = 0;
+    for (int b = 0; b < 64; ++b) sum += mine[b];
+    tot[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {              // inclusive scan over t (t = 0 is the top of the key range)
+        const unsigned add = t >= off ? tot[t - off] : 0u;
+        __syncthreads();
+        tot[t] += add;
+        __syncthreads();
+    }
+    const int nv = *n_valid;
+    const unsigned need = (unsigned)(nv < K ? nv : K);
+    if (t == 0 && need == 0) ctrl->thr_bin = TOPK_BINS;     // nothing valid: no candidates
+    const unsigned before = t ? tot[t - 1] : 0u;
+    if (need > 0 && before < need && tot[t] >= need) {      // the K-th largest key lies in one of my bins
+        unsigned acc = before;
+        for (int b = 63; b >= 0; --b) {
+            acc += mine[b];
+            if (acc >= need) { ctrl->thr_bin = TOPK_BINS - 64 * (t + 1) + b; break; }
+        }
+    }
+}
 
-// 2-D decomposition: block (bi, bj) counts, for its 256 keys i, how many keys of j-slice bj are
-// larger, and adds the partial rank with one atomic per key.  N/256 x SPLIT blocks fill the
-// chip even for N = 21 546 (a 1-D version ran on 22 CUs and took 0.5 ms).
-__global__ void __launch_bounds__(TOPK_BLOCK) k_topk_rank(const u64* keys, int N, int slice, int32_t* rank) {
+__global__ void k_topk_compact(const float* scores, const uint8_t* valid, int N, TopkCtrl* ctrl, u64* cand, int32_t* rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool take = false;
+    float sc = 0.0f;
+    if (i < N && (!valid || valid[i])) { sc = scores[i]; take = (int)(mono_f32(sc) >> 16) >= ctrl->thr_bin; }
+    const u64 b = __ballot(take);
+    if (!b) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)b) - 1) base = atomicAdd(&ctrl->n_cand, __popcll(b));     // one atomic per wave
+    base = __shfl(base, __ffsll((long long)b) - 1);
+    if (take) {
+        const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
+        cand[pos] = topk_key(sc, i);
+        rank[pos] = 0;
+    }
+}
+
+// 2-D decomposition: block (bi, bj) counts, for its 256 candidates i, how many candidates of j-slice bj are
+// larger, and adds the partial rank with one atomic per key.  The grid is sized for N (static under hipGraph
+// capture); blocks beyond the device-side candidate count exit at once.
+__global__ void __launch_bounds__(TOPK_BLOCK) k_topk_rank(const u64* keys, const TopkCtrl* ctrl, int32_t* rank) {
     __shared__ u64 tile[TOPK_BLOCK];
+    const int n = ctrl->n_cand;
+    if ((int)blockIdx.x * TOPK_BLOCK >= n) return;
+    const int slice = ((n + (int)gridDim.y - 1) / (int)gridDim.y + TOPK_BLOCK - 1) / TOPK_BLOCK * TOPK_BLOCK;
     const int i = blockIdx.x * TOPK_BLOCK + threadIdx.x;
-    const u64 mine = i < N ? keys[i] : ~0ull;
-    const int j_begin = blockIdx.y * slice, j_end = min(N, j_begin + slice);
+    const u64 mine = i < n ? keys[i] : ~0ull;
+    const int j_begin = blockIdx.y * slice, j_end = min(n, j_begin + slice);
     int cnt = 0;
     for (int t0 = j_begin; t0 < j_end; t0 += TOPK_BLOCK) {
         const int j = t0 + threadIdx.x;
@@ -50,16 +109,13 @@ __global__ void __launch_bounds__(TOPK_BLOCK) k_topk_rank(const u64* keys, int N
         for (int jj = 0; jj < TOPK_BLOCK; ++jj) cnt += tile[jj] > mine;       // LDS broadcast reads
         __syncthreads();
     }
-    if (i < N && mine != 0ull && cnt) atomicAdd(&rank[i], cnt);
+    if (i < n && cnt) atomicAdd(&rank[i], cnt);
 }
 
-__global__ void k_topk_scatter(const u64* keys, const int32_t* rank, int N, int K, int32_t* order) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N && keys[i] != 0ull && rank[i] < K) order[rank[i]] = i;
-}
-
-__global__ void k_topk_finish(int32_t* n_valid_to_n_out, int K) {
-    if (threadIdx.x == 0 && *n_valid_to_n_out > K) *n_valid_to_n_out = K;
+__global__ void k_topk_scatter(const u64* keys, const int32_t* rank, const TopkCtrl* ctrl, int K, int32_t* order, int32_t* n_valid_to_n_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ctrl->n_cand && rank[c] < K) order[rank[c]] = (int32_t)(~(unsigned)keys[c]);
+    if (c == 0 && *n_valid_to_n_out > K) *n_valid_to_n_out = K;
 }
 
 __global__ void k_gather_candidates(const float4* rois, const float* scores, const int32_t* order, const int32_t* n, int K,
@@ -235,7 +291,7 @@ extern "C" {
 
 size_t frcnn_topk_workspace_bytes(int N) {
     const size_t n = (size_t)(N > 0 ? N : 1);
-    return align_up(n * 8, 256) + align_up(n * 4, 256);
+    return (size_t)TOPK_BINS * 4 + sizeof(TopkCtrl) + align_up(n * 8, 256) + align_up(n * 4, 256);
 }
 
 int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, int32_t* order, int32_t* n_out,
@@ -248,22 +304,24 @@ int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, in
     if (!scores) return fail(FRCNN_E_ARG, "topk_order: null scores");
     if (!workspace || workspace_bytes < frcnn_topk_workspace_bytes(N))
         return fail(FRCNN_E_WORKSPACE, "topk_order: workspace needs %zu bytes", frcnn_topk_workspace_bytes(N));
-    u64* keys = (u64*)workspace;
-    int32_t* rank = (int32_t*)((char*)workspace + align_up((size_t)N * 8, 256));
-    if (hipMemsetAsync(rank, 0, (size_t)N * 4, s) != hipSuccess) return fail(FRCNN_E_HIP, "topk_order: memset failed");
-    k_topk_keys<<<(N + 255) / 256, 256, 0, s>>>(scores, valid, N, keys, n_out);
-    if (int e = check_launch("topk_order keys")) return e;
+    unsigned* hist = (unsigned*)workspace;
+    TopkCtrl* ctrl = (TopkCtrl*)((char*)workspace + (size_t)TOPK_BINS * 4);
+    u64* cand = (u64*)((char*)ctrl + sizeof(TopkCtrl));
+    int32_t* rank = (int32_t*)((char*)cand + align_up((size_t)N * 8, 256));
+    if (hipMemsetAsync(hist, 0, (size_t)TOPK_BINS * 4 + sizeof(TopkCtrl), s) != hipSuccess) return fail(FRCNN_E_HIP, "topk_order: memset failed");
     const int bi = (N + TOPK_BLOCK - 1) / TOPK_BLOCK;
+    k_topk_hist<<<bi, TOPK_BLOCK, 0, s>>>(scores, valid, N, hist, n_out);
+    if (int e = check_launch("topk_order hist")) return e;
+    k_topk_threshold<<<1, 1024, 0, s>>>(hist, n_out, K, ctrl);
+    if (int e = check_launch("topk_order threshold")) return e;
+    k_topk_compact<<<bi, TOPK_BLOCK, 0, s>>>(scores, valid, N, ctrl, cand, rank);
+    if (int e = check_launch("topk_order compact")) return e;
     int split = 2048 / bi;
-    split = split < 1 ? 1 : (split > 64 ? 64 : split);
-    int slice = ((N + split - 1) / split + TOPK_BLOCK - 1) / TOPK_BLOCK * TOPK_BLOCK;
-    split = (N + slice - 1) / slice;
-    k_topk_rank<<<dim3(bi, split), TOPK_BLOCK, 0, s>>>(keys, N, slice, rank);
+    split = split < 8 ? 8 : (split > 64 ? 64 : split);
+    k_topk_rank<<<dim3(bi, split), TOPK_BLOCK, 0, s>>>(cand, ctrl, rank);
     if (int e = check_launch("topk_order rank")) return e;
-    k_topk_scatter<<<bi, TOPK_BLOCK, 0, s>>>(keys, rank, N, K, order);
-    if (int e = check_launch("topk_order scatter")) return e;
-    k_topk_finish<<<1, 64, 0, s>>>(n_out, K);
-    return check_launch("topk_order finish");
+    k_topk_scatter<<<bi, TOPK_BLOCK, 0, s>>>(cand, rank, ctrl, K, order, n_out);
+    return check_launch("topk_order scatter");
 }
 
 int frcnn_gather_candidates(const float* rois, const float* scores, const int32_t* order, const int32_t* n, int K,

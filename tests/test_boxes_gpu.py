@@ -159,6 +159,39 @@ def test_topk_ties_and_negative(ops):
     assert list(got[:4]) == list(want[:4]) and set(got[4:6]) == {4, 5} and list(got[6:]) == list(want[6:])
 
 
+@pytest.mark.parametrize("case", ["all_equal", "three_values", "saturated", "one_binade", "wide", "k_ge_n", "none_valid"])
+def test_topk_distributions(ops, case):
+    """The histogram prefilter must never change the answer: ties by ascending index, whatever the bins hold."""
+    rs = np.random.RandomState(11)
+    N, K = 64296, 8000
+    valid = rs.rand(N) < 0.9
+    if case == "all_equal":
+        s = np.full(N, 0.5, np.float32)                              # every key in ONE bin: degrades to the full sweep
+    elif case == "three_values":
+        s = rs.choice(np.array([0.25, 0.5, 0.75], np.float32), N)
+    elif case == "saturated":
+        s = np.where(rs.rand(N) < 0.3, 1.0, rs.rand(N)).astype(np.float32)      # 30 % exactly 1.0 (sigmoid saturation)
+    elif case == "one_binade":
+        s = (0.5 + 0.001 * rs.rand(N)).astype(np.float32)            # a handful of histogram bins
+    elif case == "wide":
+        s = (rs.randn(N) * 1e3).astype(np.float32)                   # negative and positive, many binades
+    elif case == "k_ge_n":
+        N, K = 5000, 8000
+        valid = valid[:N]
+        s = rs.rand(N).astype(np.float32)
+    else:
+        s = rs.rand(N).astype(np.float32)
+        valid = np.zeros(N, bool)
+    order, n = ops.topk_order(dev(s), dev(valid.astype(np.uint8)), K)
+    idx = np.flatnonzero(valid)
+    want = idx[np.argsort(-s[idx].astype(np.float64), kind="stable")][:K]          # score descending, index ascending
+    n = int(n.item())
+    assert n == len(want)
+    got = order.cpu().numpy()
+    assert np.array_equal(got[:n], want)
+    assert (got[n:] == -1).all()
+
+
 @pytest.mark.parametrize("tag", ["tiny", "c2", "c4"])
 def test_nms_golden(ops, golden, tag):
     _, cls = synth.rpn_outputs(tag)
