@@ -41,6 +41,7 @@ SIGNATURES = {
     "frcnn_gather_rois": (I, [P, P, P, I, I, P, P]),
     "frcnn_roi_targets": (I, [P, I, P, P, P, I, I, P, P, P, P]),
     "frcnn_roi_crop_resize_fwd": (I, [P, I, I, I, P, I, I, P, P]),
+    "frcnn_roi_crop_resize_fwd_ex": (I, [P, I, I, I, P, I, I, P, I, P, P]),
     "frcnn_roi_crop_resize_bwd": (I, [P, I, I, I, P, I, I, P, P]),
     "frcnn_conv_packed_k": (I, [I, I, I]),
     "frcnn_pack_conv_weights": (I, [P, I, I, I, I, P, P]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "frcnn_cast_f32_to_bf16": (I, [P, c_size_t, P, P]),
     "frcnn_avgpool_bf16_to_f32": (I, [P, I, I, I, P, P]),
     "frcnn_roi_crop_resize_fwd_bf16": (I, [P, I, I, I, P, I, I, P, P]),
+    "frcnn_roi_crop_resize_fwd_bf16_ex": (I, [P, I, I, I, P, I, I, P, I, P, P]),
     "frcnn_detections": (I, [P, P, I, P, P, I, I, ctypes.c_float, c_double, c_double, c_double, P, P, P, P, P, P]),
 }
 

@@ -288,7 +288,8 @@ __global__ void k_avgpool_bf16_f32(const __bf16* x, int n, int hw, int C, float*
 }
 
 // RoiResizeConv on a bf16 feature map (custom_layers.py:35-56): f32 lerp, bf16 output
-__global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int rows, int cols, int C, const float4* rois, int pool, __bf16* out) {
+__global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int rows, int cols, int C, const float4* rois, int pool,
+                                                      const float* fill, int relu, __bf16* out) {
     const int pix = blockIdx.x;
     const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
     const float4 roi = rois[r];
@@ -296,7 +297,10 @@ __global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int ro
     const int h = y2 - y1, w = x2 - x1;
     __bf16* o = out + (size_t)pix * C;
     const bool ok = h > 0 && w > 0 && x1 >= 0 && y1 >= 0 && x2 <= cols && y2 <= rows;
-    if (!ok) { for (int c = threadIdx.x; c < C; c += blockDim.x) o[c] = (__bf16)0.0f; return; }
+    if (!ok) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { const float v = fill ? fill[c] : 0.0f; o[c] = (__bf16)(relu ? fmaxf(v, 0.0f) : v); }
+        return;
+    }
     const float sy = (float)h / (float)pool, sx = (float)w / (float)pool;
     const float fy = (float)py * sy, fx = (float)px * sx;
     const int ly = (int)fy, lx = (int)fx;
@@ -309,7 +313,8 @@ __global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int ro
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float a = (float)tl[c], b = (float)tr[c], d = (float)bl[c], e = (float)br[c];
         const float top = a + (b - a) * tx, bot = d + (e - d) * tx;
-        o[c] = (__bf16)(top + (bot - top) * ty);
+        const float v = top + (bot - top) * ty;
+        o[c] = (__bf16)(relu ? fmaxf(v, 0.0f) : v);
     }
 }
 
@@ -456,10 +461,16 @@ int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y,
 }
 
 int frcnn_roi_crop_resize_fwd_bf16(const void* feat_bf16, int rows, int cols, int C, const float* rois, int n, int pool, void* out_bf16, void* stream) {
+    return frcnn_roi_crop_resize_fwd_bf16_ex(feat_bf16, rows, cols, C, rois, n, pool, nullptr, 0, out_bf16, stream);
+}
+
+int frcnn_roi_crop_resize_fwd_bf16_ex(const void* feat_bf16, int rows, int cols, int C, const float* rois, int n, int pool,
+                                      const float* fill, int relu, void* out_bf16, void* stream) {
     if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16: bad shape");
     if (n == 0) return FRCNN_OK;
     if (!feat_bf16 || !rois || !out_bf16) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16: null pointer");
-    k_roi_fwd_bf16<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const __bf16*)feat_bf16, rows, cols, C, (const float4*)rois, pool, (__bf16*)out_bf16);
+    k_roi_fwd_bf16<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const __bf16*)feat_bf16, rows, cols, C, (const float4*)rois, pool,
+                                                                   fill, relu, (__bf16*)out_bf16);
     return check_launch("roi_crop_resize_fwd_bf16");
 }
 

@@ -171,15 +171,16 @@ def roi_targets(rois_i16, gt_f32, gt_f64, gt_cls, bg_idx):
 
 
 # ----------------------------------------------------------------------------- RoI crop/resize
-def roi_crop_resize(feat, rois, pool):
-    """feat: (R,C,Cf) f32 (or (1,R,C,Cf)); rois: (n,4) f32 -> (n,pool,pool,Cf) f32."""
+def roi_crop_resize(feat, rois, pool, fill=None, relu=False):
+    """feat: (R,C,Cf) f32 (or (1,R,C,Cf)); rois: (n,4) f32 -> (n,pool,pool,Cf) f32.
+    fill (Cf,) = value of an invalid RoI (default zeros); relu clamps the output (frcnn_roi_crop_resize_fwd_ex)."""
     _require_gpu()
     feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
     rows, cols, C = feat.shape
     rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
     n = rois.shape[0]
     out = torch.empty((n, pool, pool, C), dtype=torch.float32, device="cuda")
-    _lib.call("frcnn_roi_crop_resize_fwd", _p(feat), rows, cols, C, _p(rois), n, pool, _p(out), _stream())
+    _lib.call("frcnn_roi_crop_resize_fwd_ex", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, _p(out), _stream())
     return out
 
 
@@ -465,11 +466,11 @@ def avgpool_bf16(x, k):
     return out
 
 
-def roi_crop_resize_bf16(feat, rois, pool):
+def roi_crop_resize_bf16(feat, rois, pool, fill=None, relu=False):
     _require_gpu()
     feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
     rows, cols, C = feat.shape
     rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
     out = torch.empty((rois.shape[0], pool, pool, C), dtype=torch.bfloat16, device="cuda")
-    _lib.call("frcnn_roi_crop_resize_fwd_bf16", _p(feat), rows, cols, C, _p(rois), rois.shape[0], pool, _p(out), _stream())
+    _lib.call("frcnn_roi_crop_resize_fwd_bf16_ex", _p(feat), rows, cols, C, _p(rois), rois.shape[0], pool, _p(fill), 1 if relu else 0, _p(out), _stream())
     return out

@@ -134,6 +134,13 @@ int frcnn_roi_targets(const int16_t* rois, int E, const float* gt_f32, const dou
  * feat [rows][cols][C] f32, rois [n][4] f32, out [n][pool][pool][C] f32.  C % 4 == 0. */
 int frcnn_roi_crop_resize_fwd(const float* feat, int rows, int cols, int C,
                               const float* rois, int n, int pool, float* out, void* stream);
+/* Same resampling with two extras used by the hoisted detector head: `fill` ([c] or NULL = zeros) is
+ * what an invalid RoI yields, `relu` != 0 clamps the result at 0.  A 1x1 convolution + folded
+ * BatchNorm (resnet.py:351-356, 380-385: res5a_branch2a / branch1, strides (1,1)) commutes with this
+ * linear resampling, so the head may apply them once to the conv4 map and resample their outputs;
+ * `fill` = that layer's epilogue shift reproduces what an all-zero crop gives in the reference order. */
+int frcnn_roi_crop_resize_fwd_ex(const float* feat, int rows, int cols, int c, const float* rois, int n, int pool,
+                                 const float* fill, int relu, float* out, void* stream);
 /* Gradient of the above w.r.t. feat: dfeat [rows][cols][C] must be zeroed by the caller;
  * contributions are accumulated with f32 atomics. */
 int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C,
@@ -309,6 +316,8 @@ int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y,
 /* frcnn_roi_crop_resize_fwd on a bf16 feature map (f32 interpolation, bf16 result). */
 int frcnn_roi_crop_resize_fwd_bf16(const void* feat_bf16, int rows, int cols, int C, const float* rois, int n, int pool,
                                    void* out_bf16, void* stream);
+int frcnn_roi_crop_resize_fwd_bf16_ex(const void* feat_bf16, int rows, int cols, int c, const float* rois, int n, int pool,
+                                      const float* fill, int relu, void* out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

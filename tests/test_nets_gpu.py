@@ -83,3 +83,36 @@ def test_fp32_oracle_is_inside_tolerance_too():
     a = KerasGraphs(w, torch.float32).resnet_base(x)
     b = KerasGraphs(w, torch.float64).resnet_base(x)
     assert rel_err(a, b) < TOL
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_head_hoist_equals_reference_order(dtype):
+    """res5a_branch2a / branch1 applied to the conv4 map and resampled (nets.ResNetHead hoist) against the
+    reference order (resample, then convolve every crop): same class scores / regressions, including RoIs
+    the crop rejects (empty or out of range -> zeros in, BatchNorm shift out)."""
+    from faster_rcnn_amd import nets
+    from faster_rcnn_amd.weights import synthetic_resnet
+    from oracle.keras_ref import KerasGraphs
+    C = 21
+    w = synthetic_resnet(50, anchors_per_loc=9, num_classes=C, seed=5)
+    rs = np.random.RandomState(2)
+    rows, cols = 38, 63
+    feat = np.maximum(rs.randn(1, rows, cols, 1024), 0).astype(np.float32)
+    x1 = rs.randint(0, cols - 8, 40); y1 = rs.randint(0, rows - 8, 40)
+    rois = np.stack([x1, y1, x1 + 1 + rs.randint(0, 7, 40), y1 + 1 + rs.randint(0, 7, 40)], axis=1).astype(np.float32)
+    rois[5] = [0, 0, 0, 0]                                  # empty: what the padded tail of the RoI buffer holds
+    rois[6] = [10, 10, 9, 12]                               # negative width
+    rois[7] = [60, 30, 70, 36]                              # reaches past the map
+    rois[8] = [0, 0, cols, rows]                            # the whole map
+    fd = torch.from_numpy(feat).cuda()
+    rd = torch.from_numpy(rois).cuda()
+    if dtype == "bf16":
+        fd = fd.to(torch.bfloat16)
+    a = nets.ResNetHead(w, 50, C, dtype=dtype, hoist=True)(fd, rd)
+    b = nets.ResNetHead(w, 50, C, dtype=dtype, hoist=False)(fd, rd)
+    tol = 2e-5 if dtype == "f32" else 2e-2                  # bf16: the two orders round different tensors to bf16
+    assert rel_err(a[0].cpu(), b[0].cpu()) < tol and rel_err(a[1].cpu(), b[1].cpu()) < tol
+    if dtype == "f32":                                      # and both sit inside the oracle bar
+        valid = [i for i in range(40) if i not in (5, 6, 7)]
+        k64, g64 = KerasGraphs(w, torch.float64).resnet_classifier(torch.from_numpy(feat), rois[valid], C, 50)
+        assert rel_err(a[0].cpu()[valid], k64) < TOL and rel_err(a[1].cpu()[valid], g64) < TOL
