@@ -87,7 +87,7 @@ class ConvDesc(ctypes.Structure):
     """frcnn_conv_desc (include/frcnn_hip.h)."""
     _fields_ = [(k, ctypes.c_int32) for k in (
         "n", "h", "w", "cin", "cout", "kh", "kw", "stride", "pad_top", "pad_left", "ho", "wo",
-        "act", "ldy", "ldres", "tile")]
+        "act", "ldy", "ldres", "tile", "layout")]
 
 
 class PackJob(ctypes.Structure):

@@ -39,6 +39,10 @@ struct ConvArgs {
     int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
     int M, K, Kpad, act, ldy, ldres;
     int tiles_m, tiles_n;
+    int layout;             // 0: x[img][h][w][c], rows m = (img, ho, wo); 1 (v2 only): x[h][w][img][c], m = (ho, wo, img)
+    int pix_stride;         // elements between w-neighbours of one image (Cin, or n_img*Cin when layout == 1)
+    int img_stride;         // elements between images (H*W*Cin, or Cin when layout == 1)
+    int inv_S;              // ceil(65536 / S): tap / S without an integer division
     int splits;             // split-K: K-slices per output tile (1 = none)
     float* slabs;           // [tile][slice][BM*BN] f32 partial tiles
     unsigned* tickets;      // [tile] arrival counters: zero on entry, left zero on exit
@@ -274,10 +278,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
     for (int i = 0; i < PA; ++i) {
         const int m = m0 + lrow + RPP * i;
         if (m < p.M) {
-            const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
+            int wo, ho, img;
+            if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
+            else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
             a_h[i] = ho * p.stride - p.pad_top;
             a_w[i] = wo * p.stride - p.pad_left;
-            a_off[i] = (((img * p.H + a_h[i]) * p.W + a_w[i]) * p.Cin + lcol) * 4;     // may be "negative" in the halo
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * 4;     // may be "negative" in the halo
         } else {
             a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
         }
@@ -289,35 +295,63 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
         b_off[i] = n < p.Cout ? (unsigned)((n * p.Kpad + lcol) * 4) : OOB_OFFSET;
     }
 
-    // this workgroup's chunk range [kb, ke) of the packed k axis (chunk = tap-major inside a 32-channel group)
-    const int nk_all = p.Kpad / BK;
+    // Filter taps this tile needs, one bit per tap.  With position-major rows (layout 1: the detector head's
+    // [7][7][roi][c] tensors) a 128-row tile spans one or two output positions, so the taps that fall into the
+    // zero padding for ALL of them -- 14 % of the chunks of a 3x3 SAME conv on 7x7 maps -- are skipped outright;
+    // they would only add exact zeros, so the result is bit-identical.
+    const int RS = p.R * p.S;
+    const unsigned all_taps = RS >= 32 ? 0xffffffffu : (1u << RS) - 1u;
+    unsigned tap_mask = all_taps;
+    if (p.layout) {
+        const int pos_lo = m0 / p.n_img, pos_hi = (min(m0 + BM, p.M) - 1) / p.n_img;
+        if (pos_hi - pos_lo < 8) {
+            unsigned mk = 0;
+            for (int pos = pos_lo; pos <= pos_hi; ++pos) {
+                const int ho = pos / p.Wo, wo = pos - ho * p.Wo;
+                const int h0 = ho * p.stride - p.pad_top, w0 = wo * p.stride - p.pad_left;
+                for (int r = 0; r < p.R; ++r)
+                    for (int sx = 0; sx < p.S; ++sx)
+                        if ((unsigned)(h0 + r) < (unsigned)p.H && (unsigned)(w0 + sx) < (unsigned)p.W) mk |= 1u << (r * p.S + sx);
+            }
+            if (mk) tap_mask = mk;
+        }
+    }
+    const int n_taps = __popc(tap_mask);
+
+    // this workgroup's chunk range [kb, ke) of the (channel group, needed tap) sequence
+    const int nk_all = (p.Kpad / (BK * RS)) * n_taps;
     const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
     const int ke = SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all;
 
     i32x4 ra[PA], rb[PB];
-    int r_tap = 0, s_tap = 0, c0 = 0;
+    unsigned rem = tap_mask;                                 // taps of the current channel group still to load
+    int c0 = 0, w_grp = 0;                                   // channel offset / byte offset of the group's filter chunks
     if (SPLITK) {
-        const int RS = p.R * p.S, tap = kb % RS;
-        r_tap = tap / p.S; s_tap = tap - r_tap * p.S; c0 = (kb / RS) * BK;
+        const int grp = kb / n_taps;
+        c0 = grp * BK; w_grp = grp * RS * (BK * 4);
+        for (int t = kb - grp * n_taps; t > 0; --t) rem &= rem - 1;
     }
-    auto load_chunk = [&](int kc) {
-        const int tap_off = ((r_tap * p.W + s_tap) * p.Cin + c0) * 4;          // wave-uniform
+    auto load_chunk = [&](int) {
+        const int tap = __builtin_ctz(rem);                  // wave-uniform
+        const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 4;
+        const int w_off = w_grp + tap * (BK * 4);
 #pragma unroll
         for (int i = 0; i < PB; ++i)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], kc * (BK * 4), 0);
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0);
         }
-        // branch-free tap walk (a scalar branch here would split the loop body into two
+        // branch-free walk to the next needed tap (a scalar branch here would split the loop body into two
         // scheduling regions and undo the interleave below)
-        const int ws = (s_tap + 1 == p.S);
-        const int wr = ws & (r_tap + 1 == p.R);
-        s_tap = (s_tap + 1) * (1 - ws);
-        r_tap = (r_tap + ws) * (1 - wr);
-        c0 += wr * BK;
+        rem &= rem - 1;
+        const int wrap = (rem == 0);
+        rem |= wrap ? tap_mask : 0u;
+        c0 += wrap * BK;
+        w_grp += wrap * (RS * BK * 4);
     };
     auto store_chunk = [&](int buf) {
         float* a = As + buf * BM * LDS_STRIDE;
@@ -818,7 +852,7 @@ static int choose_config(const frcnn_conv_desc* d) {
     const int Kpad = (d->kh * d->kw * d->cin + BK - 1) / BK * BK;
     const bool generic = (d->cin % BK) != 0;
     const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
-    int cfg = d->tile;      // 0 = auto
+    int cfg = d->tile % 100;    // 0 = auto; the hundreds digit(s) force the split-K factor (choose_splits)
     static const int forced = getenv("FRCNN_FORCE_TILE") ? atoi(getenv("FRCNN_FORCE_TILE")) : 0;   // dev knob
     if (cfg == 0 && forced && !generic) cfg = forced;
     if (cfg == 0) {
@@ -829,7 +863,7 @@ static int choose_config(const frcnn_conv_desc* d) {
         else if (t128 >= 384 && Kpad >= 1024) cfg = 21;
         else cfg = 22;
     }
-    cfg %= 100;             // hundreds digit(s) = forced split-K factor (choose_splits)
+    if (d->layout && cfg >= 1 && cfg <= 4) cfg += 10;       // only the v2 main loop knows the position-major layout
     const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * Kpad * 4 < 0x7fffffffull;
     if (cfg >= 41 && (!fits_srd || generic)) cfg = 2;
     if (cfg >= 21 && (!fits_srd || generic)) cfg -= 20;
@@ -912,9 +946,15 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     a.act = d->act; a.ldy = d->ldy > 0 ? d->ldy : d->cout; a.ldres = d->ldres > 0 ? d->ldres : d->cout;
     a.tiles_m = a.tiles_n = 0;
     a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
+    a.layout = d->layout ? 1 : 0;
+    a.pix_stride = a.layout ? d->n * d->cin : d->cin;
+    a.img_stride = a.layout ? d->cin : d->h * d->w * d->cin;
+    a.inv_S = (65536 + d->kw - 1) / d->kw;
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
     const int cfg = choose_config(d);
+    if (a.layout && (generic || cfg < 11 || d->kh * d->kw > 32))
+        return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: position-major layout needs cin %% 32 == 0, a tensor under 2 GiB and at most 32 taps");
     if (!generic && workspace) {
         const size_t need = frcnn_conv2d_workspace_bytes(d);
         if (need) {

@@ -291,24 +291,29 @@ def _conv_launch(d, x, w, scale, shift, residual, mask, out):
     return args, ws
 
 
-def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0):
-    """x: (n,h,w,cin) f32 NHWC device tensor; pc: PackedConv -> (n,ho,wo,cout)."""
+def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0, layout=0):
+    """x: (n,h,w,cin) f32 NHWC device tensor; pc: PackedConv -> (n,ho,wo,cout).
+    layout=1: position-major tensors, x (h,w,n,cin) -> (ho,wo,n,cout) (frcnn_conv_desc.layout)."""
     _require_gpu()
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == pc.cin, (x.shape, pc.cin)
-    n, h, w, _ = x.shape
+    if layout:
+        h, w, n, _ = x.shape
+    else:
+        n, h, w, _ = x.shape
     if padding == "same":
         ho, pt = same_pad(h, pc.kh, stride)
         wo, pl = same_pad(w, pc.kw, stride)
     else:
         ho, wo, pt, pl = valid_out(h, pc.kh, stride), valid_out(w, pc.kw, stride), 0, 0
+    oshape = (ho, wo, n, pc.cout) if layout else (n, ho, wo, pc.cout)
     if out is None:
-        out = torch.empty((n, ho, wo, pc.cout), dtype=torch.float32, device="cuda")
+        out = torch.empty(oshape, dtype=torch.float32, device="cuda")
     else:
-        assert out.shape == (n, ho, wo, pc.cout) and out.is_contiguous()
+        assert out.shape == oshape and out.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
     d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc.cin, cout=pc.cout, kh=pc.kh, kw=pc.kw, stride=stride, pad_top=pt, pad_left=pl,
-                      ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile)
+                      ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile, layout=layout)
     args, ws = _conv_launch(d, x, pc.w, pc.scale, pc.shift, residual, None, out)
     if CONV_PROFILE is not None:
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
@@ -354,15 +359,18 @@ def detections(rois, n_rois, out_cls, out_reg, roi_batch, bg_idx, det_threshold,
 
 
 # ----------------------------------------------------------------------------- conv backward
-def _conv_desc(x_shape, kh, kw, cout, stride, padding, act=0):
-    n, h, w, cin = x_shape
+def _conv_desc(x_shape, kh, kw, cout, stride, padding, act=0, layout=0):
+    if layout:
+        h, w, n, cin = x_shape
+    else:
+        n, h, w, cin = x_shape
     if padding == "same":
         ho, pt = same_pad(h, kh, stride)
         wo, pl = same_pad(w, kw, stride)
     else:
         ho, wo, pt, pl = valid_out(h, kh, stride), valid_out(w, kw, stride), 0, 0
     return _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride, pad_top=pt, pad_left=pl,
-                         ho=ho, wo=wo, act=act, ldy=0, ldres=0, tile=0)
+                         ho=ho, wo=wo, act=act, ldy=0, ldres=0, tile=0, layout=layout)
 
 
 class PackedDgrad:
@@ -429,13 +437,14 @@ class PackedConvBf16:
         self.shift = None if shift is None else _dev(shift, torch.float32)
 
 
-def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f32=False, tile=0):
-    """x: (n,h,w,cin) bf16 NHWC -> (n,ho,wo,cout) bf16 (or f32 when out_f32)."""
+def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f32=False, tile=0, layout=0):
+    """x: (n,h,w,cin) bf16 NHWC -> (n,ho,wo,cout) bf16 (or f32 when out_f32); layout=1: (h,w,n,cin) -> (ho,wo,n,cout)."""
     _require_gpu()
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == pc.cin
-    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act])
+    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act], layout)
     d.tile = tile
-    out = torch.empty((x.shape[0], d.ho, d.wo, pc.cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
+    oshape = (d.ho, d.wo, d.n, pc.cout) if layout else (d.n, d.ho, d.wo, pc.cout)
+    out = torch.empty(oshape, dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
     if residual is not None:
         assert residual.dtype == torch.bfloat16 and residual.shape == out.shape and residual.is_contiguous()
     ws = _split_k_ws(_lib.load().frcnn_conv2d_workspace_bytes_bf16(ctypes.byref(d)))
@@ -443,9 +452,9 @@ def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f
             _p(ws), ws.numel() if ws is not None else 0)
     _lib.call("frcnn_conv2d_fwd_bf16_ws", *args, _stream())
     if CONV_PROFILE is not None:
-        flops = 2.0 * x.shape[0] * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin
+        flops = 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin
         keep = (d, x, pc, residual, out, ws)
-        CONV_PROFILE.append({"kernel": "k_conv_igemm_bf16", "flops": flops, "shape": (x.shape[0] * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
+        CONV_PROFILE.append({"kernel": "k_conv_igemm_bf16", "flops": flops, "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
                              "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_bf16_ws", *args, _stream())})
     return out
 

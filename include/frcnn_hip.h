@@ -171,6 +171,11 @@ typedef struct frcnn_conv_desc {
                                       21, 22: 128x128 / 64x64 v2 with the late-LDS-store schedule;
                                       41..43: 128x128 (4x2 / 2x4 waves) and 128x64 with 8 waves;
                                       + 100*s: force s split-K slices (frcnn_conv2d_fwd_ws)       */
+    int32_t layout;                /* 0: x [n][h][w][cin], y [n][ho][wo][cout] (NHWC).
+                                      1: position-major, x [h][w][n][cin], y [ho][wo][n][cout] (forward only,
+                                         cin % 32 == 0): the detector head keeps its RoI crops this way so a
+                                         128-row tile covers one or two output positions and the filter taps
+                                         that only meet zero padding are skipped (bit-identical result)     */
 } frcnn_conv_desc;
 
 /* k extent of a packed filter row: kh*kw*cin rounded up to the kernel's k-chunk (32). */

@@ -138,3 +138,39 @@ def test_split_k_workspace_reuse_and_determinism(ops):
     for x, pc, a in zip(xs, pcs, first):                          # vs the plain launch (different summation order)
         plain = ops.conv2d(x, pc, 1, "same", "relu", tile=122)
         assert (plain - a).abs().max().item() <= 2e-5 * max(1.0, plain.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, k, padding, tile
+    (300, 7, 7, 64, 128, 3, "same", 0),          # the detector head's geometry: tiles span 1-2 positions, border taps skipped
+    (300, 7, 7, 64, 128, 3, "same", 21),
+    (300, 7, 7, 64, 96, 3, "same", 22),
+    (300, 7, 7, 64, 128, 3, "same", 42),
+    (300, 7, 7, 64, 128, 3, "same", 322),        # split-K over the compacted (channel group, needed tap) sequence
+    (64, 7, 7, 128, 64, 3, "same", 0),
+    (37, 5, 9, 32, 40, 3, "same", 12),
+    (300, 7, 7, 256, 64, 1, "valid", 0),         # 1x1: one tap, nothing to skip
+    (3, 7, 7, 64, 64, 3, "same", 0),             # few images: a tile spans > 8 positions -> all taps kept
+    (50, 6, 6, 32, 64, 5, "same", 0),            # 25 taps
+    (20, 9, 9, 64, 64, 3, "valid", 0),
+])
+def test_conv2d_position_major_layout(ops, case):
+    """layout=1 ([h][w][n][c] tensors, taps that only meet padding skipped) is the SAME arithmetic as the
+    NHWC launch: skipped chunks would add exact zeros, so the two results are bitwise equal."""
+    n, h, w, cin, cout, k, padding, tile = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = torch.from_numpy(rs.randn(n, h, w, cin).astype(np.float32)).cuda()
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    pc = ops.PackedConv(wt, (1 + 0.1 * rs.randn(cout)).astype(np.float32), (0.1 * rs.randn(cout)).astype(np.float32))
+    no_split = 100 + tile % 100                              # same tile code, split-K forced off
+    want = ops.conv2d(x, pc, 1, padding, "relu", tile=no_split)
+    res = torch.from_numpy(rs.randn(*want.shape).astype(np.float32)).cuda()
+    want = ops.conv2d(x, pc, 1, padding, "relu", res, tile=no_split)
+    xp = x.permute(1, 2, 0, 3).contiguous()
+    got = ops.conv2d(xp, pc, 1, padding, "relu", res.permute(1, 2, 0, 3).contiguous(), tile=tile if tile >= 100 else no_split, layout=1)
+    assert got.shape == (want.shape[1], want.shape[2], n, cout)
+    got_nhwc = got.permute(2, 0, 1, 3)
+    if tile >= 100:                                          # split-K changes the summation order
+        assert (got_nhwc - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    else:
+        assert torch.equal(got_nhwc, want)
