@@ -41,7 +41,7 @@ SIGNATURES = {
     "frcnn_gather_rois": (I, [P, P, P, I, I, P, P]),
     "frcnn_roi_targets": (I, [P, I, P, P, P, I, I, P, P, P, P]),
     "frcnn_roi_crop_resize_fwd": (I, [P, I, I, I, P, I, I, P, P]),
-    "frcnn_roi_crop_resize_fwd_ex": (I, [P, I, I, I, P, I, I, P, I, P, P]),
+    "frcnn_roi_crop_resize_fwd_ex": (I, [P, I, I, I, P, I, I, P, I, I, P, P]),
     "frcnn_roi_crop_resize_bwd": (I, [P, I, I, I, P, I, I, P, P]),
     "frcnn_conv_packed_k": (I, [I, I, I]),
     "frcnn_pack_conv_weights": (I, [P, I, I, I, I, P, P]),
@@ -56,6 +56,7 @@ SIGNATURES = {
     "frcnn_refresh_packed": (I, [P, I, P]),
     "frcnn_colsum_batch": (I, [P, I, P]),
     "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
+    "frcnn_avgpool_pos_major": (I, [P, I, I, I, P, P]),
     "frcnn_softmax_rows": (I, [P, I, I, I, P, I, P]),
     "frcnn_loss_rpn_cls": (I, [P, P, I, I, P, P, P]),
     "frcnn_loss_rpn_reg": (I, [P, P, I, I, P, P, P]),
@@ -76,8 +77,9 @@ SIGNATURES = {
     "frcnn_conv2d_fwd_bf16_ws": (I, [P, P, P, P, P, P, P, I, P, c_size_t, P]),
     "frcnn_cast_f32_to_bf16": (I, [P, c_size_t, P, P]),
     "frcnn_avgpool_bf16_to_f32": (I, [P, I, I, I, P, P]),
+    "frcnn_avgpool_bf16_to_f32_ex": (I, [P, I, I, I, I, P, P]),
     "frcnn_roi_crop_resize_fwd_bf16": (I, [P, I, I, I, P, I, I, P, P]),
-    "frcnn_roi_crop_resize_fwd_bf16_ex": (I, [P, I, I, I, P, I, I, P, I, P, P]),
+    "frcnn_roi_crop_resize_fwd_bf16_ex": (I, [P, I, I, I, P, I, I, P, I, I, P, P]),
     "frcnn_detections": (I, [P, P, I, P, P, I, I, ctypes.c_float, c_double, c_double, c_double, P, P, P, P, P, P]),
 }
 

@@ -27,6 +27,7 @@ struct ConvArgsBf16 {
     int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
     int M, Kpad, act, out_f32;
     int tiles_m, tiles_n;
+    int layout, pix_stride, img_stride, inv_S;      // position-major layout + tap walk, as in conv_igemm.hip's ConvArgs
     int splits;             // split-K (see conv_igemm.hip): K-slices per tile, f32 partial slabs, arrival tickets
     float* slabs;
     unsigned* tickets;
@@ -80,10 +81,12 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
     for (int i = 0; i < PA; ++i) {
         const int m = m0 + lrow + 32 * i;
         if (m < p.M) {
-            const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
+            int wo, ho, img;
+            if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
+            else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
             a_h[i] = ho * p.stride - p.pad_top;
             a_w[i] = wo * p.stride - p.pad_left;
-            a_off[i] = (((img * p.H + a_h[i]) * p.W + a_w[i]) * p.Cin) * 2 + lcolb;
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride) * 2 + lcolb;
         } else {
             a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
         }
@@ -95,32 +98,56 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
         b_off[i] = n < p.Cout ? (unsigned)(n * p.Kpad * 2 + lcolb) : OOB_OFFSET_B;
     }
 
-    const int nk_all = p.Kpad / BKH;
+    // taps this tile needs (position-major rows: taps that only meet zero padding are skipped; conv_igemm.hip)
+    const int RS = p.R * p.S;
+    const unsigned all_taps = RS >= 32 ? 0xffffffffu : (1u << RS) - 1u;
+    unsigned tap_mask = all_taps;
+    if (p.layout) {
+        const int pos_lo = m0 / p.n_img, pos_hi = (min(m0 + BM, p.M) - 1) / p.n_img;
+        if (pos_hi - pos_lo < 8) {
+            unsigned mk = 0;
+            for (int pos = pos_lo; pos <= pos_hi; ++pos) {
+                const int ho = pos / p.Wo, wo = pos - ho * p.Wo;
+                const int h0 = ho * p.stride - p.pad_top, w0 = wo * p.stride - p.pad_left;
+                for (int r = 0; r < p.R; ++r)
+                    for (int sx = 0; sx < p.S; ++sx)
+                        if ((unsigned)(h0 + r) < (unsigned)p.H && (unsigned)(w0 + sx) < (unsigned)p.W) mk |= 1u << (r * p.S + sx);
+            }
+            if (mk) tap_mask = mk;
+        }
+    }
+    const int n_taps = __popc(tap_mask);
+    const int nk_all = (p.Kpad / (BKH * RS)) * n_taps;
     const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
     const int ke = SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all;
 
     i32x4 ra[PA], rb[PB];
-    int r_tap = 0, s_tap = 0, c0 = 0;
+    unsigned rem = tap_mask;
+    int c0 = 0, w_grp = 0;
     if (SPLITK) {
-        const int RS = p.R * p.S, tap = kb % RS;
-        r_tap = tap / p.S; s_tap = tap - r_tap * p.S; c0 = (kb / RS) * BKH;
+        const int grp = kb / n_taps;
+        c0 = grp * BKH; w_grp = grp * RS * (BKH * 2);
+        for (int t = kb - grp * n_taps; t > 0; --t) rem &= rem - 1;
     }
-    auto load_chunk = [&](int kc) {
-        const int tap_off = ((r_tap * p.W + s_tap) * p.Cin + c0) * 2;
+    auto load_chunk = [&](int) {
+        const int tap = __builtin_ctz(rem);
+        const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 2;
+        const int w_off = w_grp + tap * (BKH * 2);
 #pragma unroll
         for (int i = 0; i < PB; ++i)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], kc * (BKH * 2), 0);
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET_B, 0, 0);
         }
-        const int ws = (s_tap + 1 == p.S);
-        const int wr = ws & (r_tap + 1 == p.R);
-        s_tap = (s_tap + 1) * (1 - ws);
-        r_tap = (r_tap + ws) * (1 - wr);
-        c0 += wr * BKH;
+        rem &= rem - 1;
+        const int wrap = (rem == 0);
+        rem |= wrap ? tap_mask : 0u;
+        c0 += wrap * BKH;
+        w_grp += wrap * (RS * BKH * 2);
     };
     auto store_chunk = [&](int buf) {
         char* a = As + buf * BM * LDS_STRIDE_B;
@@ -276,26 +303,28 @@ __global__ void k_cast_f32_bf16(const float4* x, size_t n4, __bf16* y) {
 }
 
 // AveragePooling2D(k) over a k x k bf16 map -> f32 [n][C] (f32 accumulate)
-__global__ void k_avgpool_bf16_f32(const __bf16* x, int n, int hw, int C, float* y) {
+__global__ void k_avgpool_bf16_f32(const __bf16* x, int n, int hw, int C, int pos_major, float* y) {
     const size_t total = (size_t)n * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const size_t img = i / C;
         float acc = 0.0f;
-        for (int q = 0; q < hw; ++q) acc += (float)x[(img * hw + q) * C + c];
+        if (pos_major) for (int q = 0; q < hw; ++q) acc += (float)x[(size_t)q * total + i];           // x[pos][img][c]
+        else for (int q = 0; q < hw; ++q) acc += (float)x[(img * hw + q) * C + c];                    // x[img][pos][c]
         y[i] = acc / (float)hw;
     }
 }
 
 // RoiResizeConv on a bf16 feature map (custom_layers.py:35-56): f32 lerp, bf16 output
 __global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int rows, int cols, int C, const float4* rois, int pool,
-                                                      const float* fill, int relu, __bf16* out) {
+                                                      const float* fill, int relu, int pos_major, __bf16* out) {
     const int pix = blockIdx.x;
     const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    const size_t orow = pos_major ? (size_t)(py * pool + px) * (gridDim.x / (pool * pool)) + r : (size_t)pix;
     const float4 roi = rois[r];
     const int x1 = (int)roi.x, y1 = (int)roi.y, x2 = (int)roi.z, y2 = (int)roi.w;
     const int h = y2 - y1, w = x2 - x1;
-    __bf16* o = out + (size_t)pix * C;
+    __bf16* o = out + orow * C;
     const bool ok = h > 0 && w > 0 && x1 >= 0 && y1 >= 0 && x2 <= cols && y2 <= rows;
     if (!ok) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) { const float v = fill ? fill[c] : 0.0f; o[c] = (__bf16)(relu ? fmaxf(v, 0.0f) : v); }
@@ -420,6 +449,11 @@ int frcnn_conv2d_fwd_bf16_ws(const frcnn_conv_desc* d, const void* x_bf16, const
     a.M = d->n * d->ho * d->wo; a.Kpad = d->kh * d->kw * d->cin; a.act = d->act; a.out_f32 = y_is_f32;
     a.tiles_m = a.tiles_n = 0;
     a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
+    a.layout = d->layout ? 1 : 0;
+    a.pix_stride = a.layout ? d->n * d->cin : d->cin;
+    a.img_stride = a.layout ? d->cin : d->h * d->w * d->cin;
+    a.inv_S = (65536 + d->kw - 1) / d->kw;
+    if (d->kh * d->kw > 32) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_bf16: at most 32 filter taps");
     hipStream_t s = as_stream(stream);
     const int cfg = choose_config_bf16(d);
     static bool attr_done = false;
@@ -455,22 +489,26 @@ int frcnn_cast_f32_to_bf16(const float* x, size_t n, void* y_bf16, void* stream)
 }
 
 int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y, void* stream) {
+    return frcnn_avgpool_bf16_to_f32_ex(x_bf16, n, k, c, 0, y, stream);
+}
+
+int frcnn_avgpool_bf16_to_f32_ex(const void* x_bf16, int n, int k, int c, int layout, float* y, void* stream) {
     if (!x_bf16 || !y || n <= 0 || k <= 0 || c <= 0) return fail(FRCNN_E_ARG, "avgpool_bf16_to_f32: bad argument");
-    k_avgpool_bf16_f32<<<ew_grid_b((size_t)n * c), 256, 0, as_stream(stream)>>>((const __bf16*)x_bf16, n, k * k, c, y);
+    k_avgpool_bf16_f32<<<ew_grid_b((size_t)n * c), 256, 0, as_stream(stream)>>>((const __bf16*)x_bf16, n, k * k, c, layout, y);
     return check_launch("avgpool_bf16_to_f32");
 }
 
 int frcnn_roi_crop_resize_fwd_bf16(const void* feat_bf16, int rows, int cols, int C, const float* rois, int n, int pool, void* out_bf16, void* stream) {
-    return frcnn_roi_crop_resize_fwd_bf16_ex(feat_bf16, rows, cols, C, rois, n, pool, nullptr, 0, out_bf16, stream);
+    return frcnn_roi_crop_resize_fwd_bf16_ex(feat_bf16, rows, cols, C, rois, n, pool, nullptr, 0, 0, out_bf16, stream);
 }
 
 int frcnn_roi_crop_resize_fwd_bf16_ex(const void* feat_bf16, int rows, int cols, int C, const float* rois, int n, int pool,
-                                      const float* fill, int relu, void* out_bf16, void* stream) {
+                                      const float* fill, int relu, int layout, void* out_bf16, void* stream) {
     if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16: bad shape");
     if (n == 0) return FRCNN_OK;
     if (!feat_bf16 || !rois || !out_bf16) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16: null pointer");
     k_roi_fwd_bf16<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const __bf16*)feat_bf16, rows, cols, C, (const float4*)rois, pool,
-                                                                   fill, relu, (__bf16*)out_bf16);
+                                                                   fill, relu, layout, (__bf16*)out_bf16);
     return check_launch("roi_crop_resize_fwd_bf16");
 }
 

@@ -777,6 +777,20 @@ __global__ void k_pool(const float4* x, int n_img, int H, int W, int C4, int k, 
     }
 }
 
+// AveragePooling2D over ALL positions of position-major tensors x[pos][img][c] (frcnn_conv_desc.layout == 1):
+// y[img][c] = (sum over pos, in raster order) / npos -- the same additions and the same division as k_pool<false>
+// performs on the NHWC tensor, so the result is bit-identical.
+__global__ void k_avgpool_pos_major(const float4* x, int npos, int n_img, int C4, float4* y) {
+    const size_t total = (size_t)n_img * C4, plane = total;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int q = 0; q < npos; ++q) { const float4 v = x[(size_t)q * plane + i]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        const float inv = (float)npos;
+        acc.x /= inv; acc.y /= inv; acc.z /= inv; acc.w /= inv;
+        y[i] = acc;
+    }
+}
+
 // row softmax over the first `cols` entries of each row (Dense(..., activation='softmax'), resnet.py:522)
 __global__ void k_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, int ldy) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1097,6 +1111,15 @@ int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stri
     if (is_max) k_pool<true><<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, n, h, w, c / 4, k, stride, Ho, Wo, (float4*)y);
     else k_pool<false><<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, n, h, w, c / 4, k, stride, Ho, Wo, (float4*)y);
     return check_launch("pool2d_fwd");
+}
+
+int frcnn_avgpool_pos_major(const float* x, int npos, int n, int c, float* y, void* stream) {
+    if (!x || !y || npos <= 0 || n <= 0 || c <= 0 || (c & 3)) return fail(FRCNN_E_ARG, "avgpool_pos_major: bad argument (C must be a multiple of 4)");
+    const size_t total = (size_t)n * (c / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    k_avgpool_pos_major<<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, npos, n, c / 4, (float4*)y);
+    return check_launch("avgpool_pos_major");
 }
 
 int frcnn_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream) {

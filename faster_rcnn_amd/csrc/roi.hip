@@ -39,11 +39,13 @@ __device__ __forceinline__ Taps roi_taps(const float4 roi, int py, int px, int p
 // (interpolation weights sum to 1), so the head applies res5a_branch2a / branch1 ONCE to the conv4 map and
 // resamples their outputs; an all-zero crop would have produced the BatchNorm shift there.
 __global__ void __launch_bounds__(256) k_roi_fwd(const float4* feat, int rows, int cols, int C4,
-                                                 const float4* rois, int pool, const float4* fill, int relu, float4* out) {
+                                                 const float4* rois, int pool, const float4* fill, int relu, int pos_major, float4* out) {
     const int pix = blockIdx.x;                 // (roi, py, px)
     const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
     const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
-    float4* o = out + (size_t)pix * C4;
+    // pos_major: out[py][px][roi][c] (frcnn_conv_desc.layout == 1) instead of out[roi][py][px][c]
+    const size_t orow = pos_major ? (size_t)(py * pool + px) * (gridDim.x / (pool * pool)) + r : (size_t)pix;
+    float4* o = out + orow * C4;
     if (!t.ok) {
         for (int c = threadIdx.x; c < C4; c += blockDim.x) {
             float4 v = fill ? fill[c] : make_float4(0, 0, 0, 0);
@@ -96,16 +98,16 @@ extern "C" {
 
 int frcnn_roi_crop_resize_fwd(const float* feat, int rows, int cols, int C, const float* rois, int n, int pool,
                               float* out, void* stream) {
-    return frcnn_roi_crop_resize_fwd_ex(feat, rows, cols, C, rois, n, pool, nullptr, 0, out, stream);
+    return frcnn_roi_crop_resize_fwd_ex(feat, rows, cols, C, rois, n, pool, nullptr, 0, 0, out, stream);
 }
 
 int frcnn_roi_crop_resize_fwd_ex(const float* feat, int rows, int cols, int C, const float* rois, int n, int pool,
-                                 const float* fill, int relu, float* out, void* stream) {
+                                 const float* fill, int relu, int layout, float* out, void* stream) {
     if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || (C & 3) || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd: bad shape (C must be a multiple of 4)");
     if (n == 0) return FRCNN_OK;
     if (!feat || !rois || !out) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd: null pointer");
     k_roi_fwd<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool,
-                                                              (const float4*)fill, relu, (float4*)out);
+                                                              (const float4*)fill, relu, layout, (float4*)out);
     return check_launch("roi_crop_resize_fwd");
 }
 

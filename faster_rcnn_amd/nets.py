@@ -49,14 +49,15 @@ class ConvUnit:
         self.pc = packer(kernel, scale.astype(np.float32), shift.astype(np.float32))
         return self
 
-    def __call__(self, x, residual=None, out=None, act="unit"):
-        """``act`` overrides the unit's activation for this call ("unit" = keep it)."""
+    def __call__(self, x, residual=None, out=None, act="unit", layout=0):
+        """``act`` overrides the unit's activation for this call ("unit" = keep it); ``layout`` 1 = position-major
+        tensors (h,w,n,c), see frcnn_conv_desc.layout."""
         if self.pc is None:
             self.lower()
         act = self.act if act == "unit" else act
         if self.dtype == "bf16":
-            return ops.conv2d_bf16(x, self.pc, self.stride, self.padding, act, residual, self.out_f32, self.tile)
-        return ops.conv2d(x, self.pc, self.stride, self.padding, act, residual, out, self.tile)
+            return ops.conv2d_bf16(x, self.pc, self.stride, self.padding, act, residual, self.out_f32, self.tile, layout)
+        return ops.conv2d(x, self.pc, self.stride, self.padding, act, residual, out, self.tile, layout)
 
 
 def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dtype="f32"):
@@ -71,12 +72,12 @@ def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dt
     return u
 
 
-def run_block(u, x):
+def run_block(u, x, layout=0):
     """identity_block / conv_block (resnet.py:114-247) and their TimeDistributed twins (:250-392)."""
-    shortcut = u["1"](x) if "1" in u else x
-    t = u["2a"](x)
-    t = u["2b"](t)
-    return u["2c"](t, residual=shortcut)
+    shortcut = u["1"](x, layout=layout) if "1" in u else x
+    t = u["2a"](x, layout=layout)
+    t = u["2b"](t, layout=layout)
+    return u["2c"](t, residual=shortcut, layout=layout)
 
 
 class ResNetBase:
@@ -179,9 +180,12 @@ class ResNetHead:
     (the parity tests hold it to the same 1e-4 bar)."""
     pool = 7
 
-    def __init__(self, weights, depth, num_classes, dtype="f32", hoist=True):
+    def __init__(self, weights, depth, num_classes, dtype="f32", hoist=True, pos_major=True):
         r101 = depth == 101
         self.dtype, self.hoist = dtype, hoist
+        # RoI crops kept as [7][7][roi][c]: a 128-row conv tile then covers one or two output positions and the 3x3
+        # layers skip the filter taps that only meet zero padding (14 % of their chunks; bit-identical results)
+        self.layout = 1 if pos_major else 0
         self.blocks = [_block_units(weights, 5, b, b == "a", 1, r101, dtype) for b in "abc"]
         self.dense = _MergedDense(weights, num_classes)
 
@@ -196,22 +200,26 @@ class ResNetHead:
         u = a["2a"](fmap, act=None)                         # conv + BN on the map; its ReLU follows the resampling
         v = a["1"](fmap)                                    # shortcut conv + BN
         # an invalid (empty) RoI crops to zeros in the reference order, which these layers map to their BN shift
-        t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True)
-        s = resize(v, rois, self.pool, fill=a["1"].pc.shift)
-        return a["2c"](a["2b"](t), residual=s)
+        L = self.layout
+        t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)
+        s = resize(v, rois, self.pool, fill=a["1"].pc.shift, layout=L)
+        return a["2c"](a["2b"](t, layout=L), residual=s, layout=L)
 
     def __call__(self, feat, rois):
         resize = ops.roi_crop_resize_bf16 if self.dtype == "bf16" else ops.roi_crop_resize
+        L = self.layout
         if self.hoist:
             x = self._first_block_hoisted(feat, rois, resize)
             rest = self.blocks[1:]
         else:
-            x = resize(feat, rois, self.pool)               # (n,7,7,1024)
+            x = resize(feat, rois, self.pool, layout=L)     # (n,7,7,1024), or (7,7,n,1024) position-major
             rest = self.blocks
         for b in rest:
-            x = run_block(b, x)
+            x = run_block(b, x, L)
         if self.dtype == "bf16":
-            return self.dense(ops.avgpool_bf16(x, 7))      # pooled features and the dense layers stay f32
+            return self.dense(ops.avgpool_bf16(x, 7, L))   # pooled features and the dense layers stay f32
+        if L:
+            return self.dense(ops.avgpool_pos_major(x))     # (n,2048)
         x = ops.pool2d(x, 7, 7, False)                      # (n,1,1,2048)
         return self.dense(x.reshape(x.shape[0], -1))
 

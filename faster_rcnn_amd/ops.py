@@ -171,16 +171,25 @@ def roi_targets(rois_i16, gt_f32, gt_f64, gt_cls, bg_idx):
 
 
 # ----------------------------------------------------------------------------- RoI crop/resize
-def roi_crop_resize(feat, rois, pool, fill=None, relu=False):
-    """feat: (R,C,Cf) f32 (or (1,R,C,Cf)); rois: (n,4) f32 -> (n,pool,pool,Cf) f32.
+def roi_crop_resize(feat, rois, pool, fill=None, relu=False, layout=0):
+    """feat: (R,C,Cf) f32 (or (1,R,C,Cf)); rois: (n,4) f32 -> (n,pool,pool,Cf) f32, or (pool,pool,n,Cf) with layout=1.
     fill (Cf,) = value of an invalid RoI (default zeros); relu clamps the output (frcnn_roi_crop_resize_fwd_ex)."""
     _require_gpu()
     feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
     rows, cols, C = feat.shape
     rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
     n = rois.shape[0]
-    out = torch.empty((n, pool, pool, C), dtype=torch.float32, device="cuda")
-    _lib.call("frcnn_roi_crop_resize_fwd_ex", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, _p(out), _stream())
+    out = torch.empty((pool, pool, n, C) if layout else (n, pool, pool, C), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_roi_crop_resize_fwd_ex", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, _p(out), _stream())
+    return out
+
+
+def avgpool_pos_major(x):
+    """(h,w,n,c) f32 position-major -> (n,c): AveragePooling2D over the whole h x w window."""
+    _require_gpu()
+    h, w, n, c = x.shape
+    out = torch.empty((n, c), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_avgpool_pos_major", _p(x.contiguous()), h * w, n, c, _p(out), _stream())
     return out
 
 
@@ -466,20 +475,21 @@ def cast_bf16(x):
     return out
 
 
-def avgpool_bf16(x, k):
-    """(n,k,k,c) bf16 -> (n,c) f32."""
+def avgpool_bf16(x, k, layout=0):
+    """(n,k,k,c) bf16 (or (k,k,n,c) with layout=1) -> (n,c) f32."""
     _require_gpu()
-    n, _, _, c = x.shape
+    n, c = (x.shape[2] if layout else x.shape[0]), x.shape[3]
     out = torch.empty((n, c), dtype=torch.float32, device="cuda")
-    _lib.call("frcnn_avgpool_bf16_to_f32", _p(x.contiguous()), n, k, c, _p(out), _stream())
+    _lib.call("frcnn_avgpool_bf16_to_f32_ex", _p(x.contiguous()), n, k, c, layout, _p(out), _stream())
     return out
 
 
-def roi_crop_resize_bf16(feat, rois, pool, fill=None, relu=False):
+def roi_crop_resize_bf16(feat, rois, pool, fill=None, relu=False, layout=0):
     _require_gpu()
     feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
     rows, cols, C = feat.shape
     rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
-    out = torch.empty((rois.shape[0], pool, pool, C), dtype=torch.bfloat16, device="cuda")
-    _lib.call("frcnn_roi_crop_resize_fwd_bf16_ex", _p(feat), rows, cols, C, _p(rois), rois.shape[0], pool, _p(fill), 1 if relu else 0, _p(out), _stream())
+    n = rois.shape[0]
+    out = torch.empty((pool, pool, n, C) if layout else (n, pool, pool, C), dtype=torch.bfloat16, device="cuda")
+    _lib.call("frcnn_roi_crop_resize_fwd_bf16_ex", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, _p(out), _stream())
     return out

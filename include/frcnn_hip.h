@@ -138,9 +138,10 @@ int frcnn_roi_crop_resize_fwd(const float* feat, int rows, int cols, int C,
  * what an invalid RoI yields, `relu` != 0 clamps the result at 0.  A 1x1 convolution + folded
  * BatchNorm (resnet.py:351-356, 380-385: res5a_branch2a / branch1, strides (1,1)) commutes with this
  * linear resampling, so the head may apply them once to the conv4 map and resample their outputs;
- * `fill` = that layer's epilogue shift reproduces what an all-zero crop gives in the reference order. */
+ * `fill` = that layer's epilogue shift reproduces what an all-zero crop gives in the reference order.
+ * layout 1 writes out[pool][pool][n][c] (position-major, frcnn_conv_desc.layout) instead of out[n][pool][pool][c]. */
 int frcnn_roi_crop_resize_fwd_ex(const float* feat, int rows, int cols, int c, const float* rois, int n, int pool,
-                                 const float* fill, int relu, float* out, void* stream);
+                                 const float* fill, int relu, int layout, float* out, void* stream);
 /* Gradient of the above w.r.t. feat: dfeat [rows][cols][C] must be zeroed by the caller;
  * contributions are accumulated with f32 atomics. */
 int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C,
@@ -248,6 +249,9 @@ int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g,
 int frcnn_conv2d_config(const frcnn_conv_desc* d);
 /* MaxPooling2D / AveragePooling2D, 'valid' (resnet.py:412, 515; vgg.py:100-128). c % 4 == 0. */
 int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream);
+/* AveragePooling2D over all `npos` positions of a position-major tensor x[npos][n][c] -> y[n][c]
+ * (resnet.py:515 on frcnn_conv_desc.layout == 1 tensors; same additions and division as frcnn_pool2d_fwd). */
+int frcnn_avgpool_pos_major(const float* x, int npos, int n, int c, float* y, void* stream);
 /* softmax over the first `cols` entries of each row (Dense(activation='softmax'), resnet.py:522). */
 int frcnn_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream);
 
@@ -318,11 +322,12 @@ int frcnn_conv2d_fwd_bf16_ws(const frcnn_conv_desc* d, const void* x_bf16, const
 int frcnn_cast_f32_to_bf16(const float* x, size_t n, void* y_bf16, void* stream);
 /* AveragePooling2D(k) of a k x k bf16 map -> f32 [n][c] (resnet.py:515). */
 int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y, void* stream);
+int frcnn_avgpool_bf16_to_f32_ex(const void* x_bf16, int n, int k, int c, int layout, float* y, void* stream);
 /* frcnn_roi_crop_resize_fwd on a bf16 feature map (f32 interpolation, bf16 result). */
 int frcnn_roi_crop_resize_fwd_bf16(const void* feat_bf16, int rows, int cols, int C, const float* rois, int n, int pool,
                                    void* out_bf16, void* stream);
 int frcnn_roi_crop_resize_fwd_bf16_ex(const void* feat_bf16, int rows, int cols, int c, const float* rois, int n, int pool,
-                                      const float* fill, int relu, void* out_bf16, void* stream);
+                                      const float* fill, int relu, int layout, void* out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -109,9 +109,16 @@ def test_head_hoist_equals_reference_order(dtype):
     if dtype == "bf16":
         fd = fd.to(torch.bfloat16)
     a = nets.ResNetHead(w, 50, C, dtype=dtype, hoist=True)(fd, rd)
-    b = nets.ResNetHead(w, 50, C, dtype=dtype, hoist=False)(fd, rd)
+    b = nets.ResNetHead(w, 50, C, dtype=dtype, hoist=False, pos_major=False)(fd, rd)
     tol = 2e-5 if dtype == "f32" else 2e-2                  # bf16: the two orders round different tensors to bf16
     assert rel_err(a[0].cpu(), b[0].cpu()) < tol and rel_err(a[1].cpu(), b[1].cpu()) < tol
+    # the position-major layout alone (tap skipping) must not change a single bit (plain launches: split-K cuts
+    # the compacted chunk sequence at other places, which regroups the partial sums)
+    from faster_rcnn_amd import ops
+    with ops.conv_workspace(ops.NO_SPLIT_K):
+        b2 = nets.ResNetHead(w, 50, C, dtype=dtype, hoist=False, pos_major=False)(fd, rd)
+        c = nets.ResNetHead(w, 50, C, dtype=dtype, hoist=False, pos_major=True)(fd, rd)
+    assert torch.equal(c[0], b2[0]) and torch.equal(c[1], b2[1])
     if dtype == "f32":                                      # and both sit inside the oracle bar
         valid = [i for i in range(40) if i not in (5, 6, 7)]
         k64, g64 = KerasGraphs(w, torch.float64).resnet_classifier(torch.from_numpy(feat), rois[valid], C, 50)
