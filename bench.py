@@ -197,7 +197,7 @@ def main():
         pipes = [pipe] + [InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS) for _ in range(S - 1)]
         streams = [torch.cuda.Stream() for _ in range(S)]
         for i, (pl, st) in enumerate(zip(pipes, streams)):
-            pl.capture(HEIGHT, WIDTH, split_k=split_k)
+            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1)
             pl._static_in.copy_(torch.from_numpy(synth_image(rank * S + i)).cuda())
         torch.cuda.synchronize()
 

@@ -873,7 +873,12 @@ static int choose_config(const frcnn_conv_desc* d) {
         // measured on MI355X over every conv shape of the C2 pipeline (scripts/conv_shapes.py):
         // the 64x64 v2 kernel wins wherever the grid is small or k is short; 128x128 v2 only
         // pays once there are >= 1.5 tiles per CU slot AND a long k loop to amortise its prologue
+        // position-major multi-tap layers skip padding-only taps per tile: tiles then differ in length, and only
+        // a grid with several tiles per CU slot (64x64: 1840 tiles for the head 3x3) turns that into a shorter
+        // launch (500 vs 570 us); the 460 128x128 tiles all start at once and the full-length ones set the time
+        // (with several images in flight the neighbours fill the freed slots: pipelines then ask for tile 21)
         if (generic) cfg = 2;
+        else if (d->layout && d->kh * d->kw > 1) cfg = 22;
         else if (t128 >= 384 && Kpad >= 1024) cfg = 21;
         else cfg = 22;
     }

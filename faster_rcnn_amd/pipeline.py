@@ -57,12 +57,16 @@ class InferencePipeline:
         return res
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=True):
+    def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=True, throughput=False):
         """Capture one full pass for a fixed image size into a hipGraph.
 
         ``split_k``: let small-grid convs cut K over several workgroups.  It shortens ONE image's pass (the
         stage-4 / RPN layers fill 60 % of the CUs otherwise); with several graphs replaying concurrently the
-        chip is already full and the plain launches do less total work, so throughput set-ups pass False."""
+        chip is already full and the plain launches do less total work, so throughput set-ups pass False.
+        ``throughput``: this graph will replay beside others (several images in flight): the detector head's
+        position-major 3x3 layers then take the 128x128 tile (nets.ResNetHead.prefer_big_tiles)."""
+        if hasattr(self.det.head, "prefer_big_tiles"):
+            self.det.head.prefer_big_tiles(throughput)
         self._static_in = torch.zeros((1, height, width, 3), dtype=torch.float32, device="cuda")
         # the graph owns its split-K workspace: graphs of several pipelines replay concurrently.  The warm-up
         # passes size it, so the capture itself allocates (and re-zeroes) nothing.
