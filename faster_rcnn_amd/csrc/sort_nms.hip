@@ -31,25 +31,28 @@ __device__ __forceinline__ unsigned mono_f32(float f) {      // order-preserving
 // degenerate score distribution (everything in one bin) degrades to the N^2 sweep, never to a wrong answer.
 constexpr int TOPK_BINS = 65536;
 constexpr int TOPK_BLOCK = 256;
-struct TopkCtrl { int32_t n_cand; int32_t thr_bin; int32_t pad[62]; };
+struct TopkCtrl { int32_t n_cand; int32_t thr_bin; int32_t n_valid; int32_t pad[61]; };
+constexpr int TOPK_DIRECT_N = 32768;        // at or below this many scores the plain all-pairs sweep is faster than the four passes
 
 __device__ __forceinline__ u64 topk_key(float score, int i) { return (((u64)mono_f32(score)) << 32) | (unsigned)(~(unsigned)i); }
 
-__global__ void k_topk_hist(const float* scores, const uint8_t* valid, int N, unsigned* hist, int32_t* n_valid) {
+__global__ void k_topk_hist(const float* scores, const uint8_t* valid, int N, unsigned* hist, TopkCtrl* ctrl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool v = i < N && (!valid || valid[i]);
     if (v) atomicAdd(&hist[mono_f32(scores[i]) >> 16], 1u);
     const u64 b = __ballot(v);
-    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, __popcll(b));
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&ctrl->n_valid, __popcll(b));
 }
 
 // thread t owns the 64 bins [65536 - 64(t+1), 65536 - 64t): bins are walked from the largest key down
-__global__ void __launch_bounds__(1024) k_topk_threshold(const unsigned* hist, const int32_t* n_valid, int K, TopkCtrl* ctrl) {
+__global__ void __launch_bounds__(1024) k_topk_threshold(const unsigned* hist, int K, TopkCtrl* ctrl) {
     __shared__ unsigned tot[1024];
     const int t = threadIdx.x;
     const unsigned* mine = hist + (TOPK_BINS - 64 * (t + 1));
     unsigned sum = 0;
-    for (int b = 0; b < 64; ++b) sum += mine[b];
+    const uint4* mine4 = reinterpret_cast<const uint4*>(mine);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) { const uint4 v = mine4[b]; sum += (v.x + v.y) + (v.z + v.w); }
     tot[t] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {              // inclusive scan over t (t = 0 is the top of the key range)
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(1024) k_topk_threshold(const unsigned* hist, c
         tot[t] += add;
         __syncthreads();
     }
-    const int nv = *n_valid;
+    const int nv = ctrl->n_valid;
     const unsigned need = (unsigned)(nv < K ? nv : K);
     if (t == 0 && need == 0) ctrl->thr_bin = TOPK_BINS;     // nothing valid: no candidates
     const unsigned before = t ? tot[t - 1] : 0u;
@@ -71,16 +74,20 @@ __global__ void __launch_bounds__(1024) k_topk_threshold(const unsigned* hist, c
     }
 }
 
-__global__ void k_topk_compact(const float* scores, const uint8_t* valid, int N, TopkCtrl* ctrl, u64* cand, int32_t* rank) {
+// direct != 0: no histogram ran -- every valid key is a candidate and this pass also counts them
+__global__ void k_topk_compact(const float* scores, const uint8_t* valid, int N, TopkCtrl* ctrl, u64* cand, int32_t* rank, int direct) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool take = false;
     float sc = 0.0f;
-    if (i < N && (!valid || valid[i])) { sc = scores[i]; take = (int)(mono_f32(sc) >> 16) >= ctrl->thr_bin; }
+    if (i < N && (!valid || valid[i])) { sc = scores[i]; take = direct || (int)(mono_f32(sc) >> 16) >= ctrl->thr_bin; }
     const u64 b = __ballot(take);
     if (!b) return;
     const int lane = threadIdx.x & 63;
     int base = 0;
-    if (lane == __ffsll((long long)b) - 1) base = atomicAdd(&ctrl->n_cand, __popcll(b));     // one atomic per wave
+    if (lane == __ffsll((long long)b) - 1) {
+        base = atomicAdd(&ctrl->n_cand, __popcll(b));     // one atomic per wave
+        if (direct) atomicAdd(&ctrl->n_valid, __popcll(b));
+    }
     base = __shfl(base, __ffsll((long long)b) - 1);
     if (take) {
         const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
@@ -112,10 +119,10 @@ __global__ void __launch_bounds__(TOPK_BLOCK) k_topk_rank(const u64* keys, const
     if (i < n && cnt) atomicAdd(&rank[i], cnt);
 }
 
-__global__ void k_topk_scatter(const u64* keys, const int32_t* rank, const TopkCtrl* ctrl, int K, int32_t* order, int32_t* n_valid_to_n_out) {
+__global__ void k_topk_scatter(const u64* keys, const int32_t* rank, const TopkCtrl* ctrl, int K, int32_t* order, int32_t* n_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < ctrl->n_cand && rank[c] < K) order[rank[c]] = (int32_t)(~(unsigned)keys[c]);
-    if (c == 0 && *n_valid_to_n_out > K) *n_valid_to_n_out = K;
+    if (c == 0) *n_out = min(ctrl->n_valid, K);
 }
 
 __global__ void k_gather_candidates(const float4* rois, const float* scores, const int32_t* order, const int32_t* n, int K,
@@ -308,13 +315,18 @@ int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, in
     TopkCtrl* ctrl = (TopkCtrl*)((char*)workspace + (size_t)TOPK_BINS * 4);
     u64* cand = (u64*)((char*)ctrl + sizeof(TopkCtrl));
     int32_t* rank = (int32_t*)((char*)cand + align_up((size_t)N * 8, 256));
-    if (hipMemsetAsync(hist, 0, (size_t)TOPK_BINS * 4 + sizeof(TopkCtrl), s) != hipSuccess) return fail(FRCNN_E_HIP, "topk_order: memset failed");
     const int bi = (N + TOPK_BLOCK - 1) / TOPK_BLOCK;
-    k_topk_hist<<<bi, TOPK_BLOCK, 0, s>>>(scores, valid, N, hist, n_out);
-    if (int e = check_launch("topk_order hist")) return e;
-    k_topk_threshold<<<1, 1024, 0, s>>>(hist, n_out, K, ctrl);
-    if (int e = check_launch("topk_order threshold")) return e;
-    k_topk_compact<<<bi, TOPK_BLOCK, 0, s>>>(scores, valid, N, ctrl, cand, rank);
+    const int direct = N <= TOPK_DIRECT_N;
+    if (direct) {
+        if (hipMemsetAsync(ctrl, 0, sizeof(TopkCtrl), s) != hipSuccess) return fail(FRCNN_E_HIP, "topk_order: memset failed");
+    } else {
+        if (hipMemsetAsync(hist, 0, (size_t)TOPK_BINS * 4 + sizeof(TopkCtrl), s) != hipSuccess) return fail(FRCNN_E_HIP, "topk_order: memset failed");
+        k_topk_hist<<<bi, TOPK_BLOCK, 0, s>>>(scores, valid, N, hist, ctrl);
+        if (int e = check_launch("topk_order hist")) return e;
+        k_topk_threshold<<<1, 1024, 0, s>>>(hist, K, ctrl);
+        if (int e = check_launch("topk_order threshold")) return e;
+    }
+    k_topk_compact<<<bi, TOPK_BLOCK, 0, s>>>(scores, valid, N, ctrl, cand, rank, direct);
     if (int e = check_launch("topk_order compact")) return e;
     int split = 2048 / bi;
     split = split < 8 ? 8 : (split > 64 ? 64 : split);
