@@ -95,7 +95,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True):
         rec = g["rec"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         graph = torch.cuda.CUDAGraph()          # the product path replays hipGraphs: time the launch the same way
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             for _ in range(reps):
                 rec["relaunch"]()
         graph.replay()                          # the shader clock settles over the first launches of a shape
@@ -179,12 +179,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
+    # one rank per GPU; FRCNN_BENCH_BACKEND=gloo (dev) lets two ranks share one GPU to exercise this path on a 1-GPU box
+    backend = os.environ.get("FRCNN_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local % torch.cuda.device_count() if world > 1 else 0)
 
     pipe, weights, anchors = build_pipeline()
     x = torch.from_numpy(synth_image(rank)).cuda()
@@ -210,6 +207,14 @@ def main():
         S = 1
         step = lambda: pipe.forward_dev(x)
 
+    if world > 1:
+        # the process group comes up AFTER the hipGraph captures: its watchdog thread must not touch the HIP
+        # runtime while a capture is open
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend=backend)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -225,7 +230,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -234,7 +239,11 @@ def main():
     n_dets = int(out["n_dets"].item()) if "n_dets" in out else None
 
     if rank == 0:
-        roof, _ = conv_roofline(pipe, x, split_k=split_k)
+        try:
+            roof, _ = conv_roofline(pipe, x, split_k=split_k)
+        except Exception as e:                          # the throughput line must survive a failed per-kernel pass
+            roof = None
+            roof_error = "%s: %s" % (type(e).__name__, e)
         line = {
             "metric": "images/sec end-to-end (RPN+det) ResNet-%d %dx%d" % (DEPTH, HEIGHT, WIDTH),
             "value": round(world * S * args.steps / elapsed, 3), "unit": "img/s",
@@ -250,13 +259,16 @@ def main():
                        "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world},
             "roofline": roof,
         }
-        if HOIST:       # what the same image costs in the reference's layer order (res5a_branch2a / branch1 on every crop)
+        if roof is None:
+            line["roofline"] = {"bound": "mfma", "error": roof_error}
+        if roof is not None and HOIST:   # what the same image costs in the reference's layer order (res5a_branch2a / branch1 on every crop)
             rows_cols = int(out["rpn_cls"].shape[1] * out["rpn_cls"].shape[2])
             saved = 2.0 * 1024 * (512 + 2048) * (PROPOSALS * 49 - rows_cols) / 1e9
             roof["all_conv_launches"]["gflop_per_image_reference_order"] = round(roof["all_conv_launches"]["gflop_per_image"] + saved, 2)
         # conv FLOP actually executed per second by the whole job (all images in flight)
-        line["roofline"]["end_to_end_conv_tflops"] = round(roof["all_conv_launches"]["gflop_per_image"] * line["value"] / world / 1e3, 2)
-        if DTYPE == "bf16":
+        if roof is not None:
+            line["roofline"]["end_to_end_conv_tflops"] = round(roof["all_conv_launches"]["gflop_per_image"] * line["value"] / 1e3, 2)
+        if roof is not None and DTYPE == "bf16":
             for k in ("peak",):
                 roof[k] = PEAK_BF16_TFLOPS
             roof["frac"] = round(roof["achieved"] / PEAK_BF16_TFLOPS, 4)

@@ -79,7 +79,8 @@ class InferencePipeline:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph), ops.conv_workspace(self._conv_ws):
+        # thread_local: another thread of this process (e.g. an RCCL watchdog) may call into HIP during the capture
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
 
