@@ -173,3 +173,67 @@ def test_roi_resize_conv_layer_and_scale():
     sc = Scale(weights=[np.full(32, 2.0, np.float32), np.full(32, -1.0, np.float32)])
     sc.build(feat.shape)
     assert np.allclose(sc(feat), 2 * feat - 1)
+
+
+def test_full_size_c2_properties():
+    """BASELINE configs[1] at full size (ResNet-50, 600x1000, 9 anchors, 300 proposals, 21 classes): size-independent
+    properties of the device pipeline -- the oracle is too slow to run whole at this size."""
+    from faster_rcnn_amd import ops, resnet, util
+    from faster_rcnn_amd.pipeline import InferencePipeline
+    from faster_rcnn_amd.weights import synthetic_resnet
+    anchors = util.get_anchors([128, 256, 512])
+    w = synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=1)
+    base = resnet.resnet50_base(weights=w)
+    rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=9)
+    det = resnet.resnet50_classifier(300, 21, weights=w)
+    rs = np.random.RandomState(0)
+    x = (rs.randint(0, 256, (600, 1000, 3)).astype(np.float32) - np.array([103.939, 116.779, 123.68], np.float32))[None]
+    xd = torch.from_numpy(x).cuda()
+    pipe = InferencePipeline(rpn, det, anchors, max_proposals=300)
+    out = pipe.forward_dev(xd)
+    rows, cols = resnet.get_conv_rows_cols(600, 1000)
+    assert out["rpn_cls"].shape == (1, rows, cols, 9) and (rows, cols) == (38, 63)
+
+    # proposals: inside the map, non-empty, and the greedy-NMS invariant (+1 convention, det_util.py:237-250)
+    n = int(out["n_rois"].item())
+    rois = out["rois"].cpu().numpy()[:n]
+    assert 0 < n <= 300
+    assert (rois[:, 0] >= 0).all() and (rois[:, 1] >= 0).all() and (rois[:, 2] <= cols - 1).all() and (rois[:, 3] <= rows - 1).all()
+    assert (rois[:, 2] > rois[:, 0]).all() and (rois[:, 3] > rois[:, 1]).all()
+    r = rois.astype(np.int64)
+    area = (r[:, 2] - r[:, 0] + 1) * (r[:, 3] - r[:, 1] + 1)
+    iw = np.maximum(0, np.minimum(r[:, None, 2], r[None, :, 2]) - np.maximum(r[:, None, 0], r[None, :, 0]) + 1)
+    ih = np.maximum(0, np.minimum(r[:, None, 3], r[None, :, 3]) - np.maximum(r[:, None, 1], r[None, :, 1]) + 1)
+    ov = iw * ih / (area[:, None] + area[None, :] - iw * ih)
+    np.fill_diagonal(ov, 0)
+    assert ov.max() <= 0.7                                     # no kept pair overlaps more than the threshold
+
+    # detections: class probabilities are a distribution; emitted boxes are integer and ordered x1<=x2, y1<=y2
+    cls = out["cls"].cpu().numpy()[:n]
+    assert np.abs(cls.sum(1) - 1).max() < 1e-5
+    nd = int(out["n_dets"].item())
+    bb = out["det_bbox"].cpu().numpy()[:nd]
+    assert nd > 0 and (bb[:, 2] >= bb[:, 0]).all() and (bb[:, 3] >= bb[:, 1]).all()
+
+    # eager == hipGraph replay, bit for bit, in both capture modes; two replays agree
+    ref_cls, ref_bb = out["cls"].clone(), out["det_bbox"].clone()
+    for kw in ({"split_k": True, "throughput": False}, {"split_k": True, "throughput": True}):
+        p2 = InferencePipeline(rpn, det, anchors, max_proposals=300)
+        p2.capture(600, 1000, **kw)
+        a = p2.replay(xd)
+        a_cls, a_bb, a_nd = a["cls"].clone(), a["det_bbox"].clone(), int(a["n_dets"].item())
+        b = p2.replay(xd)
+        torch.cuda.synchronize()
+        assert torch.equal(a_cls, b["cls"]) and torch.equal(a_bb, b["det_bbox"])
+        # tile policy / split-K regroup f32 sums: same detections up to rounding, never a different picture
+        assert abs(a_nd - nd) <= 2
+        assert (a_cls[:n] - ref_cls[:n]).abs().max().item() < 1e-4
+    det.head.prefer_big_tiles(False)
+
+    # the reference's layer order in the head (no hoist, NHWC crops) gives the same scores within the fp32 bar
+    det.head.hoist, det.head.layout = False, 0
+    plain = InferencePipeline(rpn, det, anchors, max_proposals=300).forward_dev(xd)
+    det.head.hoist, det.head.layout = True, 1
+    assert int(plain["n_rois"].item()) == n
+    assert (plain["cls"][:n] - ref_cls[:n]).abs().max().item() < 1e-4
+    assert ((plain["reg"][:n] - out["reg"][:n]).abs() / out["reg"][:n].abs().clamp(min=1.0)).max().item() < 1e-4
