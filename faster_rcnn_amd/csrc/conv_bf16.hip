@@ -50,16 +50,23 @@ __device__ __forceinline__ float activate_b(float v, int act) {
     return v;
 }
 
-template <int TM, int TN, bool SPLITK = false>
-__global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, NT = 256;
-    constexpr int PA = BM / 32, PB = BN / 32;
+// WM x WN waves, each owning TM x TN 32x32 tiles.  2x2 waves is the base shape.  2x4 waves (512 threads, TM=2,
+// TN=1) put FOUR waves on a SIMD with two workgroups per CU: a bf16 chunk is only 8-16 MFMAs (256-512 cycles) per
+// wave, far less than the global->LDS->fragment latency of the next chunk, so the MFMA pipe needs more waves to
+// draw from than the f32 kernel (whose chunk is 4096 cycles of MFMA) does.
+template <int TM, int TN, bool SPLITK = false, int WM = 2, int WN = 2>
+__global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgsBf16 p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int RPP = NT / 8;                          // tile rows staged per pass (8 lanes x 16 B per row)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char* As = smem_b;                                   // [2][BM][144 B]
     char* Bs = smem_b + 2 * BM * LDS_STRIDE_B;           // [2][BN][144 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     const int splits = SPLITK ? p.splits : 1;
@@ -79,7 +86,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
     int a_h[PA], a_w[PA], a_off[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RPP * i;
         if (m < p.M) {
             int wo, ho, img;
             if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
@@ -94,7 +101,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
     unsigned b_off[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int n = n0 + lrow + 32 * i;
+        const int n = n0 + lrow + RPP * i;
         b_off[i] = n < p.Cout ? (unsigned)(n * p.Kpad * 2 + lcolb) : OOB_OFFSET_B;
     }
 
@@ -153,9 +160,9 @@ __global__ void __launch_bounds__(256) k_conv_igemm_bf16(const ConvArgsBf16 p) {
         char* a = As + buf * BM * LDS_STRIDE_B;
         char* b = Bs + buf * BN * LDS_STRIDE_B;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + 32 * i) * LDS_STRIDE_B + lcolb) = ra[i];
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + RPP * i) * LDS_STRIDE_B + lcolb) = ra[i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + 32 * i) * LDS_STRIDE_B + lcolb) = rb[i];
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + RPP * i) * LDS_STRIDE_B + lcolb) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -347,20 +354,20 @@ __global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int ro
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int WM = 2, int WN = 2>
 static int launch_bf16(const ConvArgsBf16& a, hipStream_t s) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgsBf16 p = a;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE_B;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS to %zu", lds);
         attr_done = true;
     }
-    k_conv_igemm_bf16<TM, TN><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    k_conv_igemm_bf16<TM, TN, false, WM, WN><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
     return check_launch("conv2d_fwd_bf16");
 }
 
@@ -398,7 +405,9 @@ static int choose_config_bf16(const frcnn_conv_desc* d) {
     const long long M = (long long)d->n * d->ho * d->wo;
     const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
     int cfg = d->tile % 100;
-    if (cfg == 0) cfg = t128 >= 256 ? 1 : 2;
+    // measured on MI355X (scripts/conv_shapes.py --bf16): the 8-wave 128x128 tile (2x4 waves) beats the 4-wave one on
+    // every shape with >= 1 tile per CU (+8 % head 3x3, +38 % on 512 -> 2048); thin outputs take its 128x64 sibling
+    if (cfg == 0) cfg = t128 >= 256 ? (d->cout >= 128 ? 42 : 43) : 2;
     return cfg;
 }
 
@@ -477,6 +486,10 @@ int frcnn_conv2d_fwd_bf16_ws(const frcnn_conv_desc* d, const void* x_bf16, const
         case 1: case 11: return launch_bf16<2, 2>(a, s);
         case 2: case 12: return launch_bf16<1, 1>(a, s);
         case 3: case 13: return launch_bf16<2, 1>(a, s);
+        case 41: return launch_bf16<1, 2, 4, 2>(a, s);           // 128x128, 8 waves (4x2)
+        case 42: return launch_bf16<2, 1, 2, 4>(a, s);           // 128x128, 8 waves (2x4)
+        case 43: return launch_bf16<1, 1, 4, 2>(a, s);           // 128x64, 8 waves
+        case 44: return launch_bf16<1, 1, 4, 4>(a, s);           // 128x128, 16 waves
         default: return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: unknown tile config %d", cfg);
     }
 }

@@ -19,7 +19,9 @@ torch = pytest.importorskip("torch")
                                   (1, 15, 22, 128, 192, 3, 1, "same", 302),        # split-K: 3 slices of 18 chunks, mid-filter starts
                                   (1, 38, 94, 1024, 256, 1, 1, "valid", 0),        # R101 stage-4 reduce at C4 size: auto split-K
                                   (1, 38, 94, 256, 256, 3, 1, "same", 0),          # R101 stage-4 3x3
-                                  (5, 1, 1, 2048, 64, 1, 1, "valid", 802)])        # 8 slices of 32 chunks, 5 valid rows
+                                  (5, 1, 1, 2048, 64, 1, 1, "valid", 802),         # 8 slices of 32 chunks, 5 valid rows
+                                  (2, 7, 7, 512, 512, 3, 1, "same", 41), (1, 15, 22, 128, 192, 3, 1, "same", 42),    # 8-wave tiles
+                                  (1, 30, 41, 256, 128, 1, 2, "valid", 43), (3, 7, 7, 512, 200, 3, 1, "same", 44)])  # 128x64 8-wave, 16-wave
 def test_conv2d_bf16(case):
     from faster_rcnn_amd import ops
     from oracle import keras_ref
