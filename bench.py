@@ -70,7 +70,7 @@ def build_pipeline():
     return InferencePipeline(rpn, det, anchors, max_proposals=PROPOSALS), w, anchors
 
 
-def conv_roofline(pipe, x, reps=10, split_k=True):
+def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
     """Per-launch duration of every conv launch of one image, measured with HIP events on the launch
     stream.  An event pair around ONE short kernel also measures the event packets themselves
     (tens of microseconds on this stack), so each distinct launch (kernel instantiation x shape) is
@@ -78,7 +78,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True):
     event pair brackets a replay; its average is the launch duration.  Returns the roofline object for the
     DOMINANT kernel instantiation (largest summed duration per image) plus the aggregate over all conv launches."""
     from faster_rcnn_amd import ops
-    with ops.conv_workspace(None if split_k else ops.NO_SPLIT_K):     # the same launch forms the timed graphs hold
+    with ops.conv_workspace(None if split_k else ops.NO_SPLIT_K), ops.tile_policy(throughput):     # the launch forms the timed graphs hold
         pipe.forward_dev(x)
         torch.cuda.synchronize()
         ops.CONV_PROFILE = []
@@ -240,7 +240,7 @@ def main():
 
     if rank == 0:
         try:
-            roof, _ = conv_roofline(pipe, x, split_k=split_k)
+            roof, _ = conv_roofline(pipe, x, split_k=split_k, throughput=S > 1)
         except Exception as e:                          # the throughput line must survive a failed per-kernel pass
             roof = None
             roof_error = "%s: %s" % (type(e).__name__, e)

@@ -406,8 +406,11 @@ static int choose_config_bf16(const frcnn_conv_desc* d) {
     const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
     int cfg = d->tile % 100;
     // measured on MI355X (scripts/conv_shapes.py --bf16): the 8-wave 128x128 tile (2x4 waves) beats the 4-wave one on
-    // every shape with >= 1 tile per CU (+8 % head 3x3, +38 % on 512 -> 2048); thin outputs take its 128x64 sibling
-    if (cfg == 0) cfg = t128 >= 256 ? (d->cout >= 128 ? 42 : 43) : 2;
+    // every shape with >= 1 tile per CU (+8 % head 3x3, +38 % on 512 -> 2048); thin outputs take its 128x64 sibling.
+    // Alone on the chip a launch wants >= 1 big tile per CU, else 64x64 tiles (C4 one image in flight: 312 img/s at
+    // a threshold of 256 tiles, 261 at 32); beside other images' launches (tile code 50) the big tiles' better
+    // MFMA efficiency wins down to a handful of tiles (C4 four in flight: 596 img/s at 16, 556 at 256).
+    if (cfg == 0 || cfg == 50) cfg = t128 >= (cfg == 50 ? 16 : 256) ? (d->cout >= 128 ? 42 : 43) : 2;
     return cfg;
 }
 

@@ -869,6 +869,8 @@ static int choose_config(const frcnn_conv_desc* d) {
     int cfg = d->tile % 100;    // 0 = auto; the hundreds digit(s) force the split-K factor (choose_splits)
     static const int forced = getenv("FRCNN_FORCE_TILE") ? atoi(getenv("FRCNN_FORCE_TILE")) : 0;   // dev knob
     if (cfg == 0 && forced && !generic) cfg = forced;
+    const bool shared_chip = cfg == 50;                     // "auto, other launches run beside this one" (several images in flight)
+    if (cfg == 50) cfg = 0;
     if (cfg == 0) {
         // measured on MI355X over every conv shape of the C2 pipeline (scripts/conv_shapes.py):
         // the 64x64 v2 kernel wins wherever the grid is small or k is short; 128x128 v2 only
@@ -878,7 +880,7 @@ static int choose_config(const frcnn_conv_desc* d) {
         // launch (500 vs 570 us); the 460 128x128 tiles all start at once and the full-length ones set the time
         // (with several images in flight the neighbours fill the freed slots: pipelines then ask for tile 21)
         if (generic) cfg = 2;
-        else if (d->layout && d->kh * d->kw > 1) cfg = 22;
+        else if (d->layout && d->kh * d->kw > 1 && !shared_chip) cfg = 22;
         else if (t128 >= 384 && Kpad >= 1024) cfg = 21;
         else cfg = 22;
     }

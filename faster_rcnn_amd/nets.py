@@ -189,14 +189,6 @@ class ResNetHead:
         self.blocks = [_block_units(weights, 5, b, b == "a", 1, r101, dtype) for b in "abc"]
         self.dense = _MergedDense(weights, num_classes)
 
-    def prefer_big_tiles(self, on):
-        """Tile choice of the position-major 3x3 layers.  One image in flight: 64x64 tiles, whose varying lengths
-        (skipped taps) even out over several tiles per CU slot (500 vs 570 us per launch).  Several images in
-        flight: the 128x128 tile, 5 % more efficient per MFMA, because other images' work fills the freed slots."""
-        if self.dtype == "f32":
-            for b in self.blocks:
-                b["2b"].tile = 21 if (on and self.layout) else 0
-
     def units(self):
         for b in self.blocks:
             yield from b.values()

@@ -265,6 +265,25 @@ _CONV_WS = None             # the workspace conv launches use right now (None: p
 _STREAM_WS = {}             # eager launches: HIP stream handle -> ConvWorkspace (same-stream launches serialise)
 
 
+AUTO_TILE = 0               # tile code substituted for tile=0: 0 = launch alone on the chip, 50 = beside other streams' launches
+
+
+class tile_policy:
+    """``with tile_policy(throughput=True):`` conv launches inside pick their tile for a chip shared with other
+    images' launches (frcnn_conv_desc.tile = 50) instead of for a launch that has the chip to itself."""
+
+    def __init__(self, throughput):
+        self.code = 50 if throughput else 0
+
+    def __enter__(self):
+        global AUTO_TILE
+        self.prev, AUTO_TILE = AUTO_TILE, self.code
+
+    def __exit__(self, *exc):
+        global AUTO_TILE
+        AUTO_TILE = self.prev
+
+
 class conv_workspace:
     """``with conv_workspace(ws):`` routes the split-K launches inside to ``ws``."""
 
@@ -322,7 +341,7 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
     d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc.cin, cout=pc.cout, kh=pc.kh, kw=pc.kw, stride=stride, pad_top=pt, pad_left=pl,
-                      ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile, layout=layout)
+                      ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile or AUTO_TILE, layout=layout)
     args, ws = _conv_launch(d, x, pc.w, pc.scale, pc.shift, residual, None, out)
     if CONV_PROFILE is not None:
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
@@ -451,7 +470,7 @@ def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f
     _require_gpu()
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == pc.cin
     d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act], layout)
-    d.tile = tile
+    d.tile = tile or AUTO_TILE
     oshape = (d.ho, d.wo, d.n, pc.cout) if layout else (d.n, d.ho, d.wo, pc.cout)
     out = torch.empty(oshape, dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
     if residual is not None:

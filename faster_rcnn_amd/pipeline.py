@@ -63,24 +63,23 @@ class InferencePipeline:
         ``split_k``: let small-grid convs cut K over several workgroups.  It shortens ONE image's pass (the
         stage-4 / RPN layers fill 60 % of the CUs otherwise); with several graphs replaying concurrently the
         chip is already full and the plain launches do less total work, so throughput set-ups pass False.
-        ``throughput``: this graph will replay beside others (several images in flight): the detector head's
-        position-major 3x3 layers then take the 128x128 tile (nets.ResNetHead.prefer_big_tiles)."""
-        if hasattr(self.det.head, "prefer_big_tiles"):
-            self.det.head.prefer_big_tiles(throughput)
+        ``throughput``: this graph will replay beside others (several images in flight): conv launches then pick
+        their tiles for a shared chip (ops.tile_policy: larger tiles, whose MFMA efficiency is better, even where
+        they leave CUs idle for a launch running alone)."""
         self._static_in = torch.zeros((1, height, width, 3), dtype=torch.float32, device="cuda")
         # the graph owns its split-K workspace: graphs of several pipelines replay concurrently.  The warm-up
         # passes size it, so the capture itself allocates (and re-zeroes) nothing.
         self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws):
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
             for _ in range(warmup):
                 self.forward_dev(self._static_in, resize_ratio)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         # thread_local: another thread of this process (e.g. an RCCL watchdog) may call into HIP during the capture
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws):
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
 

@@ -171,6 +171,8 @@ typedef struct frcnn_conv_desc {
                                       11..14: the same tiles with the pipelined v2 main loop;
                                       21, 22: 128x128 / 64x64 v2 with the late-LDS-store schedule;
                                       41..43: 128x128 (4x2 / 2x4 waves) and 128x64 with 8 waves;
+                                      50: auto for a launch that SHARES the chip with other streams' launches
+                                          (several images in flight): prefers the larger tiles;
                                       + 100*s: force s split-K slices (frcnn_conv2d_fwd_ws)       */
     int32_t layout;                /* 0: x [n][h][w][cin], y [n][ho][wo][cout] (NHWC).
                                       1: position-major, x [h][w][n][cin], y [ho][wo][n][cout] (forward only,

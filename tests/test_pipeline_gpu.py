@@ -228,7 +228,6 @@ def test_full_size_c2_properties():
         # tile policy / split-K regroup f32 sums: same detections up to rounding, never a different picture
         assert abs(a_nd - nd) <= 2
         assert (a_cls[:n] - ref_cls[:n]).abs().max().item() < 1e-4
-    det.head.prefer_big_tiles(False)
 
     # the reference's layer order in the head (no hoist, NHWC crops) gives the same scores within the fp32 bar
     det.head.hoist, det.head.layout = False, 0
