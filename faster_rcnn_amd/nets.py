@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .weights import STAGE_FILTERS, VGG_CONVS, resnet_block_names
+from .weights import VGG_CONVS, resnet_block_names
 
 BN_EPS_STEM = 1e-3      # Keras BatchNormalization default epsilon (bn_conv1, resnet.py:410)
 BN_EPS_BLOCK = 1e-5     # resnet.py:148, 216, 280, 349

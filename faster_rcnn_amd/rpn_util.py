@@ -9,7 +9,6 @@ host because it consumes the global Python ``random`` stream exactly like the re
 import random
 
 import numpy as np
-import torch
 
 from . import ops
 from .shared_constants import DEFAULT_ANCHORS
