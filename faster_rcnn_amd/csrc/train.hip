@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(LB) k_loss_rpn_cls(const float* y_true, const 
     __shared__ double scratch[LB / 64];
     double acc = 0.0;
     const int n = cells * A;
-    for (int i = threadIdx.x; i < n; i += LB) {
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n; i += LB) {         // unrolled: the loads of four iterations are in flight together
         const int cell = i / A, a = i % A;
         const float sel = y_true[(size_t)cell * 2 * A + a], z = y_true[(size_t)cell * 2 * A + A + a];
         const float pr = p[i];
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(LB) k_loss_rpn_reg(const float* y_true, const 
     __shared__ double scratch[LB / 64];
     double s = 0.0, msum = 0.0;
     const int n = cells * A4;
+#pragma unroll 8
     for (int i = threadIdx.x; i < n; i += LB) {
         const int cell = i / A4, k = i % A4;
         msum += (double)y_true[(size_t)cell * 2 * A4 + k];
@@ -69,6 +71,7 @@ __global__ void __launch_bounds__(LB) k_loss_rpn_reg(const float* y_true, const 
     if (threadIdx.x == 0) *loss = (float)(mean_mask * 10.0 * S / 2400.0);
     if (g_pred) {
         const float coef = (float)(mean_mask * 10.0 / 2400.0);
+#pragma unroll 8
         for (int i = threadIdx.x; i < n; i += LB) {
             const int cell = i / A4, k = i % A4;
             g_pred[i] = -coef * smooth_l1_grad(y_true[(size_t)cell * 2 * A4 + A4 + k] - pred[i]);
