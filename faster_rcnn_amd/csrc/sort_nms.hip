@@ -234,10 +234,15 @@ __global__ void __launch_bounds__(64) k_nms_scan(const u64* mask, const int32_t*
     for (int s = 0; s < NMS_SLOTS; ++s) removed[s] = 0;
     int total = 0;
     const int chunks = (n + 63) / 64;
+    u64 diag_next = lane < n ? mask[(size_t)lane * W] : 0ull;          // chunk 0's diagonal word of row `lane`
     for (int c = 0; c < chunks && total < max_boxes; ++c) {
         const int base = c * 64;
         const int i = base + lane;
-        const u64 diag = i < n ? mask[(size_t)i * W + c] : 0ull;     // issued before the resolve
+        const u64 diag = diag_next;
+        if (c + 1 < chunks) {                 // the next chunk's diagonal words do not depend on this chunk's outcome:
+            const int in = i + 64;            // fetch them now, their latency hides behind the resolve below
+            diag_next = in < n ? mask[(size_t)in * W + c + 1] : 0ull;
+        }
         u64 rem = 0;
 #pragma unroll
         for (int s = 0; s < NMS_SLOTS; ++s)
@@ -258,17 +263,27 @@ __global__ void __launch_bounds__(64) k_nms_scan(const u64* mask, const int32_t*
         if ((kept >> lane) & 1) keep[total + __popcll(kept & ((1ull << lane) - 1))] = i;
         total += __popcll(kept);
         if (total >= max_boxes) break;
-        // OR the kept rows into the bitmap for all later chunks; loads are independent
+        // OR the kept rows into the bitmap for all later chunks, EIGHT rows per round: their 24 loads are
+        // independent and in flight together (one row per round paid one memory latency per kept box)
         u64 k = kept;
         while (k) {
-            const int b = __builtin_ctzll(k);
-            k &= k - 1;
-            const u64* row = mask + (size_t)(base + b) * W;
+            u64 v[8][NMS_SLOTS];
 #pragma unroll
-            for (int s = 0; s < NMS_SLOTS; ++s) {
-                const int w = s * 64 + lane;
-                if (w > c && w < W) removed[s] |= row[w];
+            for (int u = 0; u < 8; ++u) {
+                const bool has = k != 0;
+                const int b = has ? __builtin_ctzll(k) : 0;
+                k = has ? k & (k - 1) : 0;
+                const u64* row = mask + (size_t)(base + b) * W;
+#pragma unroll
+                for (int s = 0; s < NMS_SLOTS; ++s) {
+                    const int w = s * 64 + lane;
+                    v[u][s] = (has && w > c && w < W) ? row[w] : 0ull;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int s = 0; s < NMS_SLOTS; ++s) removed[s] |= v[u][s];
         }
     }
     if (lane == 0) *n_keep = total;
