@@ -75,6 +75,13 @@ SIGNATURES = {
     "frcnn_conv2d_fwd_bf16": (I, [P, P, P, P, P, P, P, I, P]),
     "frcnn_conv2d_workspace_bytes_bf16": (c_size_t, [P]),
     "frcnn_conv2d_fwd_bf16_ws": (I, [P, P, P, P, P, P, P, I, P, c_size_t, P]),
+    "frcnn_conv2d_fwd_bf16_masked": (I, [P, P, P, P, P, P, P, P, I, P, c_size_t, P]),
+    "frcnn_refresh_packed_bf16": (I, [P, I, P]),
+    "frcnn_conv2d_wgrad_bf16": (I, [P, P, P, P, P, P, P, c_size_t, P]),
+    "frcnn_cast_bf16_to_f32": (I, [P, c_size_t, P, P]),
+    "frcnn_relu_bwd_inplace_bf16": (I, [P, P, c_size_t, P]),
+    "frcnn_avgpool_bwd_masked_bf16": (I, [P, P, I, I, I, P, P]),
+    "frcnn_roi_crop_resize_bwd_bf16": (I, [P, I, I, I, P, I, I, P, P]),
     "frcnn_cast_f32_to_bf16": (I, [P, c_size_t, P, P]),
     "frcnn_avgpool_bf16_to_f32": (I, [P, I, I, I, P, P]),
     "frcnn_avgpool_bf16_to_f32_ex": (I, [P, I, I, I, I, P, P]),
@@ -100,7 +107,7 @@ class PackJob(ctypes.Structure):
 
 class ColsumJob(ctypes.Structure):
     """frcnn_colsum_job (include/frcnn_hip.h)."""
-    _fields_ = [(k, c_void_p) for k in ("g", "scale", "out")] + [(k, ctypes.c_int32) for k in ("m", "cout")]
+    _fields_ = [(k, c_void_p) for k in ("g", "scale", "out")] + [(k, ctypes.c_int32) for k in ("m", "cout", "g_is_bf16", "reserved")]
 
 
 _lib = None

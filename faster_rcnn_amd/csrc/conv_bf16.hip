@@ -24,6 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgsBf16 {
     const __bf16* x; const __bf16* w; const float* scale; const float* shift; const __bf16* residual; void* y;
+    const __bf16* mask;     // optional [M][Cout]: output zeroed where mask <= 0 (ReLU backward fused into the input-gradient conv)
     int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
     int M, Kpad, act, out_f32;
     int tiles_m, tiles_n;
@@ -282,6 +283,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                 if (m < p.M) {
                     float v = acc[i][j][e] * sc + sh;
                     if (p.residual) v += (float)p.residual[(size_t)m * p.Cout + n];
+                    if (p.mask && !((float)p.mask[(size_t)m * p.Cout + n] > 0.0f)) v = 0.0f;
                     v = activate_b(v, p.act);
                     if (p.out_f32) reinterpret_cast<float*>(p.y)[(size_t)m * p.Cout + n] = v;
                     else reinterpret_cast<__bf16*>(p.y)[(size_t)m * p.Cout + n] = (__bf16)v;
@@ -298,6 +300,72 @@ __global__ void k_pack_hwio_bf16(const float* w, int RS, int Cin, int Cout, int 
         const int k = (int)(i % Kpad), n = (int)(i / Kpad);
         const int j = k % BKH, kc = k / BKH, tap = kc % RS, cc = kc / RS;
         out[i] = (__bf16)w[((size_t)tap * Cin + cc * BKH + j) * Cout + n];
+    }
+}
+
+// Post-optimiser-step refresh of the bf16 device forms of MANY trainable layers in one launch (the bf16 twin of
+// conv_igemm.hip's k_refresh_packed): forward pack, input-gradient pack (transposed, flipped, scale folded) and the
+// folded epilogue shift.  packed / packed_dgrad of frcnn_pack_job point at bf16 storage here.
+constexpr int REFRESH_JOBS_B = 32;
+struct RefreshTableB { frcnn_pack_job job[REFRESH_JOBS_B]; };
+__global__ void __launch_bounds__(256) k_refresh_packed_bf16(const RefreshTableB t) {
+    const frcnn_pack_job& j = t.job[blockIdx.y];
+    const int RS = j.kh * j.kw;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j.packed) {
+        // 64 x 64 (channel x cout) tiles through LDS: cout-contiguous reads, channel-contiguous 128-B writes
+        __shared__ float tile[BKH][65];
+        __bf16* out = reinterpret_cast<__bf16*>(j.packed);
+        const int Kpad = RS * j.cin, nblk = (j.cout + 63) / 64, ntiles = RS * (j.cin / BKH) * nblk;
+        const int lane = threadIdx.x & 63, jr = threadIdx.x >> 6;
+        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+            const int nb = tl % nblk, kc = tl / nblk, tap = kc % RS, cc = kc / RS, n0 = nb * 64;
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) {
+                const int c = jr + 4 * pp;
+                tile[c][lane] = n0 + lane < j.cout ? j.w_hwio[((size_t)tap * j.cin + cc * BKH + c) * j.cout + n0 + lane] : 0.0f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp) {                 // thread -> (row n = jr + 4 pp, channel = lane)
+                const int n = jr + 4 * pp;
+                if (n0 + n < j.cout) out[(size_t)(n0 + n) * Kpad + kc * BKH + lane] = (__bf16)tile[lane][n];
+            }
+            __syncthreads();
+        }
+    }
+    if (j.packed_dgrad) {
+        __bf16* out = reinterpret_cast<__bf16*>(j.packed_dgrad);
+        const int Kpad = RS * j.cout;                          // rows = cin, k over (cout chunk of 64, tap', cout % 64)
+        const size_t total = (size_t)j.cin * Kpad;
+        for (size_t i = first; i < total; i += stride) {
+            const int k = (int)(i % Kpad), ci = (int)(i / Kpad);
+            const int jj = k % BKH, kc = k / BKH, tap = kc % RS, co = (kc / RS) * BKH + jj;
+            const int r = j.kh - 1 - tap / j.kw, sx = j.kw - 1 - tap % j.kw;
+            out[i] = (__bf16)(j.w_hwio[((size_t)(r * j.kw + sx) * j.cin + ci) * j.cout + co] * (j.scale ? j.scale[co] : 1.0f));
+        }
+    }
+    if (j.shift)
+        for (size_t i = first; i < (size_t)j.cout; i += stride)
+            j.shift[i] = (j.bias ? j.bias[i] : 0.0f) * (j.scale ? j.scale[i] : 1.0f) + (j.shift_const ? j.shift_const[i] : 0.0f);
+}
+
+__global__ void k_cast_bf16_f32(const __bf16* x, size_t n, float* y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+
+// ReLU backward on bf16 tensors: g *= (y > 0)
+__global__ void k_relu_bwd_bf16(__bf16* g, const __bf16* y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (!((float)y[i] > 0.0f)) g[i] = (__bf16)0.0f;
+}
+
+// AveragePooling2D(k x k -> 1) backward fused with the ReLU in front of it: gx[n][q][c] = (y[n][q][c] > 0) * g[n][c] / hw
+__global__ void k_avgpool_bwd_masked_bf16(const float* g_pooled, const __bf16* y, int hw, int C, size_t total, float inv, __bf16* gx) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t img = i / ((size_t)hw * C);
+        gx[i] = (float)y[i] > 0.0f ? (__bf16)(g_pooled[img * C + c] * inv) : (__bf16)0.0f;
     }
 }
 
@@ -449,13 +517,19 @@ size_t frcnn_conv2d_workspace_bytes_bf16(const frcnn_conv_desc* d) {
 int frcnn_conv2d_fwd_bf16_ws(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
                              const float* scale, const float* shift, const void* residual_bf16, void* y, int y_is_f32,
                              void* workspace, size_t workspace_bytes, void* stream) {
+    return frcnn_conv2d_fwd_bf16_masked(d, x_bf16, w_packed_bf16, scale, shift, residual_bf16, nullptr, y, y_is_f32, workspace, workspace_bytes, stream);
+}
+
+int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
+                                 const float* scale, const float* shift, const void* residual_bf16, const void* mask_bf16,
+                                 void* y, int y_is_f32, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !x_bf16 || !w_packed_bf16 || !y) return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: null pointer");
     if (d->cin % BKH) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_bf16: cin must be a multiple of 64");
     if ((size_t)d->n * d->h * d->w * d->cin * 2 >= 0x7fffffffull || (size_t)d->cout * d->kh * d->kw * d->cin * 2 >= 0x7fffffffull)
         return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_bf16: tensor exceeds the 2 GiB buffer-descriptor range");
     ConvArgsBf16 a;
     a.x = (const __bf16*)x_bf16; a.w = (const __bf16*)w_packed_bf16; a.scale = scale; a.shift = shift;
-    a.residual = (const __bf16*)residual_bf16; a.y = y;
+    a.residual = (const __bf16*)residual_bf16; a.y = y; a.mask = (const __bf16*)mask_bf16;
     a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
     a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
     a.M = d->n * d->ho * d->wo; a.Kpad = d->kh * d->kw * d->cin; a.act = d->act; a.out_f32 = y_is_f32;
@@ -495,6 +569,46 @@ int frcnn_conv2d_fwd_bf16_ws(const frcnn_conv_desc* d, const void* x_bf16, const
         case 44: return launch_bf16<1, 1, 4, 4>(a, s);           // 128x128, 16 waves
         default: return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: unknown tile config %d", cfg);
     }
+}
+
+int frcnn_refresh_packed_bf16(const frcnn_pack_job* jobs, int n_jobs, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(FRCNN_E_ARG, "refresh_packed_bf16: bad argument");
+    for (int i = 0; i < n_jobs; ++i) {
+        const frcnn_pack_job& j = jobs[i];
+        if (!j.w_hwio || j.kh <= 0 || j.kw <= 0 || j.cin <= 0 || j.cout <= 0) return fail(FRCNN_E_ARG, "refresh_packed_bf16: job %d is malformed", i);
+        if (j.packed && (j.cin % BKH)) return fail(FRCNN_E_UNSUPPORTED, "refresh_packed_bf16: job %d: cin must be a multiple of 64", i);
+        if (j.packed_dgrad && (j.cout % BKH)) return fail(FRCNN_E_UNSUPPORTED, "refresh_packed_bf16: job %d: cout must be a multiple of 64 for the input-gradient form", i);
+    }
+    for (int b = 0; b < n_jobs; b += REFRESH_JOBS_B) {
+        RefreshTableB t;
+        const int n = n_jobs - b < REFRESH_JOBS_B ? n_jobs - b : REFRESH_JOBS_B;
+        for (int i = 0; i < n; ++i) t.job[i] = jobs[b + i];
+        for (int i = n; i < REFRESH_JOBS_B; ++i) t.job[i] = jobs[b];
+        k_refresh_packed_bf16<<<dim3(96, n), 256, 0, as_stream(stream)>>>(t);
+        if (int e = check_launch("refresh_packed_bf16")) return e;
+    }
+    return FRCNN_OK;
+}
+
+int frcnn_cast_bf16_to_f32(const void* x_bf16, size_t n, float* y, void* stream) {
+    if (!x_bf16 || !y) return fail(FRCNN_E_ARG, "cast_bf16_to_f32: null pointer");
+    if (n == 0) return FRCNN_OK;
+    k_cast_bf16_f32<<<ew_grid_b(n), 256, 0, as_stream(stream)>>>((const __bf16*)x_bf16, n, y);
+    return check_launch("cast_bf16_to_f32");
+}
+
+int frcnn_relu_bwd_inplace_bf16(void* g_bf16, const void* y_bf16, size_t n, void* stream) {
+    if (!g_bf16 || !y_bf16) return fail(FRCNN_E_ARG, "relu_bwd_inplace_bf16: null pointer");
+    if (n == 0) return FRCNN_OK;
+    k_relu_bwd_bf16<<<ew_grid_b(n), 256, 0, as_stream(stream)>>>((__bf16*)g_bf16, (const __bf16*)y_bf16, n);
+    return check_launch("relu_bwd_inplace_bf16");
+}
+
+int frcnn_avgpool_bwd_masked_bf16(const float* g_pooled, const void* y_bf16, int n, int k, int c, void* gx_bf16, void* stream) {
+    if (!g_pooled || !y_bf16 || !gx_bf16 || n <= 0 || k <= 0 || c <= 0) return fail(FRCNN_E_ARG, "avgpool_bwd_masked_bf16: bad argument");
+    const size_t total = (size_t)n * k * k * c;
+    k_avgpool_bwd_masked_bf16<<<ew_grid_b(total), 256, 0, as_stream(stream)>>>(g_pooled, (const __bf16*)y_bf16, k * k, c, total, 1.0f / (float)(k * k), (__bf16*)gx_bf16);
+    return check_launch("avgpool_bwd_masked_bf16");
 }
 
 int frcnn_cast_f32_to_bf16(const float* x, size_t n, void* y_bf16, void* stream) {

@@ -610,14 +610,22 @@ __global__ void __launch_bounds__(1024) k_colsum_batch(const ColsumTable t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int co = ((int)blockIdx.x - t.first_block[ji]) * 64 + lane;
     float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-    if (co < j.cout) {
-        const float* g = j.g + co;
+    if (co < j.cout && !j.g_is_bf16) {
+        const float* g = reinterpret_cast<const float*>(j.g) + co;
         int m = wave;
         for (; m + 48 < j.m; m += 64) {
             v0 += g[(size_t)m * j.cout]; v1 += g[(size_t)(m + 16) * j.cout];
             v2 += g[(size_t)(m + 32) * j.cout]; v3 += g[(size_t)(m + 48) * j.cout];
         }
         for (; m < j.m; m += 16) v0 += g[(size_t)m * j.cout];
+    } else if (co < j.cout) {
+        const __bf16* g = reinterpret_cast<const __bf16*>(j.g) + co;
+        int m = wave;
+        for (; m + 48 < j.m; m += 64) {
+            v0 += (float)g[(size_t)m * j.cout]; v1 += (float)g[(size_t)(m + 16) * j.cout];
+            v2 += (float)g[(size_t)(m + 32) * j.cout]; v3 += (float)g[(size_t)(m + 48) * j.cout];
+        }
+        for (; m < j.m; m += 16) v0 += (float)g[(size_t)m * j.cout];
     }
     part[wave][lane] = (v0 + v1) + (v2 + v3);
     __syncthreads();
@@ -638,7 +646,7 @@ __global__ void __launch_bounds__(1024) k_colsum_batch(const ColsumTable t) {
 // one filter tap; grid.z splits the pixel range, each slice writes its own partial slab and a
 // second kernel reduces the slabs in a fixed order (bitwise reproducible; no float atomics).
 struct WgradArgs {
-    const float* x; const float* g; float* partial;
+    const void* x; const void* g; float* partial;            // x / g: f32, or bf16 for the IN_BF16 instantiation
     int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo, M;
     int m_per_slice;
 };
@@ -646,6 +654,17 @@ struct WgradArgs {
 constexpr int WG_MC = 32;                 // pixels per staged chunk
 constexpr int WG_LD = 64 + 4;             // LDS row stride in floats (272 B keeps 16-B alignment for the b128 stores)
 
+// IN_BF16: activations and gradients arrive in bf16 (mixed-precision training); they are widened while being
+// staged, the products accumulate in f32 on the same f32-input MFMA, dW leaves in f32 for the master weights.
+__device__ __forceinline__ f32x4 load4_bf16(const __bf16* p) {
+    const uint2 raw = *reinterpret_cast<const uint2*>(p);                 // 4 x bf16 = 8 bytes
+    f32x4 v;
+    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    return v;
+}
+
+template <bool IN_BF16>
 __global__ void __launch_bounds__(256) k_conv_wgrad_f32(const WgradArgs p) {
     __shared__ __attribute__((aligned(16))) float Xs[2][WG_MC][WG_LD];
     __shared__ __attribute__((aligned(16))) float Gs[2][WG_MC][WG_LD];
@@ -669,13 +688,27 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_f32(const WgradArgs p) {
                 const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
                 const int hi = ho * p.stride - p.pad_top + r_tap, wi = wo * p.stride - p.pad_left + s_tap;
                 if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-                    const float* src = p.x + (((size_t)img * p.H + hi) * p.W + wi) * p.Cin + ci0 + scol;
-                    if (ci0 + scol + 3 < p.Cin) vx = *reinterpret_cast<const f32x4*>(src);
-                    else for (int e = 0; e < 4; ++e) if (ci0 + scol + e < p.Cin) vx[e] = src[e];
+                    const size_t off = (((size_t)img * p.H + hi) * p.W + wi) * p.Cin + ci0 + scol;
+                    if constexpr (IN_BF16) {
+                        const __bf16* src = reinterpret_cast<const __bf16*>(p.x) + off;
+                        if (ci0 + scol + 3 < p.Cin) vx = load4_bf16(src);
+                        else for (int e = 0; e < 4; ++e) if (ci0 + scol + e < p.Cin) vx[e] = (float)src[e];
+                    } else {
+                        const float* src = reinterpret_cast<const float*>(p.x) + off;
+                        if (ci0 + scol + 3 < p.Cin) vx = *reinterpret_cast<const f32x4*>(src);
+                        else for (int e = 0; e < 4; ++e) if (ci0 + scol + e < p.Cin) vx[e] = src[e];
+                    }
                 }
-                const float* gs = p.g + (size_t)m * p.Cout + co0 + scol;
-                if (co0 + scol + 3 < p.Cout && (p.Cout & 3) == 0) vg = *reinterpret_cast<const f32x4*>(gs);
-                else for (int e = 0; e < 4; ++e) if (co0 + scol + e < p.Cout) vg[e] = gs[e];
+                const size_t goff = (size_t)m * p.Cout + co0 + scol;
+                if constexpr (IN_BF16) {
+                    const __bf16* gs = reinterpret_cast<const __bf16*>(p.g) + goff;
+                    if (co0 + scol + 3 < p.Cout && (p.Cout & 3) == 0) vg = load4_bf16(gs);
+                    else for (int e = 0; e < 4; ++e) if (co0 + scol + e < p.Cout) vg[e] = (float)gs[e];
+                } else {
+                    const float* gs = reinterpret_cast<const float*>(p.g) + goff;
+                    if (co0 + scol + 3 < p.Cout && (p.Cout & 3) == 0) vg = *reinterpret_cast<const f32x4*>(gs);
+                    else for (int e = 0; e < 4; ++e) if (co0 + scol + e < p.Cout) vg[e] = gs[e];
+                }
             }
             rx[q] = vx; rg[q] = vg;
         }
@@ -1036,10 +1069,24 @@ size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d) {
     return align_up(dw > db ? dw : db, 256);
 }
 
+static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bool in_bf16, const float* scale,
+                      float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
 int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g, const float* scale,
                        float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_impl(d, x, g, false, scale, dw_hwio, dbias, workspace, workspace_bytes, stream);
+}
+
+int frcnn_conv2d_wgrad_bf16(const frcnn_conv_desc* d, const void* x_bf16, const void* g_bf16, const float* scale,
+                            float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_impl(d, x_bf16, g_bf16, true, scale, dw_hwio, dbias, workspace, workspace_bytes, stream);
+}
+
+static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bool in_bf16, const float* scale,
+                      float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !x || !g || !dw_hwio) return fail(FRCNN_E_ARG, "conv2d_wgrad: null pointer");
     if ((d->cin & 3) && d->cin >= 4) return fail(FRCNN_E_UNSUPPORTED, "conv2d_wgrad: cin must be a multiple of 4 (or < 4)");
+    if (in_bf16 && ((d->cin & 3) || (d->cout & 3))) return fail(FRCNN_E_UNSUPPORTED, "conv2d_wgrad_bf16: cin and cout must be multiples of 4");
     if (!workspace || workspace_bytes < frcnn_conv2d_wgrad_workspace_bytes(d))
         return fail(FRCNN_E_WORKSPACE, "conv2d_wgrad: workspace needs %zu bytes", frcnn_conv2d_wgrad_workspace_bytes(d));
     WgradArgs a;
@@ -1051,19 +1098,25 @@ int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g,
     a.m_per_slice = ((a.M + slices - 1) / slices + WG_MC - 1) / WG_MC * WG_MC;
     hipStream_t s = as_stream(stream);
     dim3 grid(d->kh * d->kw * ((d->cin + 63) / 64), (d->cout + 63) / 64, slices);
-    k_conv_wgrad_f32<<<grid, 256, 0, s>>>(a);
+    if (in_bf16) k_conv_wgrad_f32<true><<<grid, 256, 0, s>>>(a);
+    else k_conv_wgrad_f32<false><<<grid, 256, 0, s>>>(a);
     if (int e = check_launch("conv2d_wgrad")) return e;
     const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;
     int rgrid = (int)((elems + 255) / 256);
     if (rgrid > 4096) rgrid = 4096;
     k_wgrad_reduce<<<rgrid, 256, 0, s>>>((const float*)workspace, slices, elems, d->cout, scale, dw_hwio);
     if (int e = check_launch("conv2d_wgrad reduce")) return e;
+    if (dbias && in_bf16) {
+        frcnn_colsum_job job;
+        job.g = g; job.scale = scale; job.out = dbias; job.m = a.M; job.cout = d->cout; job.g_is_bf16 = 1; job.reserved = 0;
+        return frcnn_colsum_batch(&job, 1, stream);
+    }
     if (dbias) {                                   // the slab workspace is free again after the reduce (stream order)
         int cs = (a.M + 63) / 64;
         if (cs > COLSUM_SLICES) cs = COLSUM_SLICES;
         if (cs < 1) cs = 1;
         const int rows_per_slice = (a.M + cs - 1) / cs;
-        k_colsum_partial<<<dim3((d->cout + 63) / 64, cs), 256, 0, s>>>(g, a.M, d->cout, rows_per_slice, (float*)workspace);
+        k_colsum_partial<<<dim3((d->cout + 63) / 64, cs), 256, 0, s>>>((const float*)g, a.M, d->cout, rows_per_slice, (float*)workspace);
         if (int e = check_launch("conv2d_wgrad bias")) return e;
         k_colsum_final<<<(d->cout + 255) / 256, 256, 0, s>>>((const float*)workspace, cs, d->cout, scale, dbias);
         if (int e = check_launch("conv2d_wgrad bias")) return e;

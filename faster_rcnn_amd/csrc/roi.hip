@@ -90,6 +90,28 @@ __global__ void __launch_bounds__(256) k_roi_bwd(const float* dout, int rows, in
     }
 }
 
+// gradient w.r.t. the f32 feature map from a bf16 crop gradient (mixed-precision training): f32 atomics as above
+__global__ void __launch_bounds__(256) k_roi_bwd_bf16(const __bf16* dout, int rows, int cols, int C,
+                                                      const float4* rois, int pool, float* dfeat) {
+    const int pix = blockIdx.x;
+    const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
+    if (!t.ok) return;
+    const __bf16* g = dout + (size_t)pix * C;
+    float* tl = dfeat + ((size_t)t.y_lo * cols + t.x_lo) * C;
+    float* tr = dfeat + ((size_t)t.y_lo * cols + t.x_hi) * C;
+    float* bl = dfeat + ((size_t)t.y_hi * cols + t.x_lo) * C;
+    float* br = dfeat + ((size_t)t.y_hi * cols + t.x_hi) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float gv = (float)g[c];
+        const float dtop = (1.0f - t.ty) * gv, dbot = t.ty * gv;
+        atomicAdd(tl + c, dtop * (1.0f - t.tx));
+        atomicAdd(tr + c, dtop * t.tx);
+        atomicAdd(bl + c, dbot * (1.0f - t.tx));
+        atomicAdd(br + c, dbot * t.tx);
+    }
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -118,6 +140,15 @@ int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C, cons
     if (!dout || !rois || !dfeat) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd: null pointer");
     k_roi_bwd<<<n * pool * pool, 256, 0, as_stream(stream)>>>(dout, rows, cols, C, (const float4*)rois, pool, dfeat);
     return check_launch("roi_crop_resize_bwd");
+}
+
+int frcnn_roi_crop_resize_bwd_bf16(const void* dout_bf16, int rows, int cols, int C, const float* rois, int n, int pool,
+                                   float* dfeat, void* stream) {
+    if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd_bf16: bad shape");
+    if (n == 0) return FRCNN_OK;
+    if (!dout_bf16 || !rois || !dfeat) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd_bf16: null pointer");
+    k_roi_bwd_bf16<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const __bf16*)dout_bf16, rows, cols, C, (const float4*)rois, pool, dfeat);
+    return check_launch("roi_crop_resize_bwd_bf16");
 }
 
 }  // extern "C"

@@ -465,6 +465,76 @@ class PackedConvBf16:
         self.shift = None if shift is None else _dev(shift, torch.float32)
 
 
+class PackedDgradBf16:
+    """bf16 filter of the input-gradient convolution of a stride-1 layer (PackedDgrad's bf16 twin; cout % 64 == 0).
+    Filled by frcnn_refresh_packed_bf16."""
+
+    def __init__(self, w_hwio, scale=None):
+        _require_gpu()
+        w = _dev(w_hwio, torch.float32)
+        self.kh, self.kw, cin, cout = (int(v) for v in w.shape)
+        self.cin, self.cout = cout, cin                      # geometry of the dgrad convolution
+        self.w = torch.empty((cin, self.kh * self.kw * cout), dtype=torch.bfloat16, device="cuda")
+        self.scale = self.shift = None
+        sc = None if scale is None else _dev(scale, torch.float32)
+        job = _lib.PackJob(w_hwio=w.data_ptr(), packed=None, packed_dgrad=self.w.data_ptr(), bias=None,
+                           scale=None if sc is None else sc.data_ptr(), shift_const=None, shift=None,
+                           kh=self.kh, kw=self.kw, cin=cin, cout=cout)
+        _lib.call("frcnn_refresh_packed_bf16", ctypes.byref(job), 1, _stream())
+        torch.cuda.current_stream().synchronize()            # w / sc may be temporaries
+
+
+def conv2d_dgrad_bf16(gy, pd, padding="valid", residual=None, mask=None):
+    """bf16 twin of conv2d_dgrad: gy (n,ho,wo,cout_fwd) bf16 -> gradient w.r.t. the layer input, bf16."""
+    _require_gpu()
+    assert gy.dtype == torch.bfloat16
+    n, ho, wo, _ = gy.shape
+    pt = (pd.kh - 1) // 2 if padding == "same" else 0
+    pl = (pd.kw - 1) // 2 if padding == "same" else 0
+    assert padding == "same" or (pd.kh == 1 and pd.kw == 1), "dgrad supports 1x1 valid and odd 'same' kernels"
+    out = torch.empty((n, ho, wo, pd.cout), dtype=torch.bfloat16, device="cuda")
+    d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=pd.cin, cout=pd.cout, kh=pd.kh, kw=pd.kw, stride=1, pad_top=pt, pad_left=pl,
+                      ho=ho, wo=wo, act=0, ldy=0, ldres=0, tile=AUTO_TILE)
+    ws = _split_k_ws(_lib.load().frcnn_conv2d_workspace_bytes_bf16(ctypes.byref(d)))
+    _lib.call("frcnn_conv2d_fwd_bf16_masked", ctypes.byref(d), _p(gy.contiguous()), _p(pd.w), None, None, _p(residual), _p(mask), _p(out), 0,
+              _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return out
+
+
+def conv2d_wgrad_bf16(x, g, kh, kw, stride=1, padding="valid", scale=None, dw=None, dbias=None, want_bias=True):
+    """bf16 activations x (n,h,w,cin) and gradients g (n,ho,wo,cout) -> f32 (dw (kh,kw,cin,cout), dbias or None)."""
+    _require_gpu()
+    assert x.dtype == torch.bfloat16 and g.dtype == torch.bfloat16
+    cout = g.shape[-1]
+    d = _conv_desc(tuple(x.shape), kh, kw, cout, stride, padding)
+    assert (d.ho, d.wo) == (g.shape[1], g.shape[2])
+    if dw is None:
+        dw = torch.empty((kh, kw, x.shape[-1], cout), dtype=torch.float32, device="cuda")
+    if dbias is None and want_bias:
+        dbias = torch.empty(cout, dtype=torch.float32, device="cuda")
+    ws = _ws(_lib.load().frcnn_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+    _lib.call("frcnn_conv2d_wgrad_bf16", ctypes.byref(d), _p(x.contiguous()), _p(g.contiguous()), _p(scale), _p(dw), _p(dbias if want_bias else None),
+              _p(ws), ws.numel(), _stream())
+    return dw, (dbias if want_bias else None)
+
+
+def cast_f32(x):
+    """bf16 device tensor -> f32."""
+    _require_gpu()
+    assert x.dtype == torch.bfloat16
+    out = torch.empty(x.shape, dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_cast_bf16_to_f32", _p(x.contiguous()), x.numel(), _p(out), _stream())
+    return out
+
+
+def roi_crop_resize_bwd_bf16(dout, rois, rows, cols):
+    _require_gpu()
+    n, pool, _, C = dout.shape
+    dfeat = torch.zeros((rows, cols, C), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_roi_crop_resize_bwd_bf16", _p(dout.contiguous()), rows, cols, C, _p(rois.reshape(-1, 4).contiguous()), n, pool, _p(dfeat), _stream())
+    return dfeat
+
+
 def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f32=False, tile=0, layout=0):
     """x: (n,h,w,cin) bf16 NHWC -> (n,ho,wo,cout) bf16 (or f32 when out_f32); layout=1: (h,w,n,cin) -> (ho,wo,n,cout)."""
     _require_gpu()

@@ -233,10 +233,12 @@ int frcnn_refresh_packed(const frcnn_pack_job* jobs, int n_jobs, void* stream);
 /* Bias gradients of many layers in one launch: out[co] = scale[co] * sum_m g[m][co] (g [m][cout],
  * scale may be NULL).  `jobs` is a HOST array.  Fixed summation order (reproducible). */
 typedef struct frcnn_colsum_job {
-    const float* g;
+    const void* g;                 /* f32, or bf16 when g_is_bf16 != 0 */
     const float* scale;
     float* out;
     int32_t m, cout;
+    int32_t g_is_bf16;
+    int32_t reserved;
 } frcnn_colsum_job;
 int frcnn_colsum_batch(const frcnn_colsum_job* jobs, int n_jobs, void* stream);
 /* Weight / bias gradient of the convolution described by d (forward geometry):
@@ -321,6 +323,27 @@ size_t frcnn_conv2d_workspace_bytes_bf16(const frcnn_conv_desc* d);
 int frcnn_conv2d_fwd_bf16_ws(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
                              const float* scale, const float* shift, const void* residual_bf16, void* y, int y_is_f32,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* Same with a mask [M][cout] (bf16): outputs are zeroed where mask <= 0.  The input-gradient pass of a
+ * stride-1 bf16 layer, exactly as frcnn_conv2d_fwd_masked is for f32 (mixed-precision training, BASELINE
+ * configs[4]): x := bf16 gradient, w := frcnn_refresh_packed_bf16's packed_dgrad, residual := gradient arriving
+ * over the identity shortcut, mask := the forward activation in front of the layer. */
+int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, const void* w_packed_bf16,
+                                 const float* scale, const float* shift, const void* residual_bf16, const void* mask_bf16,
+                                 void* y, int y_is_f32, void* workspace, size_t workspace_bytes, void* stream);
+/* frcnn_refresh_packed for layers that run in bf16: `packed` / `packed_dgrad` of each job point at bf16
+ * storage ([cout][kh*kw*cin] and [cin][kh*kw*cout], 64-channel k-chunks); masters, bias, scale and the
+ * folded shift stay f32.  cin (and cout, when packed_dgrad is set) must be multiples of 64. */
+int frcnn_refresh_packed_bf16(const frcnn_pack_job* jobs, int n_jobs, void* stream);
+/* Weight gradient from bf16 activations / gradients: as frcnn_conv2d_wgrad with x and g in bf16; the
+ * products are accumulated in f32 and dw / dbias are f32 (they feed the f32 master weights). */
+int frcnn_conv2d_wgrad_bf16(const frcnn_conv_desc* d, const void* x_bf16, const void* g_bf16, const float* scale,
+                            float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+/* small bf16 pieces of the backward pass */
+int frcnn_cast_bf16_to_f32(const void* x_bf16, size_t n, float* y, void* stream);
+int frcnn_relu_bwd_inplace_bf16(void* g_bf16, const void* y_bf16, size_t n, void* stream);
+int frcnn_avgpool_bwd_masked_bf16(const float* g_pooled, const void* y_bf16, int n, int k, int c, void* gx_bf16, void* stream);
+int frcnn_roi_crop_resize_bwd_bf16(const void* dout_bf16, int rows, int cols, int c, const float* rois, int n, int pool,
+                                   float* dfeat, void* stream);
 int frcnn_cast_f32_to_bf16(const float* x, size_t n, void* y_bf16, void* stream);
 /* AveragePooling2D(k) of a k x k bf16 map -> f32 [n][c] (resnet.py:515). */
 int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y, void* stream);

@@ -76,3 +76,73 @@ def test_resnet101_bf16_network():
     out_cls, out_reg = det.forward_dev(fmap, torch.from_numpy(rois).cuda())
     k64, g64 = ref.resnet_classifier(f64.float(), rois, C, 101)
     assert ok(out_cls.cpu().numpy(), k64) and ok(out_reg.cpu().numpy(), g64), (err(out_cls.cpu().numpy(), k64), err(out_reg.cpu().numpy(), g64))
+
+
+# ----------------------------------------------------------------------------- mixed-precision training pieces
+def _bf(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("case", [(1, 13, 17, 64, 128, 3, "same"), (2, 7, 7, 128, 256, 3, "same"), (1, 19, 23, 256, 64, 1, "valid"),
+                                  (1, 38, 63, 1024, 256, 1, "valid")])
+def test_bf16_backward_kernels(case):
+    """Input gradient (bf16 MFMA conv on the transposed, flipped, scale-folded filter with fused ReLU mask and
+    shortcut gradient) and weight / bias gradient (bf16 in, f32 out) against torch autograd in f64 on the SAME
+    bf16-rounded tensors: only the f32 accumulation and the bf16 output rounding separate the two."""
+    import torch.nn.functional as F
+    from faster_rcnn_amd import ops
+    from oracle import keras_ref
+    n, h, w, cin, cout, k, padding = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = _bf(rs.randn(n, h, w, cin))
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(cout)).astype(np.float32)
+    g = _bf(rs.randn(n, h, w, cout))
+    res = _bf(rs.randn(n, h, w, cin))
+    mask = _bf(rs.randn(n, h, w, cin))
+    xt = x.double().requires_grad_(True)
+    wtt = torch.from_numpy(wt).double().requires_grad_(True)
+    y = keras_ref.conv2d(xt, wtt, None, 1, padding, dtype=torch.float64) * torch.from_numpy(scale).double()
+    y.backward(g.double())
+    # weight / bias gradient
+    dw, db = ops.conv2d_wgrad_bf16(x.cuda(), g.cuda(), k, k, 1, padding, scale=torch.from_numpy(scale).cuda())
+    assert dw.dtype == torch.float32
+    assert ((dw.cpu().double() - wtt.grad).abs().max() / wtt.grad.abs().max()).item() < 1e-4
+    want_db = g.double().sum((0, 1, 2)) * torch.from_numpy(scale).double()
+    assert ((db.cpu().double() - want_db).abs().max() / want_db.abs().max()).item() < 1e-4
+    # input gradient: the packed filter is bf16(w * scale), so compare against THAT filter's exact gradient
+    pd = ops.PackedDgradBf16(wt, scale)
+    wq = _bf(wt * scale).double()                           # bf16(w[ci][co] * scale[co]), what the pack stores
+    xt2 = x.double().requires_grad_(True)
+    keras_ref.conv2d(xt2, wq, None, 1, padding, dtype=torch.float64).backward(g.double())
+    want = (xt2.grad + res.double()) * (mask.double() > 0)
+    got = ops.conv2d_dgrad_bf16(g.cuda(), pd, padding, residual=res.cuda(), mask=mask.cuda())
+    assert got.dtype == torch.bfloat16
+    err = ((got.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
+    assert err < 1e-2, err                                  # one bf16 rounding of the output
+
+
+def test_refresh_packed_bf16_matches_single_pack():
+    import ctypes
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(9)
+    keep, jobs = [], []
+    for kh, kw, cin, cout in [(3, 3, 64, 128), (1, 1, 256, 64), (3, 3, 128, 192), (1, 1, 1024, 256)] * 9:      # 36 jobs: two launches
+        w = torch.from_numpy(rs.randn(kh, kw, cin, cout).astype(np.float32)).cuda()
+        bias, scale, const = (torch.from_numpy(rs.randn(cout).astype(np.float32)).cuda() for _ in range(3))
+        packed = torch.zeros((cout, kh * kw * cin), dtype=torch.bfloat16, device="cuda")
+        pdg = torch.zeros((cin, kh * kw * cout), dtype=torch.bfloat16, device="cuda")
+        shift = torch.zeros(cout, device="cuda")
+        keep.append((w, bias, scale, const, packed, pdg, shift))
+        jobs.append(_lib.PackJob(w_hwio=w.data_ptr(), packed=packed.data_ptr(), packed_dgrad=pdg.data_ptr(), bias=bias.data_ptr(),
+                                 scale=scale.data_ptr(), shift_const=const.data_ptr(), shift=shift.data_ptr(), kh=kh, kw=kw, cin=cin, cout=cout))
+    arr = (_lib.PackJob * len(jobs))(*jobs)
+    _lib.call("frcnn_refresh_packed_bf16", arr, len(jobs), ops._stream())
+    for w, bias, scale, const, packed, pdg, shift in keep:
+        kh, kw, cin, cout = w.shape
+        assert torch.equal(packed, ops.PackedConvBf16(w, scale, None).w)
+        # dgrad form: rows = cin, k = ((co // 64) * RS + tap') * 64 + co % 64, value bf16(w[flip(tap')][ci][co] * scale[co])
+        ws = (w * scale).flip(0, 1)                                         # [r'][s'][ci][co]
+        ref = ws.permute(2, 0, 1, 3).reshape(cin, kh * kw, cout // 64, 64).permute(0, 2, 1, 3).reshape(cin, -1).to(torch.bfloat16)
+        assert torch.equal(pdg, ref)
+        assert torch.allclose(shift, bias * scale + const, rtol=1e-6, atol=1e-6)
