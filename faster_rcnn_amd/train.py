@@ -91,13 +91,17 @@ class TConv:
     def __init__(self, unit, params=None, needs_dgrad=False):
         self.u, self.params, self.needs_dgrad = unit, params, needs_dgrad
         self.trainable = params is not None and unit.conv in params.views
+        # mixed precision (BASELINE configs[4]): a unit built with dtype "bf16" keeps bf16 activations and gradients and
+        # bf16 packed filters; its master weights, weight gradients, BatchNorm fold and optimiser state stay f32
+        self.bf16 = getattr(unit, "dtype", "f32") == "bf16"
         self.x = self.y = None
         if not self.trainable:
             if unit.pc is None:
                 unit.lower()
             self.pc = unit.pc
             if needs_dgrad:
-                self.pd = ops.PackedDgrad(self._kernel4d(np.asarray(unit.weights[unit.conv][0], dtype=np.float32)), self.pc.scale)
+                k4 = self._kernel4d(np.asarray(unit.weights[unit.conv][0], dtype=np.float32))
+                self.pd = (ops.PackedDgradBf16 if self.bf16 else ops.PackedDgrad)(k4, self.pc.scale)
             return
         # frozen BatchNorm / Scale -> constant epilogue scale and shift offset (nets.ConvUnit.lower)
         w = unit.weights
@@ -120,16 +124,22 @@ class TConv:
         k4 = self.wv if self.wv.dim() == 4 else self.wv.view(1, 1, *self.wv.shape)
         self.k4, self.gk4 = k4, (self.gw if self.gw.dim() == 4 else self.gw.view(1, 1, *self.gw.shape))
         self.kh, self.kw, self.cin, self.cout = (int(v) for v in k4.shape)
-        kp = _lib.load().frcnn_conv_packed_k(self.kh, self.kw, self.cin)
-        self.pc = ops.PackedConv.__new__(ops.PackedConv)
+        if self.bf16:
+            assert self.cin % 64 == 0 and (not needs_dgrad or self.cout % 64 == 0), "bf16 training layers need 64-multiple channel counts"
+            kp, kpd, wdt, cls_pc, cls_pd = self.kh * self.kw * self.cin, self.kh * self.kw * self.cout, torch.bfloat16, ops.PackedConvBf16, ops.PackedDgradBf16
+        else:
+            kp = _lib.load().frcnn_conv_packed_k(self.kh, self.kw, self.cin)
+            kpd = _lib.load().frcnn_conv_packed_k(self.kh, self.kw, self.cout)
+            wdt, cls_pc, cls_pd = torch.float32, ops.PackedConv, ops.PackedDgrad
+        self.pc = cls_pc.__new__(cls_pc)
         self.pc.kh, self.pc.kw, self.pc.cin, self.pc.cout = self.kh, self.kw, self.cin, self.cout
-        self.pc.w = torch.empty((self.cout, kp), dtype=torch.float32, device="cuda")
+        self.pc.w = torch.empty((self.cout, kp), dtype=wdt, device="cuda")
         self.pc.scale = self.scale
         self.pc.shift = torch.empty(self.cout, dtype=torch.float32, device="cuda")
         if needs_dgrad:
-            self.pd = ops.PackedDgrad.__new__(ops.PackedDgrad)
+            self.pd = cls_pd.__new__(cls_pd)
             self.pd.kh, self.pd.kw, self.pd.cin, self.pd.cout = self.kh, self.kw, self.cout, self.cin
-            self.pd.w = torch.empty((self.cin, _lib.load().frcnn_conv_packed_k(self.kh, self.kw, self.cout)), dtype=torch.float32, device="cuda")
+            self.pd.w = torch.empty((self.cin, kpd), dtype=wdt, device="cuda")
             self.pd.scale = self.pd.shift = None
         self.refresh()
 
@@ -150,18 +160,23 @@ class TConv:
 
     def forward(self, x, residual=None):
         self.x = x
-        self.y = ops.conv2d(x, self.pc, self.u.stride, self.u.padding, self.u.act, residual)
+        if self.bf16:
+            self.y = ops.conv2d_bf16(x, self.pc, self.u.stride, self.u.padding, self.u.act, residual)
+        else:
+            self.y = ops.conv2d(x, self.pc, self.u.stride, self.u.padding, self.u.act, residual)
         return self.y
 
     def wgrad(self, g):
         """g: gradient w.r.t. this layer's post-BN pre-activation output."""
         if self.trainable:
-            ops.conv2d_wgrad(self.x, g, self.kh, self.kw, self.u.stride, self.u.padding, scale=self.scale,
-                             dw=self.gk4, want_bias=False)
+            (ops.conv2d_wgrad_bf16 if self.bf16 else ops.conv2d_wgrad)(
+                self.x, g, self.kh, self.kw, self.u.stride, self.u.padding, scale=self.scale, dw=self.gk4, want_bias=False)
             if self.gb is not None:            # bias gradients of the whole step leave in ONE launch (flush_bias_grads)
                 _PENDING_BIAS.append((g if g.is_contiguous() else g.contiguous(), self.scale, self.gb))
 
     def dgrad(self, g, residual=None, mask=None):
+        if self.bf16:
+            return ops.conv2d_dgrad_bf16(g, self.pd, self.u.padding, residual=residual, mask=mask)
         return ops.conv2d_dgrad(g, self.pd, self.u.padding, residual=residual, mask=mask)
 
 
@@ -177,19 +192,25 @@ def flush_bias_grads():
         j.g, j.scale, j.out = g.data_ptr(), (None if scale is None else scale.data_ptr()), out.data_ptr()
         j.cout = g.shape[-1]
         j.m = g.numel() // g.shape[-1]
+        j.g_is_bf16 = 1 if g.dtype == torch.bfloat16 else 0
     _lib.call("frcnn_colsum_batch", jobs, len(_PENDING_BIAS), _stream())
     _PENDING_BIAS.clear()
 
 
 def make_refresh_jobs(tconvs):
-    """ctypes job table of frcnn_refresh_packed for the trainable convs (pointers are fixed for a trainer's life)."""
-    jobs = [c.pack_job() for c in tconvs if c.trainable]
-    return (_lib.PackJob * len(jobs))(*jobs)
+    """ctypes job tables (f32 layers, bf16 layers) of frcnn_refresh_packed[_bf16] for the trainable convs
+    (pointers are fixed for a trainer's life)."""
+    f32 = [c.pack_job() for c in tconvs if c.trainable and not c.bf16]
+    b16 = [c.pack_job() for c in tconvs if c.trainable and c.bf16]
+    return (_lib.PackJob * len(f32))(*f32), (_lib.PackJob * len(b16))(*b16)
 
 
 def refresh_packed(jobs):
-    if len(jobs):
-        _lib.call("frcnn_refresh_packed", jobs, len(jobs), _stream())
+    f32, b16 = jobs
+    if len(f32):
+        _lib.call("frcnn_refresh_packed", f32, len(f32), _stream())
+    if len(b16):
+        _lib.call("frcnn_refresh_packed_bf16", b16, len(b16), _stream())
 
 
 class TBlock:
@@ -254,6 +275,7 @@ class ResNetBaseTrain:
         from .weights import resnet_block_names
         net = base_model.net
         freeze = set(base_model.freeze_blocks)
+        self.bf16 = getattr(net, "dtype", "f32") == "bf16"
         self.stem, self.frozen_blocks, self.blocks = net.stem, [], []
         first = True
         for (stage, block, _), units in zip(resnet_block_names(net.depth), net.blocks):
@@ -279,6 +301,8 @@ class ResNetBaseTrain:
 
     def forward(self, x):
         t = ops.pool2d(self.stem(x), 3, 2, True)
+        if self.bf16:                                           # the 3-channel stem and its pool stay f32 (nets.ResNetBase)
+            t = ops.cast_bf16(t)
         for units in self.frozen_blocks:
             t = nets.run_block(units, t)
         for b in self.blocks:
@@ -379,9 +403,15 @@ class RpnTrainer:
         self.params = ParamSet(w, train_names)
         self.base = _make_base_train(rpn_model.base, self.params)
         self.base_trains = len(self.base.convs()) > 0
-        self.rpn_conv = TConv(rpn_model.head.conv, self.params, needs_dgrad=self.base_trains)
-        self.rpn_cls = TConv(rpn_model.head.cls, self.params, needs_dgrad=True)
-        self.rpn_reg = TConv(rpn_model.head.reg, self.params, needs_dgrad=True)
+        # mixed precision: a bf16 base hands its feature map over in f32; the RPN layers (9 / 36 output channels: no
+        # bf16 input-gradient form) train in f32
+        self.bf16 = getattr(rpn_model.base.net, "dtype", "f32") == "bf16"
+        hd = rpn_model.head
+        u_conv, u_cls, u_reg = ((nets.ConvUnit(w, "rpn_conv1", padding="same", act="relu"), nets.ConvUnit(w, "rpn_out_cls", act="sigmoid"),
+                                 nets.ConvUnit(w, "rpn_out_bbreg")) if self.bf16 else (hd.conv, hd.cls, hd.reg))
+        self.rpn_conv = TConv(u_conv, self.params, needs_dgrad=self.base_trains)
+        self.rpn_cls = TConv(u_cls, self.params, needs_dgrad=True)
+        self.rpn_reg = TConv(u_reg, self.params, needs_dgrad=True)
         # Keras sums the regulariser of every layer that was GIVEN one: the heads always (when l2 != 0), the
         # base only if it was built with regularisers (step 1 yes, step 3 no: train_rpn_step3.py:70)
         base_reg = rpn_model.base.weight_regularizer is not None if l2_base is None else bool(l2_base)
@@ -401,7 +431,8 @@ class RpnTrainer:
 
     def forward(self, x):
         self.feat = self.base.forward(x)
-        h = self.rpn_conv.forward(self.feat)
+        self.feat32 = ops.cast_f32(self.feat) if self.feat.dtype == torch.bfloat16 else self.feat
+        h = self.rpn_conv.forward(self.feat32)
         return self.rpn_cls.forward(h), self.rpn_reg.forward(h), h
 
     def train_on_batch(self, x, y, skip=False):
@@ -429,7 +460,8 @@ class RpnTrainer:
             gh = self.rpn_reg.dgrad(g_reg, residual=tmp, mask=h)
             self.rpn_conv.wgrad(gh)
             if self.base_trains:
-                self.base.backward(self.rpn_conv.dgrad(gh, mask=self.feat))
+                gfeat = self.rpn_conv.dgrad(gh, mask=self.feat32)
+                self.base.backward(ops.cast_bf16(gfeat) if self.bf16 else gfeat)
         flush_bias_grads()
         sq = p.sumsq() if self.l2 else None
         scale = _sync_grads(p)
@@ -464,13 +496,16 @@ class _ResNetHeadTrain:
         for b in self.blocks:
             c = b.forward(c)
         self.h5 = c
+        if c.dtype == torch.bfloat16:                           # pooled features and the dense layers stay f32
+            return ops.avgpool_bf16(c, 7).reshape(c.shape[0], 1, 1, c.shape[-1])
         return ops.pool2d(c, 7, 7, False)                       # (n,1,1,2048)
 
     def backward(self, g_pooled):
         """g_pooled (n,1,1,C) -> gradient w.r.t. the RoI crops (n,7,7,Cf)."""
         n = self.h5.shape[0]
         gx = torch.empty_like(self.h5)
-        _lib.call("frcnn_avgpool_bwd_masked", _p(g_pooled.contiguous()), _p(self.h5), n, 7, self.h5.shape[-1], _p(gx), _stream())
+        entry = "frcnn_avgpool_bwd_masked_bf16" if self.h5.dtype == torch.bfloat16 else "frcnn_avgpool_bwd_masked"
+        _lib.call(entry, _p(g_pooled.contiguous()), _p(self.h5), n, 7, self.h5.shape[-1], _p(gx), _stream())
         for b in reversed(self.blocks):
             gx = b.backward(gx)
         return gx
@@ -528,7 +563,8 @@ class DetTrainer:
         self.base = _make_base_train(det_model.base, self.params) if det_model.base is not None else None
         self.base_trains = self.base is not None and len(self.base.convs()) > 0
         self.head = head_cls(det_model.head, self.params)
-        self.dense = TConv(nets.ConvUnit(all_w, "dense"), self.params, needs_dgrad=True)
+        self.bf16 = getattr(det_model.head, "dtype", "f32") == "bf16"
+        self.dense = TConv(nets.ConvUnit(all_w, "dense"), self.params, needs_dgrad=True)      # f32: 101 outputs, tiny
         reg_layers = head_names + (_base_layer_names(det_model.base) if det_model.base is not None and det_model.base.weight_regularizer is not None else [])
         self.frozen_sumsq = _reg_sumsq_frozen(w, reg_layers, train_names, l2)
         self.optimizer = None
@@ -543,7 +579,9 @@ class DetTrainer:
 
     def forward(self, x, rois):
         self.feat = self.base.forward(x) if self.base is not None else x
-        crop = ops.roi_crop_resize(self.feat, rois, 7)
+        if self.bf16 and self.feat.dtype != torch.bfloat16:     # step 4: cached f32 conv features feed a bf16 head
+            self.feat = ops.cast_bf16(self.feat)
+        crop = (ops.roi_crop_resize_bf16 if self.bf16 else ops.roi_crop_resize)(self.feat, rois, 7)
         self.pooled = self.head.forward(crop)
         y = self.dense.forward(self.pooled)                    # (n,1,1,C+4(C-1))
         y2 = y.reshape(y.shape[0], -1)
@@ -570,7 +608,11 @@ class DetTrainer:
             g4 = g.reshape(n, 1, 1, C + K4)
             self.dense.wgrad(g4)
             gcrop = self.head.backward(self.dense.dgrad(g4))
-            if self.base_trains:
+            if self.base_trains and self.bf16:
+                gfeat = ops.cast_bf16(ops.roi_crop_resize_bwd_bf16(gcrop, rois, self.feat.shape[1], self.feat.shape[2]))   # f32 atomics, then bf16
+                _lib.call("frcnn_relu_bwd_inplace_bf16", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
+                self.base.backward(gfeat.reshape(self.feat.shape))
+            elif self.base_trains:
                 gfeat = ops.roi_crop_resize_bwd(gcrop, rois, self.feat.shape[1], self.feat.shape[2])
                 _lib.call("frcnn_relu_bwd_inplace", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
                 self.base.backward(gfeat.reshape(self.feat.shape))

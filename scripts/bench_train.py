@@ -12,6 +12,7 @@ rank, world = dp.init_from_env()
 if world == 1:
     torch.cuda.set_device(0)
 H, W, A, C = 600, 1000, 9, 21
+DT = "bf16" if "--bf16" in sys.argv else "f32"     # --bf16: mixed precision (bf16 activations / gradients / packed filters, f32 masters)
 rs = np.random.RandomState(rank)
 x = (rs.randint(0, 256, (H, W, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]
 rows, cols = resnet.get_conv_rows_cols(H, W)
@@ -19,7 +20,7 @@ steps, warm = 20, 3
 out = {}
 # ---- RPN step 1
 w = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=1)
-base = resnet.resnet50_base(weights=w, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
+base = resnet.resnet50_base(weights=w, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, dtype=DT)
 rpn = resnet.resnet50_rpn(base, anchors_per_loc=A)
 can_use = rs.rand(1, rows, cols, A) < 0.012; is_pos = rs.rand(1, rows, cols, A) < 0.01
 y_class = np.concatenate([can_use, is_pos], axis=3)
@@ -34,7 +35,7 @@ out["rpn_step1_ms"] = 1e3 * (time.perf_counter() - t0) / steps
 out["rpn_step1_params_MB"] = rpn._trainer.params.total * 4 / 1e6
 # ---- detector step 2
 dw = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=2)
-dbase = resnet.resnet50_base(weights=dw, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
+dbase = resnet.resnet50_base(weights=dw, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, dtype=DT)
 det = resnet.resnet50_classifier(64, C, dbase)
 n = 64
 x1 = rs.randint(0, cols - 8, n); y1 = rs.randint(0, rows - 8, n)
@@ -55,6 +56,7 @@ torch.cuda.synchronize()
 out["det_step2_ms"] = 1e3 * (time.perf_counter() - t0) / steps
 out["det_step2_params_MB"] = det._trainer.params.total * 4 / 1e6
 out["world"] = world
+out["dtype"] = DT
 out["rpn_step1_img_s"] = world * 1e3 / out["rpn_step1_ms"]
 out["det_step2_img_s"] = world * 1e3 / out["det_step2_ms"]
 if rank == 0:

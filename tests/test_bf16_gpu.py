@@ -146,3 +146,63 @@ def test_refresh_packed_bf16_matches_single_pack():
         ref = ws.permute(2, 0, 1, 3).reshape(cin, kh * kw, cout // 64, 64).permute(0, 2, 1, 3).reshape(cin, -1).to(torch.bfloat16)
         assert torch.equal(pdg, ref)
         assert torch.allclose(shift, bias * scale + const, rtol=1e-6, atol=1e-6)
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("which", ["det", "rpn"])
+def test_mixed_precision_training_step_tracks_f32(which):
+    """BASELINE configs[4] "mixed bf16": bf16 activations / gradients / packed filters with f32 master weights,
+    weight gradients and optimiser.  One SGD step from identical weights and inputs against the f32 trainer: the
+    losses agree to bf16 accuracy and every trained tensor moves in the same direction."""
+    from faster_rcnn_amd import resnet, train
+    from faster_rcnn_amd.weights import synthetic_resnet
+    A, C, H, W = 9, 21, 192, 256
+    rs = np.random.RandomState(4)
+    x = (rs.randint(0, 256, (H, W, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]
+    rows, cols = resnet.get_conv_rows_cols(H, W)
+    results = {}
+    for dt in ("f32", "bf16"):
+        w = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=7)
+        base = resnet.resnet50_base(weights=w, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, dtype=dt)
+        r2 = np.random.RandomState(5)
+        if which == "rpn":
+            m = resnet.resnet50_rpn(base, anchors_per_loc=A)
+            can_use = r2.rand(1, rows, cols, A) < 0.3; is_pos = r2.rand(1, rows, cols, A) < 0.1
+            y = [np.concatenate([can_use, is_pos], axis=3),
+                 np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32), (r2.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)]
+            xin = x
+        else:
+            m = resnet.resnet50_classifier(16, C, base)
+            n = 16
+            x1 = r2.randint(0, cols - 6, n); y1 = r2.randint(0, rows - 6, n)
+            rois = np.stack([x1, y1, x1 + 1 + r2.randint(0, 5, n), y1 + 1 + r2.randint(0, 5, n)], axis=1).astype(np.float32)[None]
+            ci = r2.randint(0, C, n)
+            yc = np.zeros((1, n, C), np.float32); yc[0, np.arange(n), ci] = 1
+            lab = np.zeros((n, 4 * (C - 1)), np.float32); tg = np.zeros((n, 4 * (C - 1)), np.float32)
+            for i, c in enumerate(ci):
+                if c < C - 1:
+                    lab[i, 4 * c:4 * c + 4] = 1; tg[i, 4 * c:4 * c + 4] = r2.randn(4)
+            y = [yc, np.concatenate([lab, tg], axis=1)[None]]
+            xin = [x, rois]
+        m.compile(train.SGD(1e-3, 0.9))
+        tr = m._trainer
+        before = tr.params.w.clone()
+        losses = m.train_on_batch(xin, y)
+        results[dt] = (losses, (tr.params.w - before).cpu(), tr.params)
+    (l32, d32, p32), (l16, d16, _) = results["f32"], results["bf16"]
+    for a, b in zip(l32, l16):
+        assert abs(a - b) <= 3e-2 * max(1.0, abs(a)), (l32, l16)
+    assert _cos(d32, d16) > 0.97                                # the whole update vector
+    off = 0
+    worst = 1.0
+    for name in p32.names:                                      # and every large tensor on its own
+        for wv, _ in p32.views[name]:
+            k = wv.numel()
+            if k >= 4096 and float(d32[off:off + k].norm()) > 0:
+                worst = min(worst, _cos(d32[off:off + k], d16[off:off + k]))
+            off += k
+    assert worst > 0.9, worst
