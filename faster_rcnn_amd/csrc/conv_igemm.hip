@@ -755,6 +755,104 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_f32(const WgradArgs p) {
     }
 }
 
+// Weight gradient on the bf16 matrix cores (mixed-precision training): x and g arrive in bf16, [pixel][channel] as
+// they lie in NHWC.  The reduction index is the PIXEL, i.e. both MFMA operands are k-strided in memory; they are
+// staged untransposed (coalesced 16-byte copies, 192-byte LDS rows) and read back with ds_read_b64_tr_b16, the
+// gfx950 transposing LDS read: a 16-lane group fetches 4 pixel rows x 16 channels and each lane receives one
+// channel's 4 pixels, so two reads form the 8-pixel operand of v_mfma_f32_32x32x16_bf16.  The 192-byte row stride
+// puts the 4 rows of a half-wave's block on disjoint 16-bank groups (conflict-free).  Same grid, slabs and
+// fixed-order reduction as the f32 kernel; 16x its MFMA rate.
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+constexpr int WB_MC = 64;                 // pixels per staged chunk
+constexpr int WB_ROW = 192;               // LDS row stride in bytes (128 B of channels + 64 B)
+
+__global__ void __launch_bounds__(256) k_conv_wgrad_bf16(const WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) char Xs[2][WB_MC][WB_ROW];
+    __shared__ __attribute__((aligned(16))) char Gs[2][WB_MC][WB_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int ci_tiles = (p.Cin + 63) / 64;
+    const int tap = blockIdx.x / ci_tiles, ci0 = (blockIdx.x % ci_tiles) * 64;
+    const int r_tap = tap / p.S, s_tap = tap % p.S;
+    const int co0 = blockIdx.y * 64;
+    const int m_begin = blockIdx.z * p.m_per_slice, m_end = min(p.M, m_begin + p.m_per_slice);
+    const __bf16* xg = reinterpret_cast<const __bf16*>(p.x);
+    const __bf16* gg = reinterpret_cast<const __bf16*>(p.g);
+
+    // staging: 256 threads move 64 pixels x 64 channels (8 x 16 B per pixel) per operand per chunk, two passes of 32 rows
+    const int srow = tid >> 3, scol = (tid & 7) * 8;       // channel offset inside the 64-wide tile
+    i32x4 rx[2], rg[2];
+    auto load = [&](int mc) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = mc + srow + 32 * q;
+            i32x4 vx = {0, 0, 0, 0}, vg = {0, 0, 0, 0};
+            if (m < m_end) {
+                const int wo = m % p.Wo, t = m / p.Wo, ho = t % p.Ho, img = t / p.Ho;
+                const int hi = ho * p.stride - p.pad_top + r_tap, wi = wo * p.stride - p.pad_left + s_tap;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W && ci0 + scol < p.Cin)
+                    vx = *reinterpret_cast<const i32x4*>(xg + (((size_t)img * p.H + hi) * p.W + wi) * p.Cin + ci0 + scol);
+                if (co0 + scol < p.Cout) vg = *reinterpret_cast<const i32x4*>(gg + (size_t)m * p.Cout + co0 + scol);
+            }
+            rx[q] = vx; rg[q] = vg;
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<i32x4*>(&Xs[buf][srow + 32 * q][scol * 2]) = rx[q];
+            *reinterpret_cast<i32x4*>(&Gs[buf][srow + 32 * q][scol * 2]) = rg[q];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+
+    // transposed-read addressing: lane 4q+p of a 16-lane group supplies (row q, channels 4p..4p+3) of its block;
+    // lanes 0-15 / 16-31 take channels 0-15 / 16-31 of the wave's 32, lanes 32-63 the next 8 pixels (lh)
+    const int g16 = lane & 15, tq = g16 >> 2, tp = g16 & 3, cblk = ((lane >> 4) & 1) * 16;
+    const int a_byte = (8 * lh + tq) * WB_ROW + (wk * 32 + cblk + 4 * tp) * 2;
+    const int b_byte = (8 * lh + tq) * WB_ROW + (wn * 32 + cblk + 4 * tp) * 2;
+    typedef i16x4 __attribute__((address_space(3))) * lds_i16x4;
+
+    const int n_chunks = (m_end - m_begin + WB_MC - 1) / WB_MC;
+    if (n_chunks > 0) {
+        load(m_begin);
+        store(0);
+        __syncthreads();
+        for (int c = 0; c < n_chunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < n_chunks) load(m_begin + (c + 1) * WB_MC);
+            const char* xa = &Xs[buf][0][0] + a_byte;
+            const char* gb = &Gs[buf][0][0] + b_byte;
+#pragma unroll
+            for (int st = 0; st < WB_MC / 16; ++st) {       // 16 pixels per MFMA
+                const i16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4)(xa + (16 * st) * WB_ROW));
+                const i16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4)(xa + (16 * st + 4) * WB_ROW));
+                const i16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4)(gb + (16 * st) * WB_ROW));
+                const i16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4)(gb + (16 * st + 4) * WB_ROW));
+                const i16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const i16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8w, av), __builtin_bit_cast(bf16x8w, bv), acc, 0, 0, 0);
+            }
+            if (c + 1 < n_chunks) store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    const int co = co0 + wn * 32 + li;
+    if (co < p.Cout) {
+        float* dst = p.partial + ((size_t)blockIdx.z * p.R * p.S + tap) * p.Cin * p.Cout;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ci = ci0 + wk * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+            if (ci < p.Cin) dst[(size_t)ci * p.Cout + co] = acc[e];
+        }
+    }
+}
+
 // dW = s[co] * sum over slices (fixed order); dbias[co] handled by k_colsum
 __global__ void k_wgrad_reduce(const float* partial, int slices, size_t elems, int Cout, const float* scale, float* dw) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
@@ -1098,7 +1196,8 @@ static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bo
     a.m_per_slice = ((a.M + slices - 1) / slices + WG_MC - 1) / WG_MC * WG_MC;
     hipStream_t s = as_stream(stream);
     dim3 grid(d->kh * d->kw * ((d->cin + 63) / 64), (d->cout + 63) / 64, slices);
-    if (in_bf16) k_conv_wgrad_f32<true><<<grid, 256, 0, s>>>(a);
+    if (in_bf16 && (d->cin & 7) == 0 && (d->cout & 7) == 0) k_conv_wgrad_bf16<<<grid, 256, 0, s>>>(a);      // bf16 MFMA
+    else if (in_bf16) k_conv_wgrad_f32<true><<<grid, 256, 0, s>>>(a);                                          // widened, f32 MFMA
     else k_conv_wgrad_f32<false><<<grid, 256, 0, s>>>(a);
     if (int e = check_launch("conv2d_wgrad")) return e;
     const size_t elems = (size_t)d->kh * d->kw * d->cin * d->cout;

@@ -84,7 +84,7 @@ def _bf(a):
 
 
 @pytest.mark.parametrize("case", [(1, 13, 17, 64, 128, 3, "same"), (2, 7, 7, 128, 256, 3, "same"), (1, 19, 23, 256, 64, 1, "valid"),
-                                  (1, 38, 63, 1024, 256, 1, "valid")])
+                                  (1, 38, 63, 1024, 256, 1, "valid"), (3, 9, 11, 64, 64, 3, "same"), (1, 61, 47, 192, 320, 1, "valid")])
 def test_bf16_backward_kernels(case):
     """Input gradient (bf16 MFMA conv on the transposed, flipped, scale-folded filter with fused ReLU mask and
     shortcut gradient) and weight / bias gradient (bf16 in, f32 out) against torch autograd in f64 on the SAME
@@ -206,3 +206,18 @@ def test_mixed_precision_training_step_tracks_f32(which):
                 worst = min(worst, _cos(d32[off:off + k], d16[off:off + k]))
             off += k
     assert worst > 0.9, worst
+
+
+def test_wgrad_bf16_widening_fallback():
+    """Channel counts that are not multiples of 8 cannot use the 16-byte bf16 staging: the kernel that widens to f32
+    while staging takes over (same contract)."""
+    from faster_rcnn_amd import ops
+    from oracle import keras_ref
+    rs = np.random.RandomState(12)
+    x, g = _bf(rs.randn(1, 19, 23, 64)), _bf(rs.randn(1, 19, 23, 36))
+    xt = x.double()
+    wtt = torch.zeros(1, 1, 64, 36, dtype=torch.float64, requires_grad=True)
+    keras_ref.conv2d(xt, wtt, None, 1, "valid", dtype=torch.float64).backward(g.double())
+    dw, db = ops.conv2d_wgrad_bf16(x.cuda(), g.cuda(), 1, 1, 1, "valid")
+    assert ((dw.cpu().double() - wtt.grad).abs().max() / wtt.grad.abs().max()).item() < 1e-4
+    assert ((db.cpu().double() - g.double().sum((0, 1, 2))).abs().max()).item() < 1e-3
