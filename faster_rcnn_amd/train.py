@@ -403,11 +403,11 @@ class RpnTrainer:
         self.params = ParamSet(w, train_names)
         self.base = _make_base_train(rpn_model.base, self.params)
         self.base_trains = len(self.base.convs()) > 0
-        # mixed precision: a bf16 base hands its feature map over in f32; the RPN layers (9 / 36 output channels: no
-        # bf16 input-gradient form) train in f32
+        # mixed precision: rpn_conv1 runs in bf16 like the base; the two output layers (9 / 36 channels: no bf16
+        # input-gradient form, negligible work) train in f32 on a widened copy of its output
         self.bf16 = getattr(rpn_model.base.net, "dtype", "f32") == "bf16"
         hd = rpn_model.head
-        u_conv, u_cls, u_reg = ((nets.ConvUnit(w, "rpn_conv1", padding="same", act="relu"), nets.ConvUnit(w, "rpn_out_cls", act="sigmoid"),
+        u_conv, u_cls, u_reg = ((nets.ConvUnit(w, "rpn_conv1", padding="same", act="relu", dtype="bf16"), nets.ConvUnit(w, "rpn_out_cls", act="sigmoid"),
                                  nets.ConvUnit(w, "rpn_out_bbreg")) if self.bf16 else (hd.conv, hd.cls, hd.reg))
         self.rpn_conv = TConv(u_conv, self.params, needs_dgrad=self.base_trains)
         self.rpn_cls = TConv(u_cls, self.params, needs_dgrad=True)
@@ -431,8 +431,9 @@ class RpnTrainer:
 
     def forward(self, x):
         self.feat = self.base.forward(x)
-        self.feat32 = ops.cast_f32(self.feat) if self.feat.dtype == torch.bfloat16 else self.feat
-        h = self.rpn_conv.forward(self.feat32)
+        h = self.rpn_conv.forward(self.feat)
+        if self.bf16:
+            h = ops.cast_f32(h)
         return self.rpn_cls.forward(h), self.rpn_reg.forward(h), h
 
     def train_on_batch(self, x, y, skip=False):
@@ -458,10 +459,11 @@ class RpnTrainer:
             self.rpn_reg.wgrad(g_reg)
             tmp = self.rpn_cls.dgrad(g_cls)
             gh = self.rpn_reg.dgrad(g_reg, residual=tmp, mask=h)
+            if self.bf16:
+                gh = ops.cast_bf16(gh)
             self.rpn_conv.wgrad(gh)
             if self.base_trains:
-                gfeat = self.rpn_conv.dgrad(gh, mask=self.feat32)
-                self.base.backward(ops.cast_bf16(gfeat) if self.bf16 else gfeat)
+                self.base.backward(self.rpn_conv.dgrad(gh, mask=self.feat))
         flush_bias_grads()
         sq = p.sumsq() if self.l2 else None
         scale = _sync_grads(p)
