@@ -326,10 +326,15 @@ __global__ void __launch_bounds__(256) k_refresh_packed_bf16(const RefreshTableB
                 tile[c][lane] = n0 + lane < j.cout ? j.w_hwio[((size_t)tap * j.cin + cc * BKH + c) * j.cout + n0 + lane] : 0.0f;
             }
             __syncthreads();
+            const int c2 = threadIdx.x & 31, nr = threadIdx.x >> 5;      // thread -> (channel pair, row): 4-byte stores, 128 B per row
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) {                 // thread -> (row n = jr + 4 pp, channel = lane)
-                const int n = jr + 4 * pp;
-                if (n0 + n < j.cout) out[(size_t)(n0 + n) * Kpad + kc * BKH + lane] = (__bf16)tile[lane][n];
+            for (int pp = 0; pp < 8; ++pp) {
+                const int n = nr + 8 * pp;
+                if (n0 + n < j.cout) {
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    bf16x2 v = {(__bf16)tile[2 * c2][n], (__bf16)tile[2 * c2 + 1][n]};
+                    *reinterpret_cast<bf16x2*>(out + (size_t)(n0 + n) * Kpad + kc * BKH + 2 * c2) = v;
+                }
             }
             __syncthreads();
         }
@@ -337,12 +342,16 @@ __global__ void __launch_bounds__(256) k_refresh_packed_bf16(const RefreshTableB
     if (j.packed_dgrad) {
         __bf16* out = reinterpret_cast<__bf16*>(j.packed_dgrad);
         const int Kpad = RS * j.cout;                          // rows = cin, k over (cout chunk of 64, tap', cout % 64)
-        const size_t total = (size_t)j.cin * Kpad;
-        for (size_t i = first; i < total; i += stride) {
+        const size_t total2 = (size_t)j.cin * Kpad / 2;        // two consecutive cout per thread: 8-byte reads, 4-byte stores
+        for (size_t i2 = first; i2 < total2; i2 += stride) {
+            const size_t i = 2 * i2;
             const int k = (int)(i % Kpad), ci = (int)(i / Kpad);
             const int jj = k % BKH, kc = k / BKH, tap = kc % RS, co = (kc / RS) * BKH + jj;
             const int r = j.kh - 1 - tap / j.kw, sx = j.kw - 1 - tap % j.kw;
-            out[i] = (__bf16)(j.w_hwio[((size_t)(r * j.kw + sx) * j.cin + ci) * j.cout + co] * (j.scale ? j.scale[co] : 1.0f));
+            const float2 wv = *reinterpret_cast<const float2*>(j.w_hwio + ((size_t)(r * j.kw + sx) * j.cin + ci) * j.cout + co);
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 v = {(__bf16)(wv.x * (j.scale ? j.scale[co] : 1.0f)), (__bf16)(wv.y * (j.scale ? j.scale[co + 1] : 1.0f))};
+            *reinterpret_cast<bf16x2*>(out + i) = v;
         }
     }
     if (j.shift)
