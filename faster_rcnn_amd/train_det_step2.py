@@ -29,6 +29,8 @@ def build_parser():
     p.add_argument("--save_weights_dest", dest="save_weights_dest", default=None)
     p.add_argument("--save_model_dest", dest="save_model_dest", default=None)
     p.add_argument("--init_weights", dest="init_weights", default=None)
+    p.add_argument("--bf16", action="store_true",
+                   help="mixed precision (not in the reference): bf16 activations / gradients / packed filters, f32 master weights and optimiser")
     return p
 
 
@@ -48,7 +50,8 @@ def main(argv=None):
     rpn_weights = load_npz(args.step1_weights_path)
     rpn_model = resnet.resnet50_rpn(base_fn(weights=rpn_weights), anchors_per_loc=len(anchors))        # frozen, not regularised
     det_weights = load_npz(args.init_weights) if args.init_weights else synthetic_resnet(depth, anchors_per_loc=len(anchors), num_classes=num_classes)
-    detector_base = base_fn(weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, weights=det_weights)
+    detector_base = base_fn(weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, weights=det_weights,
+                            dtype="bf16" if args.bf16 else "f32")
     detector_model = cls_fn(NUM_ROIS, num_classes, detector_base, weight_regularizer=resnet.WEIGHT_REGULARIZER,
                             bias_regularizer=resnet.BIAS_REGULARIZER)
     save_weights_dest = args.save_weights_dest or "models/detector_weights_{}_step2.npz".format(args.network)

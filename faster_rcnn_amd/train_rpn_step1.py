@@ -27,6 +27,8 @@ def build_parser():
     p.add_argument("--save_weights_dest", dest="save_weights_dest", default=None)
     p.add_argument("--save_model_dest", dest="save_model_dest", default=None)
     p.add_argument("--init_weights", dest="init_weights", default=None, help=".npz keyed by Keras layer names (default: seeded synthetic)")
+    p.add_argument("--bf16", action="store_true",
+                   help="mixed precision (not in the reference): bf16 activations / gradients / packed filters, f32 master weights and optimiser")
     return p
 
 
@@ -41,7 +43,8 @@ def main(argv=None):
     from .weights import load_npz, synthetic_resnet
     weights = load_npz(args.init_weights) if args.init_weights else synthetic_resnet(depth, anchors_per_loc=len(anchors))
     base_fn = resnet.resnet50_base if depth == 50 else resnet.resnet101_base
-    base_model = base_fn(weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, weights=weights)
+    base_model = base_fn(weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, weights=weights,
+                         dtype="bf16" if args.bf16 else "f32")
     rpn_model = resnet.resnet50_rpn(base_model, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER,
                                     anchors_per_loc=len(anchors))
     save_weights_dest = args.save_weights_dest or "models/rpn_weights_{}_step1.npz".format(args.network)
