@@ -12,6 +12,9 @@ rank, world = dp.init_from_env()
 if world == 1:
     torch.cuda.set_device(0)
 H, W, A, C = 600, 1000, 9, 21
+from faster_rcnn_amd import ops
+if "--big-tiles" in sys.argv:
+    ops.AUTO_TILE = 50
 DT = "bf16" if "--bf16" in sys.argv else "f32"     # --bf16: mixed precision (bf16 activations / gradients / packed filters, f32 masters)
 rs = np.random.RandomState(rank)
 x = (rs.randint(0, 256, (H, W, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]
