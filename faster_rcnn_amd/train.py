@@ -169,8 +169,18 @@ class TConv:
     def wgrad(self, g):
         """g: gradient w.r.t. this layer's post-BN pre-activation output."""
         if self.trainable:
-            (ops.conv2d_wgrad_bf16 if self.bf16 else ops.conv2d_wgrad)(
-                self.x, g, self.kh, self.kw, self.u.stride, self.u.padding, scale=self.scale, dw=self.gk4, want_bias=False)
+            fn = ops.conv2d_wgrad_bf16 if self.bf16 else ops.conv2d_wgrad
+            side = _wgrad_stream()
+            if side is None:
+                fn(self.x, g, self.kh, self.kw, self.u.stride, self.u.padding, scale=self.scale, dw=self.gk4, want_bias=False)
+            else:
+                # the weight gradient is off the critical path (nothing downstream reads it before the optimiser):
+                # it runs on a second HIP stream beside the input-gradient chain, whose small grids leave CUs idle
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    fn(self.x, g, self.kh, self.kw, self.u.stride, self.u.padding, scale=self.scale, dw=self.gk4, want_bias=False)
+                g.record_stream(side)
+                self.x.record_stream(side)
             if self.gb is not None:            # bias gradients of the whole step leave in ONE launch (flush_bias_grads)
                 _PENDING_BIAS.append((g if g.is_contiguous() else g.contiguous(), self.scale, self.gb))
 
@@ -180,11 +190,32 @@ class TConv:
         return ops.conv2d_dgrad(g, self.pd, self.u.padding, residual=residual, mask=mask)
 
 
+OVERLAP_WGRAD = True        # weight gradients on a second stream, concurrent with the input-gradient chain
+_WGRAD_STREAM = None
+
+
+def _wgrad_stream():
+    global _WGRAD_STREAM
+    if not OVERLAP_WGRAD:
+        return None
+    if _WGRAD_STREAM is None:
+        _WGRAD_STREAM = torch.cuda.Stream()
+    return _WGRAD_STREAM
+
+
+def join_wgrad_stream():
+    """The main stream waits for every weight gradient launched on the side stream."""
+    if _WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(_WGRAD_STREAM)
+
+
 _PENDING_BIAS = []          # (g, scale, dbias) of this step's trainable convs; g is kept alive until the flush
 
 
 def flush_bias_grads():
-    """dbias[co] = scale[co] * sum_m g[m][co] for every conv that ran wgrad since the last flush."""
+    """dbias[co] = scale[co] * sum_m g[m][co] for every conv that ran wgrad since the last flush; also the point
+    where the main stream rejoins the weight-gradient stream."""
+    join_wgrad_stream()
     if not _PENDING_BIAS:
         return
     jobs = (_lib.ColsumJob * len(_PENDING_BIAS))()
