@@ -55,7 +55,9 @@ __device__ __forceinline__ float activate_b(float v, int act) {
 // TN=1) put FOUR waves on a SIMD with two workgroups per CU: a bf16 chunk is only 8-16 MFMAs (256-512 cycles) per
 // wave, far less than the global->LDS->fragment latency of the next chunk, so the MFMA pipe needs more waves to
 // draw from than the f32 kernel (whose chunk is 4096 cycles of MFMA) does.
-template <int TM, int TN, bool SPLITK = false, int WM = 2, int WN = 2>
+// MASKED: the epilogue also applies the ReLU-backward mask (training's input-gradient pass).  A template parameter,
+// not a runtime test: with the test in, the inference instantiations ran 14 % slower (596 -> 514 img/s on configs[3]).
+template <int TM, int TN, bool SPLITK = false, int WM = 2, int WN = 2, bool MASKED = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgsBf16 p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                 if (m < p.M) {
                     float v = acc[i][j][e] * sc + sh;
                     if (p.residual) v += (float)p.residual[(size_t)m * p.Cout + n];
-                    if (p.mask && !((float)p.mask[(size_t)m * p.Cout + n] > 0.0f)) v = 0.0f;
+                    if constexpr (MASKED) { if (!((float)p.mask[(size_t)m * p.Cout + n] > 0.0f)) v = 0.0f; }
                     v = activate_b(v, p.act);
                     if (p.out_f32) reinterpret_cast<float*>(p.y)[(size_t)m * p.Cout + n] = v;
                     else reinterpret_cast<__bf16*>(p.y)[(size_t)m * p.Cout + n] = (__bf16)v;
@@ -431,8 +433,8 @@ __global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int ro
     }
 }
 
-template <int TM, int TN, int WM = 2, int WN = 2>
-static int launch_bf16(const ConvArgsBf16& a, hipStream_t s) {
+template <int TM, int TN, int WM, int WN, bool MASKED>
+static int launch_bf16_m(const ConvArgsBf16& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgsBf16 p = a;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -440,12 +442,17 @@ static int launch_bf16(const ConvArgsBf16& a, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE_B;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS to %zu", lds);
         attr_done = true;
     }
-    k_conv_igemm_bf16<TM, TN, false, WM, WN><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
+    k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
     return check_launch("conv2d_fwd_bf16");
+}
+
+template <int TM, int TN, int WM = 2, int WN = 2>
+static int launch_bf16(const ConvArgsBf16& a, hipStream_t s) {
+    return a.mask ? launch_bf16_m<TM, TN, WM, WN, true>(a, s) : launch_bf16_m<TM, TN, WM, WN, false>(a, s);
 }
 
 constexpr size_t SPLITK_TICKET_BYTES_B = 16384;     // same workspace layout as frcnn_conv2d_fwd_ws
@@ -455,7 +462,8 @@ static int launch_bf16_splitk(const ConvArgsBf16& a, hipStream_t s) {
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_n = (p.Cout + 63) / 64;
     const size_t lds = (size_t)2 * (64 + 64) * LDS_STRIDE_B;
-    k_conv_igemm_bf16<1, 1, true><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
+    if (p.mask) k_conv_igemm_bf16<1, 1, true, 2, 2, true><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
+    else k_conv_igemm_bf16<1, 1, true><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
     return check_launch("conv2d_fwd_bf16 (split-K)");
 }
 
