@@ -169,10 +169,15 @@ def main():
     ap.add_argument("--no-hoist", action="store_true",
                     help="detector head in the reference's order (resample, then res5a_branch2a / branch1 on every crop) instead of "
                          "applying those two 1x1 layers once to the conv4 map")
+    ap.add_argument("--dtype", choices=("config", "f32", "bf16"), default="config",
+                    help="override the config's arithmetic type (off-contract: e.g. configs[1] shapes on the bf16 conv path)")
     ap.add_argument("--streams", type=int, default=4, help="images in flight per GPU (one hipGraph + HIP stream each)")
     args = ap.parse_args()
     select_config(args.config)
-    global HOIST
+    global HOIST, DTYPE, WORKLOAD
+    if args.dtype != "config" and args.dtype != DTYPE:
+        DTYPE = args.dtype
+        WORKLOAD += " [OFF-CONTRACT: run with --dtype %s]" % args.dtype
     HOIST = not args.no_hoist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
