@@ -1,0 +1,84 @@
+"""reference behaviours that look like bugs and must be reproduced (host side, no GPU).
+Quirks 1-6 are pinned by the goldens (test_oracle_golden.py, test_boxes_gpu.py, test_pipeline_gpu.py,
+test_train_gpu.py); this file covers the data-path ones, 7, 9 and 10, and restates 5 and 6 in one place."""
+import os
+import random
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class _FakeModel:
+    def __init__(self):
+        self.seen, self.lrs = [], []
+
+    def compile(self, optimizer=None, loss=None):
+        self.lrs.append(optimizer.lr)
+
+    def train_on_batch(self, x, y):
+        self.seen.append(x)
+        return [0.0, 0.0, 0.0]
+
+
+class _FakeImg:
+    def __init__(self, name):
+        self.name, self.flipped = name, False
+
+
+class _FakeMgr:
+    anchor_dims = [(1, 1)] * 9
+
+    def batched_image(self, img):
+        return img.name
+
+    def rpn_y_true(self, img):
+        return None, None
+
+
+def test_image_schedule_is_offset_by_phase_not_a_running_counter(monkeypatch):
+    """train_util.py:39: img_idx = (i + num_iterations * phase_num) % num_train, shuffle whenever it hits 0."""
+    from faster_rcnn_amd import train, train_util
+    monkeypatch.setattr(random, "shuffle", lambda seq: None)              # keep the order observable
+    imgs = [_FakeImg("im%d" % k) for k in range(5)]
+    model = _FakeModel()
+    train_util.train_rpn(model, imgs, _FakeMgr(), train.SGD(0.0), phases=[[3, 1e-3], [4, 1e-4]])
+    # phase 0: i = 0,1,2 -> 0,1,2; phase 1: (i + 4*1) % 5 -> 4,0,1,2 (a running counter would give 3,4,0,1)
+    assert model.seen == ["im0", "im1", "im2", "im4", "im0", "im1", "im2"]
+    assert model.lrs == [1e-3, 1e-4]                                      # re-compiled with the phase's rate
+
+
+def test_annotation_coordinates_shift_minus_one_on_load_and_plus_one_on_write(tmp_path):
+    """voc_data_helpers.py:111-114 subtracts 1 from every annotation coordinate; voc_dets.py:126 adds it back."""
+    from faster_rcnn_amd import voc_dets
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+    img = extract_img_data(os.path.join(GOLD, "VOC_test"), "000005")
+    first = img.gt_boxes[0]
+    assert (first.obj_cls, first.x1, first.y1, first.x2, first.y2) == ("chair", 262, 210, 323, 338)   # xml: 263 211 324 339
+    dets = {"chair": {"000005": [{"bbox": np.array([262, 210, 323, 338]), "prob": 0.5, "cls_name": "chair"}]}}
+    voc_dets.write_dets(dets, str(tmp_path))
+    line = open(os.path.join(str(tmp_path), "comp3_det_test_chair.txt")).read().split()
+    assert line == ["000005", "0.5", "263", "211", "324", "339"]
+
+
+def test_horizontal_flip_has_no_minus_one():
+    """shapes.py:298: x -> width - x (not width - 1 - x), so a box touching the right edge lands at x1 = 0... + 1 px."""
+    from faster_rcnn_amd import shapes
+    g = shapes.GroundTruthBox("dog", False, shapes.Box(10, 20, 110, 220)).horizontal_flip(500)
+    assert (g.x1, g.y1, g.x2, g.y2) == (390, 20, 490, 220)
+    assert shapes.GroundTruthBox("dog", False, shapes.Box(0, 0, 499, 10)).horizontal_flip(500).x1 == 1
+
+
+def test_two_iou_conventions_and_empty_nms():
+    """util.cross_ious has no +1 (util.py:158-175); det_util.nms / eval_dets use +1 (det_util.py:230,243); nms([]) == []."""
+    from faster_rcnn_amd import eval_dets
+    from oracle import np_ref
+    a = np.array([[0, 0, 10, 10]], np.float32)
+    b = np.array([[5, 5, 15, 15]], np.float32)
+    assert abs(float(np_ref.cross_ious(a, b)[0, 0]) - 25.0 / 175.0) < 1e-7
+    keep = np_ref.nms(np.array([[0, 0, 10, 10], [5, 5, 15, 15]], np.int16), np.array([0.9, 0.8], np.float32), 0.17, 300)[0]
+    assert len(keep) == 1                                   # +1 convention: 36 / (121 + 121 - 36) = 0.1748 > 0.17 suppresses;
+    keep = np_ref.nms(np.array([[0, 0, 10, 10], [5, 5, 15, 15]], np.int16), np.array([0.9, 0.8], np.float32), 0.18, 300)[0]
+    assert len(keep) == 2                                   # the no-+1 value 25 / 175 = 0.1429 would have kept both at 0.17 too
+    assert np_ref.nms(np.zeros((0, 4)), np.zeros(0))[0] == []
+    assert hasattr(eval_dets, "voc_ap")
