@@ -1,4 +1,4 @@
-"""Minimal read-only HDF5 reader for Keras 2.0.x weight / model files.
+"""Minimal HDF5 reader and writer for Keras 2.0.x weight / model files.
 
 The reference loads its checkpoints with ``model.load_weights(path, by_name)`` and
 ``keras.models.load_model`` (resnet.py:32-61, 481-485; train_det_step2.py:110), i.e. through h5py,
@@ -10,6 +10,7 @@ anything outside it (chunked or compressed datasets, new-style groups, dense att
 variable-length strings) raises ``H5Error`` naming the feature instead of guessing.
 
     weights = read_keras_weights("model_frcnn_step2.h5")    # {layer_name: [arrays in get_weights() order]}
+    write_keras_weights("step2.h5", weights)                 # the same subset; h5py / Keras read it (tests/test_h5lite.py)
 """
 import numpy as np
 
@@ -294,3 +295,160 @@ def read_keras_weights(path):
         if arrays:
             out[lname] = arrays
     return out
+
+
+# ----------------------------------------------------------------------------- writer (same on-disk subset)
+def _weight_names(layer, arrays):
+    """Keras 2.0.x variable names for the layer kinds this package holds (Conv2D / Dense, BatchNormalization, the
+    reference's Scale layer custom_layers.py:93-101)."""
+    nd = [a.ndim for a in arrays]
+    if len(arrays) == 4 and all(d == 1 for d in nd):
+        return ["%s/%s:0" % (layer, k) for k in ("gamma", "beta", "moving_mean", "moving_variance")]
+    if len(arrays) == 2 and all(d == 1 for d in nd):
+        return ["%s/%s_%s:0" % (layer, layer, k) for k in ("gamma", "beta")]
+    if nd[0] >= 2:
+        return ["%s/%s:0" % (layer, k) for k in ("kernel", "bias")[:len(arrays)]]
+    return ["%s/param_%d:0" % (layer, i) for i in range(len(arrays))]
+
+
+class _Writer:
+    """Lays an HDF5 file out in memory: superblock 0, version-1 object headers, symbol-table groups (one B-tree node,
+    symbol nodes of up to 64 entries), contiguous datasets, version-1 attribute messages with fixed-length strings."""
+    O = L = 8
+    LEAF_K, INTERNAL_K = 32, 16
+    UNDEF8 = b"\xff" * 8
+
+    def __init__(self):
+        self.buf = bytearray(96)                             # superblock placeholder
+
+    def _alloc(self, data):
+        while len(self.buf) % 8:
+            self.buf.append(0)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    @staticmethod
+    def _pad8(b):
+        return b + b"\x00" * (-len(b) % 8)
+
+    def _msg(self, mtype, body):
+        body = self._pad8(body)
+        return mtype.to_bytes(2, "little") + len(body).to_bytes(2, "little") + b"\x00\x00\x00\x00" + body
+
+    def _object_header(self, msgs):
+        body = b"".join(msgs)
+        return b"\x01\x00" + len(msgs).to_bytes(2, "little") + (1).to_bytes(4, "little") + len(body).to_bytes(4, "little") + b"\x00" * 4 + body
+
+    @staticmethod
+    def _dataspace(shape):
+        return b"\x01" + bytes([len(shape)]) + b"\x00" * 6 + b"".join(int(d).to_bytes(8, "little") for d in shape)
+
+    @staticmethod
+    def _dtype_f32():
+        return (bytes([0x11, 0x20, 0x1F, 0x00]) + (4).to_bytes(4, "little") + (0).to_bytes(2, "little") + (32).to_bytes(2, "little")
+                + bytes([23, 8, 0, 23]) + (127).to_bytes(4, "little"))
+
+    @staticmethod
+    def _dtype_str(n):
+        return bytes([0x13, 0x01, 0x00, 0x00]) + int(n).to_bytes(4, "little")
+
+    def _attr_strings(self, name, values):
+        """1-D array of fixed-length (null-padded) byte strings; a zero-length array keeps itemsize 1."""
+        vals = [v.encode("utf8") if isinstance(v, str) else bytes(v) for v in values]
+        width = max([len(v) for v in vals] + [1])
+        data = b"".join(v.ljust(width, b"\x00") for v in vals)
+        return self._attr(name, self._dtype_str(width), self._dataspace((len(vals),)), data)
+
+    def _attr_scalar_string(self, name, value):
+        v = value.encode("utf8")
+        return self._attr(name, self._dtype_str(len(v)), self._dataspace(()), v)
+
+    def _attr(self, name, dtype, dspace, data):
+        nm = name.encode("utf8") + b"\x00"
+        body = (b"\x01\x00" + len(nm).to_bytes(2, "little") + len(dtype).to_bytes(2, "little") + len(dspace).to_bytes(2, "little")
+                + self._pad8(nm) + self._pad8(dtype) + self._pad8(dspace) + data)
+        if len(body) > 0xFFF0:
+            raise H5Error("attribute %s is too large for a compact object-header message (%d bytes)" % (name, len(body)))
+        return self._msg(0x0C, body)
+
+    def dataset(self, arr):
+        arr = np.ascontiguousarray(arr, dtype="<f4")
+        data_addr = self._alloc(arr.tobytes())
+        layout = b"\x03\x01" + data_addr.to_bytes(8, "little") + int(arr.nbytes).to_bytes(8, "little")
+        hdr = self._object_header([self._msg(0x01, self._dataspace(arr.shape)), self._msg(0x03, self._dtype_f32()), self._msg(0x08, layout)])
+        return self._alloc(hdr)
+
+    def group(self, links, attr_msgs=()):
+        """links: {name: (object header address, (btree, heap) or None)} -> (header address, (btree, heap))."""
+        names = sorted(links, key=lambda s: s.encode("utf8"))
+        heap = bytearray(8)                                   # offset 0: the empty name every B-tree's first key points at
+        offs = {}
+        for n in names:
+            offs[n] = len(heap)
+            heap += self._pad8(n.encode("utf8") + b"\x00")
+        heap_data = self._alloc(bytes(heap))
+        # free-list head = 1 is the library's "no free block" value (H5HL_FREE_NULL), not the undefined address
+        heap_hdr = self._alloc(b"HEAP" + b"\x00" * 4 + len(heap).to_bytes(8, "little") + (1).to_bytes(8, "little") + heap_data.to_bytes(8, "little"))
+        per = 2 * self.LEAF_K
+        n_nodes = max(1, -(-len(names) // per))
+        if n_nodes > 2 * self.INTERNAL_K:
+            raise H5Error("group with %d links needs a two-level B-tree" % len(names))
+        chunks = [names[i * len(names) // n_nodes:(i + 1) * len(names) // n_nodes] for i in range(n_nodes)]
+        keys, children = [0], []
+        for ch in chunks:
+            node = bytearray(b"SNOD\x01\x00" + len(ch).to_bytes(2, "little"))
+            for n in ch:
+                addr, sub = links[n]
+                node += offs[n].to_bytes(8, "little") + addr.to_bytes(8, "little")
+                if sub is not None:
+                    node += (1).to_bytes(4, "little") + b"\x00" * 4 + sub[0].to_bytes(8, "little") + sub[1].to_bytes(8, "little")
+                else:
+                    node += b"\x00" * 24
+            node += b"\x00" * (8 + per * 40 - len(node))
+            children.append(self._alloc(bytes(node)))
+            keys.append(offs[ch[-1]] if ch else 0)
+        tree = bytearray(b"TREE\x00\x00" + len(children).to_bytes(2, "little") + self.UNDEF8 + self.UNDEF8)
+        for i, c in enumerate(children):
+            tree += keys[i].to_bytes(8, "little") + c.to_bytes(8, "little")
+        tree += keys[len(children)].to_bytes(8, "little")
+        tree += b"\x00" * (24 + (4 * self.INTERNAL_K + 1) * 8 - len(tree))
+        btree = self._alloc(bytes(tree))
+        stab = self._msg(0x11, btree.to_bytes(8, "little") + heap_hdr.to_bytes(8, "little"))
+        return self._alloc(self._object_header([stab] + list(attr_msgs))), (btree, heap_hdr)
+
+    def finish(self, root_addr, root_sub):
+        eof = len(self.buf) + (-len(self.buf) % 8)
+        self.buf += b"\x00" * (eof - len(self.buf))
+        sb = bytearray(SIGNATURE + bytes([0, 0, 0, 0, 0, 8, 8, 0]))
+        sb += self.LEAF_K.to_bytes(2, "little") + self.INTERNAL_K.to_bytes(2, "little") + (0).to_bytes(4, "little")
+        sb += (0).to_bytes(8, "little") + self.UNDEF8 + eof.to_bytes(8, "little") + self.UNDEF8
+        sb += (0).to_bytes(8, "little") + root_addr.to_bytes(8, "little") + (1).to_bytes(4, "little") + b"\x00" * 4
+        sb += root_sub[0].to_bytes(8, "little") + root_sub[1].to_bytes(8, "little")
+        assert len(sb) == 96
+        self.buf[:96] = sb
+        return bytes(self.buf)
+
+
+def write_keras_weights(path, weights, layer_order=None, full_model=False):
+    """{layer_name: [arrays]} -> a Keras 2.0.x ``save_weights`` file (or, with ``full_model``, the ``model_weights`` group
+    of a ``model.save`` file) that Keras / h5py and ``read_keras_weights`` read back."""
+    order = list(layer_order) if layer_order is not None else list(weights)
+    w = _Writer()
+    links = {}
+    for lname in order:
+        arrays = weights[lname]
+        names = _weight_names(lname, arrays)
+        inner = {}
+        for wn, arr in zip(names, arrays):
+            inner[wn.split("/", 1)[1]] = (w.dataset(arr), None)
+        sub_addr, sub = w.group(inner)                          # the "<layer>/" part of the variable names is a nested group
+        g_addr, g_sub = w.group({lname: (sub_addr, sub)} if arrays else {}, [w._attr_strings("weight_names", names)])
+        links[lname] = (g_addr, g_sub)
+    attrs = [w._attr_strings("layer_names", order), w._attr_scalar_string("backend", "tensorflow"), w._attr_scalar_string("keras_version", "2.0.8")]
+    top, top_sub = w.group(links, attrs)
+    if full_model:
+        top, top_sub = w.group({"model_weights": (top, top_sub)},
+                               [w._attr_scalar_string("keras_version", "2.0.8"), w._attr_scalar_string("backend", "tensorflow")])
+    with open(path, "wb") as f:
+        f.write(w.finish(top, top_sub))

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import nets
-from .weights import load_npz, save_npz
+from .weights import load_npz, save_weights_file
 
 
 class _Layer:
@@ -48,9 +48,13 @@ class _Model:
         self.invalidate()
 
     def save_weights(self, path):
-        save_npz(path, self.weights)
+        """Keras ``save_weights``: ``.h5`` writes a Keras 2.0.x HDF5 weight file, any other suffix the .npz form."""
+        save_weights_file(path, self.weights)
 
-    save = save_weights
+    def save(self, path):
+        """Keras ``model.save``: for ``.h5`` the weights go under ``model_weights`` like Keras' full-model files
+        (architecture / optimiser state are not stored: the builders re-create the graph from the layer names)."""
+        save_weights_file(path, self.weights, full_model=True)
 
 
 class BaseModel(_Model):
@@ -105,7 +109,9 @@ class RpnModel(_Model):
         self._flush_trainer()
         super().save_weights(path)
 
-    save = save_weights
+    def save(self, path):
+        self._flush_trainer()
+        super().save(path)
 
     def predict_on_batch(self, x):
         self._flush_trainer()
@@ -147,7 +153,10 @@ class DetModel(_Model):
             self._trainer.sync_weights()
         super().save_weights(path)
 
-    save = save_weights
+    def save(self, path):
+        if getattr(self, "_trainer", None) is not None:
+            self._trainer.sync_weights()
+        super().save(path)
 
     def predict(self, inputs):
         first, rois = inputs

@@ -117,6 +117,15 @@ def synthetic_vgg16(anchors_per_loc=9, num_classes=21, seed=1, with_classifier=T
     return w
 
 
+def save_weights_file(path, weights, full_model=False):
+    """``.h5`` / ``.hdf5`` -> a Keras 2.0.x HDF5 file Keras itself can load (h5lite writer); anything else -> .npz."""
+    if str(path).lower().endswith((".h5", ".hdf5")):
+        from . import h5lite
+        h5lite.write_keras_weights(path, {k: [np.asarray(a, dtype=np.float32) for a in v] for k, v in weights.items()}, full_model=full_model)
+    else:
+        save_npz(path, weights)
+
+
 def save_npz(path, weights):
     flat = {}
     for name, arrs in weights.items():

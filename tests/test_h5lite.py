@@ -54,3 +54,58 @@ def test_rejects_what_it_does_not_parse(tmp_path):
     p.write_bytes(bytes(blob))
     with pytest.raises(h5lite.H5Error, match="superblock version 2"):
         h5lite.read_keras_weights(str(p))
+
+
+def _sample_weights():
+    rs = np.random.RandomState(3)
+    w = {"conv1": [rs.randn(7, 7, 3, 8).astype("f4"), rs.randn(8).astype("f4")],
+         "bn_conv1": [rs.randn(8).astype("f4") for _ in range(4)],
+         "scale_conv1": [rs.randn(8).astype("f4") for _ in range(2)],
+         "res5a_branch2b": [rs.randn(3, 3, 4, 4).astype("f4")],
+         "dense_class_21": [rs.randn(16, 21).astype("f4"), rs.randn(21).astype("f4")]}
+    for i in range(150):                                              # > 64 links: several symbol nodes under one B-tree node
+        w["pad_%03d" % i] = [rs.randn(2, 3).astype("f4")]
+    return w
+
+
+@pytest.mark.parametrize("full_model", [False, True])
+def test_writer_round_trip(tmp_path, full_model):
+    from faster_rcnn_amd.weights import save_weights_file
+    w = _sample_weights()
+    p = str(tmp_path / "w.h5")
+    save_weights_file(p, w, full_model=full_model)
+    assert h5lite.is_hdf5(p)
+    back = load_weights_file(p)
+    assert list(back) == list(w)                                      # layer_names keeps the given order
+    for k in w:
+        assert len(back[k]) == len(w[k])
+        for a, b in zip(w[k], back[k]):
+            assert np.array_equal(a, b)
+
+
+PY39 = "/opt/conda/bin/python3.9"
+
+
+@pytest.mark.skipif(not os.path.exists(PY39), reason="no h5py-capable interpreter")
+def test_written_file_is_read_by_h5py(tmp_path):
+    """The real HDF5 library (h5py under the image's second interpreter) reads what the writer lays out."""
+    import subprocess
+    from faster_rcnn_amd.weights import save_npz, save_weights_file
+    w = _sample_weights()
+    h5, npz = str(tmp_path / "w.h5"), str(tmp_path / "w.npz")
+    save_weights_file(h5, w)
+    save_npz(npz, w)
+    check = (
+        "import h5py, numpy as np\n"
+        "ref = np.load(%r)\n"
+        "f = h5py.File(%r, 'r')\n"
+        "names = [n.decode() for n in f.attrs['layer_names']]\n"
+        "assert f.attrs['keras_version'] == b'2.0.8'\n"
+        "n = 0\n"
+        "for ln in names:\n"
+        "    for i, wn in enumerate(f[ln].attrs['weight_names']):\n"
+        "        assert np.array_equal(np.asarray(f[ln][wn.decode()]), ref['%%s/%%d' %% (ln, i)]); n += 1\n"
+        "assert [x.decode() for x in f['bn_conv1'].attrs['weight_names']][2] == 'bn_conv1/moving_mean:0'\n"
+        "print(n)\n" % (npz, h5))
+    out = subprocess.run([PY39, "-W", "ignore", "-c", check], check=True, capture_output=True, text=True).stdout
+    assert int(out.strip()) == sum(len(v) for v in w.values())
