@@ -24,6 +24,7 @@ SIGNATURES = {
     "frcnn_last_error": (c_char_p, []),
     "frcnn_version": (I, []),
     "frcnn_device_count": (I, []),
+    "frcnn_preprocess_u8": (I, [P, c_size_t, P, P, P]),
     "frcnn_anchors_image": (I, [I, I, P, I, I, P, P]),
     "frcnn_anchors_conv": (I, [I, I, P, I, P, P]),
     "frcnn_cross_ious_f32": (I, [P, I, P, I, P, P]),

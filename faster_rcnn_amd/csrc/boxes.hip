@@ -239,6 +239,16 @@ static inline int grid_for(int n, int block = 256, int cap = 2048) {
     return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
+// resnet.preprocess / vgg.preprocess (resnet.py:64-75, vgg.py:52-57) on the device: the host path computes
+// float64(u8) - mean and the network input casts to f32; the same two roundings here, so the tensor is bit-identical
+// while the upload shrinks from 12 to 3 bytes per pixel.
+__global__ void k_preprocess_u8(const uint8_t* img, size_t n, double m0, double m1, double m2, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        out[i] = (float)((double)img[i] - (c == 0 ? m0 : (c == 1 ? m1 : m2)));
+    }
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -355,6 +365,16 @@ int frcnn_roi_targets(const int16_t* rois, int E, const float* gt_f32, const dou
     k_roi_targets<<<(E + 255) / 256, 256, 0, as_stream(stream)>>>(rois, E, (const float4*)gt_f32, gt_f64, gt_cls, G, bg_idx,
                                                                   eligible, cls, (float4*)targets);
     return check_launch("roi_targets");
+}
+
+int frcnn_preprocess_u8(const uint8_t* img_hwc, size_t n_pixels, const double* mean3_h, float* out, void* stream) {
+    if (!img_hwc || !mean3_h || !out) return fail(FRCNN_E_ARG, "preprocess_u8: null pointer");
+    if (n_pixels == 0) return FRCNN_OK;
+    const size_t n = n_pixels * 3;
+    size_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    k_preprocess_u8<<<(int)g, 256, 0, as_stream(stream)>>>(img_hwc, n, mean3_h[0], mean3_h[1], mean3_h[2], out);
+    return check_launch("preprocess_u8");
 }
 
 }  // extern "C"

@@ -47,6 +47,19 @@ def _ws(nbytes):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
 
 
+def preprocess_u8(img_u8, mean_bgr):
+    """(H,W,3) uint8 BGR image (numpy or device tensor) -> (1,H,W,3) f32 device tensor = float64(img) - mean, cast to f32
+    (resnet.preprocess followed by the network's f32 input cast, bit for bit)."""
+    _require_gpu()
+    t = img_u8 if isinstance(img_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img_u8, dtype=np.uint8))
+    t = t.to(device="cuda").contiguous()
+    assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3
+    out = torch.empty((1,) + tuple(t.shape), dtype=torch.float32, device="cuda")
+    mean = (ctypes.c_double * 3)(*[float(v) for v in mean_bgr])
+    _lib.call("frcnn_preprocess_u8", _p(t), t.shape[0] * t.shape[1], mean, _p(out), _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- anchors
 def anchors_image(rows, cols, anchor_hw, stride):
     _require_gpu()

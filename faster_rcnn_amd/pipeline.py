@@ -83,6 +83,13 @@ class InferencePipeline:
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
 
+    def replay_u8(self, img_u8_bgr, mean_bgr=(103.939, 116.779, 123.68)):
+        """Replay on a raw (H,W,3) uint8 BGR image: 3 bytes per pixel cross PCIe, resnet.preprocess runs on the device
+        (bit-identical to the host path) straight into the graph's input tensor."""
+        self._static_in.copy_(ops.preprocess_u8(img_u8_bgr, mean_bgr))
+        self._graph.replay()
+        return self._static_out
+
     def replay(self, x=None):
         if x is not None:
             self._static_in.copy_(x)

@@ -43,6 +43,10 @@ int frcnn_version(void);
 int frcnn_device_count(void);
 
 /* ------------------------------------------------------------------ anchors */
+/* resnet.preprocess / vgg.preprocess (resnet.py:64-75; vgg.py:52-57): out[p][c] = (float)((double)img[p][c] - mean[c])
+ * for an interleaved 3-channel u8 image (BGR as cv2.imread delivers it); mean3_h is a HOST array of 3 doubles.
+ * Bit-identical to the host path (float64 subtraction, one rounding to f32). */
+int frcnn_preprocess_u8(const uint8_t* img_hwc, size_t n_pixels, const double* mean3_h, float* out, void* stream);
 /* rpn_util._get_all_anchor_coords (rpn_util.py:276-298): all anchors in image pixels.
  * anchor_hw_h: host [A][2] = {height, width} (util.get_anchors, util.py:242-253).
  * out: [rows*cols*A][4] f32. */

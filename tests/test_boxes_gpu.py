@@ -316,3 +316,12 @@ def test_detections_device(ops):
     # nothing above threshold
     out = ops.detections(dev(rois), dev(np.array([n], np.int32)), dev(g["out_cls"][:n]), dev(g["out_reg"][:n]), 64, 20, 2.0, 16.0, 1.0)
     assert int(out["n_dets"].item()) == 0
+
+
+def test_preprocess_u8_is_bit_identical_to_the_host_path(ops):
+    from faster_rcnn_amd import resnet
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    want = resnet.preprocess(img)[None].astype(np.float32)             # float64(img) - mean, then the f32 input cast
+    got = ops.preprocess_u8(img, (103.939, 116.779, 123.68)).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
