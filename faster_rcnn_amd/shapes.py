@@ -4,7 +4,8 @@ Only what the hot path touches: ``Image`` (metadata view: width/height/gt_boxes/
 ``resize_within_bounds``, ``horizontal_flip``), ``InMemoryImage``, ``Metadata``,
 ``GroundTruthBox`` and ``Box`` with the reference's arithmetic (float coordinates after a
 resize, ``x -> width - x`` flip without -1, shapes.py:298).  Pixel decode (cv2.imread +
-INTER_CUBIC, shapes.py:19-29) is an f2 "next" row: ``Image.data`` here uses PIL when a file is
+INTER_CUBIC, shapes.py:19-29) is an f2 "next" row: the resize restates OpenCV's fixed-point INTER_CUBIC (unpinned:
+no cv2 here); ``Image.data`` decodes with PIL when a file is
 given and is NOT bit-identical to OpenCV's resampler; synthetic configs use InMemoryImage.
 """
 import numpy as np
@@ -130,8 +131,45 @@ class InMemoryImage:
         return self.resize(ratio), ratio
 
 
+def _cubic_taps(dst, src):
+    """OpenCV resize(INTER_CUBIC) tap table for one axis (imgproc/resize.cpp, 8-bit path): source coordinate
+    f = (d + 0.5) * src / dst - 0.5, s = floor(f), four taps s-1..s+2 clamped to the border (BORDER_REPLICATE), cubic
+    kernel with A = -0.75 in float32, coefficients in fixed point with 11 fractional bits (cvRound, saturate to int16)."""
+    # OpenCV: scale is a double, fx = (float)((dx + 0.5) * scale - 0.5), sx = cvFloor(fx), fx -= sx  (all in float from there)
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * (float(src) / float(dst)) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    x = f - s.astype(np.float32)
+    A = np.float32(-0.75)
+    one = np.float32(1.0)
+    c0 = ((A * (x + one) - np.float32(5) * A) * (x + one) + np.float32(8) * A) * (x + one) - np.float32(4) * A
+    c1 = ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + one
+    c2 = ((A + np.float32(2)) * (one - x) - (A + np.float32(3))) * (one - x) * (one - x) + one
+    c3 = one - c0 - c1 - c2
+    coef = np.stack([c0, c1, c2, c3], axis=1).astype(np.float32) * np.float32(2048.0)
+    icoef = np.clip(np.rint(coef), -32768, 32767).astype(np.int64)            # cvRound = round half to even
+    idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, src - 1)
+    return idx, icoef
+
+
 def _resize(img, width, height):
+    """cv2.resize(img, (width, height), interpolation=cv2.INTER_CUBIC) for uint8 images, restated in integer arithmetic
+    (shapes.py:24 of the reference resizes every image this way).  OpenCV is not installable here, so this follows the
+    published algorithm (separable, horizontal then vertical, 22-bit fixed point, FixedPtCast rounding) and is NOT
+    pinned against cv2 output; OpenCV's SIMD vertical pass rounds through float and may differ by one grey level."""
     if img.shape[0] == height and img.shape[1] == width:
         return img
-    from PIL import Image as PilImage
-    return np.asarray(PilImage.fromarray(np.ascontiguousarray(img)).resize((width, height), PilImage.BICUBIC))
+    src = np.ascontiguousarray(img)
+    squeeze = src.ndim == 2
+    if squeeze:
+        src = src[:, :, None]
+    xi, xa = _cubic_taps(width, src.shape[1])
+    yi, yb = _cubic_taps(height, src.shape[0])
+    rows = src.astype(np.int64)
+    horiz = np.zeros((src.shape[0], width, src.shape[2]), dtype=np.int64)
+    for k in range(4):
+        horiz += rows[:, xi[:, k], :] * xa[None, :, k, None]
+    out = np.zeros((height, width, src.shape[2]), dtype=np.int64)
+    for k in range(4):
+        out += horiz[yi[:, k], :, :] * yb[:, k, None, None]
+    out = np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if squeeze else out
