@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
     if (r < n) {
         const float* pc = out_cls + (size_t)r * C;
         int best = 0; float bv = pc[0];
+#pragma unroll 8
         for (int c = 1; c < C; ++c) { const float v = pc[c]; if (v > bv) { bv = v; best = c; } }   // np.argmax: first max
         if (best != bg_idx && !(bv < det_threshold)) {
             cls = best; conf = bv;
@@ -88,6 +89,7 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
     int rank = -1;
     if (cls >= 0) {
         rank = 0;
+#pragma unroll 8
         for (int j = 0; j < n; ++j) {
             const float pj = u_prob[j];
             rank += (u_cls[j] >= 0) && (pj > conf || (pj == conf && j < r));
@@ -105,8 +107,11 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
         for (int w = 0; w < W; ++w) {
             u64 bits = 0;
             const int j0 = w * 64, jn = min(64, nv - j0);
-            for (int j = 0; j < jn; ++j)
-                if (j0 + j > r && s_cls[j0 + j] == mc && det_suppresses(me, s_box[j0 + j], nms_thresh)) bits |= 1ull << j;
+            if (j0 + 63 > r) {                              // words wholly at or below the diagonal are never read
+#pragma unroll 4
+                for (int j = max(0, r + 1 - j0); j < jn; ++j)
+                    if (s_cls[j0 + j] == mc && det_suppresses(me, s_box[j0 + j], nms_thresh)) bits |= 1ull << j;
+            }
             s_mask[r][w] = bits;
         }
     }
@@ -134,23 +139,32 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
             }
             if (r == 0) s_kept[c] = kept;
             u64 k = kept;
-            while (k) {
-                const int b = __builtin_ctzll(k);
-                k &= k - 1;
-                if (r > c && r < W) removed |= s_mask[base + b][r];
+            while (k) {                      // four kept rows per round: independent LDS reads in flight together
+                u64 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool has = k != 0;
+                    const int b = has ? __builtin_ctzll(k) : 0;
+                    k = has ? k & (k - 1) : 0;
+                    v[u] = (has && r > c && r < W) ? s_mask[base + b][r] : 0ull;
+                }
+                removed |= (v[0] | v[1]) | (v[2] | v[3]);
             }
         }
     }
     __syncthreads();
 
     // ---- 5. emission order: classes by first-seen RoI index, NMS pick order inside a class
+    int* s_fj = reinterpret_cast<int*>(&s_mask[0][0]);     // the mask is dead after the scan: per-row class rank key
     const bool kept = r < nv && ((s_kept[r >> 6] >> (r & 63)) & 1);
+    if (r < nv) s_fj[r] = kept ? s_first[s_cls[r]] : 0x7fffffff;      // dropped rows sort behind everything
+    __syncthreads();
     if (kept) {
         const int mc = s_cls[r], mf = s_first[mc];
         int pos = 0;
+#pragma unroll 8
         for (int j = 0; j < nv; ++j) {
-            if (!((s_kept[j >> 6] >> (j & 63)) & 1)) continue;
-            const int fj = s_first[s_cls[j]];
+            const int fj = s_fj[j];
             pos += (fj < mf) || (fj == mf && j < r);
         }
         const double4 b = s_box[r];
