@@ -105,3 +105,22 @@ def test_cubic_resize_restates_opencv_fixed_point():
     ours = shapes._resize(smooth, 160, 120).astype(int)
     pil = np.asarray(PilImage.fromarray(smooth).resize((160, 120), PilImage.BICUBIC)).astype(int)
     assert np.abs(ours - pil).max() <= 6 and np.abs(ours - pil).mean() < 1.0
+
+
+def test_voc_eval_matches_the_reference(tmp_path, capsys):
+    """eval_dets.voc_eval against (rec, prec, ap) captured from the imported reference on the VOC_test fixture
+    (tests/golden/make_golden_eval.py): hits, duplicates, near misses, a 'difficult' object, a class with no objects."""
+    from faster_rcnn_amd import eval_dets
+    g = np.load(os.path.join(GOLD, "eval_dets.npz"))
+    voc = os.path.join(GOLD, "VOC_test")
+    imageset = os.path.join(voc, "ImageSets", "Main", "trainval.txt")
+    for cls in ("chair", "dog"):
+        f = tmp_path / ("comp3_det_test_%s.txt" % cls)
+        f.write_text("\n".join(str(s) for s in g["lines_" + cls]) + "\n")
+        rec, prec, ap = eval_dets.voc_eval(voc, str(f), imageset, cls)
+        assert np.array_equal(rec, g["rec_" + cls], equal_nan=True)
+        assert np.array_equal(prec, g["prec_" + cls])
+        assert ap == float(g["ap_" + cls])
+    aps = eval_dets.eval_all(str(tmp_path), voc, {"chair": 0, "dog": 1, "bg": 2}, img_set="trainval")
+    assert aps == [float(g["ap_chair"]), float(g["ap_dog"])]
+    assert "Mean AP" in capsys.readouterr().out
