@@ -81,3 +81,52 @@ def write_dets(dets, out_dir):
                 for det in dets[cls_name][image_name]:
                     x1, y1, x2, y2 = det["bbox"] + 1
                     outfile.write("{} {} {} {} {} {}\n".format(image_name, det["prob"], x1, y1, x2, y2))
+
+
+def build_parser():
+    """The reference's command line (voc_dets.py:132-160): two positional checkpoints + the same flags."""
+    import argparse
+    p = argparse.ArgumentParser(description="Run the RPN + detector over a VOC-style image set and write comp3_det_test_<cls>.txt files")
+    p.add_argument("step3_model_path", help="weights of the RPN trained in step 3 (Keras .h5 or this package's .npz)")
+    p.add_argument("step4_model_path", help="weights of the detector trained in step 4 (must share the RPN's base)")
+    p.add_argument("--voc_path", dest="voc_path", required=True, help="base path of the VOC-style test set")
+    p.add_argument("--kitti", dest="kitti", action="store_true", help="KITTI classes instead of Pascal VOC")
+    p.add_argument("--img_set", dest="img_set", choices=("val", "test", "trainval"), default="val")
+    p.add_argument("--resize_dims", dest="resize_dims", default="600,1000")
+    p.add_argument("--anchor_scales", dest="anchor_scales", default="128,256,512")
+    p.add_argument("--network", dest="network", choices=("vgg16", "resnet50", "resnet101"), default="vgg16")
+    p.add_argument("--out_dir", dest="out_dir", default=".")
+    p.add_argument("--det_threshold", dest="det_threshold", default=DEFAULT_DET_THRESHOLD)
+    return p
+
+
+def main(argv=None):
+    """voc_dets.py:161-192: load the two models, resize the image set, detect, write the per-class files."""
+    from . import resnet, vgg
+    from .args_util import anchor_scales_from_str, base_paths_to_imgs, resize_dims_from_str
+    from .data.voc_data_helpers import KITTI_CLASS_MAPPING, VOC_CLASS_MAPPING
+    from .util import get_anchors, resize_imgs
+    args = build_parser().parse_args(argv)
+    test_imgs = base_paths_to_imgs(args.voc_path, img_set=args.img_set, do_flip=False)
+    anchors = get_anchors(anchor_scales_from_str(args.anchor_scales))
+    print("num test_imgs: ", len(test_imgs))
+    class_mapping = KITTI_CLASS_MAPPING if args.kitti else VOC_CLASS_MAPPING
+    if args.network == "vgg16":
+        model_rpn = vgg.rpn_from_h5(args.step3_model_path, anchors_per_loc=len(anchors))
+        model_det = vgg.det_from_h5(args.step4_model_path, num_classes=len(class_mapping))
+        stride, preprocess = vgg.STRIDE, vgg.preprocess
+    else:
+        depth = 50 if args.network == "resnet50" else 101
+        model_rpn = resnet.rpn_from_h5(args.step3_model_path, anchors_per_loc=len(anchors), depth=depth)
+        model_det = resnet.det_from_h5(args.step4_model_path, num_classes=len(class_mapping), depth=depth)
+        stride, preprocess = resnet.STRIDE, resnet.preprocess
+    manager = DetTrainingManager(rpn_model=model_rpn, class_mapping=class_mapping, preprocess_func=preprocess, anchor_dims=anchors)
+    resize_min, resize_max = resize_dims_from_str(args.resize_dims)
+    processed_imgs, resized_ratios = resize_imgs(test_imgs, min_size=resize_min, max_size=resize_max)
+    dets = get_dets_by_cls(manager, model_det, resized_ratios, processed_imgs, stride=stride, det_threshold=float(args.det_threshold))
+    write_dets(dets, args.out_dir)
+    return dets
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,7 @@
 """GPU end-to-end parity through the reference-shaped Python surface (managers, get_dets) and
 the fused device pipeline.  Discrete stages (masks, indices, NMS picks, final boxes) are checked
 bit-exactly given identical inputs; float stages within 1e-4 of the f64 oracle."""
+import os
 import random
 
 import numpy as np
@@ -236,3 +237,40 @@ def test_full_size_c2_properties():
     assert int(plain["n_rois"].item()) == n
     assert (plain["cls"][:n] - ref_cls[:n]).abs().max().item() < 1e-4
     assert ((plain["reg"][:n] - out["reg"][:n]).abs() / out["reg"][:n].abs().clamp(min=1.0)).max().item() < 1e-4
+
+
+def test_voc_dets_cli_to_eval_dets_round_trip(tmp_path, capsys):
+    """The reference's inference workflow end to end: Keras-format .h5 checkpoints in (h5lite writer / reader),
+    `voc_dets` CLI over the VOC_test fixture (decode, resize, RPN, proposals, detector, per-class files), `eval_dets`
+    scoring of those files.  Random weights: the numbers mean nothing, the path and the file formats are the subject."""
+    from faster_rcnn_amd import eval_dets, voc_dets
+    from faster_rcnn_amd.data.voc_data_helpers import VOC_CLASS_MAPPING
+    from faster_rcnn_amd.weights import save_weights_file, synthetic_resnet
+    w = synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=3)
+    rpn_h5, det_h5 = str(tmp_path / "rpn_step3.h5"), str(tmp_path / "det_step4.h5")
+    save_weights_file(rpn_h5, w)
+    save_weights_file(det_h5, w, full_model=True)
+    voc = os.path.join(os.path.dirname(__file__), "golden", "VOC_test")
+    out_dir = str(tmp_path / "dets")
+    dets = voc_dets.main([rpn_h5, det_h5, "--voc_path", voc, "--img_set", "trainval", "--network", "resnet50",
+                          "--out_dir", out_dir, "--det_threshold", "0.0"])
+    files = sorted(os.listdir(out_dir))
+    assert files and all(f.startswith("comp3_det_test_") and f.endswith(".txt") for f in files)
+    n_lines = 0
+    for cls_name, per_image in dets.items():
+        lines = open(os.path.join(out_dir, "comp3_det_test_%s.txt" % cls_name)).read().split("\n")[:-1]
+        assert len(lines) == sum(len(v) for v in per_image.values())
+        for line in lines:
+            name, prob, x1, y1, x2, y2 = line.split(" ")
+            assert name == "000005" and 0.0 <= float(prob) <= 1.0 and int(x2) >= int(x1) and int(y2) >= int(y1)
+        n_lines += len(lines)
+    assert n_lines > 0
+    for cls_name in VOC_CLASS_MAPPING:                       # eval_all wants one file per class
+        path = eval_dets.get_voc_results_filename(out_dir, cls_name)
+        if cls_name != "bg" and not os.path.exists(path):
+            open(path, "w").close()
+    # a class without detections: the reference's parser would choke on an empty file too -> score the classes present
+    present = {c: i for c, i in VOC_CLASS_MAPPING.items() if c in dets}
+    aps = eval_dets.eval_all(out_dir, voc, present, img_set="trainval")
+    assert len(aps) == len(present) and all(0.0 <= a <= 1.0 for a in aps)
+    capsys.readouterr()
