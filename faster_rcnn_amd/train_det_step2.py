@@ -6,7 +6,8 @@ prefix with torchrun for N-GPU data parallelism.
 """
 import argparse
 
-from . import dp, resnet
+from . import dp
+from ._networks import NETWORKS, Family
 from .args_util import anchor_scales_from_str, base_paths_to_imgs, optimizer_from_str, phases_from_str, resize_dims_from_str
 from .data.voc_data_helpers import KITTI_CLASS_MAPPING, VOC_CLASS_MAPPING
 from .det_util import DetTrainingManager
@@ -23,7 +24,7 @@ def build_parser():
     p.add_argument("--optimizer", dest="optimizer", choices=("adam", "sgd"), default="sgd")
     p.add_argument("--kitti", dest="kitti", action="store_true")
     p.add_argument("--img_set", dest="img_set", choices=("train", "val", "trainval", "test"), default="trainval")
-    p.add_argument("--network", dest="network", choices=("resnet50", "resnet101"), default="resnet50")
+    p.add_argument("--network", dest="network", choices=NETWORKS, default="vgg16")
     p.add_argument("--resize_dims", dest="resize_dims", default="600,1000")
     p.add_argument("--anchor_scales", dest="anchor_scales", default="128,256,512")
     p.add_argument("--save_weights_dest", dest="save_weights_dest", default=None)
@@ -43,21 +44,19 @@ def main(argv=None):
     processed_imgs, _ = resize_imgs(train_imgs, min_size=resize_min, max_size=resize_max)
     class_mapping = KITTI_CLASS_MAPPING if args.kitti else VOC_CLASS_MAPPING
     num_classes = len(class_mapping)
-    depth = 50 if args.network == "resnet50" else 101
-    from .weights import load_npz, synthetic_resnet
-    base_fn = resnet.resnet50_base if depth == 50 else resnet.resnet101_base
-    cls_fn = resnet.resnet50_classifier if depth == 50 else resnet.resnet101_classifier
+    net = Family(args.network)
+    from .weights import load_npz
     rpn_weights = load_npz(args.step1_weights_path)
-    rpn_model = resnet.resnet50_rpn(base_fn(weights=rpn_weights), anchors_per_loc=len(anchors))        # frozen, not regularised
-    det_weights = load_npz(args.init_weights) if args.init_weights else synthetic_resnet(depth, anchors_per_loc=len(anchors), num_classes=num_classes)
-    detector_base = base_fn(weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, weights=det_weights,
-                            dtype="bf16" if args.bf16 else "f32")
-    detector_model = cls_fn(NUM_ROIS, num_classes, detector_base, weight_regularizer=resnet.WEIGHT_REGULARIZER,
-                            bias_regularizer=resnet.BIAS_REGULARIZER)
-    save_weights_dest = args.save_weights_dest or "models/detector_weights_{}_step2.npz".format(args.network)
-    save_model_dest = args.save_model_dest or "models/detector_model_{}_step2.npz".format(args.network)
-    manager = DetTrainingManager(rpn_model=rpn_model, class_mapping=class_mapping, preprocess_func=resnet.preprocess,
-                                 stride=resnet.STRIDE, anchor_dims=anchors)
+    rpn_model = net.rpn(net.base(weights=rpn_weights), anchors_per_loc=len(anchors))        # frozen, not regularised
+    det_weights = load_npz(args.init_weights) if args.init_weights else net.synthetic_weights(len(anchors), num_classes)
+    detector_base = net.base(weight_regularizer=net.weight_regularizer, bias_regularizer=net.bias_regularizer, weights=det_weights,
+                             **net.base_kwargs(args.bf16))
+    detector_model = net.classifier(NUM_ROIS, num_classes, detector_base, weight_regularizer=net.weight_regularizer,
+                                    bias_regularizer=net.bias_regularizer)
+    save_weights_dest = args.save_weights_dest or "models/detector_weights_{}_step2.h5".format(args.network)
+    save_model_dest = args.save_model_dest or "models/detector_model_{}_step2.h5".format(args.network)
+    manager = DetTrainingManager(rpn_model=rpn_model, class_mapping=class_mapping, preprocess_func=net.preprocess,
+                                 stride=net.stride, anchor_dims=anchors)
     train_detector_step2(detector_model, processed_imgs, manager, optimizer_from_str(args.optimizer), phases=phases_from_str(args.phases),
                          save_frequency=2000, save_weights_dest=save_weights_dest, save_model_dest=save_model_dest)
     if dp.rank() == 0:

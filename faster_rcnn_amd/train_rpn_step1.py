@@ -8,7 +8,8 @@ RCCL all-reduce of the flat gradient buffer).
 """
 import argparse
 
-from . import dp, resnet
+from . import dp
+from ._networks import NETWORKS, Family
 from .args_util import anchor_scales_from_str, base_paths_to_imgs, optimizer_from_str, phases_from_str, resize_dims_from_str
 from .rpn_util import RpnTrainingManager
 from .train_util import train_rpn
@@ -21,7 +22,7 @@ def build_parser():
     p.add_argument("--phases", dest="phases", default="60000:1e-3,20000:1e-4")
     p.add_argument("--optimizer", dest="optimizer", choices=("adam", "sgd"), default="sgd")
     p.add_argument("--img_set", dest="img_set", choices=("train", "val", "trainval", "test"), default="trainval")
-    p.add_argument("--network", dest="network", choices=("resnet50", "resnet101"), default="resnet50")
+    p.add_argument("--network", dest="network", choices=NETWORKS, default="vgg16")
     p.add_argument("--resize_dims", dest="resize_dims", default="600,1000")
     p.add_argument("--anchor_scales", dest="anchor_scales", default="128,256,512")
     p.add_argument("--save_weights_dest", dest="save_weights_dest", default=None)
@@ -39,22 +40,23 @@ def main(argv=None):
     resize_min, resize_max = resize_dims_from_str(args.resize_dims)
     anchors = get_anchors(anchor_scales_from_str(args.anchor_scales))
     processed_imgs, _ = resize_imgs(train_imgs, min_size=resize_min, max_size=resize_max)
-    depth = 50 if args.network == "resnet50" else 101
-    from .weights import load_npz, synthetic_resnet
-    weights = load_npz(args.init_weights) if args.init_weights else synthetic_resnet(depth, anchors_per_loc=len(anchors))
-    base_fn = resnet.resnet50_base if depth == 50 else resnet.resnet101_base
-    base_model = base_fn(weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, weights=weights,
-                         dtype="bf16" if args.bf16 else "f32")
-    rpn_model = resnet.resnet50_rpn(base_model, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER,
-                                    anchors_per_loc=len(anchors))
-    save_weights_dest = args.save_weights_dest or "models/rpn_weights_{}_step1.npz".format(args.network)
-    save_model_dest = args.save_model_dest or "models/rpn_model_{}_step1.npz".format(args.network)
-    manager = RpnTrainingManager(resnet.get_conv_rows_cols, resnet.STRIDE, preprocess_func=resnet.preprocess, anchor_dims=anchors)
+    net = Family(args.network)
+    from .weights import load_npz
+    weights = load_npz(args.init_weights) if args.init_weights else net.synthetic_weights(len(anchors))
+    base_model = net.base(weight_regularizer=net.weight_regularizer, bias_regularizer=net.bias_regularizer, weights=weights,
+                          **net.base_kwargs(args.bf16))
+    rpn_model = net.rpn(base_model, weight_regularizer=net.weight_regularizer, bias_regularizer=net.bias_regularizer,
+                        anchors_per_loc=len(anchors))
+    save_weights_dest = args.save_weights_dest or "models/rpn_weights_{}_step1.h5".format(args.network)
+    save_model_dest = args.save_model_dest or "models/rpn_model_{}_step1.h5".format(args.network)
+    manager = RpnTrainingManager(net.conv_dims, net.stride, preprocess_func=net.preprocess, anchor_dims=anchors)
     train_rpn(rpn_model, processed_imgs, manager, optimizer_from_str(args.optimizer), phases=phases_from_str(args.phases),
               save_frequency=2000, save_weights_dest=save_weights_dest, save_model_dest=save_model_dest)
     if dp.rank() == 0:
         rpn_model.save_weights(save_weights_dest)
         print("Saved {} rpn weights to {}".format(args.network, save_weights_dest))
+        rpn_model.save(save_model_dest)
+        print("Saved {} rpn model to {}".format(args.network, save_model_dest))
 
 
 if __name__ == "__main__":

@@ -3,7 +3,8 @@ the RPN heads on top of the step-2 detector's base, every base block frozen and 
 
     python -m faster_rcnn_amd.train_rpn_step3 --step2_weights_path models/detector_weights_resnet50_step2.npz --voc_paths ...
 """
-from . import dp, resnet
+from . import dp
+from ._networks import Family
 from .args_util import anchor_scales_from_str, base_paths_to_imgs, optimizer_from_str, phases_from_str, resize_dims_from_str
 from .rpn_util import RpnTrainingManager
 from .train_rpn_step1 import build_parser as _step1_parser
@@ -26,17 +27,16 @@ def main(argv=None):
     resize_min, resize_max = resize_dims_from_str(args.resize_dims)
     anchors = get_anchors(anchor_scales_from_str(args.anchor_scales))
     processed_imgs, _ = resize_imgs(train_imgs, min_size=resize_min, max_size=resize_max)
-    depth = 50 if args.network == "resnet50" else 101
-    from .weights import load_npz, synthetic_resnet
-    weights = load_npz(args.init_weights) if args.init_weights else synthetic_resnet(depth, anchors_per_loc=len(anchors))
-    base_fn = resnet.resnet50_base if depth == 50 else resnet.resnet101_base
-    rpn_base = base_fn(freeze_blocks=[1, 2, 3, 4], weights=weights)                      # train_rpn_step3.py:70
-    rpn_model = resnet.resnet50_rpn(rpn_base, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER,
-                                    anchors_per_loc=len(anchors))
+    net = Family(args.network)
+    from .weights import load_npz
+    weights = load_npz(args.init_weights) if args.init_weights else net.synthetic_weights(len(anchors))
+    rpn_base = net.base(freeze_blocks=net.freeze_all, weights=weights)                   # train_rpn_step3.py:60,68,75
+    rpn_model = net.rpn(rpn_base, weight_regularizer=net.weight_regularizer, bias_regularizer=net.bias_regularizer,
+                        anchors_per_loc=len(anchors))
     if args.step2_weights_path is not None:
         rpn_model.load_weights(args.step2_weights_path, by_name=True)
-    save_weights_dest = args.save_weights_dest or "models/rpn_weights_{}_step3.npz".format(args.network)
-    manager = RpnTrainingManager(resnet.get_conv_rows_cols, resnet.STRIDE, preprocess_func=resnet.preprocess, anchor_dims=anchors)
+    save_weights_dest = args.save_weights_dest or "models/rpn_weights_{}_step3.h5".format(args.network)
+    manager = RpnTrainingManager(net.conv_dims, net.stride, preprocess_func=net.preprocess, anchor_dims=anchors)
     train_rpn(rpn_model, processed_imgs, manager, optimizer_from_str(args.optimizer), phases=phases_from_str(args.phases),
               save_frequency=2000, save_weights_dest=save_weights_dest, save_model_dest=args.save_model_dest)
     if dp.rank() == 0:

@@ -270,3 +270,29 @@ def test_vgg16_det_step2_and_resnet_steps_3_4():
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (losses, ref_losses)
     det._trainer.sync_weights()
     check_updates(old, det.weights, ref_w, kt.conv_layer_names(50, [5]) + ["dense_class_21", "dense_reg_21"])
+
+
+@pytest.mark.parametrize("network", ["resnet50", "vgg16"])
+def test_four_step_scripts_chain(tmp_path, network, capsys):
+    """The reference's 4-step alternating training driven through the entry scripts with their own flags (two
+    iterations each on the VOC_test fixture, small resize): every step reads the Keras-format .h5 the previous one
+    wrote (h5lite), and the final pair feeds voc_dets."""
+    import os
+    from faster_rcnn_amd import h5lite, train_det_step2, train_det_step4, train_rpn_step1, train_rpn_step3, voc_dets
+    voc = os.path.join(os.path.dirname(__file__), "golden", "VOC_test")
+    common = ["--voc_paths", voc, "--network", network, "--phases", "2:1e-4", "--resize_dims", "208,288", "--img_set", "trainval"]
+    f = lambda n: str(tmp_path / n)
+    train_rpn_step1.main(common + ["--save_weights_dest", f("rpn1.h5"), "--save_model_dest", f("rpn1_model.h5")])
+    assert h5lite.is_hdf5(f("rpn1.h5")) and "rpn_conv1" in h5lite.read_keras_weights(f("rpn1_model.h5"))
+    train_det_step2.main([f("rpn1.h5")] + common + ["--save_weights_dest", f("det2.h5"), "--save_model_dest", f("det2_model.h5")])
+    train_rpn_step3.main(common + ["--step2_weights_path", f("det2.h5"), "--save_weights_dest", f("rpn3.h5"), "--save_model_dest", f("rpn3_model.h5")])
+    train_det_step4.main([f("rpn3.h5")] + common + ["--init_weights", f("det2.h5"), "--save_weights_dest", f("det4.h5"),
+                                                    "--save_model_dest", f("det4_model.h5"), "--save_rpn_model_dest", f("rpn3_again.h5")])
+    w3, w4 = h5lite.read_keras_weights(f("rpn3.h5")), h5lite.read_keras_weights(f("det4.h5"))
+    assert "rpn_out_cls" in w3 and any(k.startswith("dense_class_") for k in w4)
+    first = "block1_conv1" if network == "vgg16" else "conv1"
+    assert np.array_equal(w3[first][0], h5lite.read_keras_weights(f("rpn1.h5"))[first][0])       # frozen layers never move
+    dets = voc_dets.main([f("rpn3.h5"), f("det4.h5"), "--voc_path", voc, "--img_set", "trainval", "--network", network,
+                          "--resize_dims", "208,288", "--out_dir", f("dets")])
+    assert isinstance(dets, dict)
+    capsys.readouterr()
