@@ -21,7 +21,7 @@ def check_updates(old, got, want, names, tol_fro=3e-2, tol_max=0.2):
     also cannot resolve an update below an ulp of the weight.
     Sizing of the bars: ONE flipped ReLU element in a 12x16x512 activation changes that layer's input
     gradient by 1/sqrt(#nonzero) ~ 0.5-1 % in Frobenius norm, and every layer below inherits it (measured
-    on VGG block4_conv2 with scripts/debug_vgg_base.py: kernel vs conv_transpose 4.6e-7, one mask
+    on VGG block4_conv2 with tests/tools/debug_vgg_base.py: kernel vs conv_transpose 4.6e-7, one mask
     mismatch, 0.9 % gradient difference).  The kernels themselves are held to 1e-4 by test_conv_bwd_gpu."""
     for n in names:
         for o, g, w in zip(old[n], got[n], want[n]):

@@ -6,7 +6,7 @@ tolerances are the test suite's (f32: 1e-4 * max(1, |x|))."""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import torch.nn.functional as F
