@@ -230,6 +230,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32(const ConvArgs p) {
 //     instructions issue in the shadow of the wave's own MFMAs instead of in a separate
 //     phase (v1: matrix pipe 79 % busy on a 2-wave SIMD, both waves stalling in lockstep).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x3 __attribute__((ext_vector_type(3)));
 constexpr unsigned OOB_OFFSET = 0x80000000u;     // >= num_records of any tensor we accept (< 2 GiB)
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
@@ -241,7 +242,13 @@ constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100,
 // it with ONE agent-scope release and draws a ticket; the workgroup that draws the last ticket acquires, sums
 // the slabs in slice order (fixed order: two runs are bitwise equal) and runs the fused epilogue.  One launch,
 // no atomics on data (cdna guide s5 "in-launch split-K reduction").
-template <int TM, int TN, int VARIANT = 0, int WM = 2, int WN = 2, bool SPLITK = false>
+//
+// CIN3: the 3-channel stems (ResNet conv1 7x7, VGG block1_conv1 3x3).  The filter is packed as if the image had FOUR
+// channels (k = tap*4 + c, c == 3 a zero column, see packed_k), so a 32-wide chunk is eight taps and each of the eight
+// lanes that stage a row fetches ITS tap of its pixel with one 12-byte buffer load (per-lane r, s instead of the
+// wave-uniform tap walk) and appends a zero.  Taps beyond R*S load nothing.  Replaces the per-element gather of the
+// v1 kernel for these layers.
+template <int TM, int TN, int VARIANT = 0, int WM = 2, int WN = 2, bool SPLITK = false, bool CIN3 = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvArgs p) {
     // WM x WN waves, each owning TM x TN 32x32 tiles.  2x2 waves (256 threads) is the base shape; 4x2 waves
     // (512 threads) on the same 128x128 tile halves the registers per wave so FOUR waves share a SIMD
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
             else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
             a_h[i] = ho * p.stride - p.pad_top;
             a_w[i] = wo * p.stride - p.pad_left;
-            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * 4;     // may be "negative" in the halo
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + (CIN3 ? 0 : lcol)) * 4;     // may be "negative" in the halo
         } else {
             a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
         }
@@ -319,7 +326,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
     const int n_taps = __popc(tap_mask);
 
     // this workgroup's chunk range [kb, ke) of the (channel group, needed tap) sequence
-    const int nk_all = (p.Kpad / (BK * RS)) * n_taps;
+    const int nk_all = CIN3 ? p.Kpad / BK : (p.Kpad / (BK * RS)) * n_taps;
     const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
     const int ke = SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all;
 
@@ -331,7 +338,25 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
         c0 = grp * BK; w_grp = grp * RS * (BK * 4);
         for (int t = kb - grp * n_taps; t > 0; --t) rem &= rem - 1;
     }
+    int kc3 = kb;                                            // CIN3: next chunk (of eight taps) to load
     auto load_chunk = [&](int) {
+        if constexpr (CIN3) {
+            const int tap = kc3 * 8 + (tid & 7);             // per lane: this lane's tap of the chunk
+            const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+            const int tap_off = (r_tap * p.W + s_tap) * 12;  // 3 channels x 4 bytes per pixel
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], kc3 * (BK * 4), 0);
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+                const bool ok = tap < RS && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const i32x3 v = __builtin_amdgcn_raw_buffer_load_b96(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0);
+                ra[i] = i32x4{v[0], v[1], v[2], 0};
+            }
+            ++kc3;
+            return;
+        }
         const int tap = __builtin_ctz(rem);                  // wave-uniform
         const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
         const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 4;
@@ -513,12 +538,20 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
 // ------------------------------------------------------------------------------------
 // filter packing: Keras HWIO [R][S][Cin][Cout] -> [Cout][Kpad].
 //   Cin % 32 == 0 : packed k = ((c/32)*R*S + tap)*32 + c%32   (channel chunk outer, tap inner)
+//   Cin == 3      : packed k = tap*4 + c, c == 3 and taps >= R*S zero (the stem kernel stages eight taps per chunk)
 //   otherwise     : packed k = tap*Cin + c, zero padded to Kpad  (small-Cin path decodes k itself)
+__host__ __device__ __forceinline__ int packed_k(int RS, int Cin) {
+    return ((Cin == 3 ? RS * 4 : RS * Cin) + BK - 1) / BK * BK;
+}
 __device__ __forceinline__ float pack_hwio_elem(const float* w, int RS, int Cin, int Cout, int Kpad, size_t i) {
     const int k = (int)(i % Kpad), n = (int)(i / Kpad);
     if ((Cin % BK) == 0) {
         const int j = k % BK, kc = k / BK, tap = kc % RS, cc = kc / RS;
         return w[((size_t)tap * Cin + cc * BK + j) * Cout + n];
+    }
+    if (Cin == 3) {
+        const int tap = k >> 2, c = k & 3;
+        return (c < 3 && tap < RS) ? w[((size_t)tap * 3 + c) * Cout + n] : 0.0f;
     }
     return k < RS * Cin ? w[(size_t)k * Cout + n] : 0.0f;
 }
@@ -540,6 +573,7 @@ __device__ __forceinline__ float pack_dgrad_elem(const float* w, const float* sc
     const int k = (int)(i % Kpad), ci = (int)(i / Kpad);
     int tap, co;
     if ((Cout % BK) == 0) { const int j = k % BK, kc = k / BK; tap = kc % RS; co = (kc / RS) * BK + j; }
+    else if (Cout == 3) { tap = k >> 2; co = k & 3; if (co == 3 || tap >= RS) return 0.0f; }
     else { if (k >= RS * Cout) return 0.0f; tap = k / Cout; co = k % Cout; }
     const int r = R - 1 - tap / S, sx = S - 1 - tap % S;
     return w[((size_t)(r * S + sx) * Cin + ci) * Cout + co] * (scale ? scale[co] : 1.0f);
@@ -583,12 +617,12 @@ __global__ void __launch_bounds__(256) k_refresh_packed(const RefreshTable t) {
             __syncthreads();
         }
     } else if (j.packed) {
-        const int Kpad = (RS * j.cin + BK - 1) / BK * BK;
+        const int Kpad = packed_k(RS, j.cin);
         const size_t total = (size_t)j.cout * Kpad;
         for (size_t i = first; i < total; i += stride) j.packed[i] = pack_hwio_elem(j.w_hwio, RS, j.cin, j.cout, Kpad, i);
     }
     if (j.packed_dgrad) {
-        const int Kpad = (RS * j.cout + BK - 1) / BK * BK;
+        const int Kpad = packed_k(RS, j.cout);
         const size_t total = (size_t)j.cin * Kpad;
         for (size_t i = first; i < total; i += stride) j.packed_dgrad[i] = pack_dgrad_elem(j.w_hwio, j.scale, j.kh, j.kw, j.cin, j.cout, Kpad, i);
     }
@@ -968,6 +1002,15 @@ static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
     return check_launch("conv2d_fwd");
 }
 
+static int launch_conv_cin3(const ConvArgs& a, hipStream_t s) {
+    ConvArgs p = a;
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_n = (p.Cout + 63) / 64;
+    const size_t lds = (size_t)2 * (64 + 64) * LDS_STRIDE * sizeof(float);
+    k_conv_igemm_f32_v2<1, 1, 1, 2, 2, false, true><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    return check_launch("conv2d_fwd (3-channel stem)");
+}
+
 constexpr size_t SPLITK_TICKET_BYTES = 16384;      // head of the workspace: one u32 per output tile (<= 4096 tiles)
 
 template <int TM, int TN, int VARIANT = 0, int WM = 2, int WN = 2>
@@ -1048,10 +1091,7 @@ static int choose_splits(const frcnn_conv_desc* d, int cfg) {
 
 extern "C" {
 
-int frcnn_conv_packed_k(int kh, int kw, int cin) {
-    const int K = kh * kw * cin;
-    return (K + BK - 1) / BK * BK;
-}
+int frcnn_conv_packed_k(int kh, int kw, int cin) { return packed_k(kh * kw, cin); }
 
 int frcnn_pack_conv_weights(const float* w_hwio, int kh, int kw, int cin, int cout, float* packed, void* stream) {
     if (!w_hwio || !packed || kh <= 0 || kw <= 0 || cin <= 0 || cout <= 0) return fail(FRCNN_E_ARG, "pack_conv_weights: bad argument");
@@ -1107,6 +1147,11 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     const int cfg = choose_config(d);
     if (a.layout && (generic || cfg < 11 || d->kh * d->kw > 32))
         return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: position-major layout needs cin %% 32 == 0, a tensor under 2 GiB and at most 32 taps");
+    if (d->cin == 3) {                                          // the stems: filter packed 4 wide, eight taps per chunk
+        if (a.layout) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: position-major layout needs cin %% 32 == 0");
+        if ((size_t)d->n * d->h * d->w * 12 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: 3-channel input over 2 GiB");
+        return launch_conv_cin3(a, s);
+    }
     if (!generic && workspace) {
         const size_t need = frcnn_conv2d_workspace_bytes(d);
         if (need) {
