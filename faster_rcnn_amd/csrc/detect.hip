@@ -10,6 +10,7 @@
 //   cxa = f64(f32(x1+x2))/2, wa = f32(x2-x1), cx = f64(f32(tx*wa)) + cxa, w = exp(f64(tw))*f64(wa)
 // Compiled with -ffp-contract=off.
 #include "common.h"
+#include <stdlib.h>
 
 namespace frcnn {
 
@@ -183,6 +184,10 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
     __syncthreads();
     if ((r & 63) == 0 && kb) atomicAdd(&s_total, __popcll(kb));
     __syncthreads();
+    for (int i = s_total + r; i < max_rows; i += DET_MAX) {   // rows past the last detection: the same "empty" values every call
+        det_cls[i] = -1; det_prob[i] = 0.0f; det_roi[i] = -1;
+        det_bbox[4 * i + 0] = det_bbox[4 * i + 1] = det_bbox[4 * i + 2] = det_bbox[4 * i + 3] = 0;
+    }
     if (r == 0) *n_dets = s_total;
 }
 

@@ -12,6 +12,7 @@
 //        like the reference loop does.
 // Compiled with -ffp-contract=off (the f64 overlap ratio must round like numpy's).
 #include "common.h"
+#include <stdlib.h>
 
 namespace frcnn {
 
@@ -139,10 +140,17 @@ __global__ void __launch_bounds__(TOPK_BLOCK) k_topk_rank(const u64* keys, const
     if (i < n && cnt) atomicAdd(&rank[i], cnt);
 }
 
+__global__ void k_zero_u32(unsigned* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 __global__ void k_topk_scatter(const u64* keys, const int32_t* rank, const TopkCtrl* ctrl, int K, int32_t* order, int32_t* n_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < ctrl->n_cand && rank[c] < K) order[rank[c]] = (int32_t)(~(unsigned)keys[c]);
-    if (c == 0) *n_out = min(ctrl->n_valid, K);
+    const int n = min(ctrl->n_valid, K);
+    if (c >= n && c < K) order[c] = -1;                     // the tail no rank lands on
+    if (c == 0) *n_out = n;
 }
 
 __global__ void k_gather_candidates(const float4* rois, const float* scores, const int32_t* order, const int32_t* n, int K,
@@ -286,6 +294,7 @@ __global__ void __launch_bounds__(64) k_nms_scan(const u64* mask, const int32_t*
                 for (int s = 0; s < NMS_SLOTS; ++s) removed[s] |= v[u][s];
         }
     }
+    for (int i = total + lane; i < max_boxes; i += 64) keep[i] = -1;
     if (lane == 0) *n_keep = total;
 }
 
@@ -310,7 +319,8 @@ static int nms_launch(const Box4* boxes, const int32_t* n, int K, double thresh,
     if (max_boxes <= 0 || !n || !keep || !n_keep) return fail(FRCNN_E_ARG, "%s: bad argument", what);
     hipStream_t s = as_stream(stream);
     if (K == 0) {
-        if (hipMemsetAsync(n_keep, 0, 4, s) != hipSuccess) return fail(FRCNN_E_HIP, "%s: memset failed", what);
+        if (hipMemsetAsync(n_keep, 0, 4, s) != hipSuccess || hipMemsetAsync(keep, 0xFF, (size_t)max_boxes * 4, s) != hipSuccess)
+            return fail(FRCNN_E_HIP, "%s: memset failed", what);
         return FRCNN_OK;
     }
     if (!boxes) return fail(FRCNN_E_ARG, "%s: null boxes", what);
@@ -340,9 +350,11 @@ int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, in
                      void* workspace, size_t workspace_bytes, void* stream) {
     if (N < 0 || K <= 0 || !order || !n_out) return fail(FRCNN_E_ARG, "topk_order: bad argument");
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(n_out, 0, 4, s) != hipSuccess || hipMemsetAsync(order, 0xFF, (size_t)K * 4, s) != hipSuccess)
-        return fail(FRCNN_E_HIP, "topk_order: memset failed");
-    if (N == 0) return FRCNN_OK;
+    if (N == 0) {
+        if (hipMemsetAsync(n_out, 0, 4, s) != hipSuccess || hipMemsetAsync(order, 0xFF, (size_t)K * 4, s) != hipSuccess)
+            return fail(FRCNN_E_HIP, "topk_order: memset failed");
+        return FRCNN_OK;
+    }
     if (!scores) return fail(FRCNN_E_ARG, "topk_order: null scores");
     if (!workspace || workspace_bytes < frcnn_topk_workspace_bytes(N))
         return fail(FRCNN_E_WORKSPACE, "topk_order: workspace needs %zu bytes", frcnn_topk_workspace_bytes(N));
@@ -352,10 +364,16 @@ int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, in
     int32_t* rank = (int32_t*)((char*)cand + align_up((size_t)N * 8, 256));
     const int bi = (N + TOPK_BLOCK - 1) / TOPK_BLOCK;
     const int direct = N <= TOPK_DIRECT_N;
+    // The counters are cleared by a kernel, not hipMemsetAsync: captured into a hipGraph, a lone memset node between
+    // two kernel nodes was observed (ROCm 7.2, gfx950) not to be ordered against its neighbours -- k_topk_compact
+    // then appended behind the previous replay's count and ran off the end of the candidate list.
     if (direct) {
-        if (hipMemsetAsync(ctrl, 0, sizeof(TopkCtrl), s) != hipSuccess) return fail(FRCNN_E_HIP, "topk_order: memset failed");
+        k_zero_u32<<<1, 64, 0, s>>>((unsigned*)ctrl, (int)(sizeof(TopkCtrl) / 4));
+        if (int e = check_launch("topk_order reset")) return e;
     } else {
-        if (hipMemsetAsync(hist, 0, (size_t)TOPK_BINS * 4 + sizeof(TopkCtrl), s) != hipSuccess) return fail(FRCNN_E_HIP, "topk_order: memset failed");
+        const int words = TOPK_BINS + (int)(sizeof(TopkCtrl) / 4);
+        k_zero_u32<<<(words + 1023) / 1024, 1024, 0, s>>>(hist, words);
+        if (int e = check_launch("topk_order reset")) return e;
         k_topk_hist<<<bi, TOPK_BLOCK, 0, s>>>(scores, valid, N, hist, ctrl);
         if (int e = check_launch("topk_order hist")) return e;
         k_topk_threshold<<<1, 1024, 0, s>>>(hist, K, ctrl);
@@ -367,7 +385,8 @@ int frcnn_topk_order(const float* scores, const uint8_t* valid, int N, int K, in
     split = split < 8 ? 8 : (split > 64 ? 64 : split);
     k_topk_rank<<<dim3(bi, split), TOPK_BLOCK, 0, s>>>(cand, ctrl, rank);
     if (int e = check_launch("topk_order rank")) return e;
-    k_topk_scatter<<<bi, TOPK_BLOCK, 0, s>>>(cand, rank, ctrl, K, order, n_out);
+    const int bs = ((N > K ? N : K) + TOPK_BLOCK - 1) / TOPK_BLOCK;     // covers every candidate and every output slot
+    k_topk_scatter<<<bs, TOPK_BLOCK, 0, s>>>(cand, rank, ctrl, K, order, n_out);
     return check_launch("topk_order scatter");
 }
 

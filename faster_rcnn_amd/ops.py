@@ -156,8 +156,8 @@ def nms_sorted(boxes, n, thresh, max_boxes):
     -> keep (max_boxes,) i32 positions, n_keep (1,) i32."""
     _require_gpu()
     K = boxes.shape[0]
-    keep = torch.full((max_boxes,), -1, dtype=torch.int32, device="cuda")
-    n_keep = torch.zeros(1, dtype=torch.int32, device="cuda")
+    keep = torch.empty((max_boxes,), dtype=torch.int32, device="cuda")       # the call writes every slot (-1 past n_keep)
+    n_keep = torch.empty(1, dtype=torch.int32, device="cuda")
     ws = _ws(_lib.load().frcnn_nms_workspace_bytes(K))
     name = {torch.int16: "frcnn_nms_i16", torch.float64: "frcnn_nms_f64"}[boxes.dtype]
     _lib.call(name, _p(boxes.contiguous()), _p(n), K, float(thresh), int(max_boxes), _p(keep), _p(n_keep), _p(ws), ws.numel(), _stream())
@@ -388,11 +388,11 @@ def detections(rois, n_rois, out_cls, out_reg, roi_batch, bg_idx, det_threshold,
     """voc_dets.get_dets post-process on the device -> dict of device tensors."""
     _require_gpu()
     rows, C = out_cls.shape
-    det_cls = torch.full((rows,), -1, dtype=torch.int32, device="cuda")
-    det_prob = torch.zeros(rows, dtype=torch.float32, device="cuda")
-    det_bbox = torch.zeros((rows, 4), dtype=torch.int32, device="cuda")
-    det_roi = torch.full((rows,), -1, dtype=torch.int32, device="cuda")
-    n_dets = torch.zeros(1, dtype=torch.int32, device="cuda")
+    det_cls = torch.empty((rows,), dtype=torch.int32, device="cuda")          # the call writes every row (-1 / 0 past n_dets)
+    det_prob = torch.empty(rows, dtype=torch.float32, device="cuda")
+    det_bbox = torch.empty((rows, 4), dtype=torch.int32, device="cuda")
+    det_roi = torch.empty((rows,), dtype=torch.int32, device="cuda")
+    n_dets = torch.empty(1, dtype=torch.int32, device="cuda")
     _lib.call("frcnn_detections", _p(rois), _p(n_rois), rows, _p(out_cls.contiguous()), _p(out_reg.contiguous()), C, int(bg_idx),
               float(det_threshold), float(stride), float(resize_ratio), float(nms_thresh),
               _p(det_cls), _p(det_prob), _p(det_bbox), _p(det_roi), _p(n_dets), _stream())

@@ -104,8 +104,8 @@ int frcnn_gather_candidates(const float* rois, const float* scores, const int32_
 /* det_util.nms (det_util.py:209-256) on candidates ALREADY in descending score order.
  * "+1" pixel convention, keep while overlap <= thresh, stop at max_boxes.
  * n (device i32) = number of live rows (<= K <= FRCNN_NMS_MAX_BOXES).
- * keep[max_boxes] i32 receives positions into the candidate list in pick order,
- * n_keep (device i32) their count.
+ * keep[max_boxes] i32 receives positions into the candidate list in pick order (entries >= *n_keep are set
+ * to -1: the call defines every slot, the caller need not clear the buffers), n_keep (device i32) their count.
  * _i16: int16 boxes (proposal NMS).  _f64: float64 boxes (voc_dets.py:76). */
 size_t frcnn_nms_workspace_bytes(int K);
 int frcnn_nms_i16(const int16_t* boxes, const int32_t* n, int K, double thresh, int max_boxes,
@@ -272,7 +272,8 @@ int frcnn_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, in
  * out_cls [max_rows][C] f32, out_reg [max_rows][4(C-1)] f32.
  * Outputs, in the reference's emission order (classes in first-seen order, NMS pick order
  * inside a class): det_cls[max_rows] i32, det_prob[max_rows] f32, det_bbox[max_rows][4] i32,
- * det_roi[max_rows] i32 (source RoI row), *n_dets.  The reference's padded duplicate RoIs
+ * det_roi[max_rows] i32 (source RoI row), *n_dets; rows >= *n_dets are written too (det_cls = det_roi = -1,
+ * det_prob = 0, det_bbox = 0), so the caller need not clear the buffers.  The reference's padded duplicate RoIs
  * (voc_dets.py:42-46) are suppressed by its own NMS (IoU 1), so only live rows are scored. */
 int frcnn_detections(const float* rois, const int32_t* n_rois, int max_rows, const float* out_cls, const float* out_reg,
                      int num_classes, int bg_idx, float det_threshold, double stride, double resize_ratio, double nms_thresh,

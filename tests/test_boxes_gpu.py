@@ -27,6 +27,15 @@ def dev(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
+def dirty(*nbytes):
+    """Leave stale non-zero bytes in the caching allocator's free blocks of these sizes: the calls below get their
+    outputs from torch.empty and must define every element themselves."""
+    import torch
+    keep = [torch.full((max(int(n), 1),), 0x5A, dtype=torch.uint8, device="cuda") for n in nbytes]
+    torch.cuda.synchronize()
+    del keep
+
+
 def test_anchors(ops, ref, golden):
     a9, a18 = golden["anchors9"], golden["anchors18"]
     for rows, cols, anc in ((3, 4, a9), (38, 63, a9), (38, 94, a18), (1, 1, a18)):
@@ -157,6 +166,40 @@ def test_topk_ties_and_negative(ops):
     got = order.cpu().numpy()
     assert int(n.item()) == 8
     assert list(got[:4]) == list(want[:4]) and set(got[4:6]) == {4, 5} and list(got[6:]) == list(want[6:])
+    dirty(4 * 2000, 4)
+    order, n = ops.topk_order(dev(s), None, 2000)            # K far beyond N: every slot past n is written (-1)
+    got = order.cpu().numpy()
+    assert int(n.item()) == 8 and list(got[:4]) == list(want[:4]) and (got[8:] == -1).all()
+
+
+@pytest.mark.parametrize("N", [21546, 64296])
+def test_topk_in_a_replayed_graph(ops, N):
+    """Both top-K paths captured into a hipGraph between other kernels and replayed back to back: every replay starts
+    from cleared counters (a lone hipMemsetAsync node did not guarantee that, see frcnn_topk_order)."""
+    import torch
+    rs = np.random.RandomState(5)
+    s = dev(rs.rand(N).astype(np.float32))
+    rois = dev((rs.rand(N, 4) * 500).astype(np.float32))
+    K = 8000
+    want_order, want_n = ops.topk_order(s, None, K)
+    want_cand, _ = ops.gather_candidates(rois, s, want_order, want_n, K)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.topk_order(s * 1.0, None, K)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        s2 = s * 1.0                                            # a kernel node in front of the reset
+        order, n = ops.topk_order(s2, None, K)
+        cand, _ = ops.gather_candidates(rois, s2, order, n, K)
+    for _ in range(40):
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(n.item()) == int(want_n.item())
+    assert torch.equal(order, want_order) and torch.equal(cand, want_cand)
 
 
 @pytest.mark.parametrize("case", ["all_equal", "three_values", "saturated", "one_binade", "wide", "k_ge_n", "none_valid"])
@@ -206,11 +249,13 @@ def test_nms_golden(ops, golden, tag):
         cand, cs = ops.gather_candidates(dev(rois), dev(probs), dev(o), n, K)
         assert np.array_equal(cand.cpu().numpy()[:len(order)], rois[order].astype(np.int16))
         assert np.array_equal(cs.cpu().numpy()[:len(order)], probs[order])
+        dirty(post * 4, 4)
         keep, n_keep = ops.nms_sorted(cand, n, 0.7, post)
         nk = int(n_keep.item())
         want = golden[f"prop_{tag}_{pre}_pick"]
         assert nk == len(want)
         assert np.array_equal(keep.cpu().numpy()[:nk], want)
+        assert (keep.cpu().numpy()[nk:] == -1).all()
         out = ops.gather_rois(cand, keep, n_keep, 64, ((post + 63) // 64) * 64).cpu().numpy()
         assert np.array_equal(out[:nk], golden[f"prop_{tag}_{pre}_kept"].astype(np.float32))
         pad_to = (nk + 63) // 64 * 64
@@ -227,8 +272,11 @@ def test_nms_kats_and_edges(ops, ref, golden):
         got = kb[order][keep.cpu().numpy()[:int(nk.item())]]
         assert np.array_equal(got, golden[key])
     # empty input (the reference returns [] there)
+    dirty(40, 4)
     keep, nk = ops.nms_sorted(dev(np.zeros((8, 4), np.int16)), dev(np.array([0], np.int32)), 0.7, 10)
-    assert int(nk.item()) == 0
+    assert int(nk.item()) == 0 and (keep.cpu().numpy() == -1).all()
+    keep, nk = ops.nms_sorted(dev(np.zeros((0, 4), np.int16)), dev(np.array([0], np.int32)), 0.7, 10)      # K == 0: no kernel runs
+    assert int(nk.item()) == 0 and (keep.cpu().numpy() == -1).all()
     # exact-threshold case: overlap == 0.7 exactly must be KEPT (<=): boxes of area 10 with 7 shared...
     a = np.array([[0, 0, 9, 16], [0, 0, 9, 6], [0, 0, 9, 9]], dtype=np.int16)   # inter/union = 70/170, 100/170 ...
     for th in (70 / 170, 100 / 170, 0.7):
@@ -306,16 +354,19 @@ def test_detections_device(ops):
             r[:n] = rois
             if rows > n:
                 r[n:] = rois[256]
+            dirty(rows * 4, rows * 4, rows * 16, rows * 4, 4)
             out = ops.detections(dev(r), dev(np.array([rows], np.int32)), dev(g["out_cls"][:rows]), dev(g["out_reg"][:rows]),
                                  64, 20, float(thr), 16.0, float(ratio))
             nd = int(out["n_dets"].item())
+            assert (out["det_cls"].cpu().numpy()[nd:] == -1).all() and (out["det_roi"].cpu().numpy()[nd:] == -1).all()
+            assert not out["det_prob"].cpu().numpy()[nd:].any() and not out["det_bbox"].cpu().numpy()[nd:].any()
             assert nd == len(g[tag + "_cls"])
             assert np.array_equal(out["det_cls"].cpu().numpy()[:nd], g[tag + "_cls"])
             assert np.array_equal(out["det_prob"].cpu().numpy()[:nd], g[tag + "_prob"])
             assert np.array_equal(out["det_bbox"].cpu().numpy()[:nd], g[tag + "_bbox"])
     # nothing above threshold
     out = ops.detections(dev(rois), dev(np.array([n], np.int32)), dev(g["out_cls"][:n]), dev(g["out_reg"][:n]), 64, 20, 2.0, 16.0, 1.0)
-    assert int(out["n_dets"].item()) == 0
+    assert int(out["n_dets"].item()) == 0 and (out["det_cls"].cpu().numpy() == -1).all()
 
 
 def test_preprocess_u8_is_bit_identical_to_the_host_path(ops):
