@@ -1303,6 +1303,7 @@ int frcnn_colsum_batch(const frcnn_colsum_job* jobs, int n_jobs, void* stream) {
 
 int frcnn_conv2d_config(const frcnn_conv_desc* d) {
     if (!d) return fail(FRCNN_E_ARG, "conv2d_config: null descriptor");
+    if (d->cin == 3) return 30;                                 // the 3-channel stem kernel, whatever tile was asked for
     return choose_config(d);
 }
 

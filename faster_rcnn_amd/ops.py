@@ -251,7 +251,7 @@ CONV_KERNEL_NAMES = {1: "k_conv_igemm_f32<2,2,false>", 2: "k_conv_igemm_f32<1,1,
                      4: "k_conv_igemm_f32<4,2,false>", 11: "k_conv_igemm_f32_v2<2,2>", 12: "k_conv_igemm_f32_v2<1,1>",
                      13: "k_conv_igemm_f32_v2<2,1>", 14: "k_conv_igemm_f32_v2<4,2>",
                      21: "k_conv_igemm_f32_v2<2,2,1>", 22: "k_conv_igemm_f32_v2<1,1,1>",
-                     41: "k_conv_igemm_f32_v2<1,2,1,4,2>", 42: "k_conv_igemm_f32_v2<2,1,1,2,4>", 43: "k_conv_igemm_f32_v2<1,1,1,4,2>"}
+                     30: "k_conv_igemm_f32_v2<1,1,1> stem", 41: "k_conv_igemm_f32_v2<1,2,1,4,2>", 42: "k_conv_igemm_f32_v2<2,1,1,2,4>", 43: "k_conv_igemm_f32_v2<1,1,1,4,2>"}
 
 
 class ConvWorkspace:

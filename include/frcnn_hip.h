@@ -252,8 +252,8 @@ int frcnn_colsum_batch(const frcnn_colsum_job* jobs, int n_jobs, void* stream);
 size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g, const float* scale,
                        float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
-/* The tile code (see frcnn_conv_desc.tile) frcnn_conv2d_fwd will run for this descriptor:
- * lets a profiler attribute a launch to its kernel instantiation. */
+/* The tile code (see frcnn_conv_desc.tile) frcnn_conv2d_fwd will run for this descriptor (30 = the 3-channel
+ * stem kernel, which cin == 3 always takes): lets a profiler attribute a launch to its kernel instantiation. */
 int frcnn_conv2d_config(const frcnn_conv_desc* d);
 /* MaxPooling2D / AveragePooling2D, 'valid' (resnet.py:412, 515; vgg.py:100-128). c % 4 == 0. */
 int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream);

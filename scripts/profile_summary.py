@@ -7,11 +7,11 @@ root = sys.argv[1]
 
 def bench_kernel_name(k):
     """rocprof kernel name -> the name bench.py / ops.CONV_KERNEL_NAMES use for the same instantiation."""
-    m = re.search(r"k_conv_igemm_f32_v2<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false)>", k)
+    m = re.search(r"k_conv_igemm_f32_v2<(\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", k)
     if m:
-        tm, tn, var, wm, wn, sk = m.groups()
+        tm, tn, var, wm, wn, sk, stem = m.groups()
         args = [tm, tn] + ([var] if var != "0" or (wm, wn) != ("2", "2") else []) + ([wm, wn] if (wm, wn) != ("2", "2") else [])
-        return "k_conv_igemm_f32_v2<%s>" % ",".join(args) + (" split-K" if sk == "true" else "")
+        return "k_conv_igemm_f32_v2<%s>" % ",".join(args) + (" split-K" if sk == "true" else "") + (" stem" if stem == "true" else "")
     m = re.search(r"k_conv_igemm_bf16<", k)
     if m:
         return "k_conv_igemm_bf16"
