@@ -33,6 +33,31 @@ for tag in ("trace_streams1", "trace_default"):
         if float(r["Percentage"]) < 0.05:
             continue
         print("%-78s %7s %12.1f %10.2f %6.2f" % (r["Name"][:78], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+# Launches that ran ALONE on the device (no other dispatch overlaps them in time): with several images in flight a
+# kernel's duration in the trace includes the time it shares the chip with other streams' kernels, so the figure
+# comparable with bench.py's roofline (each distinct launch re-issued back to back on one stream) is the average
+# over the isolated dispatches -- which are mostly those very re-issues.
+for tag in ("trace_streams1", "trace_default"):
+    fs = glob.glob(os.path.join(root, tag, "**", "*kernel_trace.csv"), recursive=True)
+    if not fs:
+        continue
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(fs[0]))]
+    rows.sort()
+    iso = collections.defaultdict(list)
+    every = collections.defaultdict(list)
+    max_end = 0
+    for i, (st, en, name) in enumerate(rows):
+        alone = st >= max_end and (i + 1 == len(rows) or rows[i + 1][0] >= en)
+        max_end = max(max_end, en)
+        if "conv_igemm" in name:
+            every[name].append(en - st)
+            if alone:
+                iso[name].append(en - st)
+    print("\n== conv dispatches that overlap no other dispatch:", tag)
+    print("%-78s %7s %10s | %7s %10s" % ("kernel", "alone", "avg_us", "all", "avg_us"))
+    for name in sorted(every, key=lambda n: -sum(every[n])):
+        a, e = iso.get(name, []), every[name]
+        print("%-78s %7d %10.2f | %7d %10.2f" % (name.split("(")[0][:78], len(a), (sum(a) / len(a) / 1e3) if a else float("nan"), len(e), sum(e) / len(e) / 1e3))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
