@@ -247,7 +247,9 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
             *last = is_last;
         }
         __syncthreads();
-        if (!*last) return;
+        const int is_last = *last;
+        __syncthreads();                                     // the epilogue reuses this LDS word
+        if (!is_last) return;
         const float4* base = reinterpret_cast<const float4*>(p.slabs + (size_t)tile * splits * (BM * BN));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -270,6 +272,63 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     }
 
     // epilogue: C/D map col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    if ((p.Cout & 7) == 0) {
+        // Vectorised form.  In the accumulator layout a lane owns ONE column, so storing from it means 2-byte stores
+        // (and 2-byte residual / mask loads) -- 16 memory instructions per 32x32 tile, each moving 128 B.  Instead
+        // every wave turns its tiles through a private 32 x 36-float LDS patch (the operand buffers are dead: the
+        // main loop ended on a barrier): written column-per-lane, read back row-major, eight consecutive channels
+        // per lane -> one 16-byte residual load, one 16-byte mask load and one 16-byte store per lane per half tile.
+        float* stg = reinterpret_cast<float*>(smem_b) + wave * (32 * 36);
+        const int r_row = lane >> 2, r_col = (lane & 3) * 8;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nt = n0 + wn * TN * 32 + j * 32;
+            const int nc = nt + li;
+            const float sc = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
+            const float sh = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
+            const int n = nt + r_col;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mt = m0 + wm * TM * 32 + i * 32;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + li] = acc[i][j][e] * sc + sh;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int row = half * 16 + r_row, m = mt + row;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * 36 + r_col);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * 36 + r_col + 4);
+                    if (m < p.M && n < p.Cout) {
+                        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        const size_t o = (size_t)m * p.Cout + n;
+                        if (p.residual) {
+                            const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.residual + o);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] += (float)r[q];
+                        }
+                        if constexpr (MASKED) {
+                            const bf16x8 mk = *reinterpret_cast<const bf16x8*>(p.mask + o);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) if (!((float)mk[q] > 0.0f)) v[q] = 0.0f;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = activate_b(v[q], p.act);
+                        if (p.out_f32) {
+                            float* y = reinterpret_cast<float*>(p.y) + o;
+                            *reinterpret_cast<f32x4*>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                            *reinterpret_cast<f32x4*>(y + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        } else {
+                            bf16x8 ob;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) ob[q] = (__bf16)v[q];
+                            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + o) = ob;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 32 + j * 32 + li;
