@@ -185,9 +185,12 @@ typedef struct frcnn_conv_desc {
                                          that only meet zero padding are skipped (bit-identical result)     */
 } frcnn_conv_desc;
 
-/* k extent of a packed filter row: kh*kw*cin rounded up to the kernel's k-chunk (32). */
+/* k extent of a packed filter row: kh*kw*cin rounded up to the kernel's k-chunk (32); cin == 3 (the image
+ * stems, resnet.py:408 conv1, vgg.py:96 block1_conv1) is laid out four channels wide: kh*kw*4 rounded up. */
 int frcnn_conv_packed_k(int kh, int kw, int cin);
-/* Keras HWIO kernel [kh][kw][cin][cout] -> packed [cout][packed_k] (k = (r*kw+s)*cin + c). */
+/* Keras HWIO kernel [kh][kw][cin][cout] -> packed [cout][packed_k].  The packed order is private to the
+ * library (what frcnn_conv2d_fwd* read): cin % 32 == 0: k = ((c/32)*kh*kw + r*kw+s)*32 + c%32;
+ * cin == 3: k = (r*kw+s)*4 + c with a zero fourth column; otherwise k = (r*kw+s)*cin + c; zero padded. */
 int frcnn_pack_conv_weights(const float* w_hwio, int kh, int kw, int cin, int cout, float* packed, void* stream);
 /* scale / shift / residual may be NULL (1, 0, none). */
 int frcnn_conv2d_fwd(const frcnn_conv_desc* d, const float* x, const float* w_packed,
