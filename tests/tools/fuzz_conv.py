@@ -29,8 +29,8 @@ def main():
         k = int(rs.choice([1, 1, 3, 3, 5]))
         stride = int(rs.choice([1, 1, 1, 2]))
         padding = "same" if k > 1 and rs.rand() < 0.8 else "valid"
-        cin = int(rs.choice([32, 64, 96, 128, 256, 512]))
-        cout = int(rs.choice([9, 36, 64, 100, 128, 192, 256, 512]))
+        cin = int(rs.choice([3, 3, 4, 20, 32, 64, 64, 96, 128, 256, 512]))
+        cout = int(rs.choice([9, 36, 40, 64, 72, 100, 128, 192, 256, 512]))
         n = int(rs.choice([1, 1, 2, 5]))
         h, w = int(rs.randint(k, 40)), int(rs.randint(k, 40))
         tile = int(rs.choice(tiles))
@@ -59,7 +59,7 @@ def main():
         if not err <= 1e-4:
             print("FAIL fwd %.3g" % err, desc); fails += 1
         # backward (stride-1 layers only have an input-gradient form)
-        if it % 3 == 0 and cin % 4 == 0:
+        if it % 3 == 0 and cin % 4 == 0 and cin >= 32:
             g = rs.randn(*want.shape).astype(np.float32)
             xt = torch.from_numpy(x).double().requires_grad_(True)
             wtt = torch.from_numpy(wt).double().requires_grad_(True)
@@ -85,11 +85,18 @@ def main():
             xb, wb = bf(x), bf(wt)
             wantb = ref_conv(xb.double().numpy(), wb.double().numpy(), stride, padding) * torch.from_numpy(scale).double() + torch.from_numpy(shift).double()
             pcb = ops.PackedConvBf16(wb.float(), scale, shift)
-            for bt in (0, 1, 2, 3, 302, 502):
+            resb = bf(rs.randn(*wantb.shape).astype(np.float32))
+            want_r = (wantb + resb.double()).clamp(min=0)
+            for bt in (0, 1, 2, 3, 41, 42, 43, 44, 302, 502):
                 gb = ops.conv2d_bf16(xb.cuda(), pcb, stride, padding, None, None, out_f32=True, tile=bt)
                 e = ((gb.cpu().double() - wantb).abs() / wantb.abs().clamp(min=1.0)).max().item()
                 if not e <= 1e-4:
                     print("FAIL bf16 %.3g tile=%d" % (e, bt), desc); fails += 1
+                # residual + ReLU + bf16 store: one RNE rounding of the f32 epilogue value
+                gr = ops.conv2d_bf16(xb.cuda(), pcb, stride, padding, "relu", resb.cuda(), out_f32=False, tile=bt)
+                e = ((gr.cpu().double() - want_r).abs() / want_r.abs().clamp(min=1.0)).max().item()
+                if not e <= 2.0 ** -8 * 1.01:
+                    print("FAIL bf16 residual/relu %.3g tile=%d" % (e, bt), desc); fails += 1
     print("cases %d  failures %d  worst f32 forward error %.3g" % (n_cases, fails, worst))
     sys.exit(1 if fails else 0)
 
