@@ -239,6 +239,44 @@ def test_full_size_c2_properties():
     assert ((plain["reg"][:n] - out["reg"][:n]).abs() / out["reg"][:n].abs().clamp(min=1.0)).max().item() < 1e-4
 
 
+def test_four_graphs_in_flight_stay_deterministic():
+    """bench.py's execution model: one hipGraph + HIP stream per image in flight, replayed back to back without
+    host synchronisation.  Each graph owns its split-K workspace and output buffers, so concurrent replays must not
+    disturb one another: every replay of every graph reproduces that graph's first result bit for bit."""
+    from faster_rcnn_amd import resnet, util
+    from faster_rcnn_amd.pipeline import InferencePipeline
+    from faster_rcnn_amd.weights import synthetic_resnet
+    anchors = util.get_anchors([128, 256, 512])
+    w = synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=2)
+    base = resnet.resnet50_base(weights=w)
+    rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=9)
+    det = resnet.resnet50_classifier(300, 21, weights=w)
+    H, W, S = 304, 496, 4
+    rs = np.random.RandomState(8)
+    pipes = [InferencePipeline(rpn, det, anchors, max_proposals=300) for _ in range(S)]
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    for i, pl in enumerate(pipes):
+        pl.capture(H, W, split_k=True, throughput=True)
+        pl._static_in.copy_(torch.from_numpy((rs.rand(1, H, W, 3) * 255 - 110).astype(np.float32)).cuda())
+    torch.cuda.synchronize()
+    keys = ("cls", "reg", "rois", "det_bbox", "det_cls", "det_prob", "n_dets", "n_rois")
+    first = []
+    for pl in pipes:                                            # reference: each graph alone on the chip
+        pl._graph.replay()
+        torch.cuda.synchronize()
+        first.append({k: pl._static_out[k].clone() for k in keys})
+    assert all(int(f["n_rois"].item()) > 0 for f in first)
+    for rounds in range(6):
+        for _ in range(25):                                     # 100 replays queued with no host sync in between
+            for pl, st in zip(pipes, streams):
+                with torch.cuda.stream(st):
+                    pl._graph.replay()
+        torch.cuda.synchronize()
+        for pl, f in zip(pipes, first):
+            for k in keys:
+                assert torch.equal(pl._static_out[k], f[k]), (rounds, k)
+
+
 def test_voc_dets_cli_to_eval_dets_round_trip(tmp_path, capsys):
     """The reference's inference workflow end to end: Keras-format .h5 checkpoints in (h5lite writer / reader),
     `voc_dets` CLI over the VOC_test fixture (decode, resize, RPN, proposals, detector, per-class files), `eval_dets`
