@@ -134,6 +134,46 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
     return roof, groups
 
 
+def full_size_parity(pipe, weights, anchors):
+    """The oracle as CHECKER at the benchmark's own size (configs[1] only): one synthetic 600x1000 image through the
+    HIP pipeline (eager) and, stage by stage, through the CPU restatement fed with the SAME stage inputs -- float
+    stages within 1e-4 (|a-b| / max(|b|, 1)), discrete stages (proposal selection, detection emission) exact."""
+    from oracle import np_ref
+    from oracle.keras_ref import KerasGraphs
+    g = KerasGraphs(weights, torch.float32)
+    x = synth_image(100)
+    with torch.no_grad():
+        out = pipe.forward_dev(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        host = {k: v.cpu() for k, v in out.items()}
+        err = lambda a, b: float(((a.double() - b.double()).abs() / b.double().abs().clamp(min=1)).max())
+        feat = g.resnet_base(x, 50)
+        cls, reg = g.rpn(feat)
+        res = {"feat": err(host["feat"].reshape(feat.shape), feat), "rpn_cls": err(host["rpn_cls"].reshape(cls.shape), cls),
+               "rpn_reg": err(host["rpn_reg"].reshape(reg.shape), reg)}
+        # discrete: proposals chosen on the device == the numpy selection from the device's own RPN outputs
+        n = int(host["n_rois"])
+        kept = np_ref.proposals(host["rpn_reg"].numpy().reshape(reg.shape), host["rpn_cls"].numpy().reshape(cls.shape), anchors, 16, 8000, PROPOSALS)[0]
+        res["proposals_equal"] = bool(n == len(kept) and np.array_equal(host["rois"].numpy()[:n], kept.astype(np.float32)))
+        # float: detector on the device's conv4 map and RoIs
+        o_cls, o_reg = g.resnet_classifier(host["feat"].reshape(feat.shape), host["rois"].numpy()[:n], NUM_CLASSES, 50)
+        res["det_cls"] = err(host["cls"][:n], o_cls.reshape(n, -1))
+        res["det_reg"] = err(host["reg"][:n], o_reg.reshape(n, -1))
+        # discrete: emitted detections == the numpy post-process of the device's own detector outputs
+        want = np_ref.detections(host["rois"].numpy()[:n], host["cls"].numpy()[:n], host["reg"].numpy()[:n], NUM_CLASSES - 1, 1.0)
+        nd = int(host["n_dets"])
+        # (exactly tied scores inside a class: numpy's argsort order is implementation-defined, the device orders ties
+        # by ascending index -- runs of equal (class, score) are compared as sets)
+        got = [(int(host["det_cls"][i]), float(host["det_prob"][i]), tuple(int(v) for v in host["det_bbox"][i])) for i in range(nd)]
+        exp = [(int(w[0]), float(w[1]), tuple(int(v) for v in w[2])) for w in want]
+        runs = lambda seq: [sorted(b for c, p, b in seq if (c, p) == key) for key in dict.fromkeys((c, p) for c, p, _ in seq)]
+        res["detections_equal"] = bool(nd == len(want) and [g[:2] for g in got] == [e[:2] for e in exp] and runs(got) == runs(exp))
+    res = {k: (v if isinstance(v, bool) else float("%.3g" % v)) for k, v in res.items()}
+    res["ok"] = bool(res["proposals_equal"] and res["detections_equal"] and all(v < 1e-4 for v in res.values() if not isinstance(v, bool)))
+    res["n_rois"], res["n_detections"] = n, nd
+    return res
+
+
 def cpu_baseline(weights, anchors, budget_s=20.0):
     """The oracle ("port" of the Keras CPU path) on this host: full path on whole images."""
     from oracle import np_ref
@@ -280,6 +320,11 @@ def main():
             roof["all_conv_launches"]["frac"] = round(roof["all_conv_launches"]["achieved"] / PEAK_BF16_TFLOPS, 4)
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             line["cpu_baseline"] = cpu_baseline(weights, anchors)
+            if DTYPE == "f32":
+                try:
+                    line["parity"] = full_size_parity(pipe, weights, anchors)
+                except Exception as e:                              # the checker must not cost the bench line
+                    line["parity"] = {"ok": False, "error": repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()                  # rank 0 is still measuring the roofline: leave the group together

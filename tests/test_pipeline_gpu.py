@@ -239,6 +239,20 @@ def test_full_size_c2_properties():
     assert ((plain["reg"][:n] - out["reg"][:n]).abs() / out["reg"][:n].abs().clamp(min=1.0)).max().item() < 1e-4
 
 
+def test_full_size_c2_parity_with_the_oracle():
+    """configs[1] at its real size (600x1000, 300 proposals, 21 classes), stage by stage against the CPU oracle fed
+    with the device's own stage inputs: float stages within 1e-4, proposal selection and emitted detections exact
+    (bench.py reports the same object as ``parity`` next to its throughput line)."""
+    import bench
+    bench.select_config("c2")
+    pipe, weights, anchors = bench.build_pipeline()
+    res = bench.full_size_parity(pipe, weights, anchors)
+    assert res["proposals_equal"] and res["detections_equal"], res
+    for k in ("feat", "rpn_cls", "rpn_reg", "det_cls", "det_reg"):
+        assert res[k] < 1e-4, res
+    assert res["n_rois"] == 300 and res["n_detections"] > 0
+
+
 def test_four_graphs_in_flight_stay_deterministic():
     """bench.py's execution model: one hipGraph + HIP stream per image in flight, replayed back to back without
     host synchronisation.  Each graph owns its split-K workspace and output buffers, so concurrent replays must not
