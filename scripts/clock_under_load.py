@@ -49,11 +49,16 @@ def main():
     pcb = ops.PackedConvBf16(wt, np.ones(512, np.float32), np.zeros(512, np.float32))
     xb = x.to(torch.bfloat16)
     y = ops.conv2d(x, pc, 1, "same", "relu")
-    print("idle                         : %.0f MHz" % probe())
-    for tile in (21, 22, 42):
-        print("beside f32 conv tile %-3d     : %.0f MHz" % (tile, probe(lambda: ops.conv2d(x, pc, 1, "same", "relu", out=y, tile=tile))))
-    print("beside bf16 conv             : %.0f MHz" % probe(lambda: ops.conv2d_bf16(xb, pcb, 1, "same", "relu")))
-    print("idle again                   : %.0f MHz" % probe())
+    three = lambda load=None: "  ".join("%.0f" % probe(load) for _ in range(3))
+    print("idle                         : %s MHz" % three())
+    for tile in (21, 22, 42, 41):
+        print("beside f32 conv tile %-3d     : %s MHz" % (tile, three(lambda: ops.conv2d(x, pc, 1, "same", "relu", out=y, tile=tile))))
+    print("beside bf16 conv             : %s MHz" % three(lambda: ops.conv2d_bf16(xb, pcb, 1, "same", "relu")))
+    burn_out = torch.zeros(2040 * 256, dtype=torch.float32, device="cuda")       # 2040 blocks: leave the probe a slot
+    lib.mfma_burn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    burn = lambda: lib.mfma_burn(burn_out.data_ptr(), 2040, 150, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    print("beside register-only MFMA    : %s MHz" % three(burn))
+    print("idle again                   : %s MHz" % three())
 
 
 if __name__ == "__main__":

@@ -23,3 +23,26 @@ extern "C" int clock_probe(unsigned long long* out_dev, int blocks, double spin_
     k_clock_probe<<<blocks, 64, 0, (hipStream_t)stream>>>(out_dev, (unsigned long long)(spin_us * 100.0));
     return (int)hipGetLastError();
 }
+
+// Register-only MFMA load (scripts/micro/mfma_peak.hip's kernel) to run the probe beside: does the clock hold when
+// NOTHING but the matrix pipe is busy?
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) k_mfma_burn(float* out, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const float a = 0.5f + threadIdx.x * 1e-3f, b = 0.25f - threadIdx.x * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+extern "C" int mfma_burn(float* out_dev, int blocks, int iters, void* stream) {
+    k_mfma_burn<<<blocks, 256, 0, (hipStream_t)stream>>>(out_dev, iters);
+    return (int)hipGetLastError();
+}
