@@ -536,6 +536,262 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
 }
 
 // ------------------------------------------------------------------------------------
+// Balanced ("stream-K") launch form of the v2 kernel, late-store variant, 2x2 waves.
+//
+// A launch of T tiles on S concurrent workgroup slots runs ceil(T/S) rounds whatever T is: the detector head's
+// 460 128x128 tiles on 512 slots leave 52 CUs with one workgroup while 204 carry two, and the launch lasts as long
+// as the loaded ones (0.90 of the slots' work; a bare MFMA + LDS loop of this shape measures 127 vs 141 TFLOP/s,
+// scripts/micro/mfma_ladder.hip).  Here the launch has G = rounds x S workgroups and the UNIT of work is a k-chunk:
+// the tiles' chunks, tile after tile (a tile's count depends on its row range only: position-major rows skip
+// padding-only taps), form one sequence of U units and workgroup w takes units [w*U/G, (w+1)*U/G).  A range covers
+// the tail of one tile, possibly whole tiles, and the head of another.  A tile covered by ONE workgroup goes straight
+// to the epilogue; otherwise each contributor publishes its f32 partial tile in slot (w - first contributor) with
+// write-through stores and adds its chunk count to the tile's ticket -- the one that completes the count sums the
+// slots in slot order (deterministic) and runs the epilogue, exactly the split-K protocol with unequal slices.
+constexpr int SK_SLOTS = 4;             // partial-tile slots per output tile (the host keeps ranges long enough)
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) k_conv_igemm_f32_sk(const ConvArgs p) {
+    constexpr int WM = 2, WN = 2, NT = 256;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int RPP = NT / 8;
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDS_STRIDE;
+    int* pref = reinterpret_cast<int*>(smem + 2 * (BM + BN) * LDS_STRIDE);       // [tiles_m + 1] chunk-count prefix over row tiles
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    const int RS = p.R * p.S;
+    const unsigned all_taps = RS >= 32 ? 0xffffffffu : (1u << RS) - 1u;
+    const int groups = p.Kpad / (BK * RS);
+
+    auto taps_of = [&](int tile_m) -> unsigned {
+        if (!p.layout) return all_taps;
+        const int m0 = tile_m * BM;
+        const int pos_lo = m0 / p.n_img, pos_hi = (min(m0 + BM, p.M) - 1) / p.n_img;
+        if (pos_hi - pos_lo >= 8) return all_taps;
+        unsigned mk = 0;
+        for (int pos = pos_lo; pos <= pos_hi; ++pos) {
+            const int ho = pos / p.Wo, wo = pos - ho * p.Wo;
+            const int h0 = ho * p.stride - p.pad_top, w0 = wo * p.stride - p.pad_left;
+            for (int r = 0; r < p.R; ++r)
+                for (int sx = 0; sx < p.S; ++sx)
+                    if ((unsigned)(h0 + r) < (unsigned)p.H && (unsigned)(w0 + sx) < (unsigned)p.W) mk |= 1u << (r * p.S + sx);
+        }
+        return mk ? mk : all_taps;
+    };
+    for (int m = tid; m < p.tiles_m; m += NT) pref[m + 1] = groups * __popc(taps_of(m));
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        pref[0] = 0;
+        for (int m = 1; m <= p.tiles_m; ++m) { run += pref[m]; pref[m] = run; }
+    }
+    __syncthreads();
+    const int Pm = pref[p.tiles_m];
+    const long long U = (long long)Pm * p.tiles_n;
+    const int G = gridDim.x;
+    const int w = xcd_remap(blockIdx.x, G);
+    long long u = (long long)w * U / G;
+    const long long u_end = (long long)(w + 1) * U / G;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)((size_t)p.Cout * p.Kpad * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.slabs, 0, (int)((size_t)p.tiles_m * p.tiles_n * SK_SLOTS * (BM * BN) * 4), 0x00020000);
+
+    while (u < u_end) {
+        __syncthreads();                                     // the previous segment is done with the LDS (operands, flag)
+        const int tile_n = (int)(u / Pm);
+        const int r_u = (int)(u - (long long)tile_n * Pm);
+        int lo = 0, hi = p.tiles_m;                          // largest tile_m with pref[tile_m] <= r_u
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= r_u) lo = mid; else hi = mid; }
+        const int tile_m = lo;
+        const int nk_t = pref[tile_m + 1] - pref[tile_m];
+        const int kb = r_u - pref[tile_m];
+        const int ke = (int)min((long long)nk_t, kb + (u_end - u));
+        const int tile = tile_n * p.tiles_m + tile_m;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+        const unsigned tap_mask = taps_of(tile_m);
+        const int n_taps = __popc(tap_mask);
+
+        int a_h[PA], a_w[PA], a_off[PA];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int m = m0 + lrow + RPP * i;
+            if (m < p.M) {
+                int wo, ho, img;
+                if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
+                else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
+                a_h[i] = ho * p.stride - p.pad_top;
+                a_w[i] = wo * p.stride - p.pad_left;
+                a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * 4;
+            } else {
+                a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
+            }
+        }
+        unsigned b_off[PB];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int n = n0 + lrow + RPP * i;
+            b_off[i] = n < p.Cout ? (unsigned)((n * p.Kpad + lcol) * 4) : OOB_OFFSET;
+        }
+
+        i32x4 ra[PA], rb[PB];
+        unsigned rem = tap_mask;
+        const int grp0 = kb / n_taps;
+        int c0 = grp0 * BK, w_grp = grp0 * RS * (BK * 4);
+        for (int t = kb - grp0 * n_taps; t > 0; --t) rem &= rem - 1;
+        auto load_chunk = [&]() {
+            const int tap = __builtin_ctz(rem);
+            const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+            const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 4;
+            const int w_off = w_grp + tap * (BK * 4);
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0);
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int hi2 = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+                const bool ok = (unsigned)hi2 < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0);
+            }
+            rem &= rem - 1;
+            const int wrap = (rem == 0);
+            rem |= wrap ? tap_mask : 0u;
+            c0 += wrap * BK;
+            w_grp += wrap * (RS * BK * 4);
+        };
+        auto store_chunk = [&](int buf) {
+            float* a = As + buf * BM * LDS_STRIDE;
+            float* b = Bs + buf * BN * LDS_STRIDE;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + RPP * i) * LDS_STRIDE + lcol) = ra[i];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + RPP * i) * LDS_STRIDE + lcol) = rb[i];
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+        load_chunk();
+        store_chunk(0);
+        load_chunk();                                        // past the range's end at most: loaded, never multiplied
+        __syncthreads();
+
+        constexpr int MF = TM * TN * 4, NL = PA + PB, NF = TM + TN;
+        for (int kc = kb; kc < ke; ++kc) {
+            const int buf = (kc - kb) & 1;
+            const float* a = As + buf * BM * LDS_STRIDE + (wm * TM * 32 + li) * LDS_STRIDE + lh * 4;
+            const float* b = Bs + buf * BN * LDS_STRIDE + (wn * TN * 32 + li) * LDS_STRIDE + lh * 4;
+            f32x4 fa[BK / 8][TM], fb[BK / 8][TN];
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[kk][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_STRIDE + kk * 8);
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i][e], fb[kk][j][e], acc[i][j], 0, 0, 0);
+            store_chunk(buf ^ 1);
+            load_chunk();
+            SGB(SG_DS_RD, NF);
+#pragma unroll
+            for (int kk = 0; kk < BK / 8 - 1; ++kk) {
+#pragma unroll
+                for (int q = 0; q < MF; ++q) {
+                    SGB(SG_MFMA, 1);
+                    if (q < NF) SGB(SG_DS_RD, 1);
+                    else if (kk == BK / 8 - 2 && q - NF < NL) SGB(SG_DS_WR, 1);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < MF; ++q) {
+                SGB(SG_MFMA, 1);
+                if (MF - NF < NL && q < NL - (MF - NF)) SGB(SG_DS_WR, 1);
+                else if (q < NL + (MF - NF < NL ? NL - (MF - NF) : 0)) { SGB(SG_VALU, 4); SGB(SG_VMEM_RD, 1); }
+            }
+            __syncthreads();
+        }
+        u += ke - kb;
+
+        if (kb != 0 || ke != nk_t) {
+            // partial tile: which contributors does this tile have?  first = the workgroup whose range holds the tile's
+            // first unit, last = the one holding its last (w*U/G <= x  <=>  w <= ((x+1)*G - 1) / U)
+            const long long ts = (long long)tile_n * Pm + pref[tile_m];
+            const int w_first = (int)(((ts + 1) * G - 1) / U);
+            const int w_last = (int)(((ts + nk_t) * G - 1) / U);
+            const unsigned slab_off = (unsigned)(((size_t)tile * SK_SLOTS + (w - w_first)) * (BM * BN) * 4 + tid * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), srsrc,
+                                                               slab_off + ((i * TN + j) * 4 + q) * (NT * 16), 0, 16 /* sc1 */);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int* last = reinterpret_cast<int*>(smem);
+            if (tid == 0) {
+                const unsigned mine = (unsigned)(ke - kb);
+                const unsigned t = __hip_atomic_fetch_add(&p.tickets[tile], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int is_last = (t + mine == (unsigned)nk_t);
+                if (is_last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                *last = is_last;
+            }
+            __syncthreads();
+            if (!*last) continue;                             // somebody else finishes this tile
+            const float4* base = reinterpret_cast<const float4*>(p.slabs + (size_t)tile * SK_SLOTS * (BM * BN));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int sl = 0; sl <= w_last - w_first; ++sl) {
+                const float4* sp = base + (size_t)sl * (BM * BN / 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v = sp[((i * TN + j) * 4 + q) * NT + tid];
+                            acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                        }
+            }
+        }
+        epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // filter packing: Keras HWIO [R][S][Cin][Cout] -> [Cout][Kpad].
 //   Cin % 32 == 0 : packed k = ((c/32)*R*S + tap)*32 + c%32   (channel chunk outer, tap inner)
 //   Cin == 3      : packed k = tap*4 + c, c == 3 and taps >= R*S zero (the stem kernel stages eight taps per chunk)
@@ -1035,6 +1291,8 @@ static int launch_conv_v2_splitk(const ConvArgs& a, hipStream_t s) {
 using namespace frcnn;
 
 // tile / main-loop selection shared by frcnn_conv2d_fwd and frcnn_conv2d_config
+static int choose_streamk(const frcnn_conv_desc* d, int cfg);
+
 static int choose_config(const frcnn_conv_desc* d) {
     const long long M = (long long)d->n * d->ho * d->wo;
     const int Kpad = (d->kh * d->kw * d->cin + BK - 1) / BK * BK;
@@ -1054,7 +1312,7 @@ static int choose_config(const frcnn_conv_desc* d) {
         // launch (500 vs 570 us); the 460 128x128 tiles all start at once and the full-length ones set the time
         // (with several images in flight the neighbours fill the freed slots: pipelines then ask for tile 21)
         if (generic) cfg = 2;
-        else if (d->layout && d->kh * d->kw > 1 && !shared_chip) cfg = 22;
+        else if (d->layout && d->kh * d->kw > 1 && !shared_chip) cfg = choose_streamk(d, 21) ? 21 : 22;   // balanced 128x128 beats both
         else if (t128 >= 384 && Kpad >= 1024) cfg = 21;
         else cfg = 22;
     }
@@ -1089,6 +1347,77 @@ static int choose_splits(const frcnn_conv_desc* d, int cfg) {
     return s < 1 ? 1 : s;
 }
 
+// Balanced (stream-K) launch: G workgroups for this descriptor, or 0 when the plain / split-K forms are better.
+// Auto picks it for the two late-store tiles when the grid wastes >= 6 % of its last round of CU slots, the k loop is
+// long enough for the partial-tile traffic not to matter (>= 32 chunks) and no tile can meet more than SK_SLOTS
+// ranges.  desc.tile 61 / 62 force it (tests), a hundreds digit (forced split-K factor / "never split") disables it.
+static int streamk_tile_taps(const frcnn_conv_desc* d, int tile_m, int BM) {
+    const int RS = d->kh * d->kw;
+    if (!d->layout) return RS;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long m0 = (long long)tile_m * BM;
+    const long long m1 = (m0 + BM < M ? m0 + BM : M) - 1;
+    const int pos_lo = (int)(m0 / d->n), pos_hi = (int)(m1 / d->n);
+    if (pos_hi - pos_lo >= 8 || RS > 32) return RS;
+    unsigned mk = 0;
+    for (int pos = pos_lo; pos <= pos_hi; ++pos) {
+        const int ho = pos / d->wo, wo = pos - ho * d->wo;
+        const int h0 = ho * d->stride - d->pad_top, w0 = wo * d->stride - d->pad_left;
+        for (int r = 0; r < d->kh; ++r)
+            for (int sx = 0; sx < d->kw; ++sx)
+                if ((unsigned)(h0 + r) < (unsigned)d->h && (unsigned)(w0 + sx) < (unsigned)d->w) mk |= 1u << (r * d->kw + sx);
+    }
+    return mk ? __builtin_popcount(mk) : RS;
+}
+
+static int choose_streamk(const frcnn_conv_desc* d, int cfg) {
+    const bool forced = (cfg == 61 || cfg == 62);
+    if (!forced && (cfg != 21 && cfg != 22)) return 0;
+    if (d->tile / 100 != 0 || (d->cin % BK) != 0) return 0;
+    const int big = (cfg == 21 || cfg == 61);
+    const int BM = big ? 128 : 64;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long tiles_m = (M + BM - 1) / BM, tiles_n = (d->cout + BM - 1) / BM;
+    const long long tiles = tiles_m * tiles_n;
+    const int slots = 256 * (big ? 2 : 4);                   // workgroups the chip holds at once (LDS: 2 x 74 KB / 4 x 37 KB per CU)
+    const int RS = d->kh * d->kw;
+    const int groups = d->cin / BK, nk_max = groups * RS;
+    if (tiles_m > 1024 || tiles * sizeof(unsigned) > SPLITK_TICKET_BYTES) return 0;
+    if ((size_t)tiles * SK_SLOTS * BM * BM * 4 >= 0x7fffffffull) return 0;
+    const long long rounds = (tiles + slots - 1) / slots;
+    const long long G = rounds * slots;
+    if (!forced) {
+        // measured (scripts/layout_compare.py, 300 RoIs): on the 128x128 tile the balanced form wins wherever it is
+        // eligible (3x3 575 -> 483 us, 2048->512 276 -> 263, 1024->512 154 -> 149); on the 64x64 tile the partial-tile
+        // traffic eats the gain (506 -> 520, 280 -> 294), and beside other images' launches (tile 50) the idle slots
+        // are already taken: four images in flight run 3 % slower with it
+        if (!big || d->tile % 100 == 50) return 0;
+        if (nk_max < 32 || tiles * 100 > G * 94 || tiles * 2 < G) return 0;
+    }
+    long long U = 0;
+    for (int m = 0; m < tiles_m; ++m) U += (long long)groups * streamk_tile_taps(d, m, BM);
+    U *= tiles_n;
+    if (U < G || U / G < nk_max / 2 + 1) return 0;           // a tile would meet more than SK_SLOTS ranges
+    return (int)G;
+}
+
+template <int TM, int TN>
+static int launch_conv_sk(const ConvArgs& a, int G, hipStream_t s) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    ConvArgs p = a;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float) + (size_t)(p.tiles_m + 1) * sizeof(int);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_sk<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
+        attr_lds = lds;
+    }
+    k_conv_igemm_f32_sk<TM, TN><<<G, 256, lds, s>>>(p);
+    return check_launch("conv2d_fwd (balanced)");
+}
+
 extern "C" {
 
 int frcnn_conv_packed_k(int kh, int kw, int cin) { return packed_k(kh * kw, cin); }
@@ -1115,7 +1444,14 @@ int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const floa
 
 size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d) {
     if (!d || d->cin <= 0 || (d->cin % BK) != 0) return 0;
-    const int splits = choose_splits(d, choose_config(d));
+    const int cfg0 = choose_config(d);
+    if (choose_streamk(d, cfg0)) {
+        const int BM = (cfg0 == 21 || cfg0 == 61) ? 128 : 64;
+        const long long M = (long long)d->n * d->ho * d->wo;
+        const size_t tiles = (size_t)((M + BM - 1) / BM) * ((d->cout + BM - 1) / BM);
+        return SPLITK_TICKET_BYTES + tiles * SK_SLOTS * BM * BM * sizeof(float);
+    }
+    const int splits = choose_splits(d, cfg0);
     if (splits <= 1) return 0;
     const long long M = (long long)d->n * d->ho * d->wo;
     const size_t tiles = (size_t)((M + 63) / 64) * ((d->cout + 63) / 64);
@@ -1144,7 +1480,9 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     a.inv_S = (65536 + d->kw - 1) / d->kw;
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
-    const int cfg = choose_config(d);
+    int cfg = choose_config(d);
+    if (cfg == 21 && !workspace && d->tile % 100 == 0 && a.layout && d->kh * d->kw > 1)
+        cfg = 22;                                               // the 128x128 choice there counted on the balanced form
     if (a.layout && (generic || cfg < 11 || d->kh * d->kw > 32))
         return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: position-major layout needs cin %% 32 == 0, a tensor under 2 GiB and at most 32 taps");
     if (d->cin == 3) {                                          // the stems: filter packed 4 wide, eight taps per chunk
@@ -1156,6 +1494,11 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
         const size_t need = frcnn_conv2d_workspace_bytes(d);
         if (need) {
             if (workspace_bytes < need) return fail(FRCNN_E_WORKSPACE, "conv2d_fwd: workspace needs %zu bytes", need);
+            if (const int G = choose_streamk(d, cfg)) {
+                a.tickets = (unsigned*)workspace;
+                a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
+                return (cfg == 21 || cfg == 61) ? launch_conv_sk<2, 2>(a, G, s) : launch_conv_sk<1, 1>(a, G, s);
+            }
             a.splits = choose_splits(d, cfg);
             a.tickets = (unsigned*)workspace;
             a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
@@ -1170,8 +1513,8 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
         case 41: return launch_conv_v2<1, 2, 1, 4, 2>(a, s);     // 128x128, 8 waves
         case 42: return launch_conv_v2<2, 1, 1, 2, 4>(a, s);     // 128x128, 8 waves (2x4)
         case 43: return launch_conv_v2<1, 1, 1, 4, 2>(a, s);     // 128x64, 8 waves
-        case 21: return launch_conv_v2<2, 2, 1>(a, s);
-        case 22: return launch_conv_v2<1, 1, 1>(a, s);
+        case 61: case 21: return launch_conv_v2<2, 2, 1>(a, s);     // (61 / 62 without a workspace: the plain launch)
+        case 62: case 22: return launch_conv_v2<1, 1, 1>(a, s);
         case 11: return launch_conv_v2<2, 2>(a, s);
         case 12: return launch_conv_v2<1, 1>(a, s);
         case 13: return launch_conv_v2<2, 1>(a, s);
@@ -1304,7 +1647,9 @@ int frcnn_colsum_batch(const frcnn_colsum_job* jobs, int n_jobs, void* stream) {
 int frcnn_conv2d_config(const frcnn_conv_desc* d) {
     if (!d) return fail(FRCNN_E_ARG, "conv2d_config: null descriptor");
     if (d->cin == 3) return 30;                                 // the 3-channel stem kernel, whatever tile was asked for
-    return choose_config(d);
+    const int cfg = choose_config(d);
+    if (choose_streamk(d, cfg)) return (cfg == 21 || cfg == 61) ? 61 : 62;     // what a launch WITH a workspace runs
+    return (cfg == 61 || cfg == 62) ? cfg - 40 : cfg;                           // asked for, but the shape is not eligible
 }
 
 int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream) {

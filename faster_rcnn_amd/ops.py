@@ -251,7 +251,7 @@ CONV_KERNEL_NAMES = {1: "k_conv_igemm_f32<2,2,false>", 2: "k_conv_igemm_f32<1,1,
                      4: "k_conv_igemm_f32<4,2,false>", 11: "k_conv_igemm_f32_v2<2,2>", 12: "k_conv_igemm_f32_v2<1,1>",
                      13: "k_conv_igemm_f32_v2<2,1>", 14: "k_conv_igemm_f32_v2<4,2>",
                      21: "k_conv_igemm_f32_v2<2,2,1>", 22: "k_conv_igemm_f32_v2<1,1,1>",
-                     30: "k_conv_igemm_f32_v2<1,1,1> stem", 41: "k_conv_igemm_f32_v2<1,2,1,4,2>", 42: "k_conv_igemm_f32_v2<2,1,1,2,4>", 43: "k_conv_igemm_f32_v2<1,1,1,4,2>"}
+                     30: "k_conv_igemm_f32_v2<1,1,1> stem", 61: "k_conv_igemm_f32_sk<2,2>", 62: "k_conv_igemm_f32_sk<1,1>", 41: "k_conv_igemm_f32_v2<1,2,1,4,2>", 42: "k_conv_igemm_f32_v2<2,1,1,2,4>", 43: "k_conv_igemm_f32_v2<1,1,1,4,2>"}
 
 
 class ConvWorkspace:
@@ -358,7 +358,10 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
     args, ws = _conv_launch(d, x, pc.w, pc.scale, pc.shift, residual, None, out)
     if CONV_PROFILE is not None:
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
-        kname = CONV_KERNEL_NAMES.get(_lib.load().frcnn_conv2d_config(ctypes.byref(d)), "?") + (" split-K" if ws is not None else "")
+        cfg = _lib.load().frcnn_conv2d_config(ctypes.byref(d))
+        if cfg in (61, 62) and ws is None:
+            cfg -= 40                                            # balanced form needs a workspace: the plain tile ran
+        kname = CONV_KERNEL_NAMES.get(cfg, "?") + (" split-K" if ws is not None and cfg not in (61, 62) else "")
         keep = (d, x, pc, residual, out, ws)
         CONV_PROFILE.append({"kernel": kname, "flops": flops, "shape": (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
                              "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_ws", *args, _stream())})

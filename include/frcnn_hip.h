@@ -177,6 +177,8 @@ typedef struct frcnn_conv_desc {
                                       41..43: 128x128 (4x2 / 2x4 waves) and 128x64 with 8 waves;
                                       50: auto for a launch that SHARES the chip with other streams' launches
                                           (several images in flight): prefers the larger tiles;
+                                      61, 62: the balanced (stream-K) form of 21 / 22 when the shape
+                                          allows it (needs the workspace; see frcnn_conv2d_fwd_ws);
                                       + 100*s: force s split-K slices (frcnn_conv2d_fwd_ws)       */
     int32_t layout;                /* 0: x [n][h][w][cin], y [n][ho][wo][cout] (NHWC).
                                       1: position-major, x [h][w][n][cin], y [ho][wo][n][cout] (forward only,
@@ -210,7 +212,12 @@ int frcnn_conv2d_fwd_masked(const frcnn_conv_desc* d, const float* x, const floa
  * first 16 KiB (arrival tickets) must be ZERO on entry and are left zero on exit, so a buffer zeroed
  * once after allocation serves any sequence of calls on ONE stream; concurrent streams / hipGraphs
  * need one workspace each.  workspace == NULL selects the plain launch.  desc.tile / 100, when
- * non-zero, forces the number of slices (100 = never split); desc.tile % 100 is the tile code. */
+ * non-zero, forces the number of slices (100 = never split); desc.tile % 100 is the tile code.
+ * Balanced form (the same workspace, tickets and contract): when a 128x128-tile launch ALONE on the chip would
+ * leave >= 6 % of its last round of CU slots empty and has >= 32 k-chunks (the detector head's 460-tile
+ * launches at 300 RoIs), the launch takes rounds x 512 workgroups that each run an equal share of ALL k-chunks,
+ * crossing tile boundaries; tiles met by several workgroups are summed from up to four partial slots in slot
+ * order by the workgroup that completes the tile's chunk count.  Deterministic; not selected for tile code 50. */
 size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                         const float* scale, const float* shift, const float* residual, const float* mask,

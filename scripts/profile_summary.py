@@ -12,6 +12,9 @@ def bench_kernel_name(k):
         tm, tn, var, wm, wn, sk, stem = m.groups()
         args = [tm, tn] + ([var] if var != "0" or (wm, wn) != ("2", "2") else []) + ([wm, wn] if (wm, wn) != ("2", "2") else [])
         return "k_conv_igemm_f32_v2<%s>" % ",".join(args) + (" split-K" if sk == "true" else "") + (" stem" if stem == "true" else "")
+    m = re.search(r"k_conv_igemm_f32_sk<(\d+), (\d+)>", k)
+    if m:
+        return "k_conv_igemm_f32_sk<%s,%s>" % m.groups()
     m = re.search(r"k_conv_igemm_bf16<", k)
     if m:
         return "k_conv_igemm_bf16"

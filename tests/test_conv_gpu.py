@@ -180,3 +180,63 @@ def test_conv2d_position_major_layout(ops, case):
         assert (got_nhwc - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
     else:
         assert torch.equal(got_nhwc, want)
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, k, padding, tile, layout
+    (1, 48, 48, 128, 1024, 3, "same", 62, 0),        # 576 64x64 tiles on 1024 workgroups: ranges of 20.25 chunks, tiles of 36
+    (2, 48, 48, 128, 1024, 3, "same", 61, 0),        # 288 128x128 tiles on 512 workgroups
+    (150, 7, 7, 128, 512, 3, "same", 62, 1),         # position-major: tiles of 16..36 chunks (padding-only taps skipped)
+    (300, 7, 7, 128, 512, 3, "same", 61, 1),
+    (300, 7, 7, 1024, 500, 1, "valid", 61, 1),       # 1x1, cout tail inside the last column tile
+    (3, 50, 47, 512, 520, 1, "valid", 62, 0),        # ragged rows and columns (999 tiles, 16 chunks each)
+])
+def test_conv2d_balanced_launch(ops, case):
+    """The balanced (stream-K) launch form: workgroups take equal runs of k-chunks across tile boundaries, tiles met by
+    several runs are summed from partial slots in slot order.  Same values as the plain launch up to the regrouped
+    f32 sums, bit-identical from run to run, and the workspace tickets return to zero."""
+    import ctypes
+    from faster_rcnn_amd import _lib
+    n, h, w, cin, cout, k, padding, tile, layout = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = torch.from_numpy(rs.randn(n, h, w, cin).astype(np.float32)).cuda()
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    pc = ops.PackedConv(wt, (1 + 0.1 * rs.randn(cout)).astype(np.float32), (0.1 * rs.randn(cout)).astype(np.float32))
+    plain = ops.conv2d(x, pc, 1, padding, None, tile=100 + tile - 40)            # 121 / 122: the same tile, one workgroup per tile
+    res = torch.from_numpy(rs.randn(*plain.shape).astype(np.float32)).cuda()
+    want = ops.conv2d(x, pc, 1, padding, "relu", res, tile=100 + tile - 40)
+    if layout:
+        xin, rin = x.permute(1, 2, 0, 3).contiguous(), res.permute(1, 2, 0, 3).contiguous()
+    else:
+        xin, rin = x, res
+    ho, wo = want.shape[1], want.shape[2]
+    d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=k, kw=k, stride=1, pad_top=(k - 1) // 2 if padding == "same" else 0,
+                      pad_left=(k - 1) // 2 if padding == "same" else 0, ho=ho, wo=wo, act=1, ldy=0, ldres=0, tile=tile, layout=layout)
+    assert _lib.load().frcnn_conv2d_config(ctypes.byref(d)) == tile               # the shape is eligible: the balanced kernel runs
+    ws = ops.ConvWorkspace()
+    with ops.conv_workspace(ws):
+        got = ops.conv2d(xin, pc, 1, padding, "relu", rin, tile=tile, layout=layout)
+        again = ops.conv2d(xin, pc, 1, padding, "relu", rin, tile=tile, layout=layout)
+    assert ws.buf is not None and not ws.buf[:16384].any()                         # tickets back at zero
+    assert torch.equal(got, again)
+    g = got.permute(2, 0, 1, 3) if layout else got
+    assert (g - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    # slots hold stale partials: poison them
+    ws.buf[16384:].view(torch.float32).fill_(float("nan"))
+    with ops.conv_workspace(ws):
+        third = ops.conv2d(xin, pc, 1, padding, "relu", rin, tile=tile, layout=layout)
+    assert torch.equal(third, got)                                                  # every slot that is read was written first
+
+
+def test_balanced_launch_is_chosen_for_the_head_shapes(ops):
+    """Auto tile selection: alone on the chip, the detector head's 460-tile launches (300 RoIs) take the balanced form
+    (given a workspace); short-k launches, launches that share the chip and "never split" descriptors do not."""
+    import ctypes
+    from faster_rcnn_amd import _lib
+    cfg = lambda **kw: _lib.load().frcnn_conv2d_config(ctypes.byref(_lib.ConvDesc(stride=1, act=1, ldy=0, ldres=0, **kw)))
+    head = dict(n=300, h=7, w=7, ho=7, wo=7, layout=1)
+    assert cfg(cin=2048, cout=512, kh=1, kw=1, pad_top=0, pad_left=0, tile=0, **head) == 61       # 460 tiles of 128x128, 64 chunks
+    assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=0, **head) == 61        # alone on the chip
+    assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=50, **head) == 21       # beside other images' launches: plain
+    assert cfg(cin=512, cout=2048, kh=1, kw=1, pad_top=0, pad_left=0, tile=0, **head) == 22       # 16 chunks: too short
+    assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=100, **head) == 22      # "never split" turns it off
