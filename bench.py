@@ -8,7 +8,7 @@ N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-
 images shard by rank with NO data-path collective (inference has no exchange step), so the
 scaling is weak: every rank processes its own image stream.
 
-A "step" = S images (--streams, default 4: one hipGraph + HIP stream per image in flight)
+A "step" = S images (--streams, default 8 on 8 hardware queues for fp32: one hipGraph + HIP stream per image in flight)
 through the whole device-resident path (backbone convs, RPN heads,
 decode, top-8000 ordering, NMS to 300, RoI crop-resize, stage-5 head, softmax, detection
 post-process), replayed from a hipGraph.  The input is resident in HBM when timing starts.
@@ -211,10 +211,19 @@ def main():
                          "applying those two 1x1 layers once to the conv4 map")
     ap.add_argument("--dtype", choices=("config", "f32", "bf16"), default="config",
                     help="override the config's arithmetic type (off-contract: e.g. configs[1] shapes on the bf16 conv path)")
-    ap.add_argument("--streams", type=int, default=4, help="images in flight per GPU (one hipGraph + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="images in flight per GPU (one hipGraph + HIP stream each); default: 8 for the fp32 config, 4 for bf16")
     args = ap.parse_args()
-    select_config(args.config)
     global HOIST, DTYPE, WORKLOAD
+    select_config(args.config)
+    if args.streams <= 0:
+        args.streams = 8 if (DTYPE == "f32" and args.dtype in ("config", "f32")) else 4
+    # ROCm maps a process's streams onto 4 hardware queues unless told otherwise; more than four images in flight need
+    # a queue each or they queue behind one another (measured on MI355X: 8 streams on 8 queues 245.6 img/s, 8 streams on
+    # 4 queues 241.4, 4 on 4 240.7, 4 on 8 217.0; configs[3] (bf16) is fastest with 4 on 4).  Read when the HIP runtime
+    # starts, i.e. at the first device call below; an explicit setting in the environment wins.
+    if args.streams > 4:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.streams, 16)))
     if args.dtype != "config" and args.dtype != DTYPE:
         DTYPE = args.dtype
         WORKLOAD += " [OFF-CONTRACT: run with --dtype %s]" % args.dtype
@@ -231,9 +240,9 @@ def main():
     pipe, weights, anchors = build_pipeline()
     x = torch.from_numpy(synth_image(rank)).cuda()
     S = max(1, args.streams)
-    # split-K is a latency tool: measured on MI355X it gains 6-9 % with one image in flight and nothing (f32) or
-    # -4 % (bf16) with four, where concurrency already fills the small grids
-    split_k = args.split_k == "on" or (args.split_k == "auto" and (S == 1 or DTYPE == "f32"))
+    # split-K is a latency tool: measured on MI355X it gains 6-9 % with one image in flight, nothing (f32) or -4 % (bf16)
+    # with four, and costs 1.2 % (f32: 246.1 vs 249.0 img/s) with eight, where concurrency already fills the small grids
+    split_k = args.split_k == "on" or (args.split_k == "auto" and (S == 1 or (DTYPE == "f32" and S <= 4)))
     if not args.no_graph:
         from faster_rcnn_amd.pipeline import InferencePipeline
         pipes = [pipe] + [InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS) for _ in range(S - 1)]
@@ -297,7 +306,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": WORKLOAD,
-                       "images_per_step_per_gpu": S, "proposals": PROPOSALS, "classes": NUM_CLASSES,
+                       "images_per_step_per_gpu": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "proposals": PROPOSALS, "classes": NUM_CLASSES,
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
                        "head_order": "res5a 1x1 layers on the conv4 map, then RoI resampling (algebraically equal, see DESIGN 5)" if HOIST
                        else "reference order",
