@@ -18,6 +18,11 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY 
   i=$((i+1))
   rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph > $OUT/pmc$i.log 2>&1
 done
+# the launch forms of the default (several images in flight) run, one launch at a time: HBM-side traffic only
+for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph --shared-tiles > $OUT/pmc$i.log 2>&1
+done
 python3 $R/scripts/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt | head -60
 # keep only small files for the merge back
