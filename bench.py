@@ -242,8 +242,10 @@ def main():
     x = torch.from_numpy(synth_image(rank)).cuda()
     S = max(1, args.streams)
     # split-K is a latency tool: measured on MI355X it gains 6-9 % with one image in flight, nothing (f32) or -4 % (bf16)
-    # with four, and costs 1.2 % (f32: 246.1 vs 249.0 img/s) with eight, where concurrency already fills the small grids
-    split_k = args.split_k == "on" or (args.split_k == "auto" and (S == 1 or (DTYPE == "f32" and S <= 4)))
+    # with four, and costs 1.2 % (f32: 246.1 vs 249.0 img/s, `--split-k off`) with eight, where concurrency already
+    # fills the small grids.  The fp32 default keeps it on: the graphs then hold the same launch forms the roofline
+    # section times one at a time (the small-grid layers alone on the chip are what split-K is for).
+    split_k = args.split_k == "on" or (args.split_k == "auto" and (S == 1 or DTYPE == "f32"))
     if not args.no_graph:
         from faster_rcnn_amd.pipeline import InferencePipeline
         pipes = [pipe] + [InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS) for _ in range(S - 1)]
