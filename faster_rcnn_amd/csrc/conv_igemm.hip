@@ -1318,9 +1318,12 @@ static int choose_config(const frcnn_conv_desc* d) {
     }
     if (d->layout && cfg >= 1 && cfg <= 4) cfg += 10;       // only the v2 main loop knows the position-major layout
     const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * Kpad * 4 < 0x7fffffffull;
-    if (cfg >= 41 && (!fits_srd || generic)) cfg = 2;
-    if (cfg >= 21 && (!fits_srd || generic)) cfg -= 20;
-    if (cfg >= 11 && (!fits_srd || generic)) cfg -= 10;
+    // the v2 main loops walk the filter taps through a 32-bit mask: larger filters (6x6 and up) stay on the v1 kernels
+    const bool v1_only = !fits_srd || generic || d->kh * d->kw > 32;
+    if (cfg >= 61 && v1_only) cfg -= 60;
+    if (cfg >= 41 && v1_only) cfg = (cfg == 43) ? 3 : 1;
+    if (cfg >= 21 && v1_only) cfg -= 20;
+    if (cfg >= 11 && v1_only) cfg -= 10;
     if (generic) cfg = (cfg == 2) ? 2 : 3;
     return cfg;
 }

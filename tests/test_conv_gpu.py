@@ -62,6 +62,9 @@ CASES = [
     (1, 60, 80, 3, 64, 7, 2, "same", "relu", False, 0),           # stem (even size: pad 2/3)
     (1, 24, 30, 3, 64, 3, 1, "same", "relu", False, 0),           # vgg block1_conv1
     (2, 9, 11, 64, 64, 3, 2, "same", None, False, 0),             # SAME with stride 2
+    (1, 20, 23, 32, 64, 7, 1, "same", "relu", False, 0),          # 49 taps: beyond the v2 kernels' 32-bit tap mask
+    (1, 20, 23, 64, 64, 7, 2, "same", None, True, 22),
+    (1, 14, 15, 32, 32, 6, 1, "valid", None, False, 41),
     (2, 60, 80, 3, 64, 7, 2, "same", "relu", False, 0),           # stem kernel, two images (49 taps -> 7 chunks of 8)
     (1, 24, 30, 3, 96, 3, 1, "valid", None, True, 0),             # stem kernel: cout not a tile multiple, residual, 7 dead taps
     (1, 9, 9, 3, 32, 1, 1, "valid", None, False, 0),              # stem kernel: one tap

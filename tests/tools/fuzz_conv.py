@@ -26,7 +26,7 @@ def main():
     worst = 0.0
     fails = 0
     for it in range(n_cases):
-        k = int(rs.choice([1, 1, 3, 3, 5]))
+        k = int(rs.choice([1, 1, 3, 3, 5, 7]))
         stride = int(rs.choice([1, 1, 1, 2]))
         padding = "same" if k > 1 and rs.rand() < 0.8 else "valid"
         cin = int(rs.choice([3, 3, 4, 20, 32, 64, 64, 96, 128, 256, 512]))
@@ -80,7 +80,7 @@ def main():
                     if not e_x <= 1e-4:
                         print("FAIL dgrad %.3g" % e_x, desc); fails += 1
         # bf16 forward on the same shape (cin % 64 == 0 only)
-        if it % 4 == 0 and cin % 64 == 0:
+        if it % 4 == 0 and cin % 64 == 0 and k * k <= 32:
             bf = lambda a: torch.from_numpy(a).to(torch.bfloat16)
             xb, wb = bf(x), bf(wt)
             wantb = ref_conv(xb.double().numpy(), wb.double().numpy(), stride, padding) * torch.from_numpy(scale).double() + torch.from_numpy(shift).double()
