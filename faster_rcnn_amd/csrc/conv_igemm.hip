@@ -1340,6 +1340,9 @@ static int choose_splits(const frcnn_conv_desc* d, int cfg) {
         // measured on MI355X (scripts/conv_shapes.py, C2 shapes): grids under 1.5 tiles per CU with >= 16 chunks
         // gain from 3 slices (stage 3/4 3x3 and 1x1-reduce, rpn_conv1: -10..-37 %); tiny grids (RPN heads, dense)
         // take enough slices for ~2 workgroups per CU, at least 4 chunks each; shorter k loops lose to the combine
+        // 384..639 tiles with a long k loop (the detector head at 64 training RoIs: 392 tiles, 144 / 64 chunks) fill
+        // 38-60 % of the 1024 slots: four slices take 174 -> 143 us (3x3) and 85 -> 76 us (2048 -> 512)
+        if (tiles >= 384 && tiles < 640 && nk >= 64) return 4;
         if (tiles >= 384 || nk < 16) return 1;
         s = tiles >= 100 ? 3 : (int)((456 + tiles - 1) / tiles);
         if (s > nk / 4) s = nk / 4;
