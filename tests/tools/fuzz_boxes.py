@@ -116,6 +116,26 @@ def main():
         exp = [(int(w[0]), float(w[1]), tuple(int(v) for v in w[2])) for w in want]
         runs = lambda seq: [sorted(b for c, p, b in seq if (c, p) == key) for key in dict.fromkeys((c, p) for c, p, _ in seq)]
         check(nd == len(want) and [g[:2] for g in got] == [e_[:2] for e_ in exp] and runs(got) == runs(exp), "detections " + tag + " m=%d C=%d" % (m, C))
+        # RoI crop + bilinear resize (bit-exact), with the fill / ReLU / position-major variants of the hoisted head
+        if it % 2 == 0:
+            from oracle import keras_ref
+            fr, fc, Cf = int(rs.randint(2, 20)), int(rs.randint(2, 24)), int(rs.choice([4, 8, 64]))
+            feat = rs.randn(fr, fc, Cf).astype(np.float32)
+            nr = int(rs.randint(1, 12))
+            x1 = rs.randint(0, fc, nr); y1 = rs.randint(0, fr, nr)
+            x2 = np.minimum(fc, x1 + rs.randint(0, fc, nr)); y2 = np.minimum(fr, y1 + rs.randint(0, fr, nr))      # some empty
+            rr = np.stack([x1, y1, x2, y2], 1).astype(np.float32)
+            pool = int(rs.choice([3, 7]))
+            want_r = keras_ref.roi_resize(feat, rr, pool)
+            got_r = ops.roi_crop_resize(dev(feat), dev(rr), pool).cpu().numpy()
+            check(np.array_equal(got_r, want_r), "roi_crop_resize " + tag + " map %dx%dx%d" % (fr, fc, Cf))
+            fill = rs.randn(Cf).astype(np.float32)
+            empty = (x2 <= x1) | (y2 <= y1)
+            want_f = want_r.copy()
+            want_f[empty] = fill
+            want_f = np.maximum(want_f, 0)
+            got_f = ops.roi_crop_resize(dev(feat), dev(rr), pool, fill=dev(fill), relu=True, layout=1).cpu().numpy()
+            check(np.array_equal(got_f.transpose(2, 0, 1, 3), want_f), "roi_crop_resize fill/relu/pos-major " + tag)
     print("cases %d  failures %d" % (n_cases, fails))
     sys.exit(1 if fails else 0)
 
