@@ -87,7 +87,8 @@ def test_two_iou_conventions_and_empty_nms():
 def test_cubic_resize_restates_opencv_fixed_point():
     """shapes._resize = cv2.resize(..., INTER_CUBIC) restated (unpinned: no OpenCV here).  Properties any correct
     restatement has: taps sum to 2048 (so flat images stay flat), identity at equal size, a linear ramp stays monotone
-    with the cubic's small overshoot only at the replicated border, and it is close to (not equal to) PIL's a = -0.5 cubic."""
+    with the cubic's small overshoot only at the replicated border, it is close to (not equal to) PIL's a = -0.5 cubic, and
+    it agrees to one grey level with torch's float bicubic, which uses OpenCV's coefficient (a = -0.75) and pixel centres."""
     from faster_rcnn_amd import shapes
     for dst, src in ((800, 500), (600, 375), (300, 500), (7, 5)):
         idx, co = shapes._cubic_taps(dst, src)
@@ -105,6 +106,20 @@ def test_cubic_resize_restates_opencv_fixed_point():
     ours = shapes._resize(smooth, 160, 120).astype(int)
     pil = np.asarray(PilImage.fromarray(smooth).resize((160, 120), PilImage.BICUBIC)).astype(int)
     assert np.abs(ours - pil).max() <= 6 and np.abs(ours - pil).mean() < 1.0
+    # An independent implementation of the SAME kernel (Keys cubic, a = -0.75, half-pixel centres, replicated border):
+    # torch's CPU bicubic in float.  OpenCV's 8-bit path quantises the taps to 1/2048, so the two may differ by one grey
+    # level, never more -- on noise, on smooth content, enlarging and shrinking.
+    import torch
+    import torch.nn.functional as F
+    noise = rs.randint(0, 256, (93, 125, 3)).astype(np.uint8)
+    for im in (noise, smooth):
+        for (nh, nw) in ((150, 200), (167, 226), (60, 81), (im.shape[0], 2 * im.shape[1])):
+            ours = shapes._resize(im, nw, nh).astype(int)
+            t = torch.from_numpy(im).permute(2, 0, 1)[None].float()
+            ref = F.interpolate(t, size=(nh, nw), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+            ref = np.clip(np.rint(ref), 0, 255).astype(int)
+            d = np.abs(ours - ref)
+            assert d.max() <= 1 and (d > 0).mean() < 0.08, (im.shape, nh, nw, d.max(), (d > 0).mean())
 
 
 def test_voc_eval_matches_the_reference(tmp_path, capsys):
