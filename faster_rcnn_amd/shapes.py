@@ -4,9 +4,10 @@ Only what the hot path touches: ``Image`` (metadata view: width/height/gt_boxes/
 ``resize_within_bounds``, ``horizontal_flip``), ``InMemoryImage``, ``Metadata``,
 ``GroundTruthBox`` and ``Box`` with the reference's arithmetic (float coordinates after a
 resize, ``x -> width - x`` flip without -1, shapes.py:298).  Pixel decode (cv2.imread +
-INTER_CUBIC, shapes.py:19-29) is an f2 "next" row: the resize restates OpenCV's fixed-point INTER_CUBIC (unpinned:
-no cv2 here); ``Image.data`` decodes with PIL when a file is
-given and is NOT bit-identical to OpenCV's resampler; synthetic configs use InMemoryImage.
+INTER_CUBIC, shapes.py:19-29) is an f2 "next" row: the resize restates OpenCV's fixed-point INTER_CUBIC (no cv2 here
+to pin it bit for bit; tests hold it within one grey level of an independent a = -0.75 float bicubic); ``Image.data``
+decodes with PIL when a file is given, whose JPEG decoder may differ from OpenCV's by a grey level; synthetic configs
+use InMemoryImage.
 """
 import numpy as np
 
