@@ -31,7 +31,7 @@ def main():
         padding = "same" if k > 1 and rs.rand() < 0.8 else "valid"
         cin = int(rs.choice([3, 3, 4, 20, 32, 64, 64, 96, 128, 256, 512]))
         cout = int(rs.choice([9, 36, 40, 64, 72, 100, 128, 192, 256, 512]))
-        n = int(rs.choice([1, 1, 2, 5]))
+        n = int(rs.choice([1, 1, 2, 5, 40]))
         h, w = int(rs.randint(k, 40)), int(rs.randint(k, 40))
         tile = int(rs.choice(tiles))
         act = [None, "relu", "sigmoid"][rs.randint(3)]
@@ -58,6 +58,19 @@ def main():
         worst = max(worst, err)
         if not err <= 1e-4:
             print("FAIL fwd %.3g" % err, desc); fails += 1
+        # position-major twin of the same launch (tap skipping, split-K / balanced forms over the compacted walk)
+        if cin % 32 == 0 and k * k <= 32 and tile >= 11 and rs.rand() < 0.5:
+            try:
+                ws = ops.ConvWorkspace()
+                with ops.conv_workspace(ws):
+                    gp = ops.conv2d(torch.from_numpy(x).cuda().permute(1, 2, 0, 3).contiguous(), pc, stride, padding, act,
+                                    None if res is None else torch.from_numpy(res).cuda().permute(1, 2, 0, 3).contiguous(),
+                                    tile=int(rs.choice([tile, 61, 62])), layout=1)
+                e2 = ((gp.permute(2, 0, 1, 3).cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
+                if not e2 <= 1e-4:
+                    print("FAIL pos-major %.3g" % e2, desc); fails += 1
+            except Exception as e:
+                print("RAISED pos-major", desc, e); fails += 1
         # backward (stride-1 layers only have an input-gradient form)
         if it % 3 == 0 and cin % 4 == 0 and cin >= 32:
             g = rs.randn(*want.shape).astype(np.float32)
