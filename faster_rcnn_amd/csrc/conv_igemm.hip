@@ -27,6 +27,7 @@
 // + residual[m][n], activation (none / relu / sigmoid), store NHWC.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace frcnn {
 
@@ -46,6 +47,7 @@ struct ConvArgs {
     int splits;             // split-K: K-slices per output tile (1 = none)
     float* slabs;           // [tile][slice][BM*BN] f32 partial tiles
     unsigned* tickets;      // [tile] arrival counters: zero on entry, left zero on exit
+    int vec_epi;            // 1: y / residual / mask rows are 16-byte addressable (set by frcnn_conv2d_fwd_ws): the v2 / balanced kernels use epilogue_vec
 };
 
 constexpr int BK = 32;
@@ -234,7 +236,121 @@ typedef int i32x3 __attribute__((ext_vector_type(3)));
 constexpr unsigned OOB_OFFSET = 0x80000000u;     // >= num_records of any tensor we accept (< 2 GiB)
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+// Lab builds (scripts/micro/conv_lab.hip) compile this file with FRCNN_LAB_STAMPS: every workgroup then records
+// the 100 MHz wall clock at its phase boundaries.  The product library never defines it.
+#ifdef FRCNN_LAB_STAMPS
+__device__ unsigned long long* g_lab_stamps = nullptr;
+#define LAB_STAMP(i) do { if (g_lab_stamps && threadIdx.x == 0) g_lab_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LAB_STAMP(i) do { } while (0)
+#endif
 constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+
+// ------------------------------------------------------------------------------------
+// Vectorised epilogue.  In the accumulator layout a lane owns ONE output column, so the plain epilogue above moves
+// 4 bytes per lane (sixteen residual loads and sixteen stores per 32x32 tile, each touching two 128-byte row pieces)
+// and, issued after the main loop, leaves their latency exposed: on the trunk's 64x64-tile launches it lasted as
+// long as the main loop itself (in-kernel timestamps, scripts/micro/conv_lab.hip: res3 2c 10.0 us against 9.0,
+// res2 2c 9.4 against 4.2, the head's 512->2048 layers 21.7 against 21.0).  Here the workgroup turns its BM x BN
+// tile through LDS (the operand buffers are dead by then) and every thread owns 16-byte pieces of whole rows:
+// scale / shift / residual / mask / y all move as b128, one wave instruction covers 1 KB of full row segments, and
+// out-of-range rows / columns ride on the buffer descriptors (no branches).  The residual pieces of a 64x64 tile
+// are fetched BEFORE the main loop (four registers' worth per thread) when the kernel has no split-K reducer.
+// Per element the arithmetic and its order are those of epilogue(): results are bit-identical.
+template <int TM, int TN, int WM, int WN>
+struct EpiVec {
+    static constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static constexpr int LD = BN + 4;                    // floats per staged row (16-byte aligned rows)
+    static constexpr int C4 = BN / 4;                    // 16-byte pieces per row
+    static constexpr int RPP = NT / C4;                  // rows per pass
+    static constexpr int PASSES = BM / RPP;
+    static constexpr bool fits = (size_t)BM * LD <= (size_t)2 * (BM + BN) * LDS_STRIDE && BM % RPP == 0 && NT % C4 == 0;
+};
+
+// byte offsets of this thread's pieces in y (stride ldy) / residual (ldres) / mask (Cout); OOB_OFFSET outside the tensor
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ unsigned epi_piece_off(const ConvArgs& p, int m0, int n0, int tid, int q, int ld) {
+    using E = EpiVec<TM, TN, WM, WN>;
+    const int m = m0 + q * E::RPP + tid / E::C4, n = n0 + (tid % E::C4) * 4;
+    return (m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * ld + n) * 4) : OOB_OFFSET;
+}
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void epi_prefetch_residual(const ConvArgs& p, int m0, int n0, int tid, f32x4 (&rpre)[EpiVec<TM, TN, WM, WN>::PASSES]) {
+    using E = EpiVec<TM, TN, WM, WN>;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < E::PASSES; ++q)
+        rpre[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, epi_piece_off<TM, TN, WM, WN>(p, m0, n0, tid, q, p.ldres), 0, 0));
+}
+
+template <int TM, int TN, int WM, int WN, bool HAVE_PRE>
+__device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh,
+                                             float* smem, const f32x4* rpre) {
+    using E = EpiVec<TM, TN, WM, WN>;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * p.ldy * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.mask ? p.mask : p.x), 0, p.mask ? (int)((size_t)p.M * p.Cout * 4) : 0, 0x00020000);
+    // big tiles walk their passes in groups of four so the pieces in flight stay within ~32 registers: the 128x128
+    // kernels must keep (VGPR + AGPR) <= 256 for two waves per SIMD
+    constexpr int GP = E::PASSES < 4 ? E::PASSES : 4;
+    static_assert(E::PASSES % GP == 0, "passes must split into whole groups");
+    f32x4 rres[GP], rmask[GP];
+    auto fetch = [&](int g) {                               // the global reads of group g
+        if constexpr (!HAVE_PRE) {
+            if (p.residual) {
+#pragma unroll
+                for (int q = 0; q < GP; ++q)
+                    rres[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, epi_piece_off<TM, TN, WM, WN>(p, m0, n0, tid, g * GP + q, p.ldres), 0, 0));
+            }
+        }
+        if (p.mask) {
+#pragma unroll
+            for (int q = 0; q < GP; ++q)
+                rmask[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, epi_piece_off<TM, TN, WM, WN>(p, m0, n0, tid, g * GP + q, p.Cout), 0, 0));
+        }
+    };
+    fetch(0);                                               // in flight while the tile goes through LDS
+    const int n = n0 + (tid % E::C4) * 4;
+    f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (n < p.Cout) {
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    }
+    __syncthreads();                                        // every wave is done with the operand buffers (and the split-K flag word)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float* dst = smem + (wm * TM * 32 + i * 32 + 4 * lh) * E::LD + wn * TN * 32 + j * 32 + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * E::LD] = acc[i][j][e];
+        }
+    __syncthreads();
+    const float* src = smem + (tid / E::C4) * E::LD + (tid % E::C4) * 4;
+#pragma unroll 1
+    for (int g = 0; g < E::PASSES / GP; ++g) {
+        if (g) fetch(g);
+#pragma unroll
+        for (int q = 0; q < GP; ++q) {
+            const int pass = g * GP + q;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + pass * E::RPP * E::LD);
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = a[c] * sc[c] + sh[c];
+                if (p.residual) t += HAVE_PRE ? rpre[q][c] : rres[q][c];
+                if (p.mask && !(rmask[q][c] > 0.0f)) t = 0.0f;
+                v[c] = activate(t, p.act);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, epi_piece_off<TM, TN, WM, WN>(p, m0, n0, tid, pass, p.ldy), 0, 0);
+        }
+    }
+}
 
 //
 // SPLITK: small grids (stage 4, the RPN heads, the dense layers: <= 152 tiles for 256 CUs and a long k loop)
@@ -265,6 +381,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
+    LAB_STAMP(0);
 
     const int splits = SPLITK ? p.splits : 1;
     const int nwg = p.tiles_m * p.tiles_n * splits;
@@ -330,7 +447,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
     const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
     const int ke = SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all;
 
-    i32x4 ra[PA], rb[PB];
     unsigned rem = tap_mask;                                 // taps of the current channel group still to load
     int c0 = 0, w_grp = 0;                                   // channel offset / byte offset of the group's filter chunks
     if (SPLITK) {
@@ -339,20 +455,22 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
         for (int t = kb - grp * n_taps; t > 0; --t) rem &= rem - 1;
     }
     int kc3 = kb;                                            // CIN3: next chunk (of eight taps) to load
-    auto load_chunk = [&](int) {
+    // the NEXT chunk of this workgroup's sequence -> a set of staging registers (calls walk the sequence in order; calls
+    // past the end of the range fetch in-bounds or zero data that is never multiplied)
+    auto load_into = [&](i32x4 (&xa)[PA], i32x4 (&xb)[PB]) {
         if constexpr (CIN3) {
             const int tap = kc3 * 8 + (tid & 7);             // per lane: this lane's tap of the chunk
             const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
             const int tap_off = (r_tap * p.W + s_tap) * 12;  // 3 channels x 4 bytes per pixel
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], kc3 * (BK * 4), 0);
+                xb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], kc3 * (BK * 4), 0);
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
                 const bool ok = tap < RS && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 const i32x3 v = __builtin_amdgcn_raw_buffer_load_b96(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0);
-                ra[i] = i32x4{v[0], v[1], v[2], 0};
+                xa[i] = i32x4{v[0], v[1], v[2], 0};
             }
             ++kc3;
             return;
@@ -363,12 +481,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
         const int w_off = w_grp + tap * (BK * 4);
 #pragma unroll
         for (int i = 0; i < PB; ++i)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0);
+            xb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0);
+            xa[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0);
         }
         // branch-free walk to the next needed tap (a scalar branch here would split the loop body into two
         // scheduling regions and undo the interleave below)
@@ -378,13 +496,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
         c0 += wrap * BK;
         w_grp += wrap * (RS * BK * 4);
     };
-    auto store_chunk = [&](int buf) {
+    auto store_from = [&](const i32x4 (&xa)[PA], const i32x4 (&xb)[PB], int buf) {
         float* a = As + buf * BM * LDS_STRIDE;
         float* b = Bs + buf * BN * LDS_STRIDE;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + RPP * i) * LDS_STRIDE + lcol) = ra[i];
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + RPP * i) * LDS_STRIDE + lcol) = xa[i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + RPP * i) * LDS_STRIDE + lcol) = rb[i];
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + RPP * i) * LDS_STRIDE + lcol) = xb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -395,6 +513,136 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // the residual pieces this thread will add in the vector epilogue, requested now: a 64x64 tile's main loop is a few
+    // microseconds, about as long as the fetch
+    using EV = EpiVec<TM, TN, WM, WN>;
+    constexpr bool EPI_PRE = EV::fits && !SPLITK && TM * TN == 1;
+    f32x4 rpre[EPI_PRE ? EV::PASSES : 1];
+    if constexpr (EPI_PRE) {
+        if (p.vec_epi) epi_prefetch_residual<TM, TN, WM, WN>(p, m0, n0, tid, rpre);
+    }
+
+    constexpr int MF = TM * TN * 4;        // MFMAs per kk-step
+    constexpr int NL = PA + PB;            // global loads == LDS stores per chunk per thread
+    constexpr int NF = TM + TN;            // fragment reads per kk-step
+    if constexpr (VARIANT == 2) {
+        // ---- VARIANT 2: the barrier sits in the MIDDLE of a chunk and nothing waits behind it.
+        // In VARIANTs 0/1 every chunk ends [LDS stores -> barrier -> first fragment reads -> first MFMA]: a wave alone
+        // on its SIMD (stage-4 grids: one or two workgroups per CU) idles the matrix pipe for that whole chain -- timed
+        // at 1 700 cycles per 1 024-cycle chunk (scripts/micro/conv_lab.hip, stamps).  Here chunk T is multiplied as
+        //   first half : MFMAs of k-steps 0,1 (step-0 fragments were read during chunk T-1); fragment reads of steps 1..3
+        //   barrier    : all waves have finished READING buffer T%2 and their stores of chunk T+1 (made during the
+        //                second half of chunk T-1) are visible
+        //   second half: MFMAs of k-steps 2,3; LDS stores of chunk T+2 into buffer T%2; fragment reads of chunk T+1's
+        //                step 0; global loads of chunk T+4
+        // so the operands of the MFMAs that follow the barrier are already in registers, the stores and the next reads
+        // ride in the shadow of k-steps 2,3, and a chunk's global loads have TWO chunks of MFMA time to land (two
+        // staging register sets; same two LDS buffers as before).
+        // staging register sets: two for the 64-wide tiles (a chunk's loads get two chunks of MFMA time), one for the
+        // big tiles (a 128x128 chunk is 4 096 MFMA cycles per wave: one chunk of lead is plenty, and the registers are needed)
+        constexpr int SETS = TM * TN == 1 ? 2 : 1;
+        i32x4 sa0[PA], sb0[PB], sa1[SETS == 2 ? PA : 1], sb1[SETS == 2 ? PB : 1];
+        f32x4 na[TM], nb[TN];                                  // step-0 fragments of the chunk about to start
+        load_into(sa0, sb0);                                   // chunk 0
+        if constexpr (SETS == 2) {
+            load_into(sa1, sb1);                               // chunk 1
+            store_from(sa0, sb0, 0);
+            load_into(sa0, sb0);                               // chunk 2
+            store_from(sa1, sb1, 1);
+            load_into(sa1, sb1);                               // chunk 3
+        } else {
+            store_from(sa0, sb0, 0);
+            load_into(sa0, sb0);                               // chunk 1
+            store_from(sa0, sb0, 1);
+            load_into(sa0, sb0);                               // chunk 2
+        }
+        __syncthreads();
+        LAB_STAMP(1);
+        {
+            const float* a = As + (wm * TM * 32 + li) * LDS_STRIDE + lh * 4;
+            const float* b = Bs + (wn * TN * 32 + li) * LDS_STRIDE + lh * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) na[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_STRIDE);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) nb[j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_STRIDE);
+        }
+        auto chunk = [&](auto parity, auto& xa, auto& xb) {
+            constexpr int P = decltype(parity)::value;
+            const float* a = As + P * BM * LDS_STRIDE + (wm * TM * 32 + li) * LDS_STRIDE + lh * 4;
+            const float* b = Bs + P * BN * LDS_STRIDE + (wn * TN * 32 + li) * LDS_STRIDE + lh * 4;
+            const float* an = As + (P ^ 1) * BM * LDS_STRIDE + (wm * TM * 32 + li) * LDS_STRIDE + lh * 4;
+            const float* bn = Bs + (P ^ 1) * BN * LDS_STRIDE + (wn * TN * 32 + li) * LDS_STRIDE + lh * 4;
+            f32x4 fa[BK / 8][TM], fb[BK / 8][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = na[i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = nb[j];
+#pragma unroll
+            for (int kk = 1; kk < BK / 8; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[kk][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[kk][j] = *reinterpret_cast<const f32x4*>(b + j * 32 * LDS_STRIDE + kk * 8);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i][e], fb[kk][j][e], acc[i][j], 0, 0, 0);
+            SGB(SG_DS_RD, NF);                                       // step-1 fragments first
+#pragma unroll
+            for (int q = 0; q < MF; ++q) {                           // k-step 0: the step-2,3 fragment reads behind its MFMAs
+                SGB(SG_MFMA, 1);
+                if (q < NF) SGB(SG_DS_RD, 2);
+            }
+#pragma unroll
+            for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);            // k-step 1
+            __builtin_amdgcn_sched_barrier(0);                       // k-steps 0,1 stay in FRONT of the barrier: its wait then falls behind 8 queued MFMAs
+            __syncthreads();
+            store_from(xa, xb, P);                                   // chunk T+2 -> the buffer every wave has just finished reading
+            load_into(xa, xb);                                       // chunk T+4
+#pragma unroll
+            for (int i = 0; i < TM; ++i) na[i] = *reinterpret_cast<const f32x4*>(an + i * 32 * LDS_STRIDE);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) nb[j] = *reinterpret_cast<const f32x4*>(bn + j * 32 * LDS_STRIDE);
+#pragma unroll
+            for (int kk = 2; kk < BK / 8; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i][e], fb[kk][j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < MF; ++q) {                           // k-step 2: LDS stores, then the next chunk's step-0 reads
+                SGB(SG_MFMA, 1);
+                if (q < NL) SGB(SG_DS_WR, 1);
+            }
+            if (NL > MF) SGB(SG_DS_WR, NL - MF);
+            SGB(SG_DS_RD, NF);
+#pragma unroll
+            for (int q = 0; q < MF; ++q) {                           // k-step 3: global loads
+                SGB(SG_MFMA, 1);
+                if (q < NL) { SGB(SG_VALU, 4); SGB(SG_VMEM_RD, 1); }
+            }
+        };
+        int kc = kb;
+        for (; kc + 1 < ke; kc += 2) {
+            chunk(std::integral_constant<int, 0>{}, sa0, sb0);
+            if constexpr (SETS == 2) chunk(std::integral_constant<int, 1>{}, sa1, sb1);
+            else chunk(std::integral_constant<int, 1>{}, sa0, sb0);
+        }
+        if (kc < ke) chunk(std::integral_constant<int, 0>{}, sa0, sb0);
+        __syncthreads();                                             // the epilogue reuses the buffers
+    } else {
+    i32x4 ra[PA], rb[PB];
+    auto load_chunk = [&](int) { load_into(ra, rb); };
+    auto store_chunk = [&](int buf) { store_from(ra, rb, buf); };
     // Two-deep operand pipeline: chunk t+2 travels global->registers while chunk t+1 travels
     // registers->LDS and chunk t feeds the MFMAs.  The loads issued in iteration t are consumed
     // (ds_write) at the top of iteration t+1, so they have a whole chunk of MFMA time to land and
@@ -403,10 +651,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
     store_chunk(0);
     load_chunk(kb + 1 < ke ? kb + 1 : kb);
     __syncthreads();
+    LAB_STAMP(1);
 
-    constexpr int MF = TM * TN * 4;        // MFMAs per kk-step
-    constexpr int NL = PA + PB;            // global loads == LDS stores per chunk per thread
-    constexpr int NF = TM + TN;            // fragment reads per kk-step
     for (int kc = kb; kc < ke; ++kc) {
         const int buf = (kc - kb) & 1;
         if constexpr (VARIANT == 0) {
@@ -481,6 +727,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
         }
         __syncthreads();
     }
+    }
+    LAB_STAMP(2);
     if constexpr (SPLITK) {
         // publish this slice's partial tile WRITE-THROUGH (sc1 stores need no release fence: cdna guide G16 R1);
         // thread-major 16-B rows, so the stores and the reducer's loads coalesce
@@ -511,6 +759,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
             *last = is_last;
         }
         __syncthreads();
+        LAB_STAMP(3);
         if (!*last) return;
         const float4* base = reinterpret_cast<const float4*>(p.slabs + (size_t)tile * splits * (BM * BN));
 #pragma unroll
@@ -531,8 +780,24 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
                         acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
                     }
         }
+        LAB_STAMP(4);
     }
-    epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+    if constexpr (EV::fits) {
+        if (p.vec_epi) epilogue_vec<TM, TN, WM, WN, EPI_PRE>(acc, p, m0, n0, tid, wm, wn, li, lh, smem, rpre);
+        else epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+    } else {
+        epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+    }
+#ifdef FRCNN_LAB_STAMPS
+    LAB_STAMP(5);                                            // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LAB_STAMP(6);                                            // stores done
+    if (g_lab_stamps && threadIdx.x == 0) {
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_lab_stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -787,7 +1052,8 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32_sk(const ConvArgs p) {
                         }
             }
         }
-        epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+        if (p.vec_epi) epilogue_vec<TM, TN, WM, WN, false>(acc, p, m0, n0, tid, wm, wn, li, lh, smem, nullptr);
+        else epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
     }
 }
 
@@ -1290,6 +1556,8 @@ static int launch_conv_v2_splitk(const ConvArgs& a, hipStream_t s) {
 
 using namespace frcnn;
 
+static bool g_scalar_epilogue = getenv("FRCNN_SCALAR_EPILOGUE") != nullptr;      // dev knob: the 4-byte epilogue everywhere
+
 // tile / main-loop selection shared by frcnn_conv2d_fwd and frcnn_conv2d_config
 static int choose_streamk(const frcnn_conv_desc* d, int cfg);
 
@@ -1330,7 +1598,7 @@ static int choose_config(const frcnn_conv_desc* d) {
 
 // K-slices per output tile for the 64x64 kernel (1 = plain launch).  desc.tile / 100 forces a value (dev knob).
 static int choose_splits(const frcnn_conv_desc* d, int cfg) {
-    if (cfg != 22) return 1;
+    if (cfg != 22 && cfg != 23) return 1;
     const long long M = (long long)d->n * d->ho * d->wo;
     const long long tiles = ((M + 63) / 64) * ((d->cout + 63) / 64);
     const int nk = (d->kh * d->kw * d->cin + BK - 1) / BK;
@@ -1484,6 +1752,11 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     a.pix_stride = a.layout ? d->n * d->cin : d->cin;
     a.img_stride = a.layout ? d->cin : d->h * d->w * d->cin;
     a.inv_S = (65536 + d->kw - 1) / d->kw;
+    // the vector epilogue addresses rows in 16-byte pieces through 32-bit buffer offsets
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    a.vec_epi = !g_scalar_epilogue && (d->cout & 3) == 0 && (a.ldy & 3) == 0 && al16(y) && (size_t)M * a.ldy * 4 < 0x7fffffffull
+             && (!residual || ((a.ldres & 3) == 0 && al16(residual) && (size_t)M * a.ldres * 4 < 0x7fffffffull))
+             && (!mask || (al16(mask) && (size_t)M * d->cout * 4 < 0x7fffffffull)) && (!scale || al16(scale)) && (!shift || al16(shift));
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
     int cfg = choose_config(d);
@@ -1508,7 +1781,7 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
             a.splits = choose_splits(d, cfg);
             a.tickets = (unsigned*)workspace;
             a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
-            return launch_conv_v2_splitk<1, 1, 1>(a, s);
+            return cfg == 23 ? launch_conv_v2_splitk<1, 1, 2>(a, s) : launch_conv_v2_splitk<1, 1, 1>(a, s);
         }
     }
     if (generic) {
@@ -1521,6 +1794,10 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
         case 43: return launch_conv_v2<1, 1, 1, 4, 2>(a, s);     // 128x64, 8 waves
         case 61: case 21: return launch_conv_v2<2, 2, 1>(a, s);     // (61 / 62 without a workspace: the plain launch)
         case 62: case 22: return launch_conv_v2<1, 1, 1>(a, s);
+        case 23: return launch_conv_v2<1, 1, 2>(a, s);           // 64x64, mid-chunk barrier main loop
+        case 24: return launch_conv_v2<1, 2, 2>(a, s);           // 64x128
+        case 25: return launch_conv_v2<2, 1, 2>(a, s);           // 128x64
+        case 26: return launch_conv_v2<2, 2, 2>(a, s);           // 128x128
         case 11: return launch_conv_v2<2, 2>(a, s);
         case 12: return launch_conv_v2<1, 1>(a, s);
         case 13: return launch_conv_v2<2, 1>(a, s);

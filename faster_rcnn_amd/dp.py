@@ -3,6 +3,7 @@ flat gradient buffer per step (RCCL over xGMI through torch.distributed, backend
 code runs on the "gloo" backend for the CPU tests).  The reference is single-process
 (train_util.py:38-54); with world_size == 1 every function here is the identity."""
 import os
+import random
 
 import torch
 import torch.distributed as dist
@@ -54,3 +55,49 @@ def broadcast_(flat, src=0):
     if world() > 1:
         dist.broadcast(flat, src=src)
     return flat
+
+
+DP_SHUFFLE_SEED = 20171204      # every rank seeds its shuffle stream with this: identical permutations everywhere
+
+
+class ImageSchedule:
+    """Which image a rank trains on at global step ``i`` of a phase, with the reference's shuffles.
+
+    The reference walks ``img_idx = (i + num_iterations*phase_num) % num_train`` and calls
+    ``random.shuffle(images)`` whenever that index is 0, before using image 0 (train_util.py:39-41, 100-103).
+    Under data parallelism the ``world`` ranks of step ``i`` take the consecutive positions
+    ``i*world + rank`` of that walk.  A wrap can fall BETWEEN two ranks of one step (``num_train % world != 0``):
+    the ranks before it still use the old order, the ranks at and after it the reshuffled one.  So every rank
+    counts how many positions with index 0 lie at or before its own position -- previous phases included, a
+    closed form, no communication -- and applies exactly that many shuffles from a stream all ranks seed
+    identically (``random.Random(DP_SHUFFLE_SEED)``): rank-independent permutations, no duplicated or dropped
+    image.  The global ``random`` stream is left to the per-image sampling (rpn_util._apply_sampling), and with
+    world == 1 the shuffles come from it exactly as in the reference (seeded runs reproduce its order).
+    """
+
+    def __init__(self, images, rank_=None, world_=None, seed=DP_SHUFFLE_SEED):
+        self.images = images
+        self.rank = rank() if rank_ is None else rank_
+        self.world = world() if world_ is None else world_
+        self.rng = random if self.world == 1 else random.Random(seed)
+        self.applied = 0            # shuffles applied to self.images so far
+        self.before_phase = 0       # index-0 positions in the phases already finished
+        self.offset = self.steps = 0
+
+    @staticmethod
+    def _zero_hits(a, b, n):
+        """positions x in [a, b] with x % n == 0"""
+        return b // n - (a - 1) // n if b >= a else 0
+
+    def begin_phase(self, phase_num, num_iterations):
+        self.before_phase += self._zero_hits(self.offset, self.offset + self.steps * self.world - 1, len(self.images))
+        self.offset, self.steps = num_iterations * phase_num * self.world, num_iterations
+
+    def image(self, i):
+        n = len(self.images)
+        pos = self.offset + i * self.world + self.rank
+        hits = self.before_phase + self._zero_hits(self.offset, pos, n)
+        while self.applied < hits:
+            self.rng.shuffle(self.images)
+            self.applied += 1
+        return self.images[pos % n]

@@ -22,13 +22,39 @@ class _Layer:
 
 
 class _Model:
+    """Trained weights live in the trainer's flat fp32 master buffer (train.ParamSet) between steps; every way OUT of
+    the model -- ``get_layer(...).get_weights()`` right after ``train_on_batch`` (train_rpn_test.py:41), ``predict*``,
+    ``save*`` -- first flushes them back into the Keras-keyed weight dict (``_flush_trainer``), and ``load_weights``
+    after ``compile`` rebuilds the trainer on the loaded values (Keras keeps training from what was loaded)."""
+    _trainer = None
+    _dirty = False
+
     def __init__(self, weights):
         self.weights = weights
 
     def _modules(self):
         return []
 
+    def _flush_trainer(self):
+        if self._trainer is not None and self._dirty:
+            self._trainer.sync_weights()
+            self._dirty = False
+
+    def _new_trainer(self):
+        raise NotImplementedError
+
+    def compile(self, optimizer, loss=None):
+        """Keras ``compile``: a fresh train function, i.e. fresh optimiser slots (train_util.py:31-33, 95)."""
+        if self._trainer is None:
+            self._trainer = self._new_trainer()
+        self._trainer.compile(optimizer, loss)
+
+    def train_on_batch(self, x, y, skip=False):
+        self._dirty = True
+        return self._trainer.train_on_batch(x, y, skip=skip)
+
     def get_layer(self, name):
+        self._flush_trainer()
         if name not in self.weights:
             raise ValueError("No such layer: " + name)
         return _Layer(self.weights, name)
@@ -41,19 +67,30 @@ class _Model:
 
     def load_weights(self, path, by_name=False):
         """Keras ``load_weights``: ``path`` is a Keras 2.0.x .h5 (weights or full model) or this package's .npz."""
+        self._flush_trainer()                               # layers the file does not name keep their TRAINED values
         new = load_npz(path)
         for k, v in new.items():
             if k in self.weights or not by_name:
                 self.weights[k] = v
         self.invalidate()
+        if self._trainer is not None:
+            # training continues from the loaded values: new master buffers and packed filters; the optimiser object
+            # (with its step counter) and its slots carry over, as in Keras, where load_weights touches neither
+            old = self._trainer
+            self._trainer = self._new_trainer()
+            if old.optimizer is not None:
+                self._trainer.compile(old.optimizer)
+                self._trainer.params.adopt_slots(old.params)
 
     def save_weights(self, path):
         """Keras ``save_weights``: ``.h5`` writes a Keras 2.0.x HDF5 weight file, any other suffix the .npz form."""
+        self._flush_trainer()
         save_weights_file(path, self.weights)
 
     def save(self, path):
         """Keras ``model.save``: for ``.h5`` the weights go under ``model_weights`` like Keras' full-model files
         (architecture / optimiser state are not stored: the builders re-create the graph from the layer names)."""
+        self._flush_trainer()
         save_weights_file(path, self.weights, full_model=True)
 
 
@@ -88,30 +125,11 @@ class RpnModel(_Model):
         cls, reg = self.head(feat)
         return cls, reg, feat
 
-    # ---- training (train_util.py:31-54)
-    def compile(self, optimizer, loss=None):
+    # ---- training (train_util.py:31-54): compile / train_on_batch / flushing live in _Model
+    def _new_trainer(self):
         from .train import RpnTrainer
         reg = getattr(self, "weight_regularizer", None) or self.base.weight_regularizer
-        if getattr(self, "_trainer", None) is None:
-            self._trainer = RpnTrainer(self, l2=reg.l2 if reg is not None else 0.0)
-        self._trainer.compile(optimizer, loss)
-
-    def train_on_batch(self, x, y, skip=False):
-        self._dirty = True
-        return self._trainer.train_on_batch(x, y, skip=skip)
-
-    def _flush_trainer(self):
-        if getattr(self, "_trainer", None) is not None and getattr(self, "_dirty", False):
-            self._trainer.sync_weights()
-            self._dirty = False
-
-    def save_weights(self, path):
-        self._flush_trainer()
-        super().save_weights(path)
-
-    def save(self, path):
-        self._flush_trainer()
-        super().save(path)
+        return RpnTrainer(self, l2=reg.l2 if reg is not None else 0.0)
 
     def predict_on_batch(self, x):
         self._flush_trainer()
@@ -137,28 +155,14 @@ class DetModel(_Model):
         feat = self.base.net(first) if self.base is not None else first
         return self.head(feat, rois)
 
-    # ---- training (train_util.py:95-118)
-    def compile(self, optimizer, loss=None):
+    # ---- training (train_util.py:95-118): compile / train_on_batch / flushing live in _Model
+    def _new_trainer(self):
         from .train import DetTrainer
         reg = self.base.weight_regularizer if self.base is not None else getattr(self, "weight_regularizer", None)
-        if getattr(self, "_trainer", None) is None:
-            self._trainer = DetTrainer(self, l2=reg.l2 if reg is not None else 0.0)
-        self._trainer.compile(optimizer, loss)
-
-    def train_on_batch(self, x, y, skip=False):
-        return self._trainer.train_on_batch(x, y, skip=skip)
-
-    def save_weights(self, path):
-        if getattr(self, "_trainer", None) is not None:
-            self._trainer.sync_weights()
-        super().save_weights(path)
-
-    def save(self, path):
-        if getattr(self, "_trainer", None) is not None:
-            self._trainer.sync_weights()
-        super().save(path)
+        return DetTrainer(self, l2=reg.l2 if reg is not None else 0.0)
 
     def predict(self, inputs):
+        self._flush_trainer()
         first, rois = inputs
         first = nets.to_device_image(first)
         rois = torch.from_numpy(np.ascontiguousarray(np.asarray(rois, dtype=np.float32))).cuda().reshape(-1, 4)

@@ -21,14 +21,21 @@ from .ops import _p, _stream
 
 
 # ----------------------------------------------------------------------------- optimisers (args_util.py:48-59)
+# ``iterations`` mirrors Keras' ``optimizer.iterations``: a variable created in the optimiser's __init__ that counts
+# every update the OBJECT has made.  The reference builds one optimiser per run (args_util.py:56-59) and re-compiles
+# with it for every phase (train_util.py:29-33): ``get_updates`` then re-creates the moment slots, but the counter
+# keeps running, so Adam's bias correction in phase 2 starts from t = iterations + 1, not from 1 [Keras 2.0.8
+# optimizers.py, Adam.get_updates].  SGD carries the same counter (it only feeds ``decay``, which is 0 here).
 class SGD:
     def __init__(self, lr=1e-3, momentum=0.9):
         self.lr, self.momentum = lr, momentum
+        self.iterations = 0
 
 
 class Adam:
     def __init__(self, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-8):
         self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
+        self.iterations = 0
 
 
 def optimizer_from_str(optimizer_str):
@@ -59,18 +66,22 @@ class ParamSet:
                 off += k
             self.views[n] = vs
         self.slots = None
-        self.t = 0
 
     def reset_optimizer(self):
-        """Keras re-creates the optimiser slots on every compile() (train_util.py:31-33)."""
+        """Keras re-creates the optimiser SLOTS (momentum / Adam moments) on every compile() (train_util.py:31-33);
+        the step counter lives on the optimiser object and keeps running (see SGD / Adam above)."""
         self.slots = [torch.zeros_like(self.w), torch.zeros_like(self.w)]
-        self.t = 0
+
+    def adopt_slots(self, other):
+        """Take over another ParamSet's optimiser slots (same layout): load_weights after compile keeps them."""
+        if other.slots is not None and other.total == self.total and other.names == self.names:
+            self.slots = [s.clone() for s in other.slots]
 
     def step(self, opt, l2, grad_scale=1.0):
-        self.t += 1
+        opt.iterations = getattr(opt, "iterations", 0) + 1
         if isinstance(opt, Adam):
             _lib.call("frcnn_adam", _p(self.w), _p(self.g), _p(self.slots[0]), _p(self.slots[1]), self.total, float(opt.lr),
-                      float(opt.beta_1), float(opt.beta_2), float(opt.epsilon), self.t, float(l2), float(grad_scale), _stream())
+                      float(opt.beta_1), float(opt.beta_2), float(opt.epsilon), int(opt.iterations), float(l2), float(grad_scale), _stream())
         else:
             _lib.call("frcnn_sgd_momentum", _p(self.w), _p(self.g), _p(self.slots[0]), self.total, float(opt.lr),
                       float(opt.momentum), float(l2), float(grad_scale), _stream())

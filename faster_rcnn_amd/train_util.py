@@ -7,10 +7,11 @@ GPU, periodic saves (RPN loop also at i == 0, :58; detector loops only for i > 0
 Under ``torch.distributed`` each global step consumes world_size consecutive images of that
 schedule (dp.image_index), every rank runs its own image and the flat gradient buffer is
 all-reduced once.  A rank whose image yields no RoIs still joins the exchange with zero gradients
-(the reference just ``continue``s, :112-114).  Shuffles use a rank-independent seed stream so all
-ranks see the same permutation.
+(the reference just ``continue``s, :112-114).  The image walk and its shuffles live in
+``dp.ImageSchedule``: a dedicated, identically seeded shuffle stream on every rank when world > 1 (the
+global ``random`` stream keeps serving the per-image sampling), the reference's own ``random.shuffle``
+when world == 1.
 """
-import random
 import timeit
 
 from . import dp
@@ -35,17 +36,16 @@ def _save(model, i, save_frequency, save_weights_dest, save_model_dest, what, al
 def train_rpn(rpn_model, images, training_manager, optimizer, phases=[[DEFAULT_NUM_ITERATIONS, DEFAULT_LEARN_RATE]],
               save_frequency=None, save_weights_dest=None, save_model_dest=None):
     """train_util.train_rpn (train_util.py:10-66)."""
-    num_train = len(images)
     anchors_per_loc = len(training_manager.anchor_dims)
+    schedule = dp.ImageSchedule(images)
     for phase_num, (num_iterations, learn_rate) in enumerate(phases):
         optimizer.lr = learn_rate
         rpn_model.compile(optimizer=optimizer, loss=[cls_loss_rpn(anchors_per_loc=anchors_per_loc),
                                                      bbreg_loss_rpn(anchors_per_loc=anchors_per_loc)])
         print("Starting phase {} of training: {} iterations with learning rate {}".format(phase_num, num_iterations, learn_rate))
+        schedule.begin_phase(phase_num, num_iterations)
         for i in range(num_iterations):
-            if dp.image_index(i, phase_num, num_iterations, num_train, rank_=0) < dp.world():
-                random.shuffle(images)                      # same global RNG state on every rank
-            img = images[dp.image_index(i, phase_num, num_iterations, num_train)]
+            img = schedule.image(i)
             batched_img = training_manager.batched_image(img)
             y_class, y_bbreg = training_manager.rpn_y_true(img)
             start_time = timeit.default_timer()
@@ -58,16 +58,15 @@ def train_rpn(rpn_model, images, training_manager, optimizer, phases=[[DEFAULT_N
 
 
 def _train_detector(detector, images, training_manager, optimizer, phases, save_frequency, save_weights_dest, save_model_dest):
-    num_train = len(images)
     num_classes = len(training_manager.class_mapping) - 1
+    schedule = dp.ImageSchedule(images)
     for phase_num, (num_iterations, learn_rate) in enumerate(phases):
         optimizer.lr = learn_rate
         detector.compile(optimizer=optimizer, loss=[cls_loss_det, bbreg_loss_det(num_classes)])
         print("Starting phase {} of training: {} iterations with learning rate {}".format(phase_num, num_iterations, learn_rate))
+        schedule.begin_phase(phase_num, num_iterations)
         for i in range(num_iterations):
-            if dp.image_index(i, phase_num, num_iterations, num_train, rank_=0) < dp.world():
-                random.shuffle(images)
-            img = images[dp.image_index(i, phase_num, num_iterations, num_train)]
+            img = schedule.image(i)
             first_input, rois, y_class_num, y_transform = training_manager.get_training_input(img)
             skip = rois is None
             if skip and dp.world() == 1:

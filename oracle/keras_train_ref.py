@@ -66,8 +66,18 @@ def conv_layer_names(depth, stages):
 
 
 class Optim:
+    """Keras 2.0.8 SGD(momentum) / Adam (optimizers.py, get_updates).  ``t`` is the optimiser object's ``iterations``
+    variable: created in __init__, incremented by every update, NOT reset when the model is compiled again;
+    ``recompile()`` is what a new ``model.compile`` + first ``train_on_batch`` does to the same optimiser object
+    (train_util.py:29-33): the slot variables (momentum / Adam moments) are created afresh, the counter runs on."""
+
     def __init__(self, kind, lr, momentum=0.9):
         self.kind, self.lr, self.momentum, self.t, self.slots = kind, lr, momentum, 0, {}
+
+    def recompile(self, lr=None):
+        self.slots = {}
+        if lr is not None:
+            self.lr = lr
 
     def step(self, params, grads):
         self.t += 1
