@@ -59,6 +59,7 @@ SIGNATURES = {
     "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
     "frcnn_avgpool_pos_major": (I, [P, I, I, I, P, P]),
     "frcnn_softmax_rows": (I, [P, I, I, I, P, I, P]),
+    "frcnn_dense_heads_split": (I, [P, I, I, I, I, P, P, P]),
     "frcnn_loss_rpn_cls": (I, [P, P, I, I, P, P, P]),
     "frcnn_loss_rpn_reg": (I, [P, P, I, I, P, P, P]),
     "frcnn_loss_det_cls": (I, [P, P, I, I, P, P, I, P]),

@@ -47,6 +47,8 @@ struct ConvArgs {
     int splits;             // split-K: K-slices per output tile (1 = none)
     float* slabs;           // [tile][slice][BM*BN] f32 partial tiles
     unsigned* tickets;      // [tile] arrival counters: zero on entry, left zero on exit
+    int group_m;            // tile order inside an XCD's run of ids: 0 = all row tiles of one column tile, then the next column;
+                            // g > 0 = groups of g row tiles, every column tile of a group before the next group (L2 working set)
     int vec_epi;            // 1: y / residual / mask rows are 16-byte addressable (set by frcnn_conv2d_fwd_ws): the v2 / balanced kernels use epilogue_vec
 };
 
@@ -388,7 +390,18 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_f32_v2(const ConvAr
     const int logical = xcd_remap(blockIdx.x, nwg);
     const int tile = SPLITK ? logical / splits : logical;          // a tile's slices are neighbours on one XCD
     const int slice = SPLITK ? logical - tile * splits : 0;
-    const int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    if (p.group_m > 0) {
+        // Grouped order.  An XCD's workgroups hold a contiguous run of ids (xcd_remap), ~128 tiles at a time.  In the plain
+        // order those are 128 ROW tiles of one column tile: the filter slice is shared, every A tile is its own
+        // (1x1 512->2048 on the head's 14 700 rows: 128 x 128 KB = 16 MB live per 4 MB L2, A streamed from beyond L2 once
+        // per column tile, ~0.9 GB per launch).  Grouped, the run is g row tiles x 128/g column tiles: (g + 128/g) tiles of
+        // operands live, each fetched once per group.
+        const int per = p.group_m * p.tiles_n, g = tile / per, m_base = g * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - m_base), r = tile - g * per;
+        tile_n = r / gm;
+        tile_m = m_base + r - tile_n * gm;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -1490,6 +1503,21 @@ __global__ void k_softmax_rows(const float* x, int rows, int cols, int ldx, floa
     for (int c = 0; c < cols; ++c) y[(size_t)r * ldy + c] = expf(xr[c] - mx) / sum;
 }
 
+// The two dense heads of the detector run as ONE GEMM (kernels concatenated along the output axis): this splits its
+// rows back into dense_class_C (softmax over the first `cols` entries, exactly k_softmax_rows) and dense_reg_C (the
+// remaining `tail` entries, copied) -- resnet.py:522-533, vgg.py:241-247.
+__global__ void k_dense_heads_split(const float* x, int rows, int cols, int tail, int ldx, float* cls, float* reg) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* xr = x + (size_t)r * ldx;
+    float mx = -INFINITY;
+    for (int c = 0; c < cols; ++c) mx = fmaxf(mx, xr[c]);
+    float sum = 0.0f;
+    for (int c = 0; c < cols; ++c) sum += expf(xr[c] - mx);
+    for (int c = 0; c < cols; ++c) cls[(size_t)r * cols + c] = expf(xr[c] - mx) / sum;
+    for (int c = 0; c < tail; ++c) reg[(size_t)r * tail + c] = xr[cols + c];
+}
+
 template <int TM, int TN, bool G>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -1557,6 +1585,7 @@ static int launch_conv_v2_splitk(const ConvArgs& a, hipStream_t s) {
 using namespace frcnn;
 
 static bool g_scalar_epilogue = getenv("FRCNN_SCALAR_EPILOGUE") != nullptr;      // dev knob: the 4-byte epilogue everywhere
+static int g_group_m = getenv("FRCNN_GROUP_M") ? atoi(getenv("FRCNN_GROUP_M")) : -1;   // dev knob: tile-order group size (-1 = auto)
 
 // tile / main-loop selection shared by frcnn_conv2d_fwd and frcnn_conv2d_config
 static int choose_streamk(const frcnn_conv_desc* d, int cfg);
@@ -1579,10 +1608,13 @@ static int choose_config(const frcnn_conv_desc* d) {
         // a grid with several tiles per CU slot (64x64: 1840 tiles for the head 3x3) turns that into a shorter
         // launch (500 vs 570 us); the 460 128x128 tiles all start at once and the full-length ones set the time
         // (with several images in flight the neighbours fill the freed slots: pipelines then ask for tile 21)
+        // round 2 (scripts/micro/conv_lab.hip): the mid-chunk-barrier main loop (23 / 26) beats the late-store loop on
+        // every 64x64 launch (trunk + RPN head 1 355 -> 1 269 us per image, bit-identical) and on the 1x1 big-tile
+        // launches (2048->512: 253 -> 246 us); the 3x3 big-tile launches keep the late-store loop (528 vs 539 us)
         if (generic) cfg = 2;
-        else if (d->layout && d->kh * d->kw > 1 && !shared_chip) cfg = choose_streamk(d, 21) ? 21 : 22;   // balanced 128x128 beats both
-        else if (t128 >= 384 && Kpad >= 1024) cfg = 21;
-        else cfg = 22;
+        else if (d->layout && d->kh * d->kw > 1 && !shared_chip) cfg = choose_streamk(d, 21) ? 21 : 23;   // balanced 128x128 beats both
+        else if (t128 >= 384 && Kpad >= 1024) cfg = d->kh * d->kw == 1 ? 26 : 21;
+        else cfg = 23;
     }
     if (d->layout && cfg >= 1 && cfg <= 4) cfg += 10;       // only the v2 main loop knows the position-major layout
     const bool fits_srd = (size_t)d->n * d->h * d->w * d->cin * 4 < 0x7fffffffull && (size_t)d->cout * Kpad * 4 < 0x7fffffffull;
@@ -1590,6 +1622,7 @@ static int choose_config(const frcnn_conv_desc* d) {
     const bool v1_only = !fits_srd || generic || d->kh * d->kw > 32;
     if (cfg >= 61 && v1_only) cfg -= 60;
     if (cfg >= 41 && v1_only) cfg = (cfg == 43) ? 3 : 1;
+    if (cfg >= 23 && cfg <= 26 && v1_only) cfg = cfg >= 25 ? 1 : 2;
     if (cfg >= 21 && v1_only) cfg -= 20;
     if (cfg >= 11 && v1_only) cfg -= 10;
     if (generic) cfg = (cfg == 2) ? 2 : 3;
@@ -1646,9 +1679,9 @@ static int streamk_tile_taps(const frcnn_conv_desc* d, int tile_m, int BM) {
 
 static int choose_streamk(const frcnn_conv_desc* d, int cfg) {
     const bool forced = (cfg == 61 || cfg == 62);
-    if (!forced && (cfg != 21 && cfg != 22)) return 0;
+    if (!forced && (cfg != 21 && cfg != 22 && cfg != 26)) return 0;
     if (d->tile / 100 != 0 || (d->cin % BK) != 0) return 0;
-    const int big = (cfg == 21 || cfg == 61);
+    const int big = (cfg == 21 || cfg == 26 || cfg == 61);
     const int BM = big ? 128 : 64;
     const long long M = (long long)d->n * d->ho * d->wo;
     const long long tiles_m = (M + BM - 1) / BM, tiles_n = (d->cout + BM - 1) / BM;
@@ -1720,7 +1753,7 @@ size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d) {
     if (!d || d->cin <= 0 || (d->cin % BK) != 0) return 0;
     const int cfg0 = choose_config(d);
     if (choose_streamk(d, cfg0)) {
-        const int BM = (cfg0 == 21 || cfg0 == 61) ? 128 : 64;
+        const int BM = (cfg0 == 21 || cfg0 == 26 || cfg0 == 61) ? 128 : 64;
         const long long M = (long long)d->n * d->ho * d->wo;
         const size_t tiles = (size_t)((M + BM - 1) / BM) * ((d->cout + BM - 1) / BM);
         return SPLITK_TICKET_BYTES + tiles * SK_SLOTS * BM * BM * sizeof(float);
@@ -1760,8 +1793,15 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
     int cfg = choose_config(d);
+    // tile order (ConvArgs.group_m): multi-round 64x64 launches with many column tiles walk groups of four row tiles
+    // (1x1 512->2048 on 14 700 rows: 276 -> 261 us, scripts/micro/conv_lab.hip under FRCNN_GROUP_M); single-round
+    // grids and the big tiles measured no difference and keep the plain order
+    {
+        const long long t64 = ((M + 63) / 64) * ((d->cout + 63) / 64);
+        a.group_m = g_group_m >= 0 ? g_group_m : ((cfg == 22 || cfg == 23) && t64 > 1024 && d->cout >= 512 ? 4 : 0);
+    }
     if (cfg == 21 && !workspace && d->tile % 100 == 0 && a.layout && d->kh * d->kw > 1)
-        cfg = 22;                                               // the 128x128 choice there counted on the balanced form
+        cfg = 23;                                               // the 128x128 choice there counted on the balanced form
     if (a.layout && (generic || cfg < 11 || d->kh * d->kw > 32))
         return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: position-major layout needs cin %% 32 == 0, a tensor under 2 GiB and at most 32 taps");
     if (d->cin == 3) {                                          // the stems: filter packed 4 wide, eight taps per chunk
@@ -1776,7 +1816,7 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
             if (const int G = choose_streamk(d, cfg)) {
                 a.tickets = (unsigned*)workspace;
                 a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
-                return (cfg == 21 || cfg == 61) ? launch_conv_sk<2, 2>(a, G, s) : launch_conv_sk<1, 1>(a, G, s);
+                return (cfg == 21 || cfg == 26 || cfg == 61) ? launch_conv_sk<2, 2>(a, G, s) : launch_conv_sk<1, 1>(a, G, s);
             }
             a.splits = choose_splits(d, cfg);
             a.tickets = (unsigned*)workspace;
@@ -1931,7 +1971,7 @@ int frcnn_conv2d_config(const frcnn_conv_desc* d) {
     if (!d) return fail(FRCNN_E_ARG, "conv2d_config: null descriptor");
     if (d->cin == 3) return 30;                                 // the 3-channel stem kernel, whatever tile was asked for
     const int cfg = choose_config(d);
-    if (choose_streamk(d, cfg)) return (cfg == 21 || cfg == 61) ? 61 : 62;     // what a launch WITH a workspace runs
+    if (choose_streamk(d, cfg)) return (cfg == 21 || cfg == 26 || cfg == 61) ? 61 : 62;     // what a launch WITH a workspace runs
     return (cfg == 61 || cfg == 62) ? cfg - 40 : cfg;                           // asked for, but the shape is not eligible
 }
 
@@ -1961,6 +2001,14 @@ int frcnn_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, in
     if (!x || !y) return fail(FRCNN_E_ARG, "softmax_rows: null pointer");
     k_softmax_rows<<<(rows + 63) / 64, 64, 0, as_stream(stream)>>>(x, rows, cols, ldx, y, ldy);
     return check_launch("softmax_rows");
+}
+
+int frcnn_dense_heads_split(const float* x, int rows, int cols, int tail, int ldx, float* cls, float* reg, void* stream) {
+    if (rows < 0 || cols <= 0 || tail < 0 || ldx < cols + tail) return fail(FRCNN_E_ARG, "dense_heads_split: bad argument");
+    if (rows == 0) return FRCNN_OK;
+    if (!x || !cls || (tail && !reg)) return fail(FRCNN_E_ARG, "dense_heads_split: null pointer");
+    k_dense_heads_split<<<(rows + 63) / 64, 64, 0, as_stream(stream)>>>(x, rows, cols, tail, ldx, cls, reg);
+    return check_launch("dense_heads_split");
 }
 
 }  // extern "C"

@@ -161,9 +161,7 @@ class _MergedDense:
     def __call__(self, x2d):
         n, cin = x2d.shape
         y = self.unit(x2d.reshape(n, 1, 1, cin)).reshape(n, -1)
-        cls = ops.softmax_rows(y, self.C)
-        reg = y[:, self.C:].contiguous()
-        return cls, reg
+        return ops.dense_heads_split(y, self.C)                 # softmax | regressions, one launch, no torch kernels
 
 
 class ResNetHead:

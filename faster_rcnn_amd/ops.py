@@ -47,14 +47,18 @@ def _ws(nbytes):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
 
 
-def preprocess_u8(img_u8, mean_bgr):
+def preprocess_u8(img_u8, mean_bgr, out=None):
     """(H,W,3) uint8 BGR image (numpy or device tensor) -> (1,H,W,3) f32 device tensor = float64(img) - mean, cast to f32
-    (resnet.preprocess followed by the network's f32 input cast, bit for bit)."""
+    (resnet.preprocess followed by the network's f32 input cast, bit for bit).  ``out``: write into this tensor
+    (a captured graph's static input) instead of a new one."""
     _require_gpu()
     t = img_u8 if isinstance(img_u8, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img_u8, dtype=np.uint8))
     t = t.to(device="cuda").contiguous()
     assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3
-    out = torch.empty((1,) + tuple(t.shape), dtype=torch.float32, device="cuda")
+    if out is None:
+        out = torch.empty((1,) + tuple(t.shape), dtype=torch.float32, device="cuda")
+    else:
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == t.numel()
     mean = (ctypes.c_double * 3)(*[float(v) for v in mean_bgr])
     _lib.call("frcnn_preprocess_u8", _p(t), t.shape[0] * t.shape[1], mean, _p(out), _stream())
     return out
@@ -251,6 +255,7 @@ CONV_KERNEL_NAMES = {1: "k_conv_igemm_f32<2,2,false>", 2: "k_conv_igemm_f32<1,1,
                      4: "k_conv_igemm_f32<4,2,false>", 11: "k_conv_igemm_f32_v2<2,2>", 12: "k_conv_igemm_f32_v2<1,1>",
                      13: "k_conv_igemm_f32_v2<2,1>", 14: "k_conv_igemm_f32_v2<4,2>",
                      21: "k_conv_igemm_f32_v2<2,2,1>", 22: "k_conv_igemm_f32_v2<1,1,1>",
+                     23: "k_conv_igemm_f32_v2<1,1,2>", 24: "k_conv_igemm_f32_v2<1,2,2>", 25: "k_conv_igemm_f32_v2<2,1,2>", 26: "k_conv_igemm_f32_v2<2,2,2>",
                      30: "k_conv_igemm_f32_v2<1,1,1> stem", 61: "k_conv_igemm_f32_sk<2,2>", 62: "k_conv_igemm_f32_sk<1,1>", 41: "k_conv_igemm_f32_v2<1,2,1,4,2>", 42: "k_conv_igemm_f32_v2<2,1,1,2,4>", 43: "k_conv_igemm_f32_v2<1,1,1,4,2>"}
 
 
@@ -384,6 +389,18 @@ def softmax_rows(x, cols=None):
     out = torch.empty((rows, cols), dtype=torch.float32, device="cuda")
     _lib.call("frcnn_softmax_rows", _p(x.contiguous()), rows, cols, ld, _p(out), cols, _stream())
     return out
+
+
+def dense_heads_split(y, num_classes):
+    """(rows, C + 4(C-1)) output of the merged dense GEMM -> (softmax class probabilities (rows, C), regressions
+    (rows, 4(C-1))), both dense, in one launch."""
+    _require_gpu()
+    rows, ld = y.shape
+    tail = ld - num_classes
+    cls = torch.empty((rows, num_classes), dtype=torch.float32, device="cuda")
+    reg = torch.empty((rows, tail), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_dense_heads_split", _p(y.contiguous()), rows, num_classes, tail, ld, _p(cls), _p(reg), _stream())
+    return cls, reg
 
 
 # ----------------------------------------------------------------------------- detections

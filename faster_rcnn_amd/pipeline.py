@@ -86,7 +86,7 @@ class InferencePipeline:
     def replay_u8(self, img_u8_bgr, mean_bgr=(103.939, 116.779, 123.68)):
         """Replay on a raw (H,W,3) uint8 BGR image: 3 bytes per pixel cross PCIe, resnet.preprocess runs on the device
         (bit-identical to the host path) straight into the graph's input tensor."""
-        self._static_in.copy_(ops.preprocess_u8(img_u8_bgr, mean_bgr))
+        ops.preprocess_u8(img_u8_bgr, mean_bgr, out=self._static_in)
         self._graph.replay()
         return self._static_out
 

@@ -629,7 +629,8 @@ class DetTrainer:
         self.pooled = self.head.forward(crop)
         y = self.dense.forward(self.pooled)                    # (n,1,1,C+4(C-1))
         y2 = y.reshape(y.shape[0], -1)
-        return ops.softmax_rows(y2, self.C), y2[:, self.C:].contiguous(), y2
+        cls, reg = ops.dense_heads_split(y2, self.C)
+        return cls, reg, y2
 
     def train_on_batch(self, x, y, skip=False):
         """x = [image (1,H,W,3) or conv features (1,R,C,Cf), rois (1,n,4)]; y = [y_class (1,n,C), y_bbreg (1,n,8(C-1))]."""

@@ -174,6 +174,8 @@ typedef struct frcnn_conv_desc {
     int32_t tile;                  /* 0 = auto; 1: 128x128, 2: 64x64, 3: 128x64, 4: 256x128;
                                       11..14: the same tiles with the pipelined v2 main loop;
                                       21, 22: 128x128 / 64x64 v2 with the late-LDS-store schedule;
+                                      23..26: 64x64 / 64x128 / 128x64 / 128x128 with the mid-chunk-barrier schedule
+                                          (what auto picks for every 64x64 launch and the 1x1 128x128 ones);
                                       41..43: 128x128 (4x2 / 2x4 waves) and 128x64 with 8 waves;
                                       50: auto for a launch that SHARES the chip with other streams' launches
                                           (several images in flight): prefers the larger tiles;
@@ -272,6 +274,10 @@ int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stri
 int frcnn_avgpool_pos_major(const float* x, int npos, int n, int c, float* y, void* stream);
 /* softmax over the first `cols` entries of each row (Dense(activation='softmax'), resnet.py:522). */
 int frcnn_softmax_rows(const float* x, int rows, int cols, int ldx, float* y, int ldy, void* stream);
+/* Output rows of the detector's two dense heads computed as ONE GEMM (kernels concatenated): cls[r][0..cols) =
+ * softmax(x[r][0..cols)) (dense_class_C, resnet.py:522-527), reg[r][0..tail) = x[r][cols..cols+tail) (dense_reg_C,
+ * :528-533; vgg.py:241-247).  Same arithmetic as frcnn_softmax_rows; both outputs dense. */
+int frcnn_dense_heads_split(const float* x, int rows, int cols, int tail, int ldx, float* cls, float* reg, void* stream);
 
 /* ------------------------------------------------------------------ detections */
 /* voc_dets.get_dets, everything after detector.predict (voc_dets.py:51-88): per scored RoI

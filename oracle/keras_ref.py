@@ -124,21 +124,76 @@ def pool2d(x, k, stride, is_max=True):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
+# --------------------------------------------------------------------------- bf16 storage model (mixed precision)
+def _bf16_round(t):
+    torch = _torch()
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _make_quantisers():
+    """(q, qw) for the mixed-precision model of BASELINE configs[3]/[4] ("bf16 conv", "mixed bf16"): the product keeps
+    activations, activation gradients and the packed filters of its ResNet blocks in bf16 (one round-to-nearest-even
+    at every store) while it accumulates, folds BatchNorm, and keeps master weights / weight gradients in f32.
+      q(t)  -- a STORED activation: rounds the value going forward and the gradient coming back (the input-gradient
+               kernels store bf16 too);
+      qw(w) -- a packed filter: rounded going forward, gradient passed through unrounded (the weight gradient is
+               accumulated in f32 from the bf16 operands and applied to the f32 master copy)."""
+    torch = _torch()
+
+    class _Q(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return _bf16_round(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            return _bf16_round(g)
+
+    class _QW(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return _bf16_round(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    return _Q.apply, _QW.apply
+
+
 # --------------------------------------------------------------------------- Keras graphs
 class KerasGraphs:
     """Layer-by-layer restatement of the reference's model builders, evaluated with torch on
     the CPU in ``dtype`` (float32 = "the Keras CPU path"; float64 = tolerance anchor).
-    ``weights`` = {keras_layer_name: [arrays in get_weights() order]}."""
+    ``weights`` = {keras_layer_name: [arrays in get_weights() order]}.
 
-    def __init__(self, weights, dtype=None):
+    ``mixed=True`` evaluates the SAME graph under the bf16 storage model above (every ``self.q`` / ``self.qw`` below is
+    the identity otherwise): the comparand for the product's bf16 / mixed-precision paths, so that what is left between
+    the two is accumulation order, not storage precision."""
+
+    def __init__(self, weights, dtype=None, mixed=False):
         torch = _torch()
         self.w = weights
         self.dtype = dtype or torch.float32
+        self.mixed = mixed
+        if mixed:
+            self.q, self.qw = _make_quantisers()
+        else:
+            self.q = self.qw = lambda t: t
+
+    @staticmethod
+    def _bf16_layer(name):
+        """Layers whose activations / filters the product stores in bf16: every ResNet block and rpn_conv1.  The
+        3-channel stem, the RPN output layers and the dense layers stay f32 (mixed precision)."""
+        return name.startswith("res") or name == "rpn_conv1"
 
     # -- layers
     def conv(self, x, name, stride=1, padding="valid"):
         w = self.w[name]
-        return conv2d(x, w[0], w[1] if len(w) > 1 else None, stride, padding, self.dtype)
+        k = w[0]
+        if self.mixed and self._bf16_layer(name):
+            k = self.qw(_t(k, self.dtype))
+        return conv2d(x, k, w[1] if len(w) > 1 else None, stride, padding, self.dtype)
 
     def bn(self, x, name, eps):
         return batchnorm_inference(x, *self.w[name], eps=eps)
@@ -159,17 +214,19 @@ class KerasGraphs:
 
     # -- blocks (resnet.py:114-176 identity_block, :179-247 conv_block; TD twins :250-392)
     def identity_block(self, x, stage, block, separate_scale=False):
-        t = self.conv_bn(x, stage, block, "2a", separate_scale=separate_scale).clamp(min=0)
-        t = self.conv_bn(t, stage, block, "2b", padding="same", separate_scale=separate_scale).clamp(min=0)
-        t = self.conv_bn(t, stage, block, "2c", separate_scale=separate_scale)
-        return (t + x).clamp(min=0)
+        q = self.q                                          # stored activations (identity unless mixed)
+        t = q(self.conv_bn(x, stage, block, "2a", separate_scale=separate_scale).clamp(min=0))
+        t = q(self.conv_bn(t, stage, block, "2b", padding="same", separate_scale=separate_scale).clamp(min=0))
+        t = self.conv_bn(t, stage, block, "2c", separate_scale=separate_scale)      # the add and the ReLU happen before the store
+        return q((t + x).clamp(min=0))
 
     def conv_block(self, x, stage, block, stride=2, separate_scale=False):
-        t = self.conv_bn(x, stage, block, "2a", stride=stride, separate_scale=separate_scale).clamp(min=0)
-        t = self.conv_bn(t, stage, block, "2b", padding="same", separate_scale=separate_scale).clamp(min=0)
+        q = self.q
+        t = q(self.conv_bn(x, stage, block, "2a", stride=stride, separate_scale=separate_scale).clamp(min=0))
+        t = q(self.conv_bn(t, stage, block, "2b", padding="same", separate_scale=separate_scale).clamp(min=0))
         t = self.conv_bn(t, stage, block, "2c", separate_scale=separate_scale)
-        s = self.conv_bn(x, stage, block, "1", stride=stride, separate_scale=separate_scale)
-        return (t + s).clamp(min=0)
+        s = q(self.conv_bn(x, stage, block, "1", stride=stride, separate_scale=separate_scale))
+        return q((t + s).clamp(min=0))
 
     # -- bases
     def resnet_base(self, x, depth=50):
@@ -179,7 +236,7 @@ class KerasGraphs:
         x = self.bn(x, "bn_conv1", 1e-3)                                    # Keras default eps (:410)
         if r101:
             x = self.scale(x, "scale_conv1")                                # :567
-        x = pool2d(x.clamp(min=0), 3, 2, True)                              # :411-412
+        x = self.q(pool2d(x.clamp(min=0), 3, 2, True))                      # :411-412 (mixed: the f32 stem's output is cast once)
         if r101:
             plan = {2: ["a", "b", "c"], 3: ["a", "b1", "b2", "b3"], 4: ["a"] + ["b%d" % i for i in range(1, 23)]}
         else:
@@ -205,7 +262,7 @@ class KerasGraphs:
     def rpn(self, feat):
         """resnet50_rpn (resnet.py:464-474) / vgg16_rpn (vgg.py:171-185)."""
         torch = _torch()
-        t = self.conv(feat, "rpn_conv1", padding="same").clamp(min=0)
+        t = self.q(self.conv(feat, "rpn_conv1", padding="same").clamp(min=0))
         cls = torch.sigmoid(self.conv(t, "rpn_out_cls"))
         reg = self.conv(t, "rpn_out_bbreg")
         return cls, reg
@@ -219,7 +276,7 @@ class KerasGraphs:
         """Differentiable form of resnet_classifier (torch RoI resize): returns (softmax probs, reg)."""
         torch = _torch()
         r101 = depth == 101
-        x = roi_resize_torch(feat[0], rois, 7)
+        x = self.q(roi_resize_torch(feat[0], rois, 7))
         x = self.conv_block(x, 5, "a", stride=1, separate_scale=r101)
         x = self.identity_block(x, 5, "b", separate_scale=r101)
         x = self.identity_block(x, 5, "c", separate_scale=r101)
@@ -234,7 +291,7 @@ class KerasGraphs:
         torch = _torch()
         r101 = depth == 101
         crops = roi_resize(np.asarray(feat[0].to(torch.float32)), np.asarray(rois), 7)
-        x = torch.as_tensor(crops).to(self.dtype)                            # RoIs as batch
+        x = self.q(torch.as_tensor(crops).to(self.dtype))                    # RoIs as batch
         x = self.conv_block(x, 5, "a", stride=1, separate_scale=r101)
         x = self.identity_block(x, 5, "b", separate_scale=r101)
         x = self.identity_block(x, 5, "c", separate_scale=r101)

@@ -138,7 +138,7 @@ def vgg_conv_names(blocks):
 
 
 def rpn_train_step(weights, x, y_class, y_bbreg, A, optim, depth=50, freeze_blocks=(1, 2, 3), l2=0.0, dtype=torch.float64,
-                   arch="resnet", l2_base=True):
+                   arch="resnet", l2_base=True, mixed=False):
     """One compile()d train_on_batch of an RPN model (train_rpn_step1.py:59-90; step 3 = every base block
     frozen and only the heads regularised, train_rpn_step3.py:59-76).  Returns (new_weights, [total, l1, l2], grads)."""
     heads = ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"]
@@ -149,7 +149,7 @@ def rpn_train_step(weights, x, y_class, y_bbreg, A, optim, depth=50, freeze_bloc
         base_train = vgg_conv_names([b for b in (1, 2, 3, 4, 5) if b not in freeze_blocks])
         base_all = vgg_conv_names((1, 2, 3, 4, 5))
     w, params = _prepare(weights, set(base_train) | set(heads), dtype)
-    g = KerasGraphs(w, dtype)
+    g = KerasGraphs(w, dtype, mixed=mixed)                  # mixed: the bf16 storage model of BASELINE configs[4] (keras_ref)
     feat = g.resnet_base(x, depth) if arch == "resnet" else g.vgg_base(x)
     cls, reg = g.rpn(feat)
     yc = torch.tensor(np.asarray(y_class, dtype=np.float64), dtype=dtype)
@@ -163,7 +163,7 @@ def rpn_train_step(weights, x, y_class, y_bbreg, A, optim, depth=50, freeze_bloc
 
 
 def det_train_step(weights, x, rois, y_class, y_bbreg, C, optim, depth=50, freeze_blocks=(1, 2, 3), l2=0.0, dtype=torch.float64,
-                   arch="resnet", with_base=True):
+                   arch="resnet", with_base=True, mixed=False):
     """One train_on_batch of a detector model.  with_base=True: step 2 (image in, own base; train_det_step2.py:78-87);
     with_base=False: step 4 (x = conv features, only the head trains and is regularised; train_det_step4.py:67-95)."""
     dn = ["dense_class_%d" % C, "dense_reg_%d" % C]
@@ -176,11 +176,11 @@ def det_train_step(weights, x, rois, y_class, y_bbreg, C, optim, depth=50, freez
         base_all = vgg_conv_names((1, 2, 3, 4, 5))
         head = ["fc1", "fc2"]
     w, params = _prepare(weights, set(base_train) | set(head) | set(dn), dtype)
-    g = KerasGraphs(w, dtype)
+    g = KerasGraphs(w, dtype, mixed=mixed)
     if with_base:
         feat = g.resnet_base(x, depth) if arch == "resnet" else g.vgg_base(x)
     else:
-        feat = torch.tensor(np.asarray(x), dtype=dtype)
+        feat = g.q(torch.tensor(np.asarray(x), dtype=dtype))          # step 4 (mixed): cached f32 features are cast once
     rr = np.asarray(rois).reshape(-1, 4)
     if arch == "resnet":
         cls, reg = g.resnet_classifier_logits(feat, rr, C, depth)

@@ -1,66 +1,141 @@
 #!/usr/bin/env python3
 """Step time of the two training configs at C2 shapes (ResNet-50, 600x1000, 9 anchors, 21 classes):
-configs[2] RPN step 1 and configs[4] detector step 2 (64 RoIs).  One image per GPU per step; under
-torchrun the flat gradient buffer is all-reduced over RCCL every step.  Dev/measurement tool."""
-import os, sys, time, json
+BASELINE configs[2] (RPN step 1, train_rpn_step1.py) and configs[4] (detector step 2, train_det_step2.py, 64 sampled
+RoIs of <= 2000 proposals).  One image per GPU per step; with WORLD_SIZE > 1 every step all-reduces the flat
+gradient buffer (RCCL through torch.distributed; FRCNN_BENCH_BACKEND=gloo lets two ranks share one GPU on a 1-GPU box).
+
+    python scripts/bench_train.py [--bf16] [--steps K] [--warmup W] [--big-tiles]
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 scripts/bench_train.py ...
+
+Rank 0 prints ONE JSON line: per config the step time, images/s of the whole job, the gradient payload, the time of a
+stand-alone all-reduce of that payload, and a `roofline` object (algorithmic FLOP of the step, SURVEY 8(d) / BASELINE.md 3,
+over the measured step time, against the fp32 matrix peak -- or the bf16 one for the mixed-precision run)."""
+import argparse
+import json
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from faster_rcnn_amd import dp, resnet, train, util
+import numpy as np
+import torch
+
+from faster_rcnn_amd import dp, ops, resnet, train
 from faster_rcnn_amd.weights import synthetic_resnet
 
-rank, world = dp.init_from_env()
-if world == 1:
-    torch.cuda.set_device(0)
 H, W, A, C = 600, 1000, 9, 21
-from faster_rcnn_amd import ops
-if "--big-tiles" in sys.argv:
-    ops.AUTO_TILE = 50
-DT = "bf16" if "--bf16" in sys.argv else "f32"     # --bf16: mixed precision (bf16 activations / gradients / packed filters, f32 masters)
-rs = np.random.RandomState(rank)
-x = (rs.randint(0, 256, (H, W, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]
-rows, cols = resnet.get_conv_rows_cols(H, W)
-steps, warm = 20, 3
-out = {}
-# ---- RPN step 1
-w = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=1)
-base = resnet.resnet50_base(weights=w, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, dtype=DT)
-rpn = resnet.resnet50_rpn(base, anchors_per_loc=A)
-can_use = rs.rand(1, rows, cols, A) < 0.012; is_pos = rs.rand(1, rows, cols, A) < 0.01
-y_class = np.concatenate([can_use, is_pos], axis=3)
-y_bbreg = np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32), (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
-rpn.compile(train.SGD(1e-3, 0.9))
-for i in range(warm + steps):
-    if i == warm:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-    rpn.train_on_batch(x, [y_class, y_bbreg])
-torch.cuda.synchronize()
-out["rpn_step1_ms"] = 1e3 * (time.perf_counter() - t0) / steps
-out["rpn_step1_params_MB"] = rpn._trainer.params.total * 4 / 1e6
-# ---- detector step 2
-dw = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=2)
-dbase = resnet.resnet50_base(weights=dw, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, dtype=DT)
-det = resnet.resnet50_classifier(64, C, dbase)
-n = 64
-x1 = rs.randint(0, cols - 8, n); y1 = rs.randint(0, rows - 8, n)
-rois = np.stack([x1, y1, x1 + 1 + rs.randint(0, 7, n), y1 + 1 + rs.randint(0, 7, n)], axis=1).astype(np.float32)[None]
-ci = rs.randint(0, C, n)
-yc = np.zeros((1, n, C), np.float32); yc[0, np.arange(n), ci] = 1
-lab = np.zeros((n, 4 * (C - 1)), np.float32); tg = np.zeros((n, 4 * (C - 1)), np.float32)
-for i, c in enumerate(ci):
-    if c < C - 1:
-        lab[i, 4 * c:4 * c + 4] = 1; tg[i, 4 * c:4 * c + 4] = rs.randn(4)
-yb = np.concatenate([lab, tg], axis=1)[None]
-det.compile(train.SGD(1e-3, 0.9))
-for i in range(warm + steps):
-    if i == warm:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-    det.train_on_batch([x, rois], [yc, yb])
-torch.cuda.synchronize()
-out["det_step2_ms"] = 1e3 * (time.perf_counter() - t0) / steps
-out["det_step2_params_MB"] = det._trainer.params.total * 4 / 1e6
-out["world"] = world
-out["dtype"] = DT
-out["rpn_step1_img_s"] = world * 1e3 / out["rpn_step1_ms"]
-out["det_step2_img_s"] = world * 1e3 / out["det_step2_ms"]
-if rank == 0:
-    print(json.dumps(out))
+PEAK = {"f32": 157.3, "bf16": 2500.0}
+# algorithmic GFLOP per step: forward of base + heads, backward (dgrad + wgrad ~ 2x forward) of the
+# trainable part only (freeze_blocks=[1,2,3]: stage 4 (+ stage 5 + dense) and the heads)
+GFLOP = {"rpn_step1": 97.9 + 2 * (33.9 + 22.7), "det_step2": (75.2 + 93.7) + 2 * (33.9 + 93.7)}
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dp.world() > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dp.world() > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    if dp.world() > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    return 1e3 * el / steps
+
+
+def allreduce_ms(params, reps=10):
+    """One stand-alone all-reduce of the flat gradient buffer (the step's only collective)."""
+    if dp.world() == 1:
+        return 0.0
+    buf = torch.zeros_like(params.g)
+    return timed(lambda: dp.allreduce_sum_(buf), reps, 2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bf16", action="store_true", help="mixed precision: bf16 activations / gradients / packed filters, f32 masters")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--big-tiles", action="store_true")
+    ap.add_argument("--only", choices=("rpn", "det"), default=None)
+    args = ap.parse_args()
+    backend = os.environ.get("FRCNN_BENCH_BACKEND")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > 1 and backend == "gloo":
+        torch.cuda.set_device(0)                       # dev: several ranks on the one GPU of this box
+    rank, world = dp.init_from_env(backend=backend)
+    if world == 1:
+        torch.cuda.set_device(0)
+    if args.big_tiles:
+        ops.AUTO_TILE = 50
+    DT = "bf16" if args.bf16 else "f32"
+    rs = np.random.RandomState(rank)
+    x = (rs.randint(0, 256, (H, W, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]
+    rows, cols = resnet.get_conv_rows_cols(H, W)
+    out = {"world": world, "dtype": DT, "backend": (torch.distributed.get_backend() if world > 1 else None),
+           "workload": "ResNet-50 600x1000, 1 image per GPU per step, SGD momentum 0.9, l2 1e-4, synthetic data"}
+
+    def report(tag, ms, params):
+        ar = allreduce_ms(params)
+        tf = GFLOP[tag] * world / ms                   # GFLOP / ms = TFLOP/s, whole job
+        out[tag] = {"ms_per_step": round(ms, 3), "img_s": round(world * 1e3 / ms, 2), "grad_payload_MB": round(params.total * 4 / 1e6, 1),
+                    "allreduce_ms": round(ar, 3), "allreduce_share": round(ar / ms, 4),
+                    "roofline": {"bound": "mfma", "achieved": round(tf / world, 2), "peak": PEAK[DT], "unit": "TFLOP/s per GPU",
+                                 "frac": round(tf / world / PEAK[DT], 4), "gflop_per_step": round(GFLOP[tag], 1)}}
+
+    if args.only in (None, "rpn"):
+        w = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=1)
+        base = resnet.resnet50_base(weights=w, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, dtype=DT)
+        rpn = resnet.resnet50_rpn(base, anchors_per_loc=A)
+        can_use = rs.rand(1, rows, cols, A) < 0.012
+        is_pos = rs.rand(1, rows, cols, A) < 0.01
+        y_class = np.concatenate([can_use, is_pos], axis=3)
+        y_bbreg = np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32),
+                                  (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
+        rpn.compile(train.SGD(1e-3, 0.9))
+        ms = timed(lambda: rpn.train_on_batch(x, [y_class, y_bbreg]), args.steps, args.warmup)
+        report("rpn_step1", ms, rpn._trainer.params)
+        del rpn, base
+    if args.only in (None, "det"):
+        dw = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=2)
+        dbase = resnet.resnet50_base(weights=dw, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, dtype=DT)
+        det = resnet.resnet50_classifier(64, C, dbase)
+        n = 64
+        x1 = rs.randint(0, cols - 8, n)
+        y1 = rs.randint(0, rows - 8, n)
+        rois = np.stack([x1, y1, x1 + 1 + rs.randint(0, 7, n), y1 + 1 + rs.randint(0, 7, n)], axis=1).astype(np.float32)[None]
+        ci = rs.randint(0, C, n)
+        yc = np.zeros((1, n, C), np.float32)
+        yc[0, np.arange(n), ci] = 1
+        lab = np.zeros((n, 4 * (C - 1)), np.float32)
+        tg = np.zeros((n, 4 * (C - 1)), np.float32)
+        for i, c in enumerate(ci):
+            if c < C - 1:
+                lab[i, 4 * c:4 * c + 4] = 1
+                tg[i, 4 * c:4 * c + 4] = rs.randn(4)
+        yb = np.concatenate([lab, tg], axis=1)[None]
+        det.compile(train.SGD(1e-3, 0.9))
+        ms = timed(lambda: det.train_on_batch([x, rois], [yc, yb]), args.steps, args.warmup)
+        report("det_step2", ms, det._trainer.params)
+    # flat keys kept for the round-1 readers of this line
+    for tag, short in (("rpn_step1", "rpn_step1"), ("det_step2", "det_step2")):
+        if tag in out:
+            out[short + "_ms"] = out[tag]["ms_per_step"]
+            out[short + "_img_s"] = out[tag]["img_s"]
+            out[short + "_params_MB"] = out[tag]["grad_payload_MB"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

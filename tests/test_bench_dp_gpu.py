@@ -1,0 +1,83 @@
+"""Multi-GPU readiness on a 1-GPU box: the two programs the driver launches under torch.distributed.run are started
+here exactly that way (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the environment, one process per rank), with two
+ranks sharing cuda:0 over the gloo transport (FRCNN_BENCH_BACKEND=gloo; on a node the same code paths run one rank per
+GPU over RCCL).  Checks the contract of the JSON line (whole-job value, n_gpus, weak scaling, max-over-ranks timing
+reached through the barrier + all-reduce) and that the data-parallel training step reports its one collective."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(script_args, world, timeout=900):
+    """Start `world` ranks of a script like torch.distributed.run does; return rank 0's last stdout line as JSON."""
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FRCNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if world == 1:
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k)
+        procs.append(subprocess.Popen([sys.executable] + script_args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0, e[-3000:]
+    lines = [l for l in outs[0][1].strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, outs[0][1][-2000:]            # rank 0 prints ONE JSON line
+    assert not [l for l in outs[-1][1].strip().splitlines() if l.startswith("{")] or world == 1      # other ranks print none
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    flags = ["bench.py", "--steps", "3", "--warmup", "1", "--streams", "2", "--no-cpu-baseline"]
+    one = _launch(flags + ["--gpus", "1"], 1)
+    two = _launch(flags + ["--gpus", "2"], 2)
+    for line, n in ((one, 1), (two, 2)):
+        assert line["n_gpus"] == n and line["scaling"] == "weak" and line["higher_is_better"] is True
+        assert line["unit"] == "img/s" and line["dtype"] == "f32" and line["data"] == "synthetic" and line["vs_baseline"] is None
+        assert line["steps"] == 3 and line["warmup"] == 1
+        assert "replicas x%d" % n in line["config"]["parallelism"] and "configs[1]" in line["config"]["workload"]
+        # value is the WHOLE job: ranks x images in flight x steps / (max-over-ranks) time
+        assert abs(line["value"] - n * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
+        assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+        assert line["with_host_io"]["value"] > 0
+    # two ranks share ONE GPU here, so the aggregate stays in the neighbourhood of the single-rank figure
+    assert 0.5 < two["value"] / one["value"] < 1.6, (one["value"], two["value"])
+
+
+def test_bench_train_two_ranks_on_one_gpu():
+    flags = ["scripts/bench_train.py", "--steps", "2", "--warmup", "1", "--only", "rpn"]
+    one = _launch(flags, 1)
+    two = _launch(flags, 2)
+    assert one["world"] == 1 and one["rpn_step1"]["allreduce_ms"] == 0.0
+    assert two["world"] == 2 and two["backend"] == "gloo"
+    r = two["rpn_step1"]
+    assert abs(r["grad_payload_MB"] - 47.3) < 0.2                    # 11.83 M trainable parameters, fp32
+    assert r["allreduce_ms"] > 0 and 0 < r["allreduce_share"] < 1    # the step's ONE collective, timed stand-alone
+    assert r["roofline"]["gflop_per_step"] > 200 and 0 < r["roofline"]["frac"] < 1
+    assert abs(r["img_s"] - 2 * 1e3 / r["ms_per_step"]) < 0.02 * r["img_s"]

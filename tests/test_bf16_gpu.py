@@ -221,3 +221,66 @@ def test_wgrad_bf16_widening_fallback():
     dw, db = ops.conv2d_wgrad_bf16(x.cuda(), g.cuda(), 1, 1, 1, "valid")
     assert ((dw.cpu().double() - wtt.grad).abs().max() / wtt.grad.abs().max()).item() < 1e-4
     assert ((db.cpu().double() - g.double().sum((0, 1, 2))).abs().max()).item() < 1e-3
+
+
+@pytest.mark.parametrize("which", ["det", "rpn"])
+def test_mixed_precision_training_step_against_the_bf16_storage_oracle(which):
+    """The mixed-precision step against the ORACLE, not against the product's own f32 trainer: keras_train_ref evaluated
+    under the bf16 storage model (oracle/keras_ref.py ``mixed=True``: f64 arithmetic, one bf16 rounding wherever the product
+    stores an activation, an activation gradient or a packed filter in bf16).  Storage precision is then common to both
+    sides; what separates them is f32-vs-f64 accumulation and the bf16 ulps that flips.  Bars: the three losses within
+    2e-3 relative; per trained tensor the SGD update's cosine >= 0.999 and relative Frobenius error <= 0.05 (measured worst:
+    0.9996 / 0.029, res4a_branch2a); the whole update vector cosine >= 0.9995 (the f32-trainer comparison above only
+    manages 0.97: that gap IS the storage precision)."""
+    from faster_rcnn_amd import resnet, train
+    from faster_rcnn_amd.weights import synthetic_resnet
+    from oracle import keras_train_ref as kt
+    A, C, H, W = 9, 21, 192, 256
+    rs = np.random.RandomState(4)
+    x = (rs.randint(0, 256, (H, W, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]
+    rows, cols = resnet.get_conv_rows_cols(H, W)
+    w0 = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=7)
+    base = resnet.resnet50_base(weights={k: [a.copy() for a in v] for k, v in w0.items()}, dtype="bf16",
+                                weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
+    r2 = np.random.RandomState(5)
+    if which == "rpn":
+        m = resnet.resnet50_rpn(base, anchors_per_loc=A)
+        can_use = r2.rand(1, rows, cols, A) < 0.3; is_pos = r2.rand(1, rows, cols, A) < 0.1
+        y = [np.concatenate([can_use, is_pos], axis=3),
+             np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32), (r2.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)]
+        m.compile(train.SGD(1e-3, 0.9))
+        losses = m.train_on_batch(x, y)
+        ref_w, ref_losses, _ = kt.rpn_train_step(w0, x, y[0], y[1], A, kt.Optim("sgd", 1e-3), l2=1e-4, mixed=True)
+        names = kt.conv_layer_names(50, [4]) + ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"]
+    else:
+        n = 16
+        m = resnet.resnet50_classifier(n, C, base)
+        x1 = r2.randint(0, cols - 6, n); y1 = r2.randint(0, rows - 6, n)
+        rois = np.stack([x1, y1, x1 + 1 + r2.randint(0, 5, n), y1 + 1 + r2.randint(0, 5, n)], axis=1).astype(np.float32)[None]
+        ci = r2.randint(0, C, n)
+        yc = np.zeros((1, n, C), np.float32); yc[0, np.arange(n), ci] = 1
+        lab = np.zeros((n, 4 * (C - 1)), np.float32); tg = np.zeros((n, 4 * (C - 1)), np.float32)
+        for i, c in enumerate(ci):
+            if c < C - 1:
+                lab[i, 4 * c:4 * c + 4] = 1; tg[i, 4 * c:4 * c + 4] = r2.randn(4)
+        y = [yc, np.concatenate([lab, tg], axis=1)[None]]
+        m.compile(train.SGD(1e-3, 0.9))
+        losses = m.train_on_batch([x, rois], y)
+        ref_w, ref_losses, _ = kt.det_train_step(w0, x, rois, y[0], y[1], C, kt.Optim("sgd", 1e-3), l2=1e-4, mixed=True)
+        names = kt.conv_layer_names(50, [4, 5]) + ["dense_class_%d" % C, "dense_reg_%d" % C]
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (losses, ref_losses)
+    tot_dot = tot_g = tot_w = 0.0
+    report = []
+    for name in names:
+        o = np.asarray(w0[name][0], np.float64)
+        dg = m.get_layer(name).get_weights()[0].astype(np.float64) - o
+        dw = np.asarray(ref_w[name][0], np.float64) - o
+        cos = float((dg * dw).sum() / (np.linalg.norm(dg) * np.linalg.norm(dw)))
+        fro = float(np.linalg.norm(dg - dw) / np.linalg.norm(dw))
+        report.append((name, round(cos, 5), round(fro, 4)))
+        tot_dot += (dg * dw).sum(); tot_g += (dg * dg).sum(); tot_w += (dw * dw).sum()
+    print("mixed vs bf16-storage oracle (%s): losses %s / %s; worst %s" % (which, losses, ref_losses, min(report, key=lambda r: r[1])))
+    assert min(r[1] for r in report) >= 0.999, min(report, key=lambda r: r[1])
+    assert max(r[2] for r in report) <= 0.05, max(report, key=lambda r: r[2])
+    assert tot_dot / np.sqrt(tot_g * tot_w) >= 0.9995

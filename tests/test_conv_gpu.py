@@ -40,6 +40,18 @@ CASES = [
     (1, 15, 22, 128, 96, 3, 1, "same", "relu", False, 22),
     (1, 20, 31, 32, 64, 1, 1, "valid", "relu", False, 21),
     (1, 20, 31, 64, 64, 1, 1, "valid", "relu", False, 22),
+    (1, 15, 22, 128, 96, 3, 1, "same", "relu", True, 23),         # mid-chunk-barrier main loop: 64x64 (residual prefetched before the loop)
+    (1, 20, 31, 32, 64, 1, 1, "valid", "relu", False, 23),        #   one k-chunk (the prologue alone over-reads four)
+    (1, 20, 31, 64, 64, 1, 1, "valid", None, True, 23),           #   two chunks
+    (1, 20, 31, 96, 72, 1, 1, "valid", "relu", True, 23),         #   three chunks (odd count: the peeled tail), cout % 64 != 0
+    (1, 21, 33, 64, 200, 3, 1, "same", "relu", True, 24),         #   64x128 tile
+    (2, 9, 11, 64, 64, 3, 2, "same", None, True, 25),             #   128x64 tile, stride 2
+    (1, 15, 22, 128, 256, 3, 1, "same", "relu", True, 26),        #   128x128 tile (one staging set)
+    (3, 7, 7, 512, 512, 3, 1, "same", "relu", False, 26),
+    (1, 15, 22, 128, 96, 3, 1, "same", "relu", True, 323),        #   split-K, 3 slices of 12 chunks
+    (2, 9, 11, 64, 64, 3, 2, "same", "relu", False, 1823),        #   one chunk per slice
+    (1, 38, 63, 512, 36, 1, 1, "valid", None, False, 423),        #   cout = 36: 16-byte epilogue with a partial column tile
+    (1, 38, 63, 512, 9, 1, 1, "valid", "sigmoid", False, 423),    #   cout = 9: the 4-byte epilogue fallback
     (1, 15, 22, 128, 128, 3, 1, "same", "relu", True, 41),        # 8-wave 128x128 variants
     (1, 15, 22, 128, 200, 3, 1, "same", "relu", False, 42),
     (2, 9, 11, 64, 64, 3, 2, "same", None, False, 43),
@@ -100,6 +112,34 @@ def test_conv2d(ops, case):
     check(got, want)
 
 
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, k, stride, padding, act, tile
+    (1, 38, 63, 256, 1024, 1, 1, "valid", "relu", 23),           # stage-4 2c: residual prefetched before the main loop
+    (1, 38, 63, 256, 1024, 1, 1, "valid", "relu", 22),
+    (1, 21, 33, 64, 200, 3, 1, "same", None, 24),                # partial column tile (200 = 128 + 72)
+    (3, 7, 7, 512, 512, 3, 1, "same", "relu", 26),               # 128x128: sixteen passes in groups of four
+    (1, 38, 63, 256, 256, 3, 1, "same", "relu", 323),            # split-K reducer
+    (1, 38, 63, 512, 36, 1, 1, "valid", "sigmoid", 23),
+])
+def test_vector_epilogue_is_bitwise_the_scalar_epilogue(ops, case):
+    """The 16-byte epilogue (tile through LDS, b128 residual / mask loads and stores) performs the scalar epilogue's
+    arithmetic per element in the same order.  An output tensor that is NOT 16-byte aligned forces the 4-byte
+    epilogue (frcnn_conv2d_fwd_ws checks the alignment), so the two are compared bit for bit, residual included."""
+    n, h, w, cin, cout, k, stride, padding, act, tile = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = torch.from_numpy(rs.randn(n, h, w, cin).astype(np.float32)).cuda()
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    pc = ops.PackedConv(wt, (1 + 0.1 * rs.randn(cout)).astype(np.float32), (0.1 * rs.randn(cout)).astype(np.float32))
+    vec = ops.conv2d(x, pc, stride, padding, act, tile=tile)
+    res = torch.from_numpy(rs.randn(*vec.shape).astype(np.float32)).cuda()
+    vec_r = ops.conv2d(x, pc, stride, padding, act, res, tile=tile)
+    odd = torch.empty(vec.numel() + 4, dtype=torch.float32, device="cuda")[1:1 + vec.numel()].view(vec.shape)
+    assert odd.data_ptr() % 16 == 4 and odd.is_contiguous()
+    assert torch.equal(ops.conv2d(x, pc, stride, padding, act, out=odd, tile=tile), vec)
+    assert torch.equal(ops.conv2d(x, pc, stride, padding, act, res, out=odd, tile=tile), vec_r)
+    assert not torch.equal(vec, vec_r)
+
+
 def test_conv_identity_asymmetric(ops):
     """A = I against an ASYMMETRIC filter catches a transposed C write (cdna guide s3)."""
     cin = cout = 64
@@ -154,6 +194,9 @@ def test_split_k_workspace_reuse_and_determinism(ops):
     (300, 7, 7, 64, 128, 3, "same", 0),          # the detector head's geometry: tiles span 1-2 positions, border taps skipped
     (300, 7, 7, 64, 128, 3, "same", 21),
     (300, 7, 7, 64, 96, 3, "same", 22),
+    (300, 7, 7, 64, 96, 3, "same", 23),
+    (300, 7, 7, 64, 128, 3, "same", 26),
+    (300, 7, 7, 64, 128, 3, "same", 323),
     (300, 7, 7, 64, 128, 3, "same", 42),
     (300, 7, 7, 64, 128, 3, "same", 322),        # split-K over the compacted (channel group, needed tap) sequence
     (64, 7, 7, 128, 64, 3, "same", 0),
@@ -241,5 +284,5 @@ def test_balanced_launch_is_chosen_for_the_head_shapes(ops):
     assert cfg(cin=2048, cout=512, kh=1, kw=1, pad_top=0, pad_left=0, tile=0, **head) == 61       # 460 tiles of 128x128, 64 chunks
     assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=0, **head) == 61        # alone on the chip
     assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=50, **head) == 21       # beside other images' launches: plain
-    assert cfg(cin=512, cout=2048, kh=1, kw=1, pad_top=0, pad_left=0, tile=0, **head) == 22       # 16 chunks: too short
-    assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=100, **head) == 22      # "never split" turns it off
+    assert cfg(cin=512, cout=2048, kh=1, kw=1, pad_top=0, pad_left=0, tile=0, **head) == 23       # 16 chunks: too short
+    assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=100, **head) == 23      # "never split" turns it off

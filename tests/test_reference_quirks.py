@@ -139,3 +139,36 @@ def test_voc_eval_matches_the_reference(tmp_path, capsys):
     aps = eval_dets.eval_all(str(tmp_path), voc, {"chair": 0, "dog": 1, "bg": 2}, img_set="trainval")
     assert aps == [float(g["ap_chair"]), float(g["ap_dog"])]
     assert "Mean AP" in capsys.readouterr().out
+
+
+def test_inter_cubic_hand_checked_rows():
+    """f2: cv2.resize(..., INTER_CUBIC) on uint8 (shapes.py:19-29 of the reference), pinned by rows worked out BY HAND from
+    OpenCV's published 8-bit algorithm (imgproc/resize.cpp): fx = (float)((dx + .5) * scale - .5), sx = floor(fx), taps
+    sx-1..sx+2 clamped to the border, interpolateCubic with A = -0.75, coefficients cvRound(c * 2048) as int16, horizontal
+    pass in int32, vertical pass in int32, FixedPtCast: (v + (1 << 21)) >> 22, saturate to uint8.
+    Coefficient table used below (exact in binary): fx = .25 -> (-216, 1800, 536, -72); fx = .75 -> (-72, 536, 1800, -216);
+    fx = .5 -> (-192, 1216, 1216, -192); fx = 0 -> (0, 2048, 0, 0).
+    (JPEG decoding stays UNPINNED: PIL's decoder, not OpenCV's.)"""
+    from faster_rcnn_amd import shapes
+    # the coefficient rows themselves
+    idx, co = shapes._cubic_taps(8, 4)                               # scale 1/2: fx alternates .75 (sx = -1, 0, 1, 2) and .25
+    assert co[0].tolist() == [-72, 536, 1800, -216] and co[1].tolist() == [-216, 1800, 536, -72]
+    assert idx[0].tolist() == [0, 0, 0, 1] and idx[1].tolist() == [0, 0, 1, 2] and idx[7].tolist() == [2, 3, 3, 3]
+    idx, co = shapes._cubic_taps(4, 8)                               # scale 2: fx = .5 everywhere, sx = 0, 2, 4, 6
+    assert all(c.tolist() == [-192, 1216, 1216, -192] for c in co) and idx[3].tolist() == [5, 6, 7, 7]
+    # row 1: [10, 20, 40, 80] enlarged to 8 pixels.  e.g. dst 3: sx = 1, fx = .25: (-216*10 + 1800*20 + 536*40 - 72*80) = 49 520
+    # -> 49 520 / 2048 = 24.18 -> 24; dst 0: taps clamp to (10, 10, 10, 20) . (-72, 536, 1800, -216) = 18 320 -> 8.95 -> 9
+    row = np.array([[10, 20, 40, 80]], dtype=np.uint8)
+    assert shapes._resize(row, 8, 1).tolist() == [[9, 12, 16, 24, 32, 51, 72, 84]]
+    assert shapes._resize(row.T.copy(), 1, 8)[:, 0].tolist() == [9, 12, 16, 24, 32, 51, 72, 84]         # the vertical pass alone
+    # row 2: the ramp 0, 8, .., 56 halved.  Interior midpoints are exact (20, 36: a cubic reproduces a linear ramp); the two
+    # ends see the replicated border: dst 0 = (-192*0 + 1216*0 + 1216*8 - 192*16) / 2048 = 3.25 -> 3; dst 3 = 52.75 -> 53
+    ramp = np.arange(0, 64, 8, dtype=np.uint8)[None]
+    assert shapes._resize(ramp, 4, 1).tolist() == [[3, 20, 36, 53]]
+    # row 3..6: a 2x2 image enlarged to 4x4, both passes with overshoot on both sides of the range (the -34 clamps to 0).
+    # horizontal sums: row 0 -> (-21 600, 46 400, 158 400, 226 400), row 1 -> (442 000, 340 000, 172 000, 70 000); vertical
+    # weights on (row 0, row 1): (2264, -216), (1584, 464), (464, 1584), (-216, 2264); then (v + 2^21) >> 22
+    img = np.array([[0, 100], [200, 50]], dtype=np.uint8)
+    assert shapes._resize(img, 4, 4).tolist() == [[0, 8, 77, 119], [41, 55, 79, 93], [165, 134, 82, 51], [240, 181, 85, 26]]
+    # same size = identity (fx = 0 -> the single coefficient 2048)
+    assert np.array_equal(shapes._resize(img, 2, 2), img)
