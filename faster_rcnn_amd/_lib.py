@@ -54,6 +54,8 @@ SIGNATURES = {
     "frcnn_pack_conv_weights_dgrad": (I, [P, P, I, I, I, I, P, P]),
     "frcnn_conv2d_wgrad_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_wgrad": (I, [P, P, P, P, P, P, P, c_size_t, P]),
+    "frcnn_conv2d_wgrad_batch_workspace_bytes": (c_size_t, [P, I]),
+    "frcnn_conv2d_wgrad_batch": (I, [P, I, P, c_size_t, P]),
     "frcnn_refresh_packed": (I, [P, I, P]),
     "frcnn_colsum_batch": (I, [P, I, P]),
     "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
@@ -105,6 +107,11 @@ class PackJob(ctypes.Structure):
     """frcnn_pack_job (include/frcnn_hip.h)."""
     _fields_ = [(k, c_void_p) for k in ("w_hwio", "packed", "packed_dgrad", "bias", "scale", "shift_const", "shift")] + \
                [(k, ctypes.c_int32) for k in ("kh", "kw", "cin", "cout")]
+
+
+class WgradJob(ctypes.Structure):
+    """frcnn_wgrad_job (include/frcnn_hip.h)."""
+    _fields_ = [("d", ConvDesc)] + [(k, c_void_p) for k in ("x", "g", "scale", "dw")] + [(k, ctypes.c_int32) for k in ("in_bf16", "reserved")]
 
 
 class ColsumJob(ctypes.Structure):

@@ -484,6 +484,29 @@ def conv2d_wgrad(x, g, kh, kw, stride=1, padding="valid", scale=None, dw=None, d
     return dw, (dbias if want_bias else None)
 
 
+def conv2d_wgrad_batch(jobs):
+    """Weight gradients of many layers in one go (frcnn_conv2d_wgrad_batch).  jobs: list of
+    (x, g, kh, kw, stride, padding, scale or None, dw) -- x / g both f32 or both bf16, dw an f32 (kh,kw,cin,cout) tensor the
+    result is written into.  Bit-identical to conv2d_wgrad / conv2d_wgrad_bf16 per layer (without the bias gradient)."""
+    _require_gpu()
+    if not jobs:
+        return
+    arr = (_lib.WgradJob * len(jobs))()
+    keep = []
+    for j, (x, g, kh, kw, stride, padding, scale, dw) in zip(arr, jobs):
+        assert x.dtype == g.dtype and x.dtype in (torch.float32, torch.bfloat16) and dw.dtype == torch.float32 and dw.is_contiguous()
+        x, g = x.contiguous(), g.contiguous()
+        keep.append((x, g))
+        d = _conv_desc(tuple(x.shape), kh, kw, g.shape[-1], stride, padding)
+        assert (d.ho, d.wo) == (g.shape[1], g.shape[2]) and tuple(dw.shape[-4:]) == (kh, kw, x.shape[-1], g.shape[-1])
+        j.d = d
+        j.x, j.g, j.dw = x.data_ptr(), g.data_ptr(), dw.data_ptr()
+        j.scale = None if scale is None else scale.data_ptr()
+        j.in_bf16 = 1 if x.dtype == torch.bfloat16 else 0
+    ws = _ws(_lib.load().frcnn_conv2d_wgrad_batch_workspace_bytes(arr, len(jobs)))
+    _lib.call("frcnn_conv2d_wgrad_batch", arr, len(jobs), _p(ws), ws.numel(), _stream())
+
+
 # ----------------------------------------------------------------------------- bf16 conv path
 class PackedConvBf16:
     """bf16-packed filter + f32 epilogue scale/shift (configs[3]: bf16 conv)."""

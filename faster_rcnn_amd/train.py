@@ -178,22 +178,16 @@ class TConv:
         return self.y
 
     def wgrad(self, g):
-        """g: gradient w.r.t. this layer's post-BN pre-activation output."""
+        """g: gradient w.r.t. this layer's post-BN pre-activation output.  Nothing reads a weight gradient before the
+        optimiser, so the launch is only QUEUED here: flush_weight_grads issues every layer's weight gradient of the
+        step together (frcnn_conv2d_wgrad_batch) and the bias gradients in one more launch."""
         if self.trainable:
-            fn = ops.conv2d_wgrad_bf16 if self.bf16 else ops.conv2d_wgrad
-            side = _wgrad_stream()
-            if side is None:
-                fn(self.x, g, self.kh, self.kw, self.u.stride, self.u.padding, scale=self.scale, dw=self.gk4, want_bias=False)
-            else:
-                # the weight gradient is off the critical path (nothing downstream reads it before the optimiser):
-                # it runs on a second HIP stream beside the input-gradient chain, whose small grids leave CUs idle
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    fn(self.x, g, self.kh, self.kw, self.u.stride, self.u.padding, scale=self.scale, dw=self.gk4, want_bias=False)
-                g.record_stream(side)
-                self.x.record_stream(side)
-            if self.gb is not None:            # bias gradients of the whole step leave in ONE launch (flush_bias_grads)
-                _PENDING_BIAS.append((g if g.is_contiguous() else g.contiguous(), self.scale, self.gb))
+            gc = g if g.is_contiguous() else g.contiguous()
+            _PENDING_WGRAD.append((self.x, gc, self.kh, self.kw, self.u.stride, self.u.padding, self.scale, self.gk4))
+            if self.gb is not None:
+                _PENDING_BIAS.append((gc, self.scale, self.gb))
+            if len(_PENDING_WGRAD) >= WGRAD_FLUSH_JOBS:
+                _launch_pending_wgrads()
 
     def dgrad(self, g, residual=None, mask=None):
         if self.bf16:
@@ -201,32 +195,37 @@ class TConv:
         return ops.conv2d_dgrad(g, self.pd, self.u.padding, residual=residual, mask=mask)
 
 
-OVERLAP_WGRAD = True        # weight gradients on a second stream, concurrent with the input-gradient chain
+_PENDING_WGRAD = []         # (x, g, kh, kw, stride, padding, scale, dw) of this step's trainable convs, in backward order
+_PENDING_BIAS = []          # (g, scale, dbias); the tensors are kept alive until the flush
+# Weight gradients are issued in batches of this many layers (frcnn_conv2d_wgrad_batch) on a second HIP stream, beside
+# the input-gradient chain that produces the next batch's operands; the rest goes out at the end of the backward pass.
+WGRAD_FLUSH_JOBS = int(__import__("os").environ.get("FRCNN_WGRAD_FLUSH", "8"))
 _WGRAD_STREAM = None
 
 
-def _wgrad_stream():
+def _launch_pending_wgrads():
     global _WGRAD_STREAM
-    if not OVERLAP_WGRAD:
-        return None
+    if not _PENDING_WGRAD:
+        return
     if _WGRAD_STREAM is None:
         _WGRAD_STREAM = torch.cuda.Stream()
-    return _WGRAD_STREAM
+    side, cur = _WGRAD_STREAM, torch.cuda.current_stream()
+    side.wait_stream(cur)                                   # the operands were produced on the main stream
+    with torch.cuda.stream(side):
+        ops.conv2d_wgrad_batch(_PENDING_WGRAD)
+    for job in _PENDING_WGRAD:
+        job[0].record_stream(side)
+        job[1].record_stream(side)
+    _PENDING_WGRAD.clear()
 
 
-def join_wgrad_stream():
-    """The main stream waits for every weight gradient launched on the side stream."""
+def flush_weight_grads():
+    """End of the backward pass: whatever weight gradients are still queued, then (after rejoining the side stream) all
+    bias gradients (dbias[co] = scale[co] * sum_m g[m][co]) in one launch.  Launched one by one (round 1) each of these
+    small GEMMs paid its own ramp, tail and reduction launch: 44 + 2 launches per RPN step, now a handful."""
+    _launch_pending_wgrads()
     if _WGRAD_STREAM is not None:
         torch.cuda.current_stream().wait_stream(_WGRAD_STREAM)
-
-
-_PENDING_BIAS = []          # (g, scale, dbias) of this step's trainable convs; g is kept alive until the flush
-
-
-def flush_bias_grads():
-    """dbias[co] = scale[co] * sum_m g[m][co] for every conv that ran wgrad since the last flush; also the point
-    where the main stream rejoins the weight-gradient stream."""
-    join_wgrad_stream()
     if not _PENDING_BIAS:
         return
     jobs = (_lib.ColsumJob * len(_PENDING_BIAS))()
@@ -506,7 +505,7 @@ class RpnTrainer:
             self.rpn_conv.wgrad(gh)
             if self.base_trains:
                 self.base.backward(self.rpn_conv.dgrad(gh, mask=self.feat))
-        flush_bias_grads()
+        flush_weight_grads()
         sq = p.sumsq() if self.l2 else None
         scale = _sync_grads(p)
         p.step(self.optimizer, self.l2, scale)
@@ -661,7 +660,7 @@ class DetTrainer:
                 gfeat = ops.roi_crop_resize_bwd(gcrop, rois, self.feat.shape[1], self.feat.shape[2])
                 _lib.call("frcnn_relu_bwd_inplace", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
                 self.base.backward(gfeat.reshape(self.feat.shape))
-        flush_bias_grads()
+        flush_weight_grads()
         sq = p.sumsq() if self.l2 else None
         scale = _sync_grads(p)
         p.step(self.optimizer, self.l2, scale)

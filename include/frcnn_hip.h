@@ -264,6 +264,23 @@ int frcnn_colsum_batch(const frcnn_colsum_job* jobs, int n_jobs, void* stream);
 size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g, const float* scale,
                        float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+/* The weight gradients of MANY layers in one go (what Keras' train_on_batch derives for every trainable Conv2D / Dense
+ * of the model, train_util.py:54, 118): one launch per operand kind (f32; bf16 on the bf16 matrix cores; bf16 widened
+ * for channel counts that are not multiples of 8) over all jobs' workgroups, then one launch for all slice reductions.
+ * Per job exactly frcnn_conv2d_wgrad / frcnn_conv2d_wgrad_bf16 without the bias gradient (frcnn_colsum_batch does
+ * those): same slices, same fixed summation order, bit-identical dw.  `jobs` is a HOST array; x / g: f32, or bf16
+ * when in_bf16 != 0.  The workspace (frcnn_conv2d_wgrad_batch_workspace_bytes) holds every job's partial slabs. */
+typedef struct frcnn_wgrad_job {
+    frcnn_conv_desc d;             /* forward geometry of the layer */
+    const void* x;                 /* layer input  [n][h][w][cin]            */
+    const void* g;                 /* gradient w.r.t. the post-BatchNorm, pre-activation output [M][cout] */
+    const float* scale;            /* folded BatchNorm scale [cout] or NULL  */
+    float* dw;                     /* out: [kh][kw][cin][cout] f32           */
+    int32_t in_bf16;
+    int32_t reserved;
+} frcnn_wgrad_job;
+size_t frcnn_conv2d_wgrad_batch_workspace_bytes(const frcnn_wgrad_job* jobs, int n_jobs);
+int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* workspace, size_t workspace_bytes, void* stream);
 /* The tile code (see frcnn_conv_desc.tile) frcnn_conv2d_fwd will run for this descriptor (30 = the 3-channel
  * stem kernel, which cin == 3 always takes): lets a profiler attribute a launch to its kernel instantiation. */
 int frcnn_conv2d_config(const frcnn_conv_desc* d);

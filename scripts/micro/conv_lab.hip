@@ -59,6 +59,14 @@ static std::vector<Shape> shapes(int rois) {
     s.push_back({"s5_2b", 3, rois, 7, 7, 512, 512, 3, 1, true, false, 1});
     s.push_back({"s5_2c", 3, rois, 7, 7, 512, 2048, 1, 1, false, true, 1});
     s.push_back({"s5x_2a", 2, rois, 7, 7, 2048, 512, 1, 1, false, false, 1});
+    // training-only launch shapes (set 2): input-gradient convs and the detector head at 64 sampled RoIs
+    s.push_back({"rpn_dgrad", 1, 1, h, w, 512, 1024, 3, 1, true, true, 2});            // dgrad of rpn_conv1: 512 -> 1024, 3x3
+    s.push_back({"t5_2b", 6, 64, 7, 7, 512, 512, 3, 1, true, false, 2});              // stage-5 3x3 fwd / dgrad
+    s.push_back({"t5_2c", 5, 64, 7, 7, 512, 2048, 1, 1, false, true, 2});             // 512 -> 2048 (2c fwd, 2a dgrad)
+    s.push_back({"t5x_2a", 5, 64, 7, 7, 2048, 512, 1, 1, false, false, 2});           // 2048 -> 512 (2a fwd, 2c dgrad)
+    s.push_back({"t5a_2a", 1, 64, 7, 7, 1024, 512, 1, 1, false, false, 2});
+    s.push_back({"t5a_1", 1, 64, 7, 7, 1024, 2048, 1, 1, false, false, 2});
+    s.push_back({"t5a_dg", 2, 64, 7, 7, 2048, 1024, 1, 1, false, true, 2});           // dgrad into the crops (from 2a / branch1)
     return s;
 }
 
@@ -141,6 +149,8 @@ static int cmd_time(int argc, char** argv) {
     for (const Shape& sh : shapes(300)) {
         if (set == "trunk" && sh.set != 0) continue;
         if (set == "head" && sh.set != 1) continue;
+        if (set == "train" && sh.set != 2) continue;
+        if (set != "train" && set != "all" && sh.set == 2) continue;
         if (only && sh.name != only) continue;
         Problem p = make(sh);
         std::vector<double> best(tiles.size(), -1.0);

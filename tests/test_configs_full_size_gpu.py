@@ -215,8 +215,20 @@ def test_config3_resnet101_600x1500_bf16_inference():
         n = int(host["n_rois"])
         v = np.nonzero(np_ref.valid_mask(dev_boxes))[0]
         order = np_ref.score_order(cls_np.reshape(-1)[v], 8000)
-        kept = np_ref.nms(dev_boxes[v][order].astype("int16"), cls_np.reshape(-1)[v][order], 0.7, 300)[0]
-        assert n == len(kept) and np.array_equal(host["rois"].numpy()[:n], np.asarray(kept, np.float32))
+        kept, kprobs, _ = np_ref.nms(dev_boxes[v][order].astype("int16"), cls_np.reshape(-1)[v][order], 0.7, 300)
+        # bf16 activations make exactly tied scores common (~900 of the 64 296 here).  The reference's NMS walks
+        # np.argsort(probs) from the end, whose order INSIDE a run of equal scores is implementation-defined; the device
+        # walks ties by ascending index.  So: same count, same scores position by position, and inside every
+        # run of equal scores the same boxes
+        got_rois = host["rois"].numpy()[:n]
+        assert n == len(kept)
+        kprobs = np.asarray(kprobs)
+        start = 0
+        for end in list(np.nonzero(np.diff(kprobs))[0] + 1) + [n]:
+            a = sorted(map(tuple, np.asarray(kept[start:end], np.float32).tolist()))
+            b = sorted(map(tuple, got_rois[start:end].tolist()))
+            assert a == b, (start, end, a, b)
+            start = end
         o_cls, o_reg = g.resnet_classifier(dev_feat, host["rois"].numpy()[:n], C, 101)
         assert ok(host["cls"][:n], o_cls.reshape(n, -1)) and ok(host["reg"][:n], o_reg.reshape(n, -1)), \
             (rms_max(host["cls"][:n], o_cls.reshape(n, -1)), rms_max(host["reg"][:n], o_reg.reshape(n, -1)))

@@ -109,3 +109,31 @@ def test_colsum_batch():
         err = (out.double() - want).abs().max().item()
         assert err <= 1e-5 * max(1.0, want.abs().max().item()) * 10, err
         assert torch.equal(out, f)                              # fixed summation order
+
+
+def test_wgrad_batch_is_bitwise_the_single_layer_calls():
+    """frcnn_conv2d_wgrad_batch: every trainable layer's weight gradient in one launch per operand kind (+ one reduction
+    launch) -- per layer the same slices, slabs and summation order as frcnn_conv2d_wgrad / _bf16, so bit-identical."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(3)
+    shapes = [(1, 19, 23, 256, 1024, 1, 1, "valid"), (1, 19, 23, 256, 256, 3, 1, "same"), (1, 19, 23, 1024, 256, 1, 1, "valid"),
+              (1, 38, 63, 1024, 512, 3, 1, "same"), (1, 38, 63, 512, 9, 1, 1, "valid"), (1, 38, 63, 512, 36, 1, 1, "valid"),
+              (2, 9, 11, 64, 64, 3, 2, "same"), (16, 1, 1, 2048, 101, 1, 1, "valid"), (1, 37, 50, 256, 128, 1, 2, "valid")]
+    shapes = shapes * 4                                  # 36 jobs: more than one table per kind
+    jobs, single = [], []
+    for i, (n, h, w, cin, cout, k, stride, padding) in enumerate(shapes):
+        bf16 = (i % 3 == 1) and cin % 4 == 0 and cout % 4 == 0
+        x = torch.from_numpy(rs.randn(n, h, w, cin).astype(np.float32)).cuda()
+        ho = -(-h // stride) if padding == "same" else (h - k) // stride + 1
+        wo = -(-w // stride) if padding == "same" else (w - k) // stride + 1
+        g = torch.from_numpy(rs.randn(n, ho, wo, cout).astype(np.float32)).cuda()
+        if bf16:
+            x, g = x.to(torch.bfloat16), g.to(torch.bfloat16)
+        scale = torch.from_numpy((1 + 0.1 * rs.randn(cout)).astype(np.float32)).cuda() if i % 2 else None
+        dw = torch.full((k, k, cin, cout), float("nan"), dtype=torch.float32, device="cuda")
+        jobs.append((x, g, k, k, stride, padding, scale, dw))
+        fn = ops.conv2d_wgrad_bf16 if bf16 else ops.conv2d_wgrad
+        single.append(fn(x, g, k, k, stride, padding, scale=scale, want_bias=False)[0])
+    ops.conv2d_wgrad_batch(jobs)
+    for j, want in zip(jobs, single):
+        assert torch.equal(j[-1], want)
