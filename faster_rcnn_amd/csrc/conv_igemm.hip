@@ -1905,7 +1905,11 @@ int frcnn_pack_conv_weights_dgrad(const float* w_hwio, const float* scale, int k
 static int wgrad_slices(const frcnn_conv_desc* d) {
     const long long M = (long long)d->n * d->ho * d->wo;
     const long long tiles = (long long)d->kh * d->kw * ((d->cin + 63) / 64) * ((d->cout + 63) / 64);
-    long long s = (2048 + tiles - 1) / tiles;                 // aim at ~2048 workgroups
+    // ~256 workgroups per layer: the layers of a step are launched together (frcnn_conv2d_wgrad_batch), so the chip is
+    // filled by the batch, not by one layer, and fewer slices mean fewer partial slabs to write and re-read (measured,
+    // scripts/micro/train_ab2.py, target 2048 -> 256: mixed RPN step 2.36 -> 2.08 ms, detector step 3.30 -> 2.85 ms)
+    static const long long target = getenv("FRCNN_WGRAD_TARGET") ? atoll(getenv("FRCNN_WGRAD_TARGET")) : 256;   // dev knob
+    long long s = (target + tiles - 1) / tiles;
     const long long max_s = (M + 4 * WG_MC - 1) / (4 * WG_MC); // at least 4 chunks per slice
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
