@@ -49,6 +49,37 @@ def select_config(name):
     if name == "c4":
         HEIGHT, WIDTH, SCALES, NUM_CLASSES, DEPTH, DTYPE = 600, 1500, [16, 32, 64, 128, 256, 512], 10, 101, "bf16"
         WORKLOAD = "configs[3]: ResNet-101, KITTI 600x1500, anchor_scales 16-512, RPN + detector inference, bf16 conv + fp32 NMS"
+    if name == "c1":
+        DEPTH = 16                                                   # VGG16
+        WORKLOAD = "configs[0]: VGG16, 600x1000, RPN-only forward (vgg16_base + vgg16_rpn, the train_rpn_test.py path), fp32"
+
+
+class RpnOnlyPipeline:
+    """configs[0]: backbone + RPN heads only (what rpn_model.predict_on_batch runs, det_util.py:41); same capture / replay
+    surface as InferencePipeline."""
+
+    def __init__(self, rpn):
+        self.rpn, self._graph = rpn, None
+
+    def forward_dev(self, x, resize_ratio=1.0):
+        cls, reg, feat = self.rpn.forward_dev(x)
+        return {"rpn_cls": cls, "rpn_reg": reg, "feat": feat}
+
+    def capture(self, height, width, split_k=True, throughput=False):
+        from faster_rcnn_amd import ops
+        self._static_in = torch.zeros((1, height, width, 3), dtype=torch.float32, device="cuda")
+        self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+            for _ in range(2):
+                self.forward_dev(self._static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+            self._static_out = self.forward_dev(self._static_in)
+        return self
 
 
 def synth_image(seed):
@@ -62,6 +93,12 @@ def build_pipeline():
     from faster_rcnn_amd.pipeline import InferencePipeline
     from faster_rcnn_amd.weights import synthetic_resnet
     anchors = util.get_anchors(SCALES)
+    if DEPTH == 16:
+        from faster_rcnn_amd import vgg
+        from faster_rcnn_amd.weights import synthetic_vgg16
+        w = synthetic_vgg16(anchors_per_loc=len(anchors), seed=1, with_classifier=False)
+        rpn = vgg.vgg16_rpn(vgg.vgg16_base(weights=w), include_conv=True, anchors_per_loc=len(anchors))
+        return RpnOnlyPipeline(rpn), w, anchors
     w = synthetic_resnet(DEPTH, anchors_per_loc=len(anchors), num_classes=NUM_CLASSES, seed=1)
     base = (resnet.resnet50_base if DEPTH == 50 else resnet.resnet101_base)(weights=w, dtype=DTYPE)
     rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=len(anchors))
@@ -207,6 +244,35 @@ def cpu_baseline(weights, anchors, budget_s=20.0):
                       "+ numpy proposal/NMS/post-process (%.1f s)" % (n, t_total)}
 
 
+def vgg_rpn_cpu_and_parity(pipe, weights, budget_s=20.0):
+    """configs[0] is the one config the reference itself runs on the CPU (train_rpn_test.py:21-38): the oracle's torch-CPU
+    fp32 restatement of vgg16_base + vgg16_rpn timed on this host, and -- outside the timing --
+    used as the checker of the HIP forward at this size (feature map and both RPN outputs within 1e-4)."""
+    from oracle.keras_ref import KerasGraphs
+    g = KerasGraphs(weights, torch.float32)
+    n, t_total = 0, 0.0
+    with torch.no_grad():
+        while n < 1 or (t_total < budget_s and n < 12):
+            x = synth_image(100 + n)
+            t0 = time.perf_counter()
+            feat = g.vgg_base(x)
+            cls, reg = g.rpn(feat)
+            t_total += time.perf_counter() - t0
+            n += 1
+        out = pipe.forward_dev(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        err = lambda a, b: float(((a.cpu().double() - b.double()).abs() / b.double().abs().clamp(min=1)).max())
+        dev_feat = out["feat"].cpu().reshape(feat.shape)
+        c2, r2 = g.rpn(dev_feat)                                          # heads on the device's own feature map
+        par = {"feat": err(out["feat"].reshape(feat.shape), feat), "rpn_cls": err(out["rpn_cls"].reshape(cls.shape), c2),
+               "rpn_reg": err(out["rpn_reg"].reshape(reg.shape), r2)}
+    par = {k: float("%.3g" % v) for k, v in par.items()}
+    par["ok"] = bool(all(v < 1e-4 for v in par.values()))
+    base = {"value": round(n / t_total, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d synthetic 600x1000 image(s), VGG16 base + RPN heads, torch-CPU fp32 restatement of the Keras graph (%.1f s)" % (n, t_total)}
+    return base, par
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,7 +281,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--shared-tiles", action="store_true", help="with --no-graph: the launch forms of the multi-image default run")
-    ap.add_argument("--config", choices=("c2", "c4"), default="c2", help="c2 = BASELINE configs[1] (headline); c4 = configs[3]")
+    ap.add_argument("--config", choices=("c2", "c4", "c1"), default="c2",
+                    help="c2 = BASELINE configs[1] (headline); c4 = configs[3]; c1 = configs[0] (VGG16 RPN-only forward)")
     ap.add_argument("--split-k", choices=("auto", "on", "off"), default="auto", help="split-K conv launches for small grids")
     ap.add_argument("--no-hoist", action="store_true",
                     help="detector head in the reference's order (resample, then res5a_branch2a / branch1 on every crop) instead of "
@@ -260,7 +327,8 @@ def main():
     split_k = args.split_k == "on" or (args.split_k == "auto" and (S == 1 or DTYPE == "f32"))
     if not args.no_graph:
         from faster_rcnn_amd.pipeline import InferencePipeline
-        pipes = [pipe] + [InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS) for _ in range(S - 1)]
+        pipes = [pipe] + [RpnOnlyPipeline(pipe.rpn) if DEPTH == 16 else InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS)
+                          for _ in range(S - 1)]
         streams = [torch.cuda.Stream() for _ in range(S)]
         for i, (pl, st) in enumerate(zip(pipes, streams)):
             pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1)
@@ -323,7 +391,7 @@ def main():
         rs = np.random.RandomState(1000 + rank)
         frames = [torch.from_numpy(rs.randint(0, 256, (HEIGHT, WIDTH, 3)).astype(np.uint8)).pin_memory() for _ in range(4 * S)]
         dev_u8 = [torch.empty((HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda") for _ in range(S)]
-        det_keys = [k for k in ("n_dets", "det_cls", "det_prob", "det_bbox", "n_rois") if k in pipes[0]._static_out]
+        det_keys = [k for k in ("n_dets", "det_cls", "det_prob", "det_bbox", "n_rois") if k in pipes[0]._static_out] or ["rpn_cls", "rpn_reg"]
         host_out = [{k: torch.empty(pl._static_out[k].shape, dtype=pl._static_out[k].dtype).pin_memory() for k in det_keys} for pl in pipes]
         mean = (103.939, 116.779, 123.68)
 
@@ -357,7 +425,7 @@ def main():
         io = {"value": round(world * S * args.steps / elapsed_io, 3), "unit": "img/s", "ms_per_step": round(1e3 * elapsed_io / args.steps, 4),
               "distinct_frames": len(frames), "n_detections_last": int(host_out[0]["n_dets"].item()) if "n_dets" in det_keys else None,
               "what": "per image: uint8 BGR frame from pinned host memory -> H2D -> device preprocess -> hipGraph replay -> D2H of "
-                      "n_dets / det_cls / det_prob / det_bbox into pinned host memory"}
+                      "%s into pinned host memory" % " / ".join(det_keys)}
         # leave the graphs' inputs as the resident-input run had them (the roofline / parity sections below use pipe._static_out)
         for i, pl in enumerate(pipes):
             pl._static_in.copy_(torch.from_numpy(synth_image(rank * S + i)).cuda())
@@ -365,7 +433,7 @@ def main():
         torch.cuda.synchronize()
 
     out = pipe._static_out if not args.no_graph else pipe.forward_dev(x)
-    n_rois = int(out["n_rois"].item())
+    n_rois = int(out["n_rois"].item()) if "n_rois" in out else None
     n_dets = int(out["n_dets"].item()) if "n_dets" in out else None
 
     if rank == 0:
@@ -375,7 +443,8 @@ def main():
             roof = None
             roof_error = "%s: %s" % (type(e).__name__, e)
         line = {
-            "metric": "images/sec end-to-end (RPN+det) ResNet-%d %dx%d" % (DEPTH, HEIGHT, WIDTH),
+            "metric": ("images/sec RPN-only forward VGG16 %dx%d" % (HEIGHT, WIDTH)) if DEPTH == 16
+                      else "images/sec end-to-end (RPN+det) ResNet-%d %dx%d" % (DEPTH, HEIGHT, WIDTH),
             "value": round(world * S * args.steps / elapsed, 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -385,8 +454,8 @@ def main():
                        "images_per_step_per_gpu": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "proposals": PROPOSALS, "classes": NUM_CLASSES,
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
-                       "head_order": "res5a 1x1 layers on the conv4 map, then RoI resampling (algebraically equal, see DESIGN 5)" if HOIST
-                       else "reference order",
+                       "head_order": "no detector head" if DEPTH == 16 else
+                       "res5a 1x1 layers on the conv4 map, then RoI resampling (algebraically equal, see DESIGN 5)" if HOIST else "reference order",
                        "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world},
             "roofline": roof,
         }
@@ -394,7 +463,7 @@ def main():
             line["with_host_io"] = io
         if roof is None:
             line["roofline"] = {"bound": "mfma", "error": roof_error}
-        if roof is not None and HOIST:   # what the same image costs in the reference's layer order (res5a_branch2a / branch1 on every crop)
+        if roof is not None and HOIST and DEPTH != 16:   # what the same image costs in the reference's layer order (res5a_branch2a / branch1 on every crop)
             rows_cols = int(out["rpn_cls"].shape[1] * out["rpn_cls"].shape[2])
             saved = 2.0 * 1024 * (512 + 2048) * (PROPOSALS * 49 - rows_cols) / 1e9
             roof["all_conv_launches"]["gflop_per_image_reference_order"] = round(roof["all_conv_launches"]["gflop_per_image"] + saved, 2)
@@ -407,6 +476,8 @@ def main():
             roof["frac"] = round(roof["achieved"] / PEAK_BF16_TFLOPS, 4)
             roof["all_conv_launches"]["frac"] = round(roof["all_conv_launches"]["achieved"] / PEAK_BF16_TFLOPS, 4)
             roof["backbone_conv"]["frac"] = round(roof["backbone_conv"]["achieved"] / PEAK_BF16_TFLOPS, 4)
+        if world == 1 and not args.no_cpu_baseline and args.config == "c1":
+            line["cpu_baseline"], line["parity"] = vgg_rpn_cpu_and_parity(pipe, weights)
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             line["cpu_baseline"] = cpu_baseline(weights, anchors)
             if DTYPE == "f32":

@@ -1594,12 +1594,13 @@ static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
     return check_launch("conv2d_fwd");
 }
 
-static int launch_conv_cin3(const ConvArgs& a, hipStream_t s) {
+static int launch_conv_cin3(const ConvArgs& a, hipStream_t s, bool variant2) {
     ConvArgs p = a;
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_n = (p.Cout + 63) / 64;
     const size_t lds = (size_t)2 * (64 + 64) * LDS_STRIDE * sizeof(float);
-    k_conv_igemm_f32_v2<1, 1, 1, 2, 2, false, true><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    if (variant2) k_conv_igemm_f32_v2<1, 1, 2, 2, 2, false, true><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
+    else k_conv_igemm_f32_v2<1, 1, 1, 2, 2, false, true><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
     return check_launch("conv2d_fwd (3-channel stem)");
 }
 
@@ -1849,7 +1850,7 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     if (d->cin == 3) {                                          // the stems: filter packed 4 wide, eight taps per chunk
         if (a.layout) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: position-major layout needs cin %% 32 == 0");
         if ((size_t)d->n * d->h * d->w * 12 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: 3-channel input over 2 GiB");
-        return launch_conv_cin3(a, s);
+        return launch_conv_cin3(a, s, d->tile % 100 == 31);      // 31: dev code, the mid-chunk-barrier loop on the stem
     }
     if (!generic && workspace) {
         const size_t need = frcnn_conv2d_workspace_bytes(d);
