@@ -14,6 +14,8 @@
 // At these shapes the kernel is operand-bandwidth bound, not MFMA bound: a 128x128x64 step needs
 // 32 KB of operands for 16 MFMAs (512 cycles) per wave.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace frcnn {
 
@@ -57,7 +59,7 @@ __device__ __forceinline__ float activate_b(float v, int act) {
 // draw from than the f32 kernel (whose chunk is 4096 cycles of MFMA) does.
 // MASKED: the epilogue also applies the ReLU-backward mask (training's input-gradient pass).  A template parameter,
 // not a runtime test: with the test in, the inference instantiations ran 14 % slower (596 -> 514 img/s on configs[3]).
-template <int TM, int TN, bool SPLITK = false, int WM = 2, int WN = 2, bool MASKED = false>
+template <int TM, int TN, bool SPLITK = false, int WM = 2, int WN = 2, bool MASKED = false, int VARIANT = 0>
 __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgsBf16 p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -131,7 +133,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
     const int ke = SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all;
 
-    i32x4 ra[PA], rb[PB];
     unsigned rem = tap_mask;
     int c0 = 0, w_grp = 0;
     if (SPLITK) {
@@ -139,19 +140,21 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         c0 = grp * BKH; w_grp = grp * RS * (BKH * 2);
         for (int t = kb - grp * n_taps; t > 0; --t) rem &= rem - 1;
     }
-    auto load_chunk = [&](int) {
+    // the NEXT chunk of this workgroup's sequence -> a set of staging registers (calls past the end of the range fetch
+    // in-bounds or zero data that is never multiplied)
+    auto load_into = [&](i32x4 (&xa)[PA], i32x4 (&xb)[PB]) {
         const int tap = __builtin_ctz(rem);
         const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
         const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 2;
         const int w_off = w_grp + tap * (BKH * 2);
 #pragma unroll
         for (int i = 0; i < PB; ++i)
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0);
+            xb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
             const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET_B, 0, 0);
+            xa[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET_B, 0, 0);
         }
         rem &= rem - 1;
         const int wrap = (rem == 0);
@@ -159,13 +162,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         c0 += wrap * BKH;
         w_grp += wrap * (RS * BKH * 2);
     };
-    auto store_chunk = [&](int buf) {
+    auto store_from = [&](const i32x4 (&xa)[PA], const i32x4 (&xb)[PB], int buf) {
         char* a = As + buf * BM * LDS_STRIDE_B;
         char* b = Bs + buf * BN * LDS_STRIDE_B;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + RPP * i) * LDS_STRIDE_B + lcolb) = ra[i];
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<i32x4*>(a + (lrow + RPP * i) * LDS_STRIDE_B + lcolb) = xa[i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + RPP * i) * LDS_STRIDE_B + lcolb) = rb[i];
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + RPP * i) * LDS_STRIDE_B + lcolb) = xb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -176,14 +179,99 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    constexpr int MF = TM * TN;            // MFMAs per k-step (k = 16)
+    constexpr int NL = PA + PB;
+    constexpr int NF = TM + TN;
+    if constexpr (VARIANT == 2) {
+        // The mid-chunk-barrier schedule of conv_igemm.hip's VARIANT 2.  A bf16 chunk is only 4 x MF MFMAs of 32 cycles
+        // per wave (128 cycles on the 64x64 tile), far less than the [LDS stores -> barrier -> fragment reads] chain that
+        // ended every chunk of the loop below; here k-steps 0,1 multiply fragments read during the previous chunk, the
+        // barrier sits between them and k-steps 2,3, and the stores of chunk T+2, the reads of chunk T+1's step 0 and the
+        // global loads of chunk T+4 (two staging register sets) ride behind it.  Same k order: bit-identical results.
+        i32x4 sa0[PA], sb0[PB], sa1[PA], sb1[PB];
+        bf16x8 na[TM], nb[TN];
+        load_into(sa0, sb0);
+        load_into(sa1, sb1);
+        store_from(sa0, sb0, 0);
+        load_into(sa0, sb0);
+        store_from(sa1, sb1, 1);
+        load_into(sa1, sb1);
+        __syncthreads();
+        {
+            const char* a = As + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
+            const char* b = Bs + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) na[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_STRIDE_B);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) nb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_STRIDE_B);
+        }
+        auto chunk = [&](auto parity, auto& xa, auto& xb) {
+            constexpr int P = decltype(parity)::value;
+            const char* a = As + P * BM * LDS_STRIDE_B + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
+            const char* b = Bs + P * BN * LDS_STRIDE_B + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
+            const char* an = As + (P ^ 1) * BM * LDS_STRIDE_B + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
+            const char* bn = Bs + (P ^ 1) * BN * LDS_STRIDE_B + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
+            bf16x8 fa[4][TM], fb[4][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = na[i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = nb[j];
+#pragma unroll
+            for (int st = 1; st < 4; ++st) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[st][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_STRIDE_B + st * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[st][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_STRIDE_B + st * 32);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][i], fb[st][j], acc[i][j], 0, 0, 0);
+            SGB(SG_DS_RD, NF);                                       // step-1 fragments first
+#pragma unroll
+            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_DS_RD, (2 * NF + MF - 1) / MF); }      // k-step 0: steps 2,3 fragments
+#pragma unroll
+            for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);            // k-step 1
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            store_from(xa, xb, P);                                   // chunk T+2 -> the buffer every wave has just finished reading
+            load_into(xa, xb);                                       // chunk T+4
+#pragma unroll
+            for (int i = 0; i < TM; ++i) na[i] = *reinterpret_cast<const bf16x8*>(an + i * 32 * LDS_STRIDE_B);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) nb[j] = *reinterpret_cast<const bf16x8*>(bn + j * 32 * LDS_STRIDE_B);
+#pragma unroll
+            for (int st = 2; st < 4; ++st)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][i], fb[st][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_DS_WR, (NL + MF - 1) / MF); }             // k-step 2: LDS stores
+            SGB(SG_DS_RD, NF);
+#pragma unroll
+            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_VALU, 6); SGB(SG_VMEM_RD, (NL + MF - 1) / MF); }   // k-step 3: global loads
+        };
+        int kc = kb;
+        for (; kc + 1 < ke; kc += 2) {
+            chunk(std::integral_constant<int, 0>{}, sa0, sb0);
+            chunk(std::integral_constant<int, 1>{}, sa1, sb1);
+        }
+        if (kc < ke) chunk(std::integral_constant<int, 0>{}, sa0, sb0);
+        __syncthreads();
+    } else {
+    i32x4 ra[PA], rb[PB];
+    auto load_chunk = [&](int) { load_into(ra, rb); };
+    auto store_chunk = [&](int buf) { store_from(ra, rb, buf); };
     load_chunk(kb);
     store_chunk(0);
     load_chunk(kb + 1 < ke ? kb + 1 : kb);
     __syncthreads();
 
-    constexpr int MF = TM * TN;            // MFMAs per k-step (k = 16)
-    constexpr int NL = PA + PB;
-    constexpr int NF = TM + TN;
     for (int kc = kb; kc < ke; ++kc) {
         const int buf = (kc - kb) & 1;
         store_chunk(buf ^ 1);
@@ -216,6 +304,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
 #pragma unroll
         for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);
         __syncthreads();
+    }
     }
 
     if constexpr (SPLITK) {
@@ -492,8 +581,10 @@ __global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int ro
     }
 }
 
-template <int TM, int TN, int WM, int WN, bool MASKED>
-static int launch_bf16_m(const ConvArgsBf16& a, hipStream_t s) {
+static int g_bf16_variant = getenv("FRCNN_BF16_VARIANT") ? atoi(getenv("FRCNN_BF16_VARIANT")) : 2;   // dev knob: 0 = the round-1 loop
+
+template <int TM, int TN, int WM, int WN, bool MASKED, int VARIANT>
+static int launch_bf16_v(const ConvArgsBf16& a, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     ConvArgsBf16 p = a;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -501,12 +592,17 @@ static int launch_bf16_m(const ConvArgsBf16& a, hipStream_t s) {
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE_B;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS to %zu", lds);
         attr_done = true;
     }
-    k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
+    k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED, VARIANT><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
     return check_launch("conv2d_fwd_bf16");
+}
+
+template <int TM, int TN, int WM, int WN, bool MASKED>
+static int launch_bf16_m(const ConvArgsBf16& a, hipStream_t s) {
+    return g_bf16_variant == 2 ? launch_bf16_v<TM, TN, WM, WN, MASKED, 2>(a, s) : launch_bf16_v<TM, TN, WM, WN, MASKED, 0>(a, s);
 }
 
 template <int TM, int TN, int WM = 2, int WN = 2>
@@ -521,8 +617,13 @@ static int launch_bf16_splitk(const ConvArgsBf16& a, hipStream_t s) {
     p.tiles_m = (p.M + 63) / 64;
     p.tiles_n = (p.Cout + 63) / 64;
     const size_t lds = (size_t)2 * (64 + 64) * LDS_STRIDE_B;
-    if (p.mask) k_conv_igemm_bf16<1, 1, true, 2, 2, true><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
-    else k_conv_igemm_bf16<1, 1, true><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
+    if (g_bf16_variant == 2) {
+        if (p.mask) k_conv_igemm_bf16<1, 1, true, 2, 2, true, 2><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
+        else k_conv_igemm_bf16<1, 1, true, 2, 2, false, 2><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
+    } else {
+        if (p.mask) k_conv_igemm_bf16<1, 1, true, 2, 2, true><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
+        else k_conv_igemm_bf16<1, 1, true><<<p.tiles_m * p.tiles_n * p.splits, 256, lds, s>>>(p);
+    }
     return check_launch("conv2d_fwd_bf16 (split-K)");
 }
 

@@ -1688,7 +1688,9 @@ static int choose_splits(const frcnn_conv_desc* d, int cfg) {
         // 38-60 % of the 1024 slots: four slices take 174 -> 143 us (3x3) and 85 -> 76 us (2048 -> 512)
         if (tiles >= 384 && tiles < 640 && nk >= 64) return 4;
         if (tiles >= 384 || nk < 16) return 1;
-        s = tiles >= 100 ? 3 : (int)((456 + tiles - 1) / tiles);
+        // (round 2, mid-chunk-barrier loop: 100..383 tiles with a LONG k loop take five slices -- stage-4 3x3 31.9 -> 30.9 us,
+        // rpn_conv1 190.5 -> 178.8 us: 5 x 304 workgroups sit 6-deep on the 256 CUs where 3 x 304 sit 4-deep on some and 3 on others)
+        s = tiles >= 100 ? (nk >= 64 ? 5 : 3) : (int)((456 + tiles - 1) / tiles);
         if (s > nk / 4) s = nk / 4;
         if (s > 16) s = 16;
     }
@@ -1850,7 +1852,7 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     if (d->cin == 3) {                                          // the stems: filter packed 4 wide, eight taps per chunk
         if (a.layout) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: position-major layout needs cin %% 32 == 0");
         if ((size_t)d->n * d->h * d->w * 12 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd: 3-channel input over 2 GiB");
-        return launch_conv_cin3(a, s, d->tile % 100 == 31);      // 31: dev code, the mid-chunk-barrier loop on the stem
+        return launch_conv_cin3(a, s, d->tile % 100 != 32);      // the mid-chunk-barrier loop (conv1 50.6 -> 49.4 us); 32: dev code, the late-store loop
     }
     if (!generic && workspace) {
         const size_t need = frcnn_conv2d_workspace_bytes(d);

@@ -256,7 +256,7 @@ CONV_KERNEL_NAMES = {1: "k_conv_igemm_f32<2,2,false>", 2: "k_conv_igemm_f32<1,1,
                      13: "k_conv_igemm_f32_v2<2,1>", 14: "k_conv_igemm_f32_v2<4,2>",
                      21: "k_conv_igemm_f32_v2<2,2,1>", 22: "k_conv_igemm_f32_v2<1,1,1>",
                      23: "k_conv_igemm_f32_v2<1,1,2>", 24: "k_conv_igemm_f32_v2<1,2,2>", 25: "k_conv_igemm_f32_v2<2,1,2>", 26: "k_conv_igemm_f32_v2<2,2,2>",
-                     30: "k_conv_igemm_f32_v2<1,1,1> stem", 61: "k_conv_igemm_f32_sk<2,2>", 62: "k_conv_igemm_f32_sk<1,1>", 41: "k_conv_igemm_f32_v2<1,2,1,4,2>", 42: "k_conv_igemm_f32_v2<2,1,1,2,4>", 43: "k_conv_igemm_f32_v2<1,1,1,4,2>"}
+                     30: "k_conv_igemm_f32_v2<1,1,2> stem", 32: "k_conv_igemm_f32_v2<1,1,1> stem", 61: "k_conv_igemm_f32_sk<2,2>", 62: "k_conv_igemm_f32_sk<1,1>", 41: "k_conv_igemm_f32_v2<1,2,1,4,2>", 42: "k_conv_igemm_f32_v2<2,1,1,2,4>", 43: "k_conv_igemm_f32_v2<1,1,1,4,2>"}
 
 
 class ConvWorkspace:
