@@ -1329,6 +1329,139 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_f32(const WgradArgs p) {
     wgrad_body_f32<IN_BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// The 128 (ci) x 128 (co) form of the f32 weight gradient, for layers with cin, cout >= 128 (every trainable layer of the
+// ResNet stages 3-5, the RPN and VGG from block 2 on).  The 64x64 body above reads one A and one B value per MFMA
+// (ds_read_b32, and its 68-float rows put the two k-rows of a read 4 banks apart: 2-way conflicts) and moves 16 KB of
+// operands per 262 kFLOP -- ~70 TFLOP/s on the training steps' layers (profiles/round2_lab/train_trace_by_grid_f32_*).
+// Here each wave owns 64 x 64: its two 32-wide row tiles are the EVEN and the ODD channels of its 64 (the output-row
+// permutation is free, the epilogue undoes it), so ONE ds_read_b64 per operand feeds four MFMAs; a b64 read is served
+// half-wave by half-wave, each half one unpadded 128-float row segment = every bank once.  Operand traffic per FLOP
+// halves, the chunk (32 pixels) is 64 MFMAs = 4096 cycles per wave against 8 + 8 staging copies per thread, two
+// workgroups (64 KB of LDS each) share a CU.  Pixel coordinates advance incrementally (no division in the loop);
+// halo / tail / channel edges ride on the buffer descriptors.  Slab layout and the fixed-order slice reduction are
+// unchanged; the pixel order inside a slice is the 64x64 body's, only the slice boundaries move with the tile count.
+constexpr int WGB_LD = 128;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wgrad_body_f32_big(const WgradArgs& p, int bx, int by, int bz) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][WG_MC][WGB_LD];
+    __shared__ __attribute__((aligned(16))) float Gs[2][WG_MC][WGB_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int ci_tiles = (p.Cin + 127) / 128;
+    const int tap = bx / ci_tiles, ci0 = (bx % ci_tiles) * 128;
+    const int r_tap = tap / p.S, s_tap = tap % p.S;
+    const int co0 = by * 128;
+    const int m_begin = bz * p.m_per_slice, m_end = min(p.M, m_begin + p.m_per_slice);
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.g), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+
+    // staging: 256 threads move 32 pixels x 128 channels per operand per chunk: 8 rows per pass, 4 passes
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    const bool ci_ok = ci0 + scol < p.Cin, co_ok = co0 + scol < p.Cout;
+    const float inv_wo = 1.0f / (float)p.Wo, inv_ho = 1.0f / (float)p.Ho;
+    // n / d for 0 <= n < 2^23 (the host keeps M below that): the float product is within one of the quotient
+    auto divmod = [](int n, int d, float inv, int& q, int& r) {
+        q = (int)((float)n * inv); r = n - q * d;
+        if (r < 0) { r += d; --q; }
+        if (r >= d) { r -= d; ++q; }
+    };
+    int mc = m_begin;
+    i32x4 rx[4], rg[4];
+    auto load = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = mc + srow + 8 * q;
+            int wo, t, ho, img;
+            divmod(m, p.Wo, inv_wo, t, wo);
+            divmod(t, p.Ho, inv_ho, img, ho);
+            const int hi = ho * p.stride - p.pad_top + r_tap, wi = wo * p.stride - p.pad_left + s_tap;
+            const bool in = m < m_end && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned xoff = (unsigned)(((img * p.H + hi) * p.W + wi) * p.Cin + ci0 + scol) * 4u;
+            rx[q] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in && ci_ok ? xoff : OOB_OFFSET, 0, 0);
+            const unsigned goff = (unsigned)(m * p.Cout + co0 + scol) * 4u;
+            rg[q] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, m < m_end && co_ok ? goff : OOB_OFFSET, 0, 0);
+        }
+        mc += WG_MC;
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<i32x4*>(&Xs[buf][srow + 8 * q][scol]) = rx[q];
+            *reinterpret_cast<i32x4*>(&Gs[buf][srow + 8 * q][scol]) = rg[q];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // chunk c multiplies from LDS buffer c & 1 while chunk c+1 (in registers since the previous iteration) moves into the
+    // other buffer and chunk c+2 is requested: every global load has a whole chunk (64 MFMAs = 4096 cycles) to land.
+    // Loads past the slice carry m >= m_end: zeros.
+    const int n_chunks = (m_end - m_begin + WG_MC - 1) / WG_MC;
+    if (n_chunks > 0) {
+        load();
+        store(0);
+        load();
+        __syncthreads();
+        for (int c = 0; c < n_chunks; ++c) {
+            const int buf = c & 1;
+            store(buf ^ 1);
+            load();
+            const float* xa = &Xs[buf][lh][wk * 64 + 2 * li];
+            const float* gb = &Gs[buf][lh][wn * 64 + 2 * li];
+            f32x2 fa[WG_MC / 2], fb[WG_MC / 2];
+#pragma unroll
+            for (int st = 0; st < WG_MC / 2; ++st) {
+                fa[st] = *reinterpret_cast<const f32x2*>(xa + 2 * st * WGB_LD);
+                fb[st] = *reinterpret_cast<const f32x2*>(gb + 2 * st * WGB_LD);
+            }
+#pragma unroll
+            for (int st = 0; st < WG_MC / 2; ++st) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st][0], fb[st][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st][0], fb[st][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st][1], fb[st][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st][1], fb[st][1], acc[1][1], 0, 0, 0);
+            }
+            // issue order: fragment reads run ahead of the MFMAs that need them, the LDS stores ride behind the first
+            // MFMAs, the address arithmetic and the eight global loads behind the middle ones
+            SGB(SG_DS_RD, 4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { SGB(SG_MFMA, 1); SGB(SG_DS_WR, 1); SGB(SG_DS_RD, 1); }
+#pragma unroll
+            for (int q = 8; q < 28; ++q) { SGB(SG_MFMA, 1); SGB(SG_DS_RD, 1); }
+#pragma unroll
+            for (int q = 28; q < 36; ++q) { SGB(SG_MFMA, 1); SGB(SG_VALU, 16); SGB(SG_VMEM_RD, 1); }
+#pragma unroll
+            for (int q = 36; q < 64; ++q) SGB(SG_MFMA, 1);
+            __syncthreads();
+        }
+    }
+    // partial slab layout = HWIO: [slice][tap][ci][co]; tile (i, j) of this wave = channels 2*row + i, 2*col + j
+    float* dst = p.partial + ((size_t)bz * p.R * p.S + tap) * p.Cin * p.Cout;
+    const int co = co0 + wn * 64 + 2 * li;
+    if (co < p.Cout) {                               // cout is a multiple of 4: the pair is inside together
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = ci0 + wk * 64 + 2 * (4 * lh + (e & 3) + 8 * (e >> 2)) + i;
+                if (ci < p.Cin) {
+                    f32x2 v; v[0] = acc[i][0][e]; v[1] = acc[i][1][e];
+                    *reinterpret_cast<f32x2*>(dst + (size_t)ci * p.Cout + co) = v;
+                }
+            }
+    }
+}
+
 // Weight gradient on the bf16 matrix cores (mixed-precision training): x and g arrive in bf16, [pixel][channel] as
 // they lie in NHWC.  The reduction index is the PIXEL, i.e. both MFMA operands are k-strided in memory; they are
 // staged untransposed (coalesced 16-byte copies, 192-byte LDS rows) and read back with ds_read_b64_tr_b16, the
@@ -1454,14 +1587,19 @@ struct WgradBatch { WgradArgs job[WGRAD_BATCH]; int first_block[WGRAD_BATCH + 1]
 struct WgradReduceJob { const float* partial; const float* scale; float* dw; unsigned long long elems; int slices, cout; };
 struct WgradReduceBatch { WgradReduceJob job[2 * WGRAD_BATCH]; int n; };
 
-template <int KIND>          // 0: f32 operands; 1: bf16 operands on the bf16 MFMA; 2: bf16 operands widened onto the f32 MFMA
+template <int KIND>          // 0: f32 operands; 1: bf16 operands on the bf16 MFMA; 2: bf16 operands widened onto the f32 MFMA; 3: f32, 128x128 tiles
 __global__ void __launch_bounds__(256) k_conv_wgrad_batch(const WgradBatch t) {
     int j = 0;
     while (j + 1 < t.n && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
     const int local = (int)blockIdx.x - t.first_block[j];
     const int bx = local % t.gx[j], r = local / t.gx[j], by = r % t.gy[j], bz = r / t.gy[j];
     if constexpr (KIND == 1) wgrad_body_bf16(t.job[j], bx, by, bz);
+    else if constexpr (KIND == 3) wgrad_body_f32_big(t.job[j], bx, by, bz);
     else wgrad_body_f32<KIND == 2>(t.job[j], bx, by, bz);
+}
+
+__global__ void __launch_bounds__(256) k_conv_wgrad_f32_big(const WgradArgs p) {
+    wgrad_body_f32_big(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 __global__ void __launch_bounds__(256) k_wgrad_reduce_batch(const WgradReduceBatch t) {
@@ -1905,24 +2043,39 @@ int frcnn_pack_conv_weights_dgrad(const float* w_hwio, const float* scale, int k
     return check_launch("pack_conv_weights_dgrad");
 }
 
-static int wgrad_slices(const frcnn_conv_desc* d) {
+// f32 operands, cin and cout >= 128: the 128x128-tile kernel (dev knob FRCNN_WGRAD_BIG=0: the 64x64 kernel everywhere)
+static bool wgrad_big(const frcnn_conv_desc* d, bool in_bf16) {
+    static const bool on = !(getenv("FRCNN_WGRAD_BIG") && atoi(getenv("FRCNN_WGRAD_BIG")) == 0);
+    if (!on || in_bf16 || d->cin < 128 || d->cout < 128 || (d->cin & 3) || (d->cout & 3)) return false;
+    const size_t xb = (size_t)d->n * d->h * d->w * d->cin * 4, gb = (size_t)d->n * d->ho * d->wo * d->cout * 4;
+    return xb < 0x80000000ull && gb < 0x80000000ull && (long long)d->n * d->ho * d->wo < (1 << 23);         // 32-bit buffer offsets, float-exact pixel index
+}
+
+static int wgrad_slices(const frcnn_conv_desc* d, bool big) {
     const long long M = (long long)d->n * d->ho * d->wo;
-    const long long tiles = (long long)d->kh * d->kw * ((d->cin + 63) / 64) * ((d->cout + 63) / 64);
+    const int tw = big ? 128 : 64;
+    const long long tiles = (long long)d->kh * d->kw * ((d->cin + tw - 1) / tw) * ((d->cout + tw - 1) / tw);
     // ~256 workgroups per layer: the layers of a step are launched together (frcnn_conv2d_wgrad_batch), so the chip is
     // filled by the batch, not by one layer, and fewer slices mean fewer partial slabs to write and re-read (measured,
     // scripts/micro/train_ab2.py, target 2048 -> 256: mixed RPN step 2.36 -> 2.08 ms, detector step 3.30 -> 2.85 ms)
     static const long long target = getenv("FRCNN_WGRAD_TARGET") ? atoll(getenv("FRCNN_WGRAD_TARGET")) : 256;   // dev knob
-    long long s = (target + tiles - 1) / tiles;
+    static const long long target_big = getenv("FRCNN_WGRAD_TARGET_BIG") ? atoll(getenv("FRCNN_WGRAD_TARGET_BIG")) : 256;
+    const long long tg = big ? target_big : target;
+    long long s = (tg + tiles - 1) / tiles;
     const long long max_s = (M + 4 * WG_MC - 1) / (4 * WG_MC); // at least 4 chunks per slice
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
     return (int)s;
 }
+static int wgrad_slices_max(const frcnn_conv_desc* d) {
+    const int a = wgrad_slices(d, false), b = wgrad_big(d, false) ? wgrad_slices(d, true) : 0;
+    return a > b ? a : b;
+}
 
 size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d) {
     if (!d) return 0;
-    const size_t dw = (size_t)wgrad_slices(d) * d->kh * d->kw * d->cin * d->cout * sizeof(float);
+    const size_t dw = (size_t)wgrad_slices_max(d) * d->kh * d->kw * d->cin * d->cout * sizeof(float);
     const size_t db = (size_t)COLSUM_SLICES * d->cout * sizeof(float);
     return align_up(dw > db ? dw : db, 256);
 }
@@ -1952,11 +2105,14 @@ static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bo
     a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
     a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
     a.M = d->n * d->ho * d->wo;
-    const int slices = wgrad_slices(d);
+    const bool big = wgrad_big(d, in_bf16);
+    const int slices = wgrad_slices(d, big);
     a.m_per_slice = ((a.M + slices - 1) / slices + WG_MC - 1) / WG_MC * WG_MC;
     hipStream_t s = as_stream(stream);
-    dim3 grid(d->kh * d->kw * ((d->cin + 63) / 64), (d->cout + 63) / 64, slices);
-    if (in_bf16 && (d->cin & 7) == 0 && (d->cout & 7) == 0) k_conv_wgrad_bf16<<<grid, 256, 0, s>>>(a);      // bf16 MFMA
+    const int tw = big ? 128 : 64;
+    dim3 grid(d->kh * d->kw * ((d->cin + tw - 1) / tw), (d->cout + tw - 1) / tw, slices);
+    if (big) k_conv_wgrad_f32_big<<<grid, 256, 0, s>>>(a);
+    else if (in_bf16 && (d->cin & 7) == 0 && (d->cout & 7) == 0) k_conv_wgrad_bf16<<<grid, 256, 0, s>>>(a);      // bf16 MFMA
     else if (in_bf16) k_conv_wgrad_f32<true><<<grid, 256, 0, s>>>(a);                                          // widened, f32 MFMA
     else k_conv_wgrad_f32<false><<<grid, 256, 0, s>>>(a);
     if (int e = check_launch("conv2d_wgrad")) return e;
@@ -1984,12 +2140,12 @@ static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bo
 }
 
 static int wgrad_kind(const frcnn_wgrad_job& j) {
-    if (!j.in_bf16) return 0;
+    if (!j.in_bf16) return wgrad_big(&j.d, false) ? 3 : 0;
     return ((j.d.cin & 7) == 0 && (j.d.cout & 7) == 0) ? 1 : 2;
 }
 
 static size_t wgrad_slab_bytes(const frcnn_conv_desc* d) {
-    return align_up((size_t)wgrad_slices(d) * d->kh * d->kw * d->cin * d->cout * sizeof(float), 256);
+    return align_up((size_t)wgrad_slices_max(d) * d->kh * d->kw * d->cin * d->cout * sizeof(float), 256);
 }
 
 size_t frcnn_conv2d_wgrad_batch_workspace_bytes(const frcnn_wgrad_job* jobs, int n_jobs) {
@@ -2016,7 +2172,7 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
         slab[i] = (float*)((char*)workspace + off);
         off += wgrad_slab_bytes(&j.d);
     }
-    for (int kind = 0; kind < 3; ++kind) {
+    for (int kind = 0; kind < 4; ++kind) {
         WgradBatch t;
         t.n = 0;
         int blocks = 0;
@@ -2026,7 +2182,8 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             for (int q = t.n; q < WGRAD_BATCH; ++q) { t.job[q] = t.job[0]; t.gx[q] = t.gy[q] = 1; t.first_block[q + 1] = blocks; }
             if (kind == 0) k_conv_wgrad_batch<0><<<blocks, 256, 0, s>>>(t);
             else if (kind == 1) k_conv_wgrad_batch<1><<<blocks, 256, 0, s>>>(t);
-            else k_conv_wgrad_batch<2><<<blocks, 256, 0, s>>>(t);
+            else if (kind == 2) k_conv_wgrad_batch<2><<<blocks, 256, 0, s>>>(t);
+            else k_conv_wgrad_batch<3><<<blocks, 256, 0, s>>>(t);
             t.n = 0; blocks = 0;
             return check_launch("conv2d_wgrad_batch");
         };
@@ -2039,10 +2196,11 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
             a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
             a.M = d->n * d->ho * d->wo;
-            const int slices = wgrad_slices(d);
+            const int slices = wgrad_slices(d, kind == 3);
             a.m_per_slice = ((a.M + slices - 1) / slices + WG_MC - 1) / WG_MC * WG_MC;
-            t.gx[t.n] = d->kh * d->kw * ((d->cin + 63) / 64);
-            t.gy[t.n] = (d->cout + 63) / 64;
+            const int tw = kind == 3 ? 128 : 64;
+            t.gx[t.n] = d->kh * d->kw * ((d->cin + tw - 1) / tw);
+            t.gy[t.n] = (d->cout + tw - 1) / tw;
             t.first_block[t.n] = blocks;
             blocks += t.gx[t.n] * t.gy[t.n] * slices;
             if (++t.n == WGRAD_BATCH) if (int e = flush()) return e;
@@ -2058,7 +2216,7 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             const frcnn_conv_desc* d = &jobs[q].d;
             r.job[i].partial = slab[q]; r.job[i].scale = jobs[q].scale; r.job[i].dw = jobs[q].dw;
             r.job[i].elems = (unsigned long long)d->kh * d->kw * d->cin * d->cout;
-            r.job[i].slices = wgrad_slices(d); r.job[i].cout = d->cout;
+            r.job[i].slices = wgrad_slices(d, wgrad_kind(jobs[q]) == 3); r.job[i].cout = d->cout;
         }
         k_wgrad_reduce_batch<<<dim3(512, r.n), 256, 0, s>>>(r);
         if (int e = check_launch("conv2d_wgrad_batch reduce")) return e;

@@ -49,9 +49,14 @@ class _Model:
             self._trainer = self._new_trainer()
         self._trainer.compile(optimizer, loss)
 
-    def train_on_batch(self, x, y, skip=False):
+    supports_deferred_losses = True
+
+    def train_on_batch(self, x, y, skip=False, defer=False):
+        """Keras' train_on_batch: [total, loss 1, loss 2].  ``defer=True`` (not in Keras) only ENQUEUES the step and
+        returns a train.PendingLosses; its ``result()`` is that list.  The training loops use it to prepare the next
+        image while the GPU runs this step."""
         self._dirty = True
-        return self._trainer.train_on_batch(x, y, skip=skip)
+        return self._trainer.train_on_batch(x, y, skip=skip, defer=defer)
 
     def get_layer(self, name):
         self._flush_trainer()

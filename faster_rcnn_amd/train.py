@@ -12,6 +12,7 @@ One flat buffer of gradients means data-parallel training needs exactly ONE all-
 (RCCL through torch.distributed); the optimiser is one launch over the flat parameter buffer.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -442,13 +443,10 @@ class _StepDriver:
     Removed again: DESIGN 11.)"""
 
     def _init_driver(self):
-        self._pinned = {}           # input-shape key -> pinned float32 staging buffers
+        self._pinned = {}           # input-shape key -> [two sets of pinned float32 staging buffers, upload events, toggle]
         self._conv_ws = ops.ConvWorkspace()
-
-    def _finish_host(self, loss1, loss2, sq):
-        l1, l2v = float(loss1.item()), float(loss2.item())
-        reg_term = self.l2 * (float(sq.item()) + self.frozen_sumsq) if self.l2 else 0.0
-        return [l1 + l2v + reg_term, l1, l2v]
+        self._loss_ring = [None] * LOSS_RING          # steps whose three scalars are still on their way to the host
+        self._loss_pos = 0
 
     def _update(self, sq_out):
         """After the backward pass: L2 sum, the ONE exchange of the flat gradient buffer, optimiser, re-pack."""
@@ -465,28 +463,72 @@ class _StepDriver:
     def _stage(self, key, host_inputs):
         """Host arrays (any dtype: Keras hands float64 images and bool targets) -> this shape's pinned float32 staging
         buffers in ONE pass (the cast happens while writing into pinned memory), ready for an asynchronous upload;
-        a separate astype + pageable copy of a 600x1000 image costs ~1 ms per step with the GPU idle."""
-        pins = self._pinned.get(key)
-        if pins is None:
+        a separate astype + pageable copy of a 600x1000 image costs ~1 ms per step with the GPU idle.  Two sets per
+        shape, used alternately, each guarded by the event of its last upload: a deferred step (``defer=True``) lets
+        the host stage the NEXT image while this one's step is still running."""
+        ent = self._pinned.get(key)
+        if ent is None:
             if len(self._pinned) >= 8:
                 self._pinned.clear()
-            pins = self._pinned[key] = [torch.empty(shape, dtype=torch.float32).pin_memory() for _, shape in host_inputs]
-        for pin, (a, shape) in zip(pins, host_inputs):
+            ent = self._pinned[key] = {"sets": [[torch.empty(shape, dtype=torch.float32).pin_memory() for _, shape in host_inputs] for _ in range(2)],
+                                       "uploaded": [None, None], "next": 0}
+        k = ent["next"]
+        ent["next"] = k ^ 1
+        if ent["uploaded"][k] is not None:
+            ent["uploaded"][k].synchronize()
+        for pin, (a, shape) in zip(ent["sets"][k], host_inputs):
             np.copyto(pin.numpy(), np.asarray(a).reshape(shape), casting="unsafe")
-        return pins
+        return ent, k
 
-    def _run_step(self, host_inputs, skip):
-        """host_inputs: list of (array, device shape); the arrays may have any dtype (cast to float32 on the way)."""
+    def _run_step(self, host_inputs, skip, defer=False):
+        """host_inputs: list of (array, device shape); the arrays may have any dtype (cast to float32 on the way).
+        Returns Keras' [total, loss 1, loss 2] -- or, with ``defer``, a PendingLosses whose ``result()`` is that list: the
+        step is then only ENQUEUED when this returns, and the caller may prepare the next image meanwhile."""
         assert self.optimizer is not None, "call compile() first"
-        out = [torch.zeros(1, dtype=torch.float32, device="cuda") for _ in range(3)]       # loss 1, loss 2, sum of squares
+        out3 = torch.zeros(3, dtype=torch.float32, device="cuda")                          # loss 1, loss 2, sum of squares
+        out = [out3[0:1], out3[1:2], out3[2:3]]
         with ops.conv_workspace(self._conv_ws):
             if skip:
                 self.params.g.zero_()
                 self._update(out[2])
             else:
-                pins = self._stage(tuple(shape for _, shape in host_inputs), host_inputs)
-                self._device_step([p.to("cuda", non_blocking=True) for p in pins], out)
-        return self._finish_host(*out)                              # (.item() inside: the staging buffers are free again)
+                ent, k = self._stage(tuple(shape for _, shape in host_inputs), host_inputs)
+                dev = [p.to("cuda", non_blocking=True) for p in ent["sets"][k]]
+                ev = ent["uploaded"][k] = ent["uploaded"][k] or torch.cuda.Event()
+                ev.record()
+                self._device_step(dev, out)
+        slot = self._loss_ring[self._loss_pos]
+        if slot is None:
+            slot = self._loss_ring[self._loss_pos] = [torch.empty(3, dtype=torch.float32).pin_memory(), torch.cuda.Event(), None]
+        elif slot[2] is not None and slot[2]() is not None:
+            slot[2]().result()                          # the ring wrapped around an unread step: read it before its slot is reused
+        self._loss_pos = (self._loss_pos + 1) % LOSS_RING
+        slot[0].copy_(out3, non_blocking=True)
+        slot[1].record()
+        pending = PendingLosses(slot[0], slot[1], self.l2, self.frozen_sumsq)
+        slot[2] = weakref.ref(pending)
+        return pending if defer else pending.result()
+
+
+LOSS_RING = 8
+
+
+class PendingLosses:
+    """The three scalars of an enqueued training step (loss 1, loss 2, sum of squared trainable weights) on their way
+    into pinned host memory; ``result()`` waits for that copy and returns what Keras' train_on_batch returns."""
+
+    def __init__(self, pin, event, l2, frozen_sumsq):
+        self._pin, self._event, self._l2, self._frozen = pin, event, l2, frozen_sumsq
+        self._value = None
+
+    def result(self):
+        if self._value is None:
+            self._event.synchronize()
+            l1, l2v, sq = (float(v) for v in self._pin.tolist())
+            reg_term = self._l2 * (sq + self._frozen) if self._l2 else 0.0
+            self._value = [l1 + l2v + reg_term, l1, l2v]
+            self._pin = self._event = None
+        return self._value
 
 
 # ----------------------------------------------------------------------------- RPN steps 1 and 3
@@ -539,13 +581,14 @@ class RpnTrainer(_StepDriver):
             h = ops.cast_f32(h)
         return self.rpn_cls.forward(h), self.rpn_reg.forward(h), h
 
-    def train_on_batch(self, x, y, skip=False):
+    def train_on_batch(self, x, y, skip=False, defer=False):
         """x (1,H,W,3); y = [y_class (1,R,C,2A) bool, y_bbreg (1,R,C,8A) f32].  ``skip`` = this rank has no
-        usable image this step: it still joins the all-reduce with zero gradients (train_util.py:112-114)."""
+        usable image this step: it still joins the all-reduce with zero gradients (train_util.py:112-114).
+        ``defer``: return a PendingLosses instead of waiting for the step (see _StepDriver._run_step)."""
         if skip:
-            return self._run_step([], True)
+            return self._run_step([], True, defer)
         cells = int(np.prod(np.shape(y[0])[:-1]))
-        return self._run_step([(x, (1,) + tuple(np.shape(x)[-3:])), (y[0], (cells, 2 * self.A)), (y[1], (cells, 8 * self.A))], False)
+        return self._run_step([(x, (1,) + tuple(np.shape(x)[-3:])), (y[0], (cells, 2 * self.A)), (y[1], (cells, 8 * self.A))], False, defer)
 
     def _device_step(self, dev, out):
         xd, yc, yr = dev
@@ -683,12 +726,12 @@ class DetTrainer(_StepDriver):
         cls, reg = ops.dense_heads_split(y2, self.C)
         return cls, reg, y2
 
-    def train_on_batch(self, x, y, skip=False):
+    def train_on_batch(self, x, y, skip=False, defer=False):
         """x = [image (1,H,W,3) or conv features (1,R,C,Cf), rois (1,n,4)]; y = [y_class (1,n,C), y_bbreg (1,n,8(C-1))]."""
         if skip:
-            return self._run_step([], True)
+            return self._run_step([], True, defer)
         n, C, K4 = int(np.size(x[1])) // 4, self.C, 4 * (self.C - 1)
-        return self._run_step([(x[0], (1,) + tuple(np.shape(x[0])[-3:])), (x[1], (n, 4)), (y[0], (n, C)), (y[1], (n, 2 * K4))], False)
+        return self._run_step([(x[0], (1,) + tuple(np.shape(x[0])[-3:])), (x[1], (n, 4)), (y[0], (n, C)), (y[1], (n, 2 * K4))], False, defer)
 
     def _device_step(self, dev, out):
         xd, rois, yc, yr = dev

@@ -23,6 +23,35 @@ def _is_root():
     return dp.rank() == 0
 
 
+class _LossLog:
+    """The reference prints each iteration's losses right after train_on_batch (train_util.py:54-57, 118-121), which
+    makes the host wait for the step.  Here the step is only enqueued (``defer=True``) and its line is printed once the
+    NEXT iteration's step has been enqueued -- the host decodes / samples the next image while the GPU trains on this
+    one -- or earlier when something else is about to print.  Same lines, same order."""
+
+    def __init__(self):
+        self._pending = None
+
+    def flush(self):
+        if self._pending is not None:
+            fmt, args, losses, t0 = self._pending
+            self._pending = None
+            value = losses.result() if hasattr(losses, "result") else losses
+            if _is_root():
+                print(fmt.format(*args, value, timeit.default_timer() - t0))
+
+    def push(self, fmt, args, losses, t0):
+        self.flush()
+        self._pending = (fmt, args, losses, t0)
+
+
+def _enqueue_step(model, x, y, **kw):
+    """train_on_batch, deferred when the model offers it (models._Model does; a plain Keras-style model returns its list)."""
+    if getattr(model, "supports_deferred_losses", False):
+        return model.train_on_batch(x, y, defer=True, **kw)
+    return model.train_on_batch(x, y, **kw)
+
+
 def _save(model, i, save_frequency, save_weights_dest, save_model_dest, what, allow_zero):
     if save_frequency and (allow_zero or i > 0) and i % save_frequency == 0 and _is_root():
         if save_weights_dest is not None:
@@ -44,16 +73,18 @@ def train_rpn(rpn_model, images, training_manager, optimizer, phases=[[DEFAULT_N
                                                      bbreg_loss_rpn(anchors_per_loc=anchors_per_loc)])
         print("Starting phase {} of training: {} iterations with learning rate {}".format(phase_num, num_iterations, learn_rate))
         schedule.begin_phase(phase_num, num_iterations)
+        log = _LossLog()
         for i in range(num_iterations):
             img = schedule.image(i)
             batched_img = training_manager.batched_image(img)
             y_class, y_bbreg = training_manager.rpn_y_true(img)
             start_time = timeit.default_timer()
-            loss_rpn = rpn_model.train_on_batch(batched_img, [y_class, y_bbreg])
-            if _is_root():
-                print("phase {} iteration {} image {} flipped {}: loss_rpn {} ({:.4f} s)".format(
-                    phase_num, i, img.name, img.flipped, loss_rpn, timeit.default_timer() - start_time))
+            loss_rpn = _enqueue_step(rpn_model, batched_img, [y_class, y_bbreg])
+            log.push("phase {} iteration {} image {} flipped {}: loss_rpn {} ({:.4f} s)", (phase_num, i, img.name, img.flipped), loss_rpn, start_time)
+            if save_frequency and i % save_frequency == 0:
+                log.flush()
             _save(rpn_model, i, save_frequency, save_weights_dest, save_model_dest, "rpn", allow_zero=True)
+        log.flush()
     return rpn_model
 
 
@@ -65,19 +96,22 @@ def _train_detector(detector, images, training_manager, optimizer, phases, save_
         detector.compile(optimizer=optimizer, loss=[cls_loss_det, bbreg_loss_det(num_classes)])
         print("Starting phase {} of training: {} iterations with learning rate {}".format(phase_num, num_iterations, learn_rate))
         schedule.begin_phase(phase_num, num_iterations)
+        log = _LossLog()
         for i in range(num_iterations):
             img = schedule.image(i)
             first_input, rois, y_class_num, y_transform = training_manager.get_training_input(img)
             skip = rois is None
             if skip and dp.world() == 1:
+                log.flush()
                 print("Found no rois for this image")
                 continue
             start_time = timeit.default_timer()
-            loss_frcnn = detector.train_on_batch([first_input, rois], [y_class_num, y_transform], skip=skip)
-            if _is_root():
-                print("phase {} iteration {} image {} flipped {}: loss_frcnn {} ({:.4f} s)".format(
-                    phase_num, i, img.name, img.flipped, loss_frcnn, timeit.default_timer() - start_time))
+            loss_frcnn = _enqueue_step(detector, [first_input, rois], [y_class_num, y_transform], skip=skip)
+            log.push("phase {} iteration {} image {} flipped {}: loss_frcnn {} ({:.4f} s)", (phase_num, i, img.name, img.flipped), loss_frcnn, start_time)
+            if save_frequency and i % save_frequency == 0:
+                log.flush()
             _save(detector, i, save_frequency, save_weights_dest, save_model_dest, "detector", allow_zero=False)
+        log.flush()
     return detector
 
 

@@ -31,14 +31,28 @@ GFLOP = {"rpn_step1": 97.9 + 2 * (33.9 + 22.7), "det_step2": (75.2 + 93.7) + 2 *
 
 
 def timed(fn, steps, warmup):
+    """fn() may return a train.PendingLosses (deferred step): it is read one step late, like train_util._LossLog does;
+    every step's losses are read inside the timed region."""
+    prev = None
     for _ in range(warmup):
-        fn()
+        cur = fn()
+        if hasattr(prev, "result"):
+            prev.result()
+        prev = cur
+    if hasattr(prev, "result"):
+        prev.result()
+    prev = None
     torch.cuda.synchronize()
     if dp.world() > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        fn()
+        cur = fn()
+        if hasattr(prev, "result"):
+            prev.result()
+        prev = cur
+    if hasattr(prev, "result"):
+        prev.result()
     torch.cuda.synchronize()
     if dp.world() > 1:
         torch.distributed.barrier()
@@ -65,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--big-tiles", action="store_true")
     ap.add_argument("--only", choices=("rpn", "det"), default=None)
+    ap.add_argument("--sync-each-step", action="store_true", help="read the losses back after every step (Keras' train_on_batch) instead of "
+                    "one step late, the way train_util's loops do")
     args = ap.parse_args()
     backend = os.environ.get("FRCNN_BENCH_BACKEND")
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,7 +96,8 @@ def main():
     x = (rs.randint(0, 256, (H, W, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]
     rows, cols = resnet.get_conv_rows_cols(H, W)
     out = {"world": world, "dtype": DT, "backend": (torch.distributed.get_backend() if world > 1 else None),
-           "workload": "ResNet-50 600x1000, 1 image per GPU per step, SGD momentum 0.9, l2 1e-4, synthetic data"}
+           "workload": "ResNet-50 600x1000, 1 image per GPU per step, SGD momentum 0.9, l2 1e-4, synthetic data",
+           "losses_read": "after every step" if args.sync_each_step else "one step late (train_util's loops), all inside the timed region"}
 
     def report(tag, ms, params):
         ar = allreduce_ms(params)
@@ -100,7 +117,7 @@ def main():
         y_bbreg = np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32),
                                   (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
         rpn.compile(train.SGD(1e-3, 0.9))
-        ms = timed(lambda: rpn.train_on_batch(x, [y_class, y_bbreg]), args.steps, args.warmup)
+        ms = timed(lambda: rpn.train_on_batch(x, [y_class, y_bbreg], defer=not args.sync_each_step), args.steps, args.warmup)
         report("rpn_step1", ms, rpn._trainer.params)
         del rpn, base
     if args.only in (None, "det"):
@@ -122,7 +139,7 @@ def main():
                 tg[i, 4 * c:4 * c + 4] = rs.randn(4)
         yb = np.concatenate([lab, tg], axis=1)[None]
         det.compile(train.SGD(1e-3, 0.9))
-        ms = timed(lambda: det.train_on_batch([x, rois], [yc, yb]), args.steps, args.warmup)
+        ms = timed(lambda: det.train_on_batch([x, rois], [yc, yb], defer=not args.sync_each_step), args.steps, args.warmup)
         report("det_step2", ms, det._trainer.params)
     # flat keys kept for the round-1 readers of this line
     for tag, short in (("rpn_step1", "rpn_step1"), ("det_step2", "det_step2")):

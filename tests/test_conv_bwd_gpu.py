@@ -29,6 +29,9 @@ CASES = [  # n,h,w,cin,cout,k,stride,padding
     (5, 1, 1, 256, 101, 1, 1, "valid"),        # dense
     (1, 12, 16, 512, 512, 3, 1, "same"),       # vgg block4 (long k: 144 chunks)
     (1, 6, 8, 512, 512, 3, 1, "same"),         # vgg block5
+    (3, 7, 7, 192, 136, 3, 1, "same"),         # 128x128-tile weight gradient: ragged channel tiles, rows wrapping over images
+    (2, 15, 18, 160, 132, 3, 2, "same"),       # ... stride 2 with the asymmetric SAME halo
+    (1, 37, 50, 256, 128, 1, 2, "valid"),      # ... strided 1x1 (res3a / res4a)
 ]
 
 

@@ -419,3 +419,31 @@ def test_weights_are_current_at_every_way_out_of_the_model(tmp_path):
     after = det.predict([x, rois])[0]
     assert not np.array_equal(before, after)
     assert not np.array_equal(det.get_layer("dense_class_%d" % C).get_weights()[0], dense0)
+
+
+def test_deferred_steps_are_the_same_steps():
+    """train_on_batch(defer=True) only enqueues the step (train_util's loops read the losses one step late, so the
+    host prepares the next image while the GPU trains): three deferred steps on three DIFFERENT images -- staged into
+    the alternating pinned sets while the previous step is still running -- give bit for bit the losses and weights of
+    three synchronous steps, in any order of reading the results, also when the 8-slot loss ring wraps."""
+    from faster_rcnn_amd import resnet, train
+    from faster_rcnn_amd.weights import synthetic_resnet
+    A = 9
+    w0 = synthetic_resnet(50, anchors_per_loc=A, num_classes=21, seed=43)
+    rows, cols = resnet.get_conv_rows_cols(96, 128)
+    xs = [image(96, 128, seed=20 + i) for i in range(11)]
+    ys = [rpn_targets(rows, cols, A, seed=30 + i) for i in range(11)]
+
+    def run(defer):
+        rpn = resnet.resnet50_rpn(resnet.resnet50_base(weights={k: [a.copy() for a in v] for k, v in w0.items()}), anchors_per_loc=A)
+        rpn.compile(train.SGD(1e-2, 0.9))
+        got = [rpn.train_on_batch(x, list(y), defer=defer) for x, y in zip(xs, ys)]
+        if defer:
+            assert all(isinstance(g, train.PendingLosses) for g in got)
+            got = [g.result() for g in reversed(got)][::-1]             # last first; the first three were read when the ring wrapped
+        return got, rpn.get_layer("rpn_conv1").get_weights()[0], rpn.get_layer("res4f_branch2c").get_weights()[0]
+
+    l_sync, a_sync, b_sync = run(False)
+    l_def, a_def, b_def = run(True)
+    assert l_sync == l_def
+    assert np.array_equal(a_sync, a_def) and np.array_equal(b_sync, b_def)
