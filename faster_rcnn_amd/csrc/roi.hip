@@ -69,46 +69,98 @@ __global__ void __launch_bounds__(256) k_roi_fwd(const float4* feat, int rows, i
     }
 }
 
-__global__ void __launch_bounds__(256) k_roi_bwd(const float* dout, int rows, int cols, int C,
-                                                 const float4* rois, int pool, float* dfeat) {
-    const int pix = blockIdx.x;
-    const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
-    const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
-    if (!t.ok) return;
-    const float* g = dout + (size_t)pix * C;
-    float* tl = dfeat + ((size_t)t.y_lo * cols + t.x_lo) * C;
-    float* tr = dfeat + ((size_t)t.y_lo * cols + t.x_hi) * C;
-    float* bl = dfeat + ((size_t)t.y_hi * cols + t.x_lo) * C;
-    float* br = dfeat + ((size_t)t.y_hi * cols + t.x_hi) * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float gv = g[c];
-        const float dtop = (1.0f - t.ty) * gv, dbot = t.ty * gv;      // TF ResizeBilinearGrad order
-        atomicAdd(tl + c, dtop * (1.0f - t.tx));
-        atomicAdd(tr + c, dtop * t.tx);
-        atomicAdd(bl + c, dbot * (1.0f - t.tx));
-        atomicAdd(br + c, dbot * t.tx);
+// Gradient w.r.t. the feature map as a GATHER: one workgroup per feature cell lists the RoIs whose box contains the
+// cell (ascending), walks those RoIs' pool x pool samples and lists the corner taps that land on the cell -- sample-major,
+// then top-left, top-right, bottom-left, bottom-right: the order in which TF's CPU ResizeBilinearGrad walks them -- and
+// every lane sums its channels over that list.  Fixed summation order (the f32-atomic scatter this replaces made a
+// detector training step depend on the order in which workgroups happened to run), no zero-fill of dfeat, each cell
+// written once.  Per tap ((wy * g) * wx), TF's order of operations.
+__device__ __forceinline__ int block_excl_scan(int cnt, int lane, int wave, int* wave_tot, int& total) {
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
     }
+    __syncthreads();                                         // the previous use of wave_tot is over
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = incl - cnt;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wave) off += wave_tot[w]; total += wave_tot[w]; }
+    return off;
 }
 
-// gradient w.r.t. the f32 feature map from a bf16 crop gradient (mixed-precision training): f32 atomics as above
-__global__ void __launch_bounds__(256) k_roi_bwd_bf16(const __bf16* dout, int rows, int cols, int C,
-                                                      const float4* rois, int pool, float* dfeat) {
-    const int pix = blockIdx.x;
-    const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
-    const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
-    if (!t.ok) return;
-    const __bf16* g = dout + (size_t)pix * C;
-    float* tl = dfeat + ((size_t)t.y_lo * cols + t.x_lo) * C;
-    float* tr = dfeat + ((size_t)t.y_lo * cols + t.x_hi) * C;
-    float* bl = dfeat + ((size_t)t.y_hi * cols + t.x_lo) * C;
-    float* br = dfeat + ((size_t)t.y_hi * cols + t.x_hi) * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float gv = (float)g[c];
-        const float dtop = (1.0f - t.ty) * gv, dbot = t.ty * gv;
-        atomicAdd(tl + c, dtop * (1.0f - t.tx));
-        atomicAdd(tr + c, dtop * t.tx);
-        atomicAdd(bl + c, dbot * (1.0f - t.tx));
-        atomicAdd(br + c, dbot * t.tx);
+template <typename T>
+__global__ void __launch_bounds__(256) k_roi_bwd_gather(const T* dout, int rows, int cols, int C,
+                                                        const float4* rois, int n, int pool, float* dfeat) {
+    __shared__ int roi_list[256];
+    __shared__ int e_s[1024];
+    __shared__ float e_wy[1024], e_wx[1024];
+    __shared__ int wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cell = blockIdx.x, cy = cell / cols, cx = cell % cols;
+    const int pp = pool * pool;
+    for (int cb = 0; cb < C; cb += 1024) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int r0 = 0; r0 < n; r0 += 256) {
+            // the RoIs of this chunk that can touch the cell: every tap of a valid RoI lies inside its box
+            bool covers = false;
+            if (r0 + tid < n) {
+                const float4 roi = rois[r0 + tid];
+                const int x1 = (int)roi.x, y1 = (int)roi.y, x2 = (int)roi.z, y2 = (int)roi.w;
+                covers = y2 - y1 > 0 && x2 - x1 > 0 && x1 >= 0 && y1 >= 0 && x2 <= cols && y2 <= rows &&
+                         cy >= y1 && cy < y2 && cx >= x1 && cx < x2;
+            }
+            int m;
+            const int slot = block_excl_scan(covers ? 1 : 0, lane, wave, wave_tot, m);
+            if (covers) roi_list[slot] = r0 + tid;
+            __syncthreads();
+            for (int base = 0; base < m * pp; base += 256) {
+                const int q = base + tid;
+                int cnt = 0, smp = 0;
+                float wy[4], wx[4];
+                if (q < m * pp) {
+                    const int r = roi_list[q / pp], rem = q % pp, py = rem / pool, px = rem % pool;
+                    smp = r * pp + rem;
+                    const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
+                    if (t.y_lo == cy && t.x_lo == cx) { wy[cnt] = 1.0f - t.ty; wx[cnt] = 1.0f - t.tx; ++cnt; }
+                    if (t.y_lo == cy && t.x_hi == cx) { wy[cnt] = 1.0f - t.ty; wx[cnt] = t.tx; ++cnt; }
+                    if (t.y_hi == cy && t.x_lo == cx) { wy[cnt] = t.ty; wx[cnt] = 1.0f - t.tx; ++cnt; }
+                    if (t.y_hi == cy && t.x_hi == cx) { wy[cnt] = t.ty; wx[cnt] = t.tx; ++cnt; }
+                }
+                int total;
+                const int off = block_excl_scan(cnt, lane, wave, wave_tot, total);     // (its barriers also fence e_* reuse)
+                for (int k = 0; k < cnt; ++k) { e_s[off + k] = smp; e_wy[off + k] = wy[k]; e_wx[off + k] = wx[k]; }
+                __syncthreads();
+                // eight taps' loads in flight at a time (a 1x1 RoI puts all its 196 taps on one cell: one at a time that
+                // cell alone took > 100 us); the additions stay in list order
+                for (int e0 = 0; e0 < total; e0 += 8) {
+                    T gv[8][4];                              // unconditional loads (clamped index): no branch, no wait between them
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const T* g = dout + (size_t)e_s[min(e0 + u, total - 1)] * C;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gv[u][j] = g[min(cb + tid + 256 * j, C - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (e0 + u < total) {
+                            const float a = e_wy[e0 + u], b = e_wx[e0 + u];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[j] += (a * (float)gv[u][j]) * b;
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                 // roi_list is rewritten by the next chunk
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = cb + tid + 256 * j;
+            if (c < C) dfeat[(size_t)cell * C + c] = acc[j];
+        }
     }
 }
 
@@ -136,18 +188,24 @@ int frcnn_roi_crop_resize_fwd_ex(const float* feat, int rows, int cols, int C, c
 int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C, const float* rois, int n, int pool,
                               float* dfeat, void* stream) {
     if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd: bad shape");
-    if (n == 0) return FRCNN_OK;
+    if (n == 0) {
+        if (!dfeat) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd: null pointer");
+        return hipMemsetAsync(dfeat, 0, (size_t)rows * cols * C * sizeof(float), as_stream(stream)) == hipSuccess ? FRCNN_OK : fail(FRCNN_E_HIP, "roi_crop_resize_bwd: memset failed");
+    }
     if (!dout || !rois || !dfeat) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd: null pointer");
-    k_roi_bwd<<<n * pool * pool, 256, 0, as_stream(stream)>>>(dout, rows, cols, C, (const float4*)rois, pool, dfeat);
+    k_roi_bwd_gather<float><<<rows * cols, 256, 0, as_stream(stream)>>>(dout, rows, cols, C, (const float4*)rois, n, pool, dfeat);
     return check_launch("roi_crop_resize_bwd");
 }
 
 int frcnn_roi_crop_resize_bwd_bf16(const void* dout_bf16, int rows, int cols, int C, const float* rois, int n, int pool,
                                    float* dfeat, void* stream) {
     if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd_bf16: bad shape");
-    if (n == 0) return FRCNN_OK;
+    if (n == 0) {
+        if (!dfeat) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd_bf16: null pointer");
+        return hipMemsetAsync(dfeat, 0, (size_t)rows * cols * C * sizeof(float), as_stream(stream)) == hipSuccess ? FRCNN_OK : fail(FRCNN_E_HIP, "roi_crop_resize_bwd_bf16: memset failed");
+    }
     if (!dout_bf16 || !rois || !dfeat) return fail(FRCNN_E_ARG, "roi_crop_resize_bwd_bf16: null pointer");
-    k_roi_bwd_bf16<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const __bf16*)dout_bf16, rows, cols, C, (const float4*)rois, pool, dfeat);
+    k_roi_bwd_gather<__bf16><<<rows * cols, 256, 0, as_stream(stream)>>>((const __bf16*)dout_bf16, rows, cols, C, (const float4*)rois, n, pool, dfeat);
     return check_launch("roi_crop_resize_bwd_bf16");
 }
 

@@ -213,7 +213,7 @@ def avgpool_pos_major(x):
 def roi_crop_resize_bwd(dout, rois, rows, cols):
     _require_gpu()
     n, pool, _, C = dout.shape
-    dfeat = torch.zeros((rows, cols, C), dtype=torch.float32, device="cuda")
+    dfeat = torch.empty((rows, cols, C), dtype=torch.float32, device="cuda")
     _lib.call("frcnn_roi_crop_resize_bwd", _p(dout.contiguous()), rows, cols, C, _p(rois.reshape(-1, 4).contiguous()), n, pool, _p(dfeat), _stream())
     return dfeat
 
@@ -586,7 +586,7 @@ def cast_f32(x):
 def roi_crop_resize_bwd_bf16(dout, rois, rows, cols):
     _require_gpu()
     n, pool, _, C = dout.shape
-    dfeat = torch.zeros((rows, cols, C), dtype=torch.float32, device="cuda")
+    dfeat = torch.empty((rows, cols, C), dtype=torch.float32, device="cuda")
     _lib.call("frcnn_roi_crop_resize_bwd_bf16", _p(dout.contiguous()), rows, cols, C, _p(rois.reshape(-1, 4).contiguous()), n, pool, _p(dfeat), _stream())
     return dfeat
 

@@ -342,15 +342,23 @@ class ResNetBaseTrain:
     def convs(self):
         return [c for b in self.blocks for c in b.convs()]
 
-    def forward(self, x):
+    def forward_frozen(self, x):
+        """Stem and the frozen stages: no trainable weight is read, so a step driver may run this for the NEXT image
+        while the previous step is still in its backward pass (_StepDriver._run_step)."""
         t = ops.pool2d(self.stem(x), 3, 2, True)
         if self.bf16:                                           # the 3-channel stem and its pool stay f32 (nets.ResNetBase)
             t = ops.cast_bf16(t)
         for units in self.frozen_blocks:
             t = nets.run_block(units, t)
+        return t
+
+    def forward_rest(self, t):
         for b in self.blocks:
             t = b.forward(t)
         return t
+
+    def forward(self, x):
+        return self.forward_rest(self.forward_frozen(x))
 
     def backward(self, g):
         """g: gradient w.r.t. the pre-ReLU value of the feature map (already masked)."""
@@ -383,15 +391,26 @@ class VggBaseTrain:
     def convs(self):
         return [l for _, l, t in self.layers if t]
 
-    def forward(self, x):
-        self.pools = {}
-        for name, layer, trainable in self.layers:
+    def _run(self, x, layers):
+        for name, layer, trainable in layers:
             x = layer.forward(x) if trainable else layer(x)
             if name in self.POOL_AFTER:
                 y = ops.pool2d(x, 2, 2, True)
-                self.pools[name] = (x, y)
+                if trainable:
+                    self.pools[name] = (x, y)
                 x = y
         return x
+
+    def forward_frozen(self, x):
+        """The frozen leading blocks (see ResNetBaseTrain.forward_frozen)."""
+        return self._run(x, [l for l in self.layers if not l[2]])
+
+    def forward_rest(self, x):
+        self.pools = {}
+        return self._run(x, [l for l in self.layers if l[2]])
+
+    def forward(self, x):
+        return self.forward_rest(self.forward_frozen(x))
 
     def backward(self, g):
         for name, layer, trainable in reversed(self.layers):
@@ -445,6 +464,7 @@ class _StepDriver:
     def _init_driver(self):
         self._pinned = {}           # input-shape key -> [two sets of pinned float32 staging buffers, upload events, toggle]
         self._conv_ws = ops.ConvWorkspace()
+        self._conv_ws_prefix = ops.ConvWorkspace()   # split-K tickets of the launches on the prefix stream
         self._loss_ring = [None] * LOSS_RING          # steps whose three scalars are still on their way to the host
         self._loss_pos = 0
 
@@ -487,16 +507,27 @@ class _StepDriver:
         assert self.optimizer is not None, "call compile() first"
         out3 = torch.zeros(3, dtype=torch.float32, device="cuda")                          # loss 1, loss 2, sum of squares
         out = [out3[0:1], out3[1:2], out3[2:3]]
-        with ops.conv_workspace(self._conv_ws):
-            if skip:
+        if skip:
+            with ops.conv_workspace(self._conv_ws):
                 self.params.g.zero_()
                 self._update(out[2])
-            else:
-                ent, k = self._stage(tuple(shape for _, shape in host_inputs), host_inputs)
+        else:
+            # Upload and the FROZEN leading part of the base (stem .. last frozen stage: it reads no trainable weight) go
+            # to a second stream.  When the caller defers its steps the host is a step ahead, so this part of image i+1
+            # runs beside the backward pass of image i, whose short dependent launches leave most of the chip idle; the
+            # main stream joins before the first trainable layer.  Same kernels, same order per tensor: bit-identical.
+            ent, k = self._stage(tuple(shape for _, shape in host_inputs), host_inputs)
+            main, side = torch.cuda.current_stream(), _prefix_stream()
+            with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws_prefix):
                 dev = [p.to("cuda", non_blocking=True) for p in ent["sets"][k]]
                 ev = ent["uploaded"][k] = ent["uploaded"][k] or torch.cuda.Event()
                 ev.record()
-                self._device_step(dev, out)
+                pre = self._frozen_prefix(dev)
+            main.wait_stream(side)
+            for t in dev + ([pre] if pre is not None else []):
+                t.record_stream(main)                   # allocated on the side stream, read (and released) under the main one
+            with ops.conv_workspace(self._conv_ws):
+                self._device_step(dev, out, pre)
         slot = self._loss_ring[self._loss_pos]
         if slot is None:
             slot = self._loss_ring[self._loss_pos] = [torch.empty(3, dtype=torch.float32).pin_memory(), torch.cuda.Event(), None]
@@ -511,6 +542,14 @@ class _StepDriver:
 
 
 LOSS_RING = 8
+_PREFIX_STREAM = None
+
+
+def _prefix_stream():
+    global _PREFIX_STREAM
+    if _PREFIX_STREAM is None:
+        _PREFIX_STREAM = torch.cuda.Stream()
+    return _PREFIX_STREAM
 
 
 class PendingLosses:
@@ -574,8 +613,11 @@ class RpnTrainer(_StepDriver):
     def _tconvs(self):
         return self.base.convs() + [self.rpn_conv, self.rpn_cls, self.rpn_reg]
 
-    def forward(self, x):
-        self.feat = self.base.forward(x)
+    def _frozen_prefix(self, dev):
+        return self.base.forward_frozen(dev[0])
+
+    def forward(self, x, pre=None):
+        self.feat = self.base.forward_rest(pre if pre is not None else self.base.forward_frozen(x))
         h = self.rpn_conv.forward(self.feat)
         if self.bf16:
             h = ops.cast_f32(h)
@@ -590,10 +632,10 @@ class RpnTrainer(_StepDriver):
         cells = int(np.prod(np.shape(y[0])[:-1]))
         return self._run_step([(x, (1,) + tuple(np.shape(x)[-3:])), (y[0], (cells, 2 * self.A)), (y[1], (cells, 8 * self.A))], False, defer)
 
-    def _device_step(self, dev, out):
+    def _device_step(self, dev, out, pre=None):
         xd, yc, yr = dev
         loss1, loss2, sq = out
-        cls, reg, h = self.forward(xd)
+        cls, reg, h = self.forward(xd, pre)
         cells = cls.shape[1] * cls.shape[2]
         g_cls = torch.empty_like(cls)
         g_reg = torch.empty_like(reg)
@@ -715,8 +757,14 @@ class DetTrainer(_StepDriver):
     def _tconvs(self):
         return (self.base.convs() if self.base is not None else []) + self.head.convs() + [self.dense]
 
-    def forward(self, x, rois):
-        self.feat = self.base.forward(x) if self.base is not None else x
+    def _frozen_prefix(self, dev):
+        return self.base.forward_frozen(dev[0]) if self.base is not None else None
+
+    def forward(self, x, rois, pre=None):
+        if self.base is not None:
+            self.feat = self.base.forward_rest(pre if pre is not None else self.base.forward_frozen(x))
+        else:
+            self.feat = x
         if self.bf16 and self.feat.dtype != torch.bfloat16:     # step 4: cached f32 conv features feed a bf16 head
             self.feat = ops.cast_bf16(self.feat)
         crop = (ops.roi_crop_resize_bf16 if self.bf16 else ops.roi_crop_resize)(self.feat, rois, 7)
@@ -733,11 +781,11 @@ class DetTrainer(_StepDriver):
         n, C, K4 = int(np.size(x[1])) // 4, self.C, 4 * (self.C - 1)
         return self._run_step([(x[0], (1,) + tuple(np.shape(x[0])[-3:])), (x[1], (n, 4)), (y[0], (n, C)), (y[1], (n, 2 * K4))], False, defer)
 
-    def _device_step(self, dev, out):
+    def _device_step(self, dev, out, pre=None):
         xd, rois, yc, yr = dev
         loss1, loss2, sq = out
         n, C, K4 = rois.shape[0], self.C, 4 * (self.C - 1)
-        cls, reg, y2 = self.forward(xd, rois)
+        cls, reg, y2 = self.forward(xd, rois, pre)
         g = torch.empty((n, C + K4), dtype=torch.float32, device="cuda")     # [d logits | d reg]
         _lib.call("frcnn_loss_det_cls", _p(yc), _p(cls), n, C, _p(loss1), _p(g), C + K4, _stream())
         _lib.call("frcnn_loss_det_reg", _p(yr), _p(reg), n, C - 1, _p(loss2), ctypes.c_void_p(g.data_ptr() + 4 * C), C + K4, _stream())

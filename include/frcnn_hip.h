@@ -146,8 +146,9 @@ int frcnn_roi_crop_resize_fwd(const float* feat, int rows, int cols, int C,
  * layout 1 writes out[pool][pool][n][c] (position-major, frcnn_conv_desc.layout) instead of out[n][pool][pool][c]. */
 int frcnn_roi_crop_resize_fwd_ex(const float* feat, int rows, int cols, int c, const float* rois, int n, int pool,
                                  const float* fill, int relu, int layout, float* out, void* stream);
-/* Gradient of the above w.r.t. feat: dfeat [rows][cols][C] must be zeroed by the caller;
- * contributions are accumulated with f32 atomics. */
+/* Gradient of the above w.r.t. feat: dfeat [rows][cols][C] is OVERWRITTEN (cells no RoI touches get 0).  A gather per
+ * feature cell: the taps that land on it are summed in sample order (roi, py, px; top-left, top-right, bottom-left,
+ * bottom-right), the order of TF's CPU ResizeBilinearGrad -- deterministic, no atomics. */
 int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C,
                               const float* rois, int n, int pool, float* dfeat, void* stream);
 

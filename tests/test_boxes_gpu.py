@@ -340,6 +340,27 @@ def test_roi_crop_resize(ops):
     lhs = float((dout.astype(np.float64) * want.astype(np.float64)).sum())
     rhs = float((dfeat.astype(np.float64) * feat.astype(np.float64)).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    # ... and bit for bit the sequential f32 scatter in the order TF's CPU ResizeBilinearGrad walks the samples
+    # (roi, py, px; top-left, top-right, bottom-left, bottom-right): the gather sums every cell's taps in that order
+    seq = np.zeros_like(feat)
+    one = np.float32(1)
+    for r, (x1, y1, x2, y2) in enumerate(rois.astype(np.int64)):
+        h, w = y2 - y1, x2 - x1
+        sy, sx = np.float32(h) / np.float32(7), np.float32(w) / np.float32(7)
+        for py in range(7):
+            fy = np.float32(py) * sy
+            ly = int(fy); ty = fy - np.float32(ly); yl, yh = y1 + ly, y1 + min(ly + 1, h - 1)
+            for px in range(7):
+                fx = np.float32(px) * sx
+                lx = int(fx); tx = fx - np.float32(lx); xl, xh = x1 + lx, x1 + min(lx + 1, w - 1)
+                gv = dout[r, py, px]
+                dtop, dbot = (one - ty) * gv, ty * gv
+                seq[yl, xl] += dtop * (one - tx)
+                seq[yl, xh] += dtop * tx
+                seq[yh, xl] += dbot * (one - tx)
+                seq[yh, xh] += dbot * tx
+    assert np.array_equal(dfeat, seq)
+    assert not ops.roi_crop_resize_bwd(dev(dout[:0]), dev(rois[:0]), 38, 63).any().item()      # no RoIs: zeros
 
 
 def test_detections_device(ops):

@@ -447,3 +447,25 @@ def test_deferred_steps_are_the_same_steps():
     l_def, a_def, b_def = run(True)
     assert l_sync == l_def
     assert np.array_equal(a_sync, a_def) and np.array_equal(b_sync, b_def)
+
+    # the detector step (frozen stages 1-3 of image i+1 on the second stream beside the backward pass of image i)
+    C, n = 21, 8
+    dw0 = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=44)
+    rs = np.random.RandomState(5)
+    batches = []
+    for i in range(5):
+        rois = np.stack([rs.randint(0, 3, n), rs.randint(0, 2, n), rs.randint(4, cols - 1, n), rs.randint(3, rows - 1, n)], axis=1).astype(np.float32)[None]
+        yc = np.zeros((1, n, C), np.int32); yc[0, np.arange(n), rs.randint(0, C, n)] = 1
+        yb = (rs.randn(1, n, 8 * (C - 1)) * (rs.rand(1, n, 8 * (C - 1)) < 0.1)).astype(np.float32)
+        batches.append(([xs[i], rois], [yc, yb]))
+
+    def run_det(defer):
+        det = resnet.resnet50_classifier(n, C, base_model=resnet.resnet50_base(weights={k: [a.copy() for a in v] for k, v in dw0.items()}))
+        det.compile(train.SGD(1e-2, 0.9))
+        got = [det.train_on_batch(x, y, defer=defer) for x, y in batches]
+        got = [g.result() for g in got] if defer else got
+        return got, det.get_layer("res4a_branch2a").get_weights()[0], det.get_layer("dense_class_%d" % C).get_weights()[0]
+
+    d_sync, d_def = run_det(False), run_det(True)
+    assert d_sync[0] == d_def[0]
+    assert np.array_equal(d_sync[1], d_def[1]) and np.array_equal(d_sync[2], d_def[2])
