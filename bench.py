@@ -181,6 +181,44 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
     return roof, groups
 
 
+def backbone_in_flight(pipe, n_images, base_gflop, steps=20):
+    """The backbone (conv1 .. last base stage, with its pools) of `n_images` images at once, one hipGraph per image on its
+    own stream -- how the timed pipeline keeps the chip busy -- timed as a whole: ms per image and the conv TFLOP/s that
+    is.  The per-launch sum in `backbone_conv` is the latency view of the same launches."""
+    from faster_rcnn_amd import ops
+    net = pipe.rpn.base.net
+    streams = [torch.cuda.Stream() for _ in range(n_images)]
+    graphs = []
+    for i, st in enumerate(streams):
+        x = torch.from_numpy(synth_image(200 + i)).cuda()
+        ws = ops.ConvWorkspace()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st), ops.conv_workspace(ws), ops.tile_policy(n_images > 1):
+            net(x); net(x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"), ops.conv_workspace(ws), ops.tile_policy(n_images > 1):
+            y = net(x)
+        graphs.append((g, x, y, ws))
+
+    def step():
+        for (g, _, _, _), st in zip(graphs, streams):
+            with torch.cuda.stream(st):
+                g.replay()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / (steps * n_images)
+    tf = base_gflop / ms
+    return {"images_in_flight": n_images, "ms_per_image": round(ms, 3), "achieved": round(tf, 2),
+            "frac": round(tf / (PEAK_BF16_TFLOPS if DTYPE == "bf16" else PEAK_F32_MATRIX_TFLOPS), 4),
+            "what": "one hipGraph of the base network per image, %d replaying concurrently on their own streams, wall clock over %d rounds" % (n_images, steps)}
+
+
 def full_size_parity(pipe, weights, anchors):
     """The oracle as CHECKER at the benchmark's own size (configs[1] only): one synthetic 600x1000 image through the
     HIP pipeline (eager) and, stage by stage, through the CPU restatement fed with the SAME stage inputs -- float
@@ -470,6 +508,11 @@ def main():
         # conv FLOP actually executed per second by the whole job (all images in flight)
         if roof is not None:
             line["roofline"]["end_to_end_conv_tflops"] = round(roof["all_conv_launches"]["gflop_per_image"] * line["value"] / 1e3, 2)
+        if roof is not None and S > 1 and world == 1:
+            try:
+                roof["backbone_conv"]["in_flight"] = backbone_in_flight(pipe, S, roof["backbone_conv"]["gflop_per_image"])
+            except Exception as e:
+                roof["backbone_conv"]["in_flight"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if roof is not None and DTYPE == "bf16":
             for k in ("peak",):
                 roof[k] = PEAK_BF16_TFLOPS

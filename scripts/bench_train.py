@@ -99,13 +99,15 @@ def main():
            "workload": "ResNet-50 600x1000, 1 image per GPU per step, SGD momentum 0.9, l2 1e-4, synthetic data",
            "losses_read": "after every step" if args.sync_each_step else "one step late (train_util's loops), all inside the timed region"}
 
-    def report(tag, ms, params):
+    def report(tag, ms, params, ms_sync=None):
         ar = allreduce_ms(params)
         tf = GFLOP[tag] * world / ms                   # GFLOP / ms = TFLOP/s, whole job
         out[tag] = {"ms_per_step": round(ms, 3), "img_s": round(world * 1e3 / ms, 2), "grad_payload_MB": round(params.total * 4 / 1e6, 1),
                     "allreduce_ms": round(ar, 3), "allreduce_share": round(ar / ms, 4),
                     "roofline": {"bound": "mfma", "achieved": round(tf / world, 2), "peak": PEAK[DT], "unit": "TFLOP/s per GPU",
                                  "frac": round(tf / world / PEAK[DT], 4), "gflop_per_step": round(GFLOP[tag], 1)}}
+        if ms_sync is not None:
+            out[tag]["ms_per_step_losses_read_every_step"] = round(ms_sync, 3)
 
     if args.only in (None, "rpn"):
         w = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=1)
@@ -118,7 +120,8 @@ def main():
                                   (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
         rpn.compile(train.SGD(1e-3, 0.9))
         ms = timed(lambda: rpn.train_on_batch(x, [y_class, y_bbreg], defer=not args.sync_each_step), args.steps, args.warmup)
-        report("rpn_step1", ms, rpn._trainer.params)
+        ms_sync = None if args.sync_each_step else timed(lambda: rpn.train_on_batch(x, [y_class, y_bbreg]), args.steps, 2)
+        report("rpn_step1", ms, rpn._trainer.params, ms_sync)
         del rpn, base
     if args.only in (None, "det"):
         dw = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=2)
@@ -140,7 +143,8 @@ def main():
         yb = np.concatenate([lab, tg], axis=1)[None]
         det.compile(train.SGD(1e-3, 0.9))
         ms = timed(lambda: det.train_on_batch([x, rois], [yc, yb], defer=not args.sync_each_step), args.steps, args.warmup)
-        report("det_step2", ms, det._trainer.params)
+        ms_sync = None if args.sync_each_step else timed(lambda: det.train_on_batch([x, rois], [yc, yb]), args.steps, 2)
+        report("det_step2", ms, det._trainer.params, ms_sync)
     # flat keys kept for the round-1 readers of this line
     for tag, short in (("rpn_step1", "rpn_step1"), ("det_step2", "det_step2")):
         if tag in out:
