@@ -12,7 +12,7 @@ python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 $R/bench.py --steps 50 --warmup 10 --streams 1 > $OUT/bench_streams1.json 2> $OUT/bench_streams1.err
 python3 $R/bench.py --config c1 --steps 50 --warmup 10 > $OUT/bench_c1_vgg16_rpn.json 2> $OUT/bench_c1.err
 python3 $R/bench.py --config c1 --steps 50 --warmup 10 --streams 1 --no-cpu-baseline > $OUT/bench_c1_vgg16_rpn_streams1.json 2>> $OUT/bench_c1.err
-python3 $R/bench.py --config c4 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_c4_default.json 2> $OUT/bench_c4.err
+python3 $R/bench.py --config c4 --steps 50 --warmup 10 > $OUT/bench_c4_default.json 2> $OUT/bench_c4.err
 python3 $R/bench.py --config c4 --steps 50 --warmup 10 --streams 1 --no-cpu-baseline > $OUT/bench_c4_streams1.json 2>> $OUT/bench_c4.err
 python3 $R/scripts/bench_train.py > $OUT/bench_train_f32.json 2> $OUT/bench_train.err
 python3 $R/scripts/bench_train.py --bf16 > $OUT/bench_train_mixed_bf16.json 2>> $OUT/bench_train.err
@@ -35,6 +35,11 @@ done
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph --shared-tiles > $OUT/pmc$i.log 2>&1
+done
+# configs[3] (bf16 kernels): HBM-side traffic of its conv launches
+for ctrs in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --config c4 --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph --shared-tiles > $OUT/pmc$i.log 2>&1
 done
 python3 $R/scripts/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 head -40 $OUT/summary.txt

@@ -66,7 +66,9 @@ for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), 
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "conv_igemm" in k or "nms" in k or "topk_rank" in k or "roi_fwd" in k:
-            acc[k.split("(")[0][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            # bench.py reports ONE bf16 conv kernel (all instantiations, averaged over an image's launches): same key here
+            key = "frcnn::k_conv_igemm_bf16<all instantiations>" if "k_conv_igemm_bf16<" in k else k.split("(")[0][:70]
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 traffic = {}
 if acc:
     print("\n== PMC means per dispatch (rocprofv3 --pmc, separate passes, eager single stream)")
