@@ -72,7 +72,8 @@ def build_library(force=False, verbose=True):
         if verbose and out.strip():
             print(out)
     if force or procs or not _newer(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        # -z defs: an unresolved kernel stub must fail HERE, not as an "undefined symbol" when the library is loaded on the GPU box
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,-z,defs", "-o", LIB] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -66,9 +66,11 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     constexpr int RPP = NT / 8;                          // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int PA = BM / RPP, PB = BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+    static_assert(VARIANT != 3 || (NT == 512 && !SPLITK), "the direct-to-LDS form is written for eight waves, whole-K tiles");
+    constexpr int LSTR = VARIANT == 3 ? 128 : LDS_STRIDE_B;   // VARIANT 3: unpadded rows, XOR-swizzled 16-byte slots
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    char* As = smem_b;                                   // [2][BM][144 B]
-    char* Bs = smem_b + 2 * BM * LDS_STRIDE_B;           // [2][BN][144 B]
+    char* As = smem_b;                                   // [2][BM][LSTR]
+    char* Bs = smem_b + 2 * BM * LSTR;                   // [2][BN][LSTR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -79,7 +81,11 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     const int logical = xcd_remap_b(blockIdx.x, nwg);
     const int tile = SPLITK ? logical / splits : logical;
     const int slice = SPLITK ? logical - tile * splits : 0;
-    const int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    // VARIANT 3 (256-wide column tiles, a handful per row tile): the column tiles of ONE row tile are adjacent, so an XCD's
+    // resident workgroups share their A rows in L2 and the whole filter (<= 4 MB on the head) stays there; the other forms
+    // walk row tiles first (their column tile's filter slice is what the neighbours share)
+    const int tile_n = VARIANT == 3 ? tile % p.tiles_n : tile / p.tiles_m;
+    const int tile_m = VARIANT == 3 ? tile / p.tiles_n : tile - tile_n * p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -87,7 +93,10 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(p.w), 0, (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000);
 
-    const int lrow = tid >> 3, lcolb = (tid & 7) * 16;         // byte column inside the 128-B chunk row
+    // byte column inside the 128-B chunk row this thread stages.  VARIANT 3: the LDS slot is the lane's position in the
+    // wave instruction (tid & 7); slot g' of row r holds granule g' ^ ((r >> 1) & 7), so THAT is what the lane fetches
+    // (rows advance by 64 per pass: the XOR term is the same for all of a thread's rows)
+    const int lrow = tid >> 3, lcolb = VARIANT == 3 ? (((tid & 7) ^ ((lrow >> 1) & 7)) * 16) : (tid & 7) * 16;
     int a_h[PA], a_w[PA], a_off[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -182,7 +191,70 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     constexpr int MF = TM * TN;            // MFMAs per k-step (k = 16)
     constexpr int NL = PA + PB;
     constexpr int NF = TM + TN;
-    if constexpr (VARIANT == 2) {
+    if constexpr (VARIANT == 3) {
+        // Direct global -> LDS staging (buffer_load ... lds) for the 256-wide tiles of the detector head (round 2).
+        // The 128x128 tile reads 1.5 fragments per MFMA and moves 32 KB of operands per 512 CU-cycles of matrix work; a
+        // 128x64 (256x256 tile) or 64x64 (128x256) patch per wave reads 0.75 / 1.0 and halves the operand traffic.  What
+        // made that tile lose in round 1 was the staging: at one workgroup per CU nothing hides the VGPR round trip.
+        // Here a wave instruction lands 8 rows x 128 B straight in LDS (lane-linear destination: rows are unpadded and
+        // the bank-conflict swizzle is applied on the SOURCE granule and again on the fragment read), chunk T+1 is
+        // requested at the top of chunk T into the buffer everybody finished reading before the last barrier, and one
+        // raw s_barrier per chunk follows `s_waitcnt vmcnt(0) lgkmcnt(0)`: this wave's share of T+1 has landed and its
+        // reads of T are done.  Halo / tail rows ride on the buffer descriptor (zeros land in LDS).  Same k order as the
+        // other loops.  Lab: scripts/micro/bf16_lab.hip (512->512 3x3 as a GEMM 995 TFLOP/s, 1024->2048 962).
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        auto stage = [&](int buf) {
+            const int tap = __builtin_ctz(rem);
+            const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+            const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 2;
+            const int w_off = w_grp + tap * (BKH * 2);
+            char* a = As + buf * BM * LSTR + wave * 8 * LSTR;
+            char* b = Bs + buf * BN * LSTR + wave * 8 * LSTR;
+#if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass silently DROPS an instantiation whose body casts to an LDS pointer in dependent code (undefined kernel stub at load time)
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(b + i * RPP * LSTR), 16, b_off[i], w_off, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+                const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(a + i * RPP * LSTR), 16, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET_B, 0, 0, 0);
+            }
+#endif
+            rem &= rem - 1;
+            const int wrap = (rem == 0);
+            rem |= wrap ? tap_mask : 0u;
+            c0 += wrap * BKH;
+            w_grp += wrap * (RS * BKH * 2);
+        };
+        const int arow = wm * TM * 32 + li, brow = wn * TN * 32 + li;
+        const int sw = (li >> 1) & 7;                             // (row >> 1) & 7 of every fragment row of this lane (tiles are 32 rows apart)
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kc = kb; kc < ke; ++kc) {
+            const int buf = (kc - kb) & 1;
+            if (kc + 1 < ke) stage(buf ^ 1);
+            const char* a = As + buf * BM * LSTR + arow * LSTR;
+            const char* b = Bs + buf * BN * LSTR + brow * LSTR;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int slot = ((2 * st + lh) ^ sw) * 16;
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LSTR + slot);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LSTR + slot);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else if constexpr (VARIANT == 2) {
         // The mid-chunk-barrier schedule of conv_igemm.hip's VARIANT 2.  A bf16 chunk is only 4 x MF MFMAs of 32 cycles
         // per wave (128 cycles on the 64x64 tile), far less than the [LDS stores -> barrier -> fragment reads] chain that
         // ended every chunk of the loop below; here k-steps 0,1 multiply fragments read during the previous chunk, the
@@ -589,7 +661,7 @@ static int launch_bf16_v(const ConvArgsBf16& a, hipStream_t s) {
     ConvArgsBf16 p = a;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE_B;
+    const size_t lds = (size_t)2 * (BM + BN) * (VARIANT == 3 ? 128 : LDS_STRIDE_B);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -655,7 +727,16 @@ static int choose_config_bf16(const frcnn_conv_desc* d) {
     // Alone on the chip a launch wants >= 1 big tile per CU, else 64x64 tiles (C4 one image in flight: 312 img/s at
     // a threshold of 256 tiles, 261 at 32); beside other images' launches (tile code 50) the big tiles' better
     // MFMA efficiency wins down to a handful of tiles (C4 four in flight: 596 img/s at 16, 556 at 256).
-    if (cfg == 0 || cfg == 50) cfg = t128 >= (cfg == 50 ? 16 : 256) ? (d->cout >= 128 ? 42 : 43) : 2;
+    if (cfg == 0 || cfg == 50) {
+        // the 256-wide direct-to-LDS tiles (round 2; one workgroup per CU): 256x256 with at least one tile per CU,
+        // else 128x256 with >= 200 tiles (the head's 512-wide layers over 300 RoIs: 230) -- lab table in DESIGN 7
+        static const bool wide = !(getenv("FRCNN_BF16_WIDE") && atoi(getenv("FRCNN_BF16_WIDE")) == 0);   // dev knob
+        const long long nt256 = (d->cout + 255) / 256;
+        const long long t256 = ((M + 255) / 256) * nt256, t128x256 = ((M + 127) / 128) * nt256;
+        if (wide && (d->cout % 256) == 0 && t256 >= 256) return 45;
+        if (wide && (d->cout % 256) == 0 && t128x256 >= 200) return 46;
+        cfg = t128 >= (cfg == 50 ? 16 : 256) ? (d->cout >= 128 ? 42 : 43) : 2;
+    }
     return cfg;
 }
 
@@ -744,6 +825,10 @@ int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, c
         case 42: return launch_bf16<2, 1, 2, 4>(a, s);           // 128x128, 8 waves (2x4)
         case 43: return launch_bf16<1, 1, 4, 2>(a, s);           // 128x64, 8 waves
         case 44: return launch_bf16<1, 1, 4, 4>(a, s);           // 128x128, 16 waves
+        case 45: if (!a.mask) return launch_bf16_v<4, 2, 2, 4, false, 3>(a, s);     // 256x256, 8 waves, direct-to-LDS staging
+                 return launch_bf16<2, 1, 2, 4>(a, s);
+        case 46: if (!a.mask) return launch_bf16_v<2, 2, 2, 4, false, 3>(a, s);     // 128x256, 8 waves, direct-to-LDS staging
+                 return launch_bf16<2, 1, 2, 4>(a, s);
         default: return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: unknown tile config %d", cfg);
     }
 }

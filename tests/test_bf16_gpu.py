@@ -21,7 +21,12 @@ torch = pytest.importorskip("torch")
                                   (1, 38, 94, 256, 256, 3, 1, "same", 0),          # R101 stage-4 3x3
                                   (5, 1, 1, 2048, 64, 1, 1, "valid", 802),         # 8 slices of 32 chunks, 5 valid rows
                                   (2, 7, 7, 512, 512, 3, 1, "same", 41), (1, 15, 22, 128, 192, 3, 1, "same", 42),    # 8-wave tiles
-                                  (1, 30, 41, 256, 128, 1, 2, "valid", 43), (3, 7, 7, 512, 200, 3, 1, "same", 44)])  # 128x64 8-wave, 16-wave
+                                  (1, 30, 41, 256, 128, 1, 2, "valid", 43), (3, 7, 7, 512, 200, 3, 1, "same", 44),   # 128x64 8-wave, 16-wave
+                                  # the 256-wide tiles staged straight into LDS (45: 256x256, 46: 128x256): a single ragged tile
+                                  # of 3x3 halo rows, row / column tails, stride 2, many k-chunks
+                                  (3, 7, 7, 512, 256, 3, 1, "same", 45), (2, 15, 22, 128, 512, 3, 1, "same", 46),
+                                  (1, 30, 41, 256, 320, 1, 2, "valid", 45), (1, 30, 41, 256, 320, 1, 2, "valid", 46),
+                                  (6, 14, 14, 1024, 512, 1, 1, "valid", 46), (6, 14, 14, 256, 1024, 3, 1, "same", 45)])
 def test_conv2d_bf16(case):
     from faster_rcnn_amd import ops
     from oracle import keras_ref
@@ -44,6 +49,10 @@ def test_conv2d_bf16(case):
     got32 = ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), out_f32=True, tile=tile)
     err32 = ((got32.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
     assert err32 < 1e-4, err32                      # f32 accumulate on identical operands
+    if tile in (45, 46):                            # same k order, same MFMA: bit for bit the 128x128 tile's result,
+        ref42 = ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), tile=42)
+        for _ in range(8):                          # every time (the staging is asynchronous: a race would come and go)
+            assert torch.equal(ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), tile=tile), ref42)
 
 
 def test_resnet101_bf16_network():
