@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     constexpr int RPP = NT / 8;                          // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int PA = BM / RPP, PB = BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-    static_assert(VARIANT != 3 || (NT == 512 && !SPLITK), "the direct-to-LDS form is written for eight waves, whole-K tiles");
+    static_assert(VARIANT != 3 || !SPLITK, "the direct-to-LDS form takes whole-K tiles");
     constexpr int LSTR = VARIANT == 3 ? 128 : LDS_STRIDE_B;   // VARIANT 3: unpadded rows, XOR-swizzled 16-byte slots
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     char* As = smem_b;                                   // [2][BM][LSTR]
@@ -730,12 +730,17 @@ static int choose_config_bf16(const frcnn_conv_desc* d) {
     if (cfg == 0 || cfg == 50) {
         // the 256-wide direct-to-LDS tiles (round 2; one workgroup per CU): 256x256 with at least one tile per CU,
         // else 128x256 with >= 200 tiles (the head's 512-wide layers over 300 RoIs: 230) -- lab table in DESIGN 7
-        static const bool wide = !(getenv("FRCNN_BF16_WIDE") && atoi(getenv("FRCNN_BF16_WIDE")) == 0);   // dev knob
+        static const bool wide = getenv("FRCNN_BF16_WIDE") && atoi(getenv("FRCNN_BF16_WIDE")) != 0;   // dev knob (off: code 47 ties or beats them)
         const long long nt256 = (d->cout + 255) / 256;
         const long long t256 = ((M + 255) / 256) * nt256, t128x256 = ((M + 127) / 128) * nt256;
         if (wide && (d->cout % 256) == 0 && t256 >= 256) return 45;
         if (wide && (d->cout % 256) == 0 && t128x256 >= 200) return 46;
-        cfg = t128 >= (cfg == 50 ? 16 : 256) ? (d->cout >= 128 ? 42 : 43) : 2;
+        static const bool dma64 = getenv("FRCNN_BF16_DMA64") && atoi(getenv("FRCNN_BF16_DMA64")) != 0;   // dev knob
+        static const int big = getenv("FRCNN_BF16_BIG") ? atoi(getenv("FRCNN_BF16_BIG")) : 47;            // dev knob: 42 = register-staged
+        // 47 (direct-to-LDS 128x128) on long row ranges -- the detector head over 300 RoIs: 1024->2048 103 -> 81 us, 3x3
+        // 83 -> 77 (901 TFLOP/s), 512->2048 69 -> 51 -- and the register-staged 42 on the training steps' 2-3 k rows
+        // (measured equal to 1-2 % slower there, beside the weight-gradient stream)
+        cfg = t128 >= (cfg == 50 ? 16 : 256) ? (d->cout >= 128 ? (M >= 8192 ? big : 42) : 43) : (dma64 ? 48 : 2);
     }
     return cfg;
 }
@@ -829,6 +834,8 @@ int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, c
                  return launch_bf16<2, 1, 2, 4>(a, s);
         case 46: if (!a.mask) return launch_bf16_v<2, 2, 2, 4, false, 3>(a, s);     // 128x256, 8 waves, direct-to-LDS staging
                  return launch_bf16<2, 1, 2, 4>(a, s);
+        case 47: return a.mask ? launch_bf16_v<2, 1, 2, 4, true, 3>(a, s) : launch_bf16_v<2, 1, 2, 4, false, 3>(a, s);   // 128x128, 8 waves, direct-to-LDS staging (two workgroups per CU)
+        case 48: return a.mask ? launch_bf16_v<1, 1, 2, 2, true, 3>(a, s) : launch_bf16_v<1, 1, 2, 2, false, 3>(a, s);   // 64x64, 4 waves, direct-to-LDS staging
         default: return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: unknown tile config %d", cfg);
     }
 }

@@ -177,7 +177,9 @@ typedef struct frcnn_conv_desc {
                                       21, 22: 128x128 / 64x64 v2 with the late-LDS-store schedule;
                                       23..26: 64x64 / 64x128 / 128x64 / 128x128 with the mid-chunk-barrier schedule
                                           (what auto picks for every 64x64 launch and the 1x1 128x128 ones);
-                                      41..43: 128x128 (4x2 / 2x4 waves) and 128x64 with 8 waves;
+                                      41..44 (bf16 path): 128x128 (4x2 / 2x4 waves), 128x64 with 8 waves, 128x128 with 16;
+                                      45..48 (bf16 path): operands staged straight into LDS (buffer_load ... lds):
+                                          256x256 / 128x256 / 128x128 on 8 waves, 64x64 on 4; auto takes 47 where it took 42;
                                       50: auto for a launch that SHARES the chip with other streams' launches
                                           (several images in flight): prefers the larger tiles;
                                       61, 62: the balanced (stream-K) form of 21 / 22 when the shape

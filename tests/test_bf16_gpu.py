@@ -26,7 +26,9 @@ torch = pytest.importorskip("torch")
                                   # of 3x3 halo rows, row / column tails, stride 2, many k-chunks
                                   (3, 7, 7, 512, 256, 3, 1, "same", 45), (2, 15, 22, 128, 512, 3, 1, "same", 46),
                                   (1, 30, 41, 256, 320, 1, 2, "valid", 45), (1, 30, 41, 256, 320, 1, 2, "valid", 46),
-                                  (6, 14, 14, 1024, 512, 1, 1, "valid", 46), (6, 14, 14, 256, 1024, 3, 1, "same", 45)])
+                                  (6, 14, 14, 1024, 512, 1, 1, "valid", 46), (6, 14, 14, 256, 1024, 3, 1, "same", 45),
+                                  (2, 15, 22, 128, 192, 3, 1, "same", 47), (6, 14, 14, 256, 1024, 3, 1, "same", 47),     # 128x128 (the auto pick)
+                                  (1, 30, 41, 256, 320, 1, 2, "valid", 48), (3, 7, 7, 512, 200, 3, 1, "same", 48)])     # 64x64
 def test_conv2d_bf16(case):
     from faster_rcnn_amd import ops
     from oracle import keras_ref
@@ -49,7 +51,7 @@ def test_conv2d_bf16(case):
     got32 = ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), out_f32=True, tile=tile)
     err32 = ((got32.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
     assert err32 < 1e-4, err32                      # f32 accumulate on identical operands
-    if tile in (45, 46):                            # same k order, same MFMA: bit for bit the 128x128 tile's result,
+    if tile in (45, 46, 47, 48):                    # same k order, same MFMA: bit for bit the 128x128 tile's result,
         ref42 = ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), tile=42)
         for _ in range(8):                          # every time (the staging is asynchronous: a race would come and go)
             assert torch.equal(ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), tile=tile), ref42)
