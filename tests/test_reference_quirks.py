@@ -172,3 +172,49 @@ def test_inter_cubic_hand_checked_rows():
     assert shapes._resize(img, 4, 4).tolist() == [[0, 8, 77, 119], [41, 55, 79, 93], [165, 134, 82, 51], [240, 181, 85, 26]]
     # same size = identity (fx = 0 -> the single coefficient 2048)
     assert np.array_equal(shapes._resize(img, 2, 2), img)
+
+
+def test_training_loop_prints_the_reference_lines_in_order_with_deferred_losses(monkeypatch, capsys):
+    """train_util's loops enqueue a step and print its losses one iteration late (train_util._LossLog) so the host can
+    prepare the next image meanwhile; the lines, their order and their position relative to the 'Saved ...' lines are the
+    reference's (train_util.py:54-62): every iteration's line precedes that iteration's save message."""
+    from faster_rcnn_amd import train, train_util
+    monkeypatch.setattr(random, "shuffle", lambda seq: None)
+
+    class Pending:
+        def __init__(self, log, i):
+            self.log, self.i = log, i
+
+        def result(self):
+            self.log.append(("read", self.i))
+            return [float(self.i), 0.0, 0.0]
+
+    class Model(_FakeModel):
+        supports_deferred_losses = True
+
+        def __init__(self):
+            super().__init__()
+            self.events = []
+
+        def train_on_batch(self, x, y, defer=False):
+            assert defer
+            self.events.append(("enqueue", len(self.seen)))
+            self.seen.append(x)
+            return Pending(self.events, len(self.seen) - 1)
+
+        def save_weights(self, path):
+            self.events.append(("save", len(self.seen) - 1))
+
+    m = Model()
+    imgs = [_FakeImg("im%d" % k) for k in range(5)]
+    train_util.train_rpn(m, imgs, _FakeMgr(), train.SGD(0.0), phases=[[5, 1e-3]], save_frequency=2, save_weights_dest="w.npz")
+    out = [l for l in capsys.readouterr().out.splitlines() if l.startswith(("phase", "Saved"))]
+    want = []
+    for i in range(5):
+        want.append("phase 0 iteration %d image im%d flipped False: loss_rpn [%s, 0.0, 0.0]" % (i, i, float(i)))
+        if i % 2 == 0:
+            want.append("Saved rpn weights to w.npz")
+    assert [l.split(" (")[0] for l in out] == want
+    # iteration 1's losses are read only after iteration 2 has been enqueued; a save reads its own iteration first
+    ev = m.events
+    assert ev.index(("enqueue", 2)) < ev.index(("read", 1)) and ev.index(("read", 2)) < ev.index(("save", 2))
