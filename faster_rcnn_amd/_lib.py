@@ -64,6 +64,9 @@ SIGNATURES = {
     "frcnn_dense_heads_split": (I, [P, I, I, I, I, P, P, P]),
     "frcnn_loss_rpn_cls": (I, [P, P, I, I, P, P, P]),
     "frcnn_loss_rpn_reg": (I, [P, P, I, I, P, P, P]),
+    "frcnn_loss_workspace_bytes": (ctypes.c_size_t, []),
+    "frcnn_loss_rpn_cls_ws": (I, [P, P, I, I, P, P, P, P]),
+    "frcnn_loss_rpn_reg_ws": (I, [P, P, I, I, P, P, P, P]),
     "frcnn_loss_det_cls": (I, [P, P, I, I, P, P, I, P]),
     "frcnn_loss_det_reg": (I, [P, P, I, I, P, P, I, P]),
     "frcnn_relu_bwd_inplace": (I, [P, P, c_size_t, P]),
@@ -152,4 +155,6 @@ def check(code, what=""):
 
 def call(name, *args):
     """Call an int-returning entry point and raise FrcnnError on a non-zero status."""
-    check(getattr(load(), name)(*args), name)
+    code = getattr(_lib or load(), name)(*args)
+    if code != 0:
+        check(code, name)

@@ -639,8 +639,10 @@ class RpnTrainer(_StepDriver):
         cells = cls.shape[1] * cls.shape[2]
         g_cls = torch.empty_like(cls)
         g_reg = torch.empty_like(reg)
-        _lib.call("frcnn_loss_rpn_cls", _p(yc), _p(cls), cells, self.A, _p(loss1), _p(g_cls), _stream())
-        _lib.call("frcnn_loss_rpn_reg", _p(yr), _p(reg), cells, self.A, _p(loss2), _p(g_reg), _stream())
+        ws = torch.empty(2 * int(_lib.load().frcnn_loss_workspace_bytes()), dtype=torch.uint8, device="cuda")     # one half per loss
+        half = ctypes.c_void_p(ws.data_ptr() + ws.numel() // 2)
+        _lib.call("frcnn_loss_rpn_cls_ws", _p(yc), _p(cls), cells, self.A, _p(loss1), _p(g_cls), _p(ws), _stream())
+        _lib.call("frcnn_loss_rpn_reg_ws", _p(yr), _p(reg), cells, self.A, _p(loss2), _p(g_reg), half, _stream())
         self.rpn_cls.wgrad(g_cls)
         self.rpn_reg.wgrad(g_reg)
         tmp = self.rpn_cls.dgrad(g_cls)

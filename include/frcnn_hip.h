@@ -327,6 +327,12 @@ int frcnn_detections(const float* rois, const int32_t* n_rois, int max_rows, con
  *   det_reg: y_true [n][8K] = [mask | targets], y_pred [n][4K], K = classes excl. background (:65). */
 int frcnn_loss_rpn_cls(const float* y_true, const float* y_pred, int cells, int A, float* loss, float* grad_logit, void* stream);
 int frcnn_loss_rpn_reg(const float* y_true, const float* y_pred, int cells, int A, float* loss, float* grad_pred, void* stream);
+/* The same two losses spread over many workgroups (what the training step calls): per-workgroup f64 partials in
+ * `workspace` (frcnn_loss_workspace_bytes(), private to the call until the stream has passed it) summed in index order --
+ * reproducible; equal to the one-workgroup forms up to the last ulp of the f64 sums. */
+size_t frcnn_loss_workspace_bytes(void);
+int frcnn_loss_rpn_cls_ws(const float* y_true, const float* y_pred, int cells, int A, float* loss, float* grad_logit, void* workspace, void* stream);
+int frcnn_loss_rpn_reg_ws(const float* y_true, const float* y_pred, int cells, int A, float* loss, float* grad_pred, void* workspace, void* stream);
 int frcnn_loss_det_cls(const float* y_true, const float* y_pred, int n_rois, int C, float* loss, float* grad_logit, int ldg, void* stream);
 int frcnn_loss_det_reg(const float* y_true, const float* y_pred, int n_rois, int num_classes_excl_bg, float* loss, float* grad_pred, int ldg, void* stream);
 /* g *= (y > 0): ReLU backward where no conv epilogue can carry it.  n % 4 == 0. */

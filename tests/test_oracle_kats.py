@@ -328,6 +328,9 @@ def _loss_call(name, y_true, y_pred, *dims):
     g = torch.zeros_like(yp)
     if name in ("frcnn_loss_det_cls", "frcnn_loss_det_reg"):
         _lib.call(name, _p(yt), _p(yp), *dims, _p(loss), _p(g), g.shape[1], _stream())
+    elif name.endswith("_ws"):
+        ws = torch.empty(int(_lib.load().frcnn_loss_workspace_bytes()), dtype=torch.uint8, device="cuda")
+        _lib.call(name, _p(yt), _p(yp), *dims, _p(loss), _p(g), _p(ws), _stream())
     else:
         _lib.call(name, _p(yt), _p(yp), *dims, _p(loss), _p(g), _stream())
     return float(loss.item()), g.cpu().numpy()
@@ -344,6 +347,24 @@ def test_gpu_losses_known_answers():
     l, g = _loss_call("frcnn_loss_rpn_reg", [[1, 1, 1, 1, 0.5, -2.0, 0.0, 1.0], [0, 0, 0, 0, 0, 0, 0, 0]], [[0, 0, 0, 0], [3.0, 0, 0, 0]], 2, 1)
     assert abs(l - 0.009635416666666667) < 1e-8
     assert g[1, 0] != 0.0                                         # the unselected anchor's error IS in the sum, so it has a gradient
+    # the many-workgroup forms the training step calls: same known answers, and on a full-size RPN map (2 394 cells x 9
+    # anchors) the one-workgroup form's loss to 1e-6 relative and its gradient bit for bit
+    l, g = _loss_call("frcnn_loss_rpn_cls_ws", [[1, 1], [1, 0], [0, 1], [1, 1], [1, 1]], [[0.5], [0.25], [0.9], [0.0], [1.0]], 5, 1)
+    assert abs(l - want) < 1e-6 * want and g[2, 0] == 0.0
+    l, g = _loss_call("frcnn_loss_rpn_reg_ws", [[1, 1, 1, 1, 0.5, -2.0, 0.0, 1.0], [0, 0, 0, 0, 0, 0, 0, 0]], [[0, 0, 0, 0], [3.0, 0, 0, 0]], 2, 1)
+    assert abs(l - 0.009635416666666667) < 1e-8 and g[1, 0] != 0.0
+    rs = np.random.RandomState(0)
+    cells, A = 2394, 9
+    yc = np.concatenate([rs.rand(cells, A) < 0.05, rs.rand(cells, A) < 0.02], axis=1).astype(np.float32)
+    pc = rs.rand(cells, A).astype(np.float32)
+    pc[rs.rand(cells, A) < 0.01] = 0.0                          # clipped probabilities
+    yr = np.concatenate([np.repeat(rs.rand(cells, A) < 0.02, 4, axis=1), rs.randn(cells, 4 * A)], axis=1).astype(np.float32)
+    pr = rs.randn(cells, 4 * A).astype(np.float32)
+    for name, yt, yp in (("frcnn_loss_rpn_cls", yc, pc), ("frcnn_loss_rpn_reg", yr, pr)):
+        l1, g1 = _loss_call(name, yt, yp, cells, A)
+        l2, g2 = _loss_call(name + "_ws", yt, yp, cells, A)
+        assert abs(l1 - l2) <= 1e-6 * abs(l1) and np.array_equal(g1, g2), name
+        assert (l2, g2.tobytes()) == (lambda r: (r[0], r[1].tobytes()))(_loss_call(name + "_ws", yt, yp, cells, A))      # reproducible
     # detector losses
     l, _ = _loss_call("frcnn_loss_det_reg", [[1, 1, 1, 1, 1.0, 1.0, 1.0, 1.0], [0, 0, 0, 0, 9.0, 9.0, 9.0, 9.0]], [[0, 0, 0, 3.0], [5.0, 5.0, 5.0, 5.0]], 2, 1)
     assert abs(l - 0.7498500299940012) < 1e-6
