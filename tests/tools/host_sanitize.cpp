@@ -1,0 +1,76 @@
+// Host-side sanitizer driver ("sanitizers on the CPU build").  Linked against the C-ABI objects compiled with
+// -fsanitize=address,undefined (host code only: GPU ASan is not available on this pool) by scripts/sanitize_host.sh.
+// It walks the HOST logic behind the entry points -- tile / split-K policy, workspace sizing, job-table packing, argument
+// validation and error strings -- over a sweep of shapes.  No kernel needs to run: without a GPU every launch fails
+// cleanly with a HIP error, which is itself one of the paths checked.
+#include "../../include/frcnn_hip.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+static unsigned rng_state = 12345u;
+static unsigned rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
+static int pick(std::initializer_list<int> v) { return v.begin()[rnd() % v.size()]; }
+
+int main() {
+    int checked = 0, failures = 0;
+    // ---- conv descriptors: workspace sizing runs choose_config / choose_splits for both precisions
+    for (int it = 0; it < 20000; ++it) {
+        frcnn_conv_desc d;
+        memset(&d, 0, sizeof d);
+        d.n = pick({1, 1, 1, 2, 5, 64, 300});
+        d.h = 1 + rnd() % 160; d.w = 1 + rnd() % 260;
+        if (d.n > 5) { d.h = pick({1, 7, 14}); d.w = d.h; }
+        d.cin = pick({3, 4, 32, 64, 128, 256, 512, 1024, 2048, 96, 36});
+        d.cout = pick({9, 36, 64, 101, 128, 256, 512, 1024, 2048, 84, 320});
+        d.kh = d.kw = pick({1, 1, 3, 3, 7});
+        d.stride = pick({1, 1, 2});
+        const bool same = rnd() & 1;
+        d.ho = same ? (d.h + d.stride - 1) / d.stride : (d.h - d.kh) / d.stride + 1;
+        d.wo = same ? (d.w + d.stride - 1) / d.stride : (d.w - d.kw) / d.stride + 1;
+        if (d.ho <= 0 || d.wo <= 0) continue;
+        d.pad_top = same ? ((d.ho - 1) * d.stride + d.kh - d.h > 0 ? ((d.ho - 1) * d.stride + d.kh - d.h) / 2 : 0) : 0;
+        d.pad_left = same ? ((d.wo - 1) * d.stride + d.kw - d.w > 0 ? ((d.wo - 1) * d.stride + d.kw - d.w) / 2 : 0) : 0;
+        d.act = rnd() % 3;
+        d.tile = pick({0, 0, 0, 50, 2, 21, 22, 23, 26, 61, 62, 123, 302, 42, 45, 46, 47, 48, 999});
+        d.layout = (d.n > 5 && (d.cin % 32) == 0) ? (rnd() & 1) : 0;
+        const size_t a = frcnn_conv2d_workspace_bytes(&d);
+        const size_t b = frcnn_conv2d_workspace_bytes_bf16(&d);
+        const size_t c = frcnn_conv2d_wgrad_workspace_bytes(&d);
+        const int k = frcnn_conv_packed_k(d.kh, d.kw, d.cin);
+        if (k < d.kh * d.kw * d.cin) { printf("packed_k too small for %dx%dx%d\n", d.kh, d.kw, d.cin); ++failures; }
+        if (a > ((size_t)1 << 33) || b > ((size_t)1 << 33) || c > ((size_t)1 << 36)) { printf("implausible workspace %zu %zu %zu\n", a, b, c); ++failures; }
+        ++checked;
+    }
+    // ---- weight-gradient job tables (sized on the host, never launched here)
+    for (int it = 0; it < 200; ++it) {
+        std::vector<frcnn_wgrad_job> jobs(1 + rnd() % 70);
+        for (auto& j : jobs) {
+            memset(&j, 0, sizeof j);
+            j.d.n = 1; j.d.h = j.d.ho = 1 + rnd() % 40; j.d.w = j.d.wo = 1 + rnd() % 64;
+            j.d.cin = pick({64, 128, 256, 512, 1024}); j.d.cout = pick({9, 36, 64, 256, 1024, 2048});
+            j.d.kh = j.d.kw = pick({1, 3}); j.d.stride = 1;
+            j.in_bf16 = rnd() & 1;
+        }
+        const size_t ws = frcnn_conv2d_wgrad_batch_workspace_bytes(jobs.data(), (int)jobs.size());
+        if (ws == 0) { printf("empty batch workspace\n"); ++failures; }
+        // null operands are refused before any launch
+        if (frcnn_conv2d_wgrad_batch(jobs.data(), (int)jobs.size(), nullptr, 0, nullptr) == FRCNN_OK) { printf("wgrad_batch accepted a null workspace\n"); ++failures; }
+        ++checked;
+    }
+    // ---- argument validation and the error string
+    frcnn_conv_desc d;
+    memset(&d, 0, sizeof d);
+    d.n = 1; d.h = d.w = d.ho = d.wo = 8; d.cin = 64; d.cout = 64; d.kh = d.kw = 1; d.stride = 1;
+    if (frcnn_conv2d_fwd(&d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == FRCNN_OK) { printf("conv2d_fwd accepted null tensors\n"); ++failures; }
+    const char* msg = frcnn_last_error();
+    if (!msg || !strstr(msg, "conv2d")) { printf("error string missing: %s\n", msg ? msg : "(null)"); ++failures; }
+    if (frcnn_roi_crop_resize_bwd(nullptr, 0, 0, 0, nullptr, 1, 7, nullptr, nullptr) == FRCNN_OK) { printf("roi bwd accepted a bad shape\n"); ++failures; }
+    if (frcnn_loss_rpn_cls_ws(nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr) == FRCNN_OK) { printf("loss accepted nulls\n"); ++failures; }
+    if (frcnn_loss_workspace_bytes() < 1024) { printf("loss workspace too small\n"); ++failures; }
+    if (frcnn_refresh_packed(nullptr, 3, nullptr) == FRCNN_OK) { printf("refresh_packed accepted a null table\n"); ++failures; }
+    checked += 6;
+    printf("host sanitizer driver: %d checks, %d failures\n", checked, failures);
+    return failures ? 1 : 0;
+}
