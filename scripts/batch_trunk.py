@@ -42,18 +42,24 @@ def timed(step, n=30):
 
 
 def main():
-    anchors = util.get_anchors([128, 256, 512])
-    w = synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=1)
-    base = resnet.resnet50_base(weights=w)
-    rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=9)
+    c4 = "--c4" in sys.argv                      # configs[3]: ResNet-101, 600x1500, 18 anchors, bf16
+    H, W = (600, 1500) if c4 else (600, 1000)
+    if c4:
+        w = synthetic_resnet(101, anchors_per_loc=18, num_classes=10, seed=1)
+        base = resnet.resnet101_base(weights=w, dtype="bf16")
+        rpn = resnet.resnet101_rpn(base, include_conv=True, anchors_per_loc=18)
+    else:
+        w = synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=1)
+        base = resnet.resnet50_base(weights=w)
+        rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=9)
     rs = np.random.RandomState(0)
-    for B in (1, 2, 4):
-        x = torch.from_numpy(rs.randn(B, 600, 1000, 3).astype(np.float32) * 50).cuda()
+    for B in (1, 2, 4, 8):
+        x = torch.from_numpy(rs.randn(B, H, W, 3).astype(np.float32) * 50).cuda()
         for thr in (False, True):
             g, out, ws = graph_of(lambda: rpn.forward_dev(x), thr)
             ms = timed(g.replay)
             print("batch %d in one pass (tile policy %s): %.3f ms = %.3f ms per image" % (B, "shared" if thr else "alone", ms, ms / B))
-    x1 = [torch.from_numpy(rs.randn(1, 600, 1000, 3).astype(np.float32) * 50).cuda() for _ in range(4)]
+    x1 = [torch.from_numpy(rs.randn(1, H, W, 3).astype(np.float32) * 50).cuda() for _ in range(4)]
     for thr in (False, True):
         gs = [graph_of(lambda xx=xx: rpn.forward_dev(xx), thr) for xx in x1]
         streams = [torch.cuda.Stream() for _ in range(4)]
