@@ -722,7 +722,7 @@ class _VggHeadTrain:
 class DetTrainer(_StepDriver):
     """detector.compile + detector.train_on_batch([image or conv features, rois], [y_cls, y_reg])
     (train_util.py:95-118, 159-182): [base forward,] RoiResizeConv, head, the two detector losses (+ L2),
-    backward through the head, the RoI crop (atomic scatter) and the trainable part of the base.
+    backward through the head, the RoI crop (a deterministic gather per feature cell) and the trainable part of the base.
     Step 2 feeds images through the detector's own base; step 4 feeds cached conv features (no base)."""
 
     def __init__(self, det_model, l2=0.0):
@@ -795,7 +795,7 @@ class DetTrainer(_StepDriver):
         self.dense.wgrad(g4)
         gcrop = self.head.backward(self.dense.dgrad(g4))
         if self.base_trains and self.bf16:
-            gfeat = ops.cast_bf16(ops.roi_crop_resize_bwd_bf16(gcrop, rois, self.feat.shape[1], self.feat.shape[2]))   # f32 atomics, then bf16
+            gfeat = ops.cast_bf16(ops.roi_crop_resize_bwd_bf16(gcrop, rois, self.feat.shape[1], self.feat.shape[2]))   # f32 gather, then bf16
             _lib.call("frcnn_relu_bwd_inplace_bf16", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
             self.base.backward(gfeat.reshape(self.feat.shape))
         elif self.base_trains:
