@@ -834,8 +834,11 @@ int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, c
                  return launch_bf16<2, 1, 2, 4>(a, s);
         case 46: if (!a.mask) return launch_bf16_v<2, 2, 2, 4, false, 3>(a, s);     // 128x256, 8 waves, direct-to-LDS staging
                  return launch_bf16<2, 1, 2, 4>(a, s);
-        case 47: return a.mask ? launch_bf16_v<2, 1, 2, 4, true, 3>(a, s) : launch_bf16_v<2, 1, 2, 4, false, 3>(a, s);   // 128x128, 8 waves, direct-to-LDS staging (two workgroups per CU)
-        case 48: return a.mask ? launch_bf16_v<1, 1, 2, 2, true, 3>(a, s) : launch_bf16_v<1, 1, 2, 2, false, 3>(a, s);   // 64x64, 4 waves, direct-to-LDS staging
+        // (the masked launches -- training's input gradients, 2-3 k rows -- stay on the register-staged forms)
+        case 47: if (!a.mask) return launch_bf16_v<2, 1, 2, 4, false, 3>(a, s);     // 128x128, 8 waves, direct-to-LDS staging (two workgroups per CU)
+                 return launch_bf16<2, 1, 2, 4>(a, s);
+        case 48: if (!a.mask) return launch_bf16_v<1, 1, 2, 2, false, 3>(a, s);     // 64x64, 4 waves, direct-to-LDS staging
+                 return launch_bf16<1, 1>(a, s);
         default: return fail(FRCNN_E_ARG, "conv2d_fwd_bf16: unknown tile config %d", cfg);
     }
 }
