@@ -468,12 +468,26 @@ class _StepDriver:
         self._loss_ring = [None] * LOSS_RING          # steps whose three scalars are still on their way to the host
         self._loss_pos = 0
 
-    def _update(self, sq_out):
-        """After the backward pass: L2 sum, the ONE exchange of the flat gradient buffer, optimiser, re-pack."""
+    def _publish_losses(self):
+        """Called by ``_device_step`` as soon as the two loss kernels are enqueued (and by a skipped step at once): the L2
+        sum over the trainable weights -- they do not change before the optimiser runs at the END of the step -- then the
+        three scalars leave for pinned host memory on a stream of their own.  train_on_batch's return value is therefore
+        available after the FORWARD pass; the backward pass and the update run on while the caller reads the losses and
+        stages the next image (Keras semantics kept: every way of reading weights back is stream-ordered behind the step)."""
+        out3, slot = self._cur
+        if self.l2:
+            self.params.sumsq(out=out3[2:3])
+        main, side = torch.cuda.current_stream(), _loss_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            slot[0].copy_(out3, non_blocking=True)
+            slot[1].record()
+        out3.record_stream(side)
+
+    def _update(self, sq_out=None):
+        """After the backward pass: the ONE exchange of the flat gradient buffer, optimiser, re-pack."""
         p = self.params
         flush_weight_grads()
-        if self.l2:
-            p.sumsq(out=sq_out)
         scale = _sync_grads(p)
         p.step(self.optimizer, self.l2, scale)
         if self._refresh_jobs is None:
@@ -507,10 +521,18 @@ class _StepDriver:
         assert self.optimizer is not None, "call compile() first"
         out3 = torch.zeros(3, dtype=torch.float32, device="cuda")                          # loss 1, loss 2, sum of squares
         out = [out3[0:1], out3[1:2], out3[2:3]]
+        slot = self._loss_ring[self._loss_pos]
+        if slot is None:
+            slot = self._loss_ring[self._loss_pos] = [torch.empty(3, dtype=torch.float32).pin_memory(), torch.cuda.Event(), None]
+        elif slot[2] is not None and slot[2]() is not None:
+            slot[2]().result()                          # the ring wrapped around an unread step: read it before its slot is reused
+        self._loss_pos = (self._loss_pos + 1) % LOSS_RING
+        self._cur = (out3, slot)
         if skip:
             with ops.conv_workspace(self._conv_ws):
                 self.params.g.zero_()
-                self._update(out[2])
+                self._publish_losses()
+                self._update()
         else:
             # Upload and the FROZEN leading part of the base (stem .. last frozen stage: it reads no trainable weight) go
             # to a second stream.  When the caller defers its steps the host is a step ahead, so this part of image i+1
@@ -528,14 +550,7 @@ class _StepDriver:
                 t.record_stream(main)                   # allocated on the side stream, read (and released) under the main one
             with ops.conv_workspace(self._conv_ws):
                 self._device_step(dev, out, pre)
-        slot = self._loss_ring[self._loss_pos]
-        if slot is None:
-            slot = self._loss_ring[self._loss_pos] = [torch.empty(3, dtype=torch.float32).pin_memory(), torch.cuda.Event(), None]
-        elif slot[2] is not None and slot[2]() is not None:
-            slot[2]().result()                          # the ring wrapped around an unread step: read it before its slot is reused
-        self._loss_pos = (self._loss_pos + 1) % LOSS_RING
-        slot[0].copy_(out3, non_blocking=True)
-        slot[1].record()
+        self._cur = None
         pending = PendingLosses(slot[0], slot[1], self.l2, self.frozen_sumsq)
         slot[2] = weakref.ref(pending)
         return pending if defer else pending.result()
@@ -543,6 +558,14 @@ class _StepDriver:
 
 LOSS_RING = 8
 _PREFIX_STREAM = None
+_LOSS_STREAM = None
+
+
+def _loss_stream():
+    global _LOSS_STREAM
+    if _LOSS_STREAM is None:
+        _LOSS_STREAM = torch.cuda.Stream()
+    return _LOSS_STREAM
 
 
 def _prefix_stream():
@@ -643,6 +666,7 @@ class RpnTrainer(_StepDriver):
         half = ctypes.c_void_p(ws.data_ptr() + ws.numel() // 2)
         _lib.call("frcnn_loss_rpn_cls_ws", _p(yc), _p(cls), cells, self.A, _p(loss1), _p(g_cls), _p(ws), _stream())
         _lib.call("frcnn_loss_rpn_reg_ws", _p(yr), _p(reg), cells, self.A, _p(loss2), _p(g_reg), half, _stream())
+        self._publish_losses()
         self.rpn_cls.wgrad(g_cls)
         self.rpn_reg.wgrad(g_reg)
         tmp = self.rpn_cls.dgrad(g_cls)
@@ -652,7 +676,7 @@ class RpnTrainer(_StepDriver):
         self.rpn_conv.wgrad(gh)
         if self.base_trains:
             self.base.backward(self.rpn_conv.dgrad(gh, mask=self.feat))
-        self._update(sq)
+        self._update()
 
     def sync_weights(self):
         """Write the trained master weights back into the model's Keras-keyed weight dict."""
@@ -791,6 +815,7 @@ class DetTrainer(_StepDriver):
         g = torch.empty((n, C + K4), dtype=torch.float32, device="cuda")     # [d logits | d reg]
         _lib.call("frcnn_loss_det_cls", _p(yc), _p(cls), n, C, _p(loss1), _p(g), C + K4, _stream())
         _lib.call("frcnn_loss_det_reg", _p(yr), _p(reg), n, C - 1, _p(loss2), ctypes.c_void_p(g.data_ptr() + 4 * C), C + K4, _stream())
+        self._publish_losses()
         g4 = g.reshape(n, 1, 1, C + K4)
         self.dense.wgrad(g4)
         gcrop = self.head.backward(self.dense.dgrad(g4))
@@ -802,7 +827,7 @@ class DetTrainer(_StepDriver):
             gfeat = ops.roi_crop_resize_bwd(gcrop, rois, self.feat.shape[1], self.feat.shape[2])
             _lib.call("frcnn_relu_bwd_inplace", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
             self.base.backward(gfeat.reshape(self.feat.shape))
-        self._update(sq)
+        self._update()
 
     def sync_weights(self):
         w = self.model.weights

@@ -79,8 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--big-tiles", action="store_true")
     ap.add_argument("--only", choices=("rpn", "det"), default=None)
-    ap.add_argument("--sync-each-step", action="store_true", help="read the losses back after every step (Keras' train_on_batch) instead of "
-                    "one step late, the way train_util's loops do")
+    ap.add_argument("--sync-each-step", action="store_true", help="time only the plain Keras call (losses read back after every step); by default "
+                    "the loop reads them one step late, the way train_util's loops do, and the per-step figure is reported beside it")
     args = ap.parse_args()
     backend = os.environ.get("FRCNN_BENCH_BACKEND")
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
