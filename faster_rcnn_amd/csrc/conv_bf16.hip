@@ -529,18 +529,26 @@ __global__ void k_pack_hwio_bf16(const float* w, int RS, int Cin, int Cout, int 
 // conv_igemm.hip's k_refresh_packed): forward pack, input-gradient pack (transposed, flipped, scale folded) and the
 // folded epilogue shift.  packed / packed_dgrad of frcnn_pack_job point at bf16 storage here.
 constexpr int REFRESH_JOBS_B = 32;
-struct RefreshTableB { frcnn_pack_job job[REFRESH_JOBS_B]; };
+struct RefreshTableB { frcnn_pack_job job[REFRESH_JOBS_B]; int first_block[REFRESH_JOBS_B + 1]; int n; };   // workgroups in proportion to job size (conv_igemm.hip)
+static int refresh_blocks_b(const frcnn_pack_job& j) {
+    const long long elems = (long long)j.kh * j.kw * j.cin * j.cout;
+    long long g = (elems + 8191) / 8192;
+    return (int)(g < 4 ? 4 : (g > 2048 ? 2048 : g));
+}
 __global__ void __launch_bounds__(256) k_refresh_packed_bf16(const RefreshTableB t) {
-    const frcnn_pack_job& j = t.job[blockIdx.y];
+    int ji = 0;
+    while (ji + 1 < t.n && (int)blockIdx.x >= t.first_block[ji + 1]) ++ji;
+    const frcnn_pack_job& j = t.job[ji];
+    const int bx = (int)blockIdx.x - t.first_block[ji], gsz = t.first_block[ji + 1] - t.first_block[ji];
     const int RS = j.kh * j.kw;
-    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gsz * blockDim.x, first = (size_t)bx * blockDim.x + threadIdx.x;
     if (j.packed) {
         // 64 x 64 (channel x cout) tiles through LDS: cout-contiguous reads, channel-contiguous 128-B writes
         __shared__ float tile[BKH][65];
         __bf16* out = reinterpret_cast<__bf16*>(j.packed);
         const int Kpad = RS * j.cin, nblk = (j.cout + 63) / 64, ntiles = RS * (j.cin / BKH) * nblk;
         const int lane = threadIdx.x & 63, jr = threadIdx.x >> 6;
-        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        for (int tl = bx; tl < ntiles; tl += gsz) {
             const int nb = tl % nblk, kc = tl / nblk, tap = kc % RS, cc = kc / RS, n0 = nb * 64;
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp) {
@@ -854,9 +862,12 @@ int frcnn_refresh_packed_bf16(const frcnn_pack_job* jobs, int n_jobs, void* stre
     for (int b = 0; b < n_jobs; b += REFRESH_JOBS_B) {
         RefreshTableB t;
         const int n = n_jobs - b < REFRESH_JOBS_B ? n_jobs - b : REFRESH_JOBS_B;
-        for (int i = 0; i < n; ++i) t.job[i] = jobs[b + i];
-        for (int i = n; i < REFRESH_JOBS_B; ++i) t.job[i] = jobs[b];
-        k_refresh_packed_bf16<<<dim3(96, n), 256, 0, as_stream(stream)>>>(t);
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) { t.job[i] = jobs[b + i]; t.first_block[i] = blocks; blocks += refresh_blocks_b(jobs[b + i]); }
+        for (int i = n; i < REFRESH_JOBS_B; ++i) { t.job[i] = jobs[b]; t.first_block[i] = blocks; }
+        t.first_block[REFRESH_JOBS_B] = blocks;
+        t.n = n;
+        k_refresh_packed_bf16<<<blocks, 256, 0, as_stream(stream)>>>(t);
         if (int e = check_launch("refresh_packed_bf16")) return e;
     }
     return FRCNN_OK;

@@ -1123,18 +1123,28 @@ __global__ void k_pack_dgrad(const float* w, const float* scale, int R, int S, i
 // optimiser step: forward pack, input-gradient pack and the folded epilogue shift.  The job table rides in
 // the kernel arguments (no table upload); blockIdx.y = job.
 constexpr int REFRESH_JOBS = 32;
-struct RefreshTable { frcnn_pack_job job[REFRESH_JOBS]; };
+// Workgroups are dealt out in proportion to each job's size (first_block: prefix over the jobs): with a fixed 96 per job
+// the 4.7 M-element RPN filter kept 96 workgroups busy long after the 1x1 layers' had left (159 us per fp32 RPN step).
+struct RefreshTable { frcnn_pack_job job[REFRESH_JOBS]; int first_block[REFRESH_JOBS + 1]; int n; };
+static int refresh_blocks(const frcnn_pack_job& j) {
+    const long long elems = (long long)j.kh * j.kw * j.cin * j.cout;
+    long long g = (elems + 8191) / 8192;
+    return (int)(g < 4 ? 4 : (g > 2048 ? 2048 : g));
+}
 __global__ void __launch_bounds__(256) k_refresh_packed(const RefreshTable t) {
-    const frcnn_pack_job& j = t.job[blockIdx.y];
+    int ji = 0;
+    while (ji + 1 < t.n && (int)blockIdx.x >= t.first_block[ji + 1]) ++ji;
+    const frcnn_pack_job& j = t.job[ji];
+    const int bx = (int)blockIdx.x - t.first_block[ji], gsz = t.first_block[ji + 1] - t.first_block[ji];
     const int RS = j.kh * j.kw;
-    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gsz * blockDim.x, first = (size_t)bx * blockDim.x + threadIdx.x;
     if (j.packed && (j.cin % BK) == 0) {
         // HWIO has cout fastest, the packed rows have the 32 channels of a chunk fastest: transpose 32 x 64
         // (channel x cout) tiles through LDS so both the reads (256 B) and the writes (128 B) are whole segments
         __shared__ float tile[BK][65];
         const int Kpad = RS * j.cin, nblk = (j.cout + 63) / 64, ntiles = RS * (j.cin / BK) * nblk;
         const int lane = threadIdx.x & 63, jr = threadIdx.x >> 6, wn = threadIdx.x >> 3, j4 = (threadIdx.x & 7) * 4;
-        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        for (int tl = bx; tl < ntiles; tl += gsz) {
             const int nb = tl % nblk, kc = tl / nblk, tap = kc % RS, cc = kc / RS, n0 = nb * 64;
 #pragma unroll
             for (int pp = 0; pp < 8; ++pp) {
@@ -2232,9 +2242,12 @@ int frcnn_refresh_packed(const frcnn_pack_job* jobs, int n_jobs, void* stream) {
     for (int b = 0; b < n_jobs; b += REFRESH_JOBS) {
         RefreshTable t;
         const int n = n_jobs - b < REFRESH_JOBS ? n_jobs - b : REFRESH_JOBS;
-        for (int i = 0; i < n; ++i) t.job[i] = jobs[b + i];
-        for (int i = n; i < REFRESH_JOBS; ++i) t.job[i] = jobs[b];        // never indexed (grid.y == n)
-        k_refresh_packed<<<dim3(96, n), 256, 0, as_stream(stream)>>>(t);
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) { t.job[i] = jobs[b + i]; t.first_block[i] = blocks; blocks += refresh_blocks(jobs[b + i]); }
+        for (int i = n; i < REFRESH_JOBS; ++i) { t.job[i] = jobs[b]; t.first_block[i] = blocks; }        // never indexed
+        t.first_block[REFRESH_JOBS] = blocks;
+        t.n = n;
+        k_refresh_packed<<<blocks, 256, 0, as_stream(stream)>>>(t);
         if (int e = check_launch("refresh_packed")) return e;
     }
     return FRCNN_OK;
