@@ -1595,7 +1595,7 @@ __global__ void k_wgrad_reduce(const float* partial, int slices, size_t elems, i
 constexpr int WGRAD_BATCH = 32;
 struct WgradBatch { WgradArgs job[WGRAD_BATCH]; int first_block[WGRAD_BATCH + 1]; int gx[WGRAD_BATCH]; int gy[WGRAD_BATCH]; int n; };
 struct WgradReduceJob { const float* partial; const float* scale; float* dw; unsigned long long elems; int slices, cout; };
-struct WgradReduceBatch { WgradReduceJob job[2 * WGRAD_BATCH]; int n; };
+struct WgradReduceBatch { WgradReduceJob job[2 * WGRAD_BATCH]; int first_block[2 * WGRAD_BATCH + 1]; int n; };   // workgroups in proportion to job size
 
 template <int KIND>          // 0: f32 operands; 1: bf16 operands on the bf16 MFMA; 2: bf16 operands widened onto the f32 MFMA; 3: f32, 128x128 tiles
 __global__ void __launch_bounds__(256) k_conv_wgrad_batch(const WgradBatch t) {
@@ -1613,8 +1613,11 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_f32_big(const WgradArgs p) {
 }
 
 __global__ void __launch_bounds__(256) k_wgrad_reduce_batch(const WgradReduceBatch t) {
-    const WgradReduceJob& j = t.job[blockIdx.y];
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < j.elems; i += (size_t)gridDim.x * blockDim.x) {
+    int ji = 0;
+    while (ji + 1 < t.n && (int)blockIdx.x >= t.first_block[ji + 1]) ++ji;
+    const WgradReduceJob& j = t.job[ji];
+    const size_t bx = (size_t)((int)blockIdx.x - t.first_block[ji]), gsz = (size_t)(t.first_block[ji + 1] - t.first_block[ji]);
+    for (size_t i = bx * blockDim.x + threadIdx.x; i < j.elems; i += gsz * blockDim.x) {
         float v = 0.0f;
         for (int sidx = 0; sidx < j.slices; ++sidx) v += j.partial[(size_t)sidx * j.elems + i];
         j.dw[i] = j.scale ? v * j.scale[i % j.cout] : v;
@@ -2228,7 +2231,15 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             r.job[i].elems = (unsigned long long)d->kh * d->kw * d->cin * d->cout;
             r.job[i].slices = wgrad_slices(d, wgrad_kind(jobs[q]) == 3); r.job[i].cout = d->cout;
         }
-        k_wgrad_reduce_batch<<<dim3(512, r.n), 256, 0, s>>>(r);
+        int rblocks = 0;
+        for (int i = 0; i <= 2 * WGRAD_BATCH; ++i) {
+            r.first_block[i] = rblocks;
+            if (i < r.n) {
+                const unsigned long long g = (r.job[i].elems + 2047) / 2048;       // 8 elements (x slices) per thread
+                rblocks += (int)(g < 4 ? 4 : (g > 2048 ? 2048 : g));
+            }
+        }
+        k_wgrad_reduce_batch<<<rblocks, 256, 0, s>>>(r);
         if (int e = check_launch("conv2d_wgrad_batch reduce")) return e;
     }
     return FRCNN_OK;
