@@ -51,10 +51,9 @@ def get_dets(training_manager, detector, image, resize_ratio, num_rois=64, strid
         out_reg = torch.from_numpy(np.concatenate(reg_parts).astype(np.float32)).cuda()
     n_rows = torch.tensor([len(padded)], dtype=torch.int32, device="cuda")
     res = ops.detections(rois_d, n_rows, out_cls, out_reg, num_rois, class_mapping["bg"], det_threshold, stride, resize_ratio)
-    nd = int(res["n_dets"].item())
-    det_cls = res["det_cls"].cpu().numpy()[:nd]
-    det_prob = res["det_prob"].cpu().numpy()[:nd]
-    det_bbox = res["det_bbox"].cpu().numpy()[:nd]
+    n_dets, bbox, cls, prob, _ = ops.split_detections(res["det_packed"].cpu())      # one copy for all five outputs
+    nd = int(n_dets.item())
+    det_cls, det_prob, det_bbox = cls.numpy()[:nd], prob.numpy()[:nd], bbox.numpy()[:nd]
     return [{"bbox": det_bbox[i].astype(np.int64), "cls_name": rev_class_mapping[int(det_cls[i])], "prob": det_prob[i]}
             for i in range(nd)]
 
