@@ -17,7 +17,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
-struct GemmArgs { const void* A; const void* B; void* C; int M, N, K; int tiles_m, tiles_n; };
+struct GemmArgs { const void* A; const void* B; void* C; int M, N, K; int tiles_m, tiles_n; int skip_epilogue; };
 
 constexpr int BK = 64;                    // bf16 elements per stage = 128 B per row = eight 16-byte granules
 constexpr unsigned OOB = 0x80000000u;
@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(512) k_gemm256(const GemmArgs p) {
 
     // plain epilogue (lab): lane owns column li of each 32-wide tile, rows 8 (e >> 2) + 4 lh + (e & 3)
     __bf16* C = reinterpret_cast<__bf16*>(p.C);
+    if (p.skip_epilogue) { if (acc[0][0][0] == 123.456f) C[0] = (__bf16)1.0f; return; }      // (main loop + prologue only)
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -220,7 +221,7 @@ int main(int argc, char** argv) {
         CHECK(hipMalloc(&A, (size_t)sh.M * sh.K * 2)); CHECK(hipMalloc(&B, (size_t)sh.N * sh.K * 2)); CHECK(hipMalloc(&C, (size_t)sh.M * sh.N * 2));
         k_fill<<<1024, 256, 0, s>>>(A, (size_t)sh.M * sh.K, 1u);
         k_fill<<<1024, 256, 0, s>>>(B, (size_t)sh.N * sh.K, 2u);
-        GemmArgs a{A, B, C, sh.M, sh.N, sh.K, (sh.M + 255) / 256, (sh.N + 255) / 256};
+        GemmArgs a{A, B, C, sh.M, sh.N, sh.K, (sh.M + 255) / 256, (sh.N + 255) / 256, argc > 1 && !strcmp(argv[1], "noepi") && strcmp(sh.name, "check") ? 1 : 0};
         for (int variant = 0; variant < 4; ++variant) {           // 0, 1: 256-row tiles; 2, 3: 128-row tiles
             auto run = [&]() { if (variant == 0) launch<0, 4>(a, s); else if (variant == 1) launch<1, 4>(a, s); else if (variant == 2) launch<0, 2>(a, s); else launch<1, 2>(a, s); };
             if (!strcmp(sh.name, "check")) {
