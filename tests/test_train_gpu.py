@@ -469,3 +469,27 @@ def test_deferred_steps_are_the_same_steps():
     d_sync, d_def = run_det(False), run_det(True)
     assert d_sync[0] == d_def[0]
     assert np.array_equal(d_sync[1], d_def[1]) and np.array_equal(d_sync[2], d_def[2])
+
+
+def test_many_steps_keep_device_memory_flat():
+    """The step driver allocates on three streams (upload + frozen stages, main, loss read-back) and hands tensors across
+    them (record_stream): 60 RPN steps, every other one deferred, must neither grow the allocator's reservation nor
+    produce a non-finite loss."""
+    from faster_rcnn_amd import resnet, train
+    from faster_rcnn_amd.weights import synthetic_resnet
+    A = 9
+    w0 = synthetic_resnet(50, anchors_per_loc=A, num_classes=21, seed=45)
+    rows, cols = resnet.get_conv_rows_cols(192, 256)
+    rpn = resnet.resnet50_rpn(resnet.resnet50_base(weights=w0, dtype="bf16"), anchors_per_loc=A)
+    rpn.compile(train.SGD(1e-4, 0.9))
+    xs = [image(192, 256, seed=50 + i) for i in range(4)]
+    ys = [rpn_targets(rows, cols, A, seed=60 + i) for i in range(4)]
+    reserved = []
+    for it in range(60):
+        l = rpn.train_on_batch(xs[it % 4], list(ys[it % 4]), defer=bool(it & 1))
+        v = l.result() if hasattr(l, "result") else l
+        assert all(np.isfinite(v)), (it, v)
+        if it in (19, 59):
+            torch.cuda.synchronize()
+            reserved.append(torch.cuda.memory_reserved())
+    assert reserved[1] <= reserved[0], reserved
