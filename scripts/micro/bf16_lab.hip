@@ -17,7 +17,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
-struct GemmArgs { const void* A; const void* B; void* C; int M, N, K; int tiles_m, tiles_n; int skip_epilogue; };
+struct GemmArgs { const void* A; const void* B; void* C; int M, N, K; int tiles_m, tiles_n; int skip_epilogue; int persistent; };
 
 constexpr int BK = 64;                    // bf16 elements per stage = 128 B per row = eight 16-byte granules
 constexpr unsigned OOB = 0x80000000u;
@@ -41,11 +41,15 @@ __global__ void __launch_bounds__(512) k_gemm256(const GemmArgs p) {
     const int li = lane & 31, lh = lane >> 5;
     // XCD-aware tile map: consecutive workgroup ids go to different XCDs; give each XCD a contiguous run of tiles
     const int nwg = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
+    // persistent form: gridDim.x workgroups (one per CU) walk the tiles round by round; a tile's output stores are fire
+    // and forget, so they drain while the next tile's operands stream in and multiply
+    const int nround = p.persistent ? (int)gridDim.x : nwg;
+    int bid0 = blockIdx.x;
     {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+        const int q = nround / 8, r = nround % 8, xcd = bid0 % 8;
+        bid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid0 / 8;
     }
+  for (int bid = bid0; bid < nwg; bid += nround) {
     const int tm = bid / p.tiles_n, tn = bid % p.tiles_n;           // column tiles of one row tile adjacent: A rows shared in L2
     const int m0 = tm * BM, n0 = tn * TILE;
 
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(512) k_gemm256(const GemmArgs p) {
 
     // plain epilogue (lab): lane owns column li of each 32-wide tile, rows 8 (e >> 2) + 4 lh + (e & 3)
     __bf16* C = reinterpret_cast<__bf16*>(p.C);
-    if (p.skip_epilogue) { if (acc[0][0][0] == 123.456f) C[0] = (__bf16)1.0f; return; }      // (main loop + prologue only)
+    if (p.skip_epilogue) { if (acc[0][0][0] == 123.456f) C[0] = (__bf16)1.0f; continue; }      // (main loop + prologue only)
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -181,6 +185,7 @@ __global__ void __launch_bounds__(512) k_gemm256(const GemmArgs p) {
                 if (m < p.M && n < p.N) C[(size_t)m * p.N + n] = (__bf16)acc[i][j][e];
             }
         }
+  }
 #endif
 }
 
@@ -206,7 +211,8 @@ static void launch(GemmArgs a, hipStream_t s) {
     const int ldsb = 2 * (64 * TMW + 256) * BK * 2;
     a.tiles_m = (a.M + 64 * TMW - 1) / (64 * TMW);
     if (!once) { CHECK(hipFuncSetAttribute((const void*)k_gemm256<VARIANT, TMW>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb)); once = true; }
-    k_gemm256<VARIANT, TMW><<<a.tiles_m * a.tiles_n, 512, ldsb, s>>>(a);
+    const int nt = a.tiles_m * a.tiles_n;
+    k_gemm256<VARIANT, TMW><<<a.persistent && nt > 256 ? 256 : nt, 512, ldsb, s>>>(a);
 }
 
 int main(int argc, char** argv) {
@@ -221,9 +227,11 @@ int main(int argc, char** argv) {
         CHECK(hipMalloc(&A, (size_t)sh.M * sh.K * 2)); CHECK(hipMalloc(&B, (size_t)sh.N * sh.K * 2)); CHECK(hipMalloc(&C, (size_t)sh.M * sh.N * 2));
         k_fill<<<1024, 256, 0, s>>>(A, (size_t)sh.M * sh.K, 1u);
         k_fill<<<1024, 256, 0, s>>>(B, (size_t)sh.N * sh.K, 2u);
-        GemmArgs a{A, B, C, sh.M, sh.N, sh.K, (sh.M + 255) / 256, (sh.N + 255) / 256, argc > 1 && !strcmp(argv[1], "noepi") && strcmp(sh.name, "check") ? 1 : 0};
-        for (int variant = 0; variant < 4; ++variant) {           // 0, 1: 256-row tiles; 2, 3: 128-row tiles
-            auto run = [&]() { if (variant == 0) launch<0, 4>(a, s); else if (variant == 1) launch<1, 4>(a, s); else if (variant == 2) launch<0, 2>(a, s); else launch<1, 2>(a, s); };
+        GemmArgs a{A, B, C, sh.M, sh.N, sh.K, (sh.M + 255) / 256, (sh.N + 255) / 256, argc > 1 && !strcmp(argv[1], "noepi") && strcmp(sh.name, "check") ? 1 : 0, 0};
+        const bool try_persistent = argc > 1 && !strcmp(argv[1], "persistent");
+        for (int variant = 0; variant < (try_persistent ? 6 : 4); ++variant) {           // 0, 1: 256-row tiles; 2, 3: 128-row tiles; 4, 5: 0 and 2 persistent
+            a.persistent = variant >= 4;
+            auto run = [&]() { if (variant == 0 || variant == 4) launch<0, 4>(a, s); else if (variant == 1) launch<1, 4>(a, s); else if (variant == 2 || variant == 5) launch<0, 2>(a, s); else launch<1, 2>(a, s); };
             if (!strcmp(sh.name, "check")) {
                 float* R;
                 CHECK(hipMalloc(&R, (size_t)sh.M * sh.N * 4));
@@ -258,7 +266,7 @@ int main(int argc, char** argv) {
                 if (ms / 10 < best) best = ms / 10;
             }
             printf("%-18s M=%6d N=%5d K=%5d  variant %d  %9.1f us  %7.1f TFLOP/s  (%d tiles)\n", sh.name, sh.M, sh.N, sh.K, variant,
-                   best * 1e3, 2.0 * sh.M * sh.N * sh.K / (best * 1e-3) / 1e12, ((sh.M + (variant < 2 ? 255 : 127)) / (variant < 2 ? 256 : 128)) * a.tiles_n);
+                   best * 1e3, 2.0 * sh.M * sh.N * sh.K / (best * 1e-3) / 1e12, ((sh.M + ((variant < 2 || variant == 4) ? 255 : 127)) / ((variant < 2 || variant == 4) ? 256 : 128)) * a.tiles_n);
         }
         CHECK(hipFree(A)); CHECK(hipFree(B)); CHECK(hipFree(C));
     }
