@@ -4,9 +4,13 @@ ResNet-50, 600x1000 synthetic image, anchor scales 128/256/512, 300 proposals, 2
 fp32 (BASELINE.json configs[1]) on N MI355X GPUs of one node.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`;
-images shard by rank with NO data-path collective (inference has no exchange step), so the
-scaling is weak: every rank processes its own image stream.
+N > 1: one rank per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ...` (RANK / WORLD_SIZE in the
+environment) this process IS a rank; started plainly as `python bench.py --gpus N`, it starts the N ranks itself
+(fresh child processes, before this process has touched the GPU), relays rank 0's JSON line and exits non-zero if any
+rank fails.  Images shard by rank with NO data-path collective (inference has no exchange step), so the scaling is
+weak: every rank processes its own image stream.  The N > 1 line also carries `train_dp`: a few data-parallel RPN
+step-1 training steps (BASELINE configs[2], one image per GPU) whose flat gradient buffer goes through the path's
+ONE collective -- an RCCL all-reduce -- so a scaling run shows what RCCL saw and what the collective costs.
 
 A "step" = S images (--streams, default 8 on 8 hardware queues for fp32: one hipGraph + HIP stream per image in flight)
 through the whole device-resident path (backbone convs, RPN heads,
@@ -368,6 +372,109 @@ def vgg_rpn_cpu_and_parity(pipe, weights, budget_s=20.0):
     return base, par
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a rank environment: start N ranks of this same command line, one per GPU, the
+    way torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), wait for them, print
+    rank 0's JSON line.  Runs BEFORE this process makes any HIP call (torch.cuda.device_count() does not initialise the
+    runtime on this stack; a process that has must never exec or fork GPU work)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("FRCNN_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if have < n and backend != "gloo":
+        sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing (one rank per GPU over RCCL; "
+                         "FRCNN_BENCH_BACKEND=gloo lets ranks share a GPU for a functional check)\n" % (n, have))
+        sys.exit(2)
+    if have < 1:
+        sys.stderr.write("bench.py: no HIP device visible\n")
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        sys.exit(1)
+    sys.exit(0)
+
+
+def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=3):
+    """BASELINE configs[2] inside the N > 1 line: ResNet-50 RPN step-1 training steps at 600x1000, one image per GPU
+    per step (train_util.py:38-54 under data parallelism), the flat gradient buffer through the path's ONE collective
+    (dp.allreduce_sum_begin -> RCCL all-reduce over xGMI).  Every rank runs this; returns the object rank 0 prints.
+    `exposed_allreduce_ms` = step time with the collective - step time with the collective left out (same kernels)."""
+    import torch.distributed as dist
+    from faster_rcnn_amd import dp, resnet, train
+    A = len(anchors)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    seen = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(seen)                                           # what the collective library saw
+    base = resnet.resnet50_base(weights=dict(weights), weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
+    rpn = resnet.resnet50_rpn(base, anchors_per_loc=A)
+    rs = np.random.RandomState(500 + rank)
+    x = synth_image(500 + rank).astype(np.float64)                  # the managers hand float64 (Keras casts on feed)
+    rows, cols = resnet.get_conv_rows_cols(HEIGHT, WIDTH)
+    can_use = rs.rand(1, rows, cols, A) < 0.012
+    is_pos = rs.rand(1, rows, cols, A) < 0.01
+    y_class = np.concatenate([can_use, is_pos], axis=3)
+    y_bbreg = np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32),
+                              (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
+    rpn.compile(train.SGD(1e-3, 0.9))
+    params = rpn._trainer.params
+
+    def timed(fn, k, w):
+        prev = None
+        for i in range(w + k):
+            if i == w:
+                if hasattr(prev, "result"):
+                    prev.result()
+                prev = None
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+            cur = fn()
+            if hasattr(prev, "result"):
+                prev.result()                                       # losses read one step late, like train_util's loops
+            prev = cur
+        if hasattr(prev, "result"):
+            prev.result()
+        train.finish_pending_updates()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return 1e3 * float(t.item()) / k
+
+    step = lambda: rpn.train_on_batch(x, [y_class, y_bbreg], defer=True)
+    ms = timed(step, steps, warmup)
+    train.DP_SYNC = False
+    try:
+        ms_local = timed(step, steps, 1)
+    finally:
+        train.DP_SYNC = True
+    buf = torch.zeros_like(params.g)
+    ar = timed(lambda: (dp.allreduce_sum_(buf), torch.cuda.synchronize()), 10, 2)
+    return {"workload": "configs[2]: ResNet-50 RPN step-1 training, 600x1000, 1 image per GPU per step, SGD momentum, l2 1e-4, fp32, synthetic",
+            "ranks_seen": int(seen.item()), "backend": dist.get_backend(), "steps": steps,
+            "ms_per_step": round(ms, 3), "img_s": round(world * 1e3 / ms, 2),
+            "grad_payload_MB": round(params.total * 4 / 1e6, 1), "collectives_per_step": 1,
+            "allreduce_ms": round(ar, 3), "ms_per_step_without_allreduce": round(ms_local, 3),
+            "exposed_allreduce_ms": round(max(ms - ms_local, 0.0), 3),
+            "overlap": "the all-reduce starts behind the last weight-gradient batch; optimiser + re-pack wait for it, the next image's "
+                       "host staging, upload and frozen stages (stem..res3) run beside it"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,7 +495,10 @@ def main():
                     help="skip the second, I/O-inclusive timing (fresh uint8 images from pinned host memory in, detections out)")
     ap.add_argument("--streams", type=int, default=0,
                     help="images in flight per GPU (one hipGraph + HIP stream each); default: 8 for the fp32 config, 4 for bf16")
+    ap.add_argument("--no-train-dp", action="store_true", help="N > 1: leave the data-parallel training steps (`train_dp`) out of the line")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                      # does not return
     global HOIST, DTYPE, WORKLOAD
     select_config(args.config)
     if args.streams <= 0:
@@ -529,6 +639,13 @@ def main():
             pl._graph.replay()
         torch.cuda.synchronize()
 
+    train_dp = None
+    if dist is not None and args.config == "c2" and not args.no_train_dp:
+        try:
+            train_dp = train_dp_leg(weights, anchors, rank, world)
+        except Exception as e:                              # (a rank that fails here fails the collective for all: report, do not hang)
+            train_dp = {"error": "%s: %s" % (type(e).__name__, e)}
+
     out = pipe._static_out if not args.no_graph else pipe.forward_dev(x)
     n_rois = int(out["n_rois"].item()) if "n_rois" in out else None
     n_dets = int(out["n_dets"].item()) if "n_dets" in out else None
@@ -558,6 +675,8 @@ def main():
         }
         if io is not None:
             line["with_host_io"] = io
+        if train_dp is not None:
+            line["train_dp"] = train_dp
         if roof is None:
             line["roofline"] = {"bound": "mfma", "error": roof_error}
         if roof is not None and HOIST and DEPTH != 16:   # what the same image costs in the reference's layer order (res5a_branch2a / branch1 on every crop)

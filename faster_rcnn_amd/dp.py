@@ -50,6 +50,16 @@ def allreduce_sum_(flat):
     return 1.0 / w
 
 
+def allreduce_sum_begin(flat):
+    """Start the in-place sum over ranks of the flat gradient buffer without waiting for it: returns
+    (handle, 1/world scale).  ``handle.wait()`` orders the CURRENT stream behind the collective (RCCL: stream-wise, the
+    host does not block; gloo: the host blocks until the exchange has happened).  world == 1: (None, 1.0)."""
+    w = world()
+    if w == 1:
+        return None, 1.0
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), 1.0 / w
+
+
 def broadcast_(flat, src=0):
     """Identical initial weights on every rank."""
     if world() > 1:

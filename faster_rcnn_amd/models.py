@@ -64,11 +64,12 @@ class _Model:
             raise ValueError("No such layer: " + name)
         return _Layer(self.weights, name)
 
-    def invalidate(self):
-        """Re-lower (re-pack / re-fold) after weights changed."""
+    def invalidate(self, only=None):
+        """Re-lower (re-pack / re-fold) after weights changed; ``only``: the conv layer names that changed."""
         for m in self._modules():
             for u in m.units():
-                u.pc = None
+                if only is None or u.conv in only:
+                    u.pc = None
 
     def load_weights(self, path, by_name=False):
         """Keras ``load_weights``: ``path`` is a Keras 2.0.x .h5 (weights or full model) or this package's .npz."""

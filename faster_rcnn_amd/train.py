@@ -295,10 +295,16 @@ class TBlock:
         return self.c2a.dgrad(g1, residual=tmp, mask=mask)
 
 
-def _sync_grads(params):
-    """Data-parallel exchange: ONE all-reduce (sum) of the flat gradient buffer over RCCL."""
+DP_SYNC = True          # False: leave the collective out of the step (bench.py / bench_train.py measure what it costs that way)
+
+
+def _sync_grads_begin(params):
+    """Data-parallel exchange: ONE all-reduce (sum) of the flat gradient buffer over RCCL, STARTED here (behind the last
+    weight-gradient batch on the current stream) and not waited for.  Returns (handle or None, 1/world scale)."""
     from . import dp
-    return dp.allreduce_sum_(params.g)
+    if not DP_SYNC:
+        return None, 1.0
+    return dp.allreduce_sum_begin(params.g)
 
 
 def _l2_of(weights, names):
@@ -462,11 +468,34 @@ class _StepDriver:
     Removed again: DESIGN 11.)"""
 
     def _init_driver(self):
-        self._pinned = {}           # input-shape key -> [two sets of pinned float32 staging buffers, upload events, toggle]
+        self._pin_sets = [_PinnedSet(), _PinnedSet()]   # two grow-only pinned staging areas, used alternately
+        self._pin_next = 0
         self._conv_ws = ops.ConvWorkspace()
         self._conv_ws_prefix = ops.ConvWorkspace()   # split-K tickets of the launches on the prefix stream
         self._loss_ring = [None] * LOSS_RING          # steps whose three scalars are still on their way to the host
         self._loss_pos = 0
+        self._pending_update = None                   # (all-reduce handle, 1/world, optimiser) of a step whose update is not enqueued yet
+        _LIVE_DRIVERS.add(self)
+        self._lower_frozen()
+
+    def _frozen_units(self):
+        """ConvUnits the prefix stream runs (stem + frozen stages of the base): they read no trainable weight."""
+        base = getattr(self, "base", None)
+        if base is None:
+            return []
+        if hasattr(base, "frozen_blocks"):
+            return [base.stem] + [u for units in base.frozen_blocks for u in units.values()]
+        return [layer for _, layer, trainable in base.layers if not trainable]
+
+    def _lower_frozen(self):
+        """Pack the frozen layers' filters NOW, on the stream the trainer is built on, and mark the point with an event
+        the prefix stream waits for: a lazy lowering at first use would run on the prefix stream, unordered against
+        main-stream readers of the same packed filters (predict) and allocated in that stream's pool."""
+        for u in self._frozen_units():
+            if u.pc is None:
+                u.lower()
+        self._frozen_ready = torch.cuda.Event()
+        self._frozen_ready.record()
 
     def _publish_losses(self):
         """Called by ``_device_step`` as soon as the two loss kernels are enqueued (and by a skipped step at once): the L2
@@ -485,34 +514,52 @@ class _StepDriver:
         out3.record_stream(side)
 
     def _update(self, sq_out=None):
-        """After the backward pass: the ONE exchange of the flat gradient buffer, optimiser, re-pack."""
-        p = self.params
+        """After the backward pass: the ONE exchange of the flat gradient buffer, optimiser, re-pack.
+
+        world == 1: optimiser and re-pack are enqueued at once.  world > 1: the all-reduce is only STARTED (on the
+        collective's own stream, behind this step's last gradient kernel) and the optimiser is left pending:
+        ``_finish_update`` enqueues it behind the collective the next time anything needs the new weights -- the next
+        step, after that step has staged its image and put upload + frozen stages on the prefix stream (so host staging
+        and those launches run BESIDE the collective instead of behind it), or any read-out of the weights
+        (sync_weights / compile).  Same kernels in the same order per tensor: bit-identical to the serial form."""
         flush_weight_grads()
-        scale = _sync_grads(p)
-        p.step(self.optimizer, self.l2, scale)
+        handle, scale = _sync_grads_begin(self.params)
+        if handle is None:
+            self._apply_update(scale)
+        else:
+            self._pending_update = (handle, scale, self.optimizer)
+
+    def _finish_update(self):
+        """Wait (stream-wise on RCCL; gloo also blocks the host) for the pending all-reduce, then optimiser + re-pack."""
+        if self._pending_update is not None:
+            (handle, scale, opt), self._pending_update = self._pending_update, None
+            handle.wait()
+            with ops.conv_workspace(self._conv_ws):
+                self._apply_update(scale, opt)
+
+    def _apply_update(self, scale, opt=None):
+        p = self.params
+        p.step(opt or self.optimizer, self.l2, scale)
         if self._refresh_jobs is None:
             self._refresh_jobs = make_refresh_jobs(self._tconvs())
         refresh_packed(self._refresh_jobs)
 
-    def _stage(self, key, host_inputs):
-        """Host arrays (any dtype: Keras hands float64 images and bool targets) -> this shape's pinned float32 staging
-        buffers in ONE pass (the cast happens while writing into pinned memory), ready for an asynchronous upload;
-        a separate astype + pageable copy of a 600x1000 image costs ~1 ms per step with the GPU idle.  Two sets per
-        shape, used alternately, each guarded by the event of its last upload: a deferred step (``defer=True``) lets
-        the host stage the NEXT image while this one's step is still running."""
-        ent = self._pinned.get(key)
-        if ent is None:
-            if len(self._pinned) >= 8:
-                self._pinned.clear()
-            ent = self._pinned[key] = {"sets": [[torch.empty(shape, dtype=torch.float32).pin_memory() for _, shape in host_inputs] for _ in range(2)],
-                                       "uploaded": [None, None], "next": 0}
-        k = ent["next"]
-        ent["next"] = k ^ 1
-        if ent["uploaded"][k] is not None:
-            ent["uploaded"][k].synchronize()
-        for pin, (a, shape) in zip(ent["sets"][k], host_inputs):
-            np.copyto(pin.numpy(), np.asarray(a).reshape(shape), casting="unsafe")
-        return ent, k
+    def _stage(self, host_inputs):
+        """Host arrays (any dtype: Keras hands float64 images and bool targets) -> pinned float32 staging memory in ONE
+        pass (the cast happens while writing into pinned memory; the image's cast is cut into row bands over a few
+        threads -- numpy releases the GIL inside the cast loop -- because one core converts a float64 600x1000 image in
+        ~1.1 ms, more than the GPU part of a mixed-precision RPN step leaves to hide it), ready for an asynchronous
+        upload.  Two staging areas used alternately, each guarded by the event of its last upload: a deferred step
+        (``defer=True``) lets the host stage the NEXT image while this one's step is still running.  The areas are
+        flat and grow-only, sized by the largest request so far: real VOC / KITTI training walks through hundreds of
+        image shapes, and a per-shape cache would pin (and never return) a fresh 7 MB block for most of them."""
+        k = self._pin_next
+        self._pin_next = k ^ 1
+        pset = self._pin_sets[k]
+        views = pset.views([shape for _, shape in host_inputs])
+        for pin, (a, shape) in zip(views, host_inputs):
+            _cast_into(pin.numpy(), np.asarray(a).reshape(shape))
+        return pset, views
 
     def _run_step(self, host_inputs, skip, defer=False):
         """host_inputs: list of (array, device shape); the arrays may have any dtype (cast to float32 on the way).
@@ -528,35 +575,96 @@ class _StepDriver:
             slot[2]().result()                          # the ring wrapped around an unread step: read it before its slot is reused
         self._loss_pos = (self._loss_pos + 1) % LOSS_RING
         self._cur = (out3, slot)
-        if skip:
-            with ops.conv_workspace(self._conv_ws):
-                self.params.g.zero_()
-                self._publish_losses()
-                self._update()
-        else:
-            # Upload and the FROZEN leading part of the base (stem .. last frozen stage: it reads no trainable weight) go
-            # to a second stream.  When the caller defers its steps the host is a step ahead, so this part of image i+1
-            # runs beside the backward pass of image i, whose short dependent launches leave most of the chip idle; the
-            # main stream joins before the first trainable layer.  Same kernels, same order per tensor: bit-identical.
-            ent, k = self._stage(tuple(shape for _, shape in host_inputs), host_inputs)
-            main, side = torch.cuda.current_stream(), _prefix_stream()
-            with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws_prefix):
-                dev = [p.to("cuda", non_blocking=True) for p in ent["sets"][k]]
-                ev = ent["uploaded"][k] = ent["uploaded"][k] or torch.cuda.Event()
-                ev.record()
-                pre = self._frozen_prefix(dev)
-            main.wait_stream(side)
-            for t in dev + ([pre] if pre is not None else []):
-                t.record_stream(main)                   # allocated on the side stream, read (and released) under the main one
-            with ops.conv_workspace(self._conv_ws):
-                self._device_step(dev, out, pre)
-        self._cur = None
+        try:
+            if skip:
+                self._finish_update()
+                with ops.conv_workspace(self._conv_ws):
+                    self.params.g.zero_()
+                    self._publish_losses()
+                    self._update()
+            else:
+                # Upload and the FROZEN leading part of the base (stem .. last frozen stage: it reads no trainable weight) go
+                # to a second stream.  When the caller defers its steps the host is a step ahead, so this part of image i+1
+                # runs beside the backward pass of image i, whose short dependent launches leave most of the chip idle -- and,
+                # data parallel, beside image i's all-reduce, whose optimiser is enqueued only now (_finish_update); the
+                # main stream joins before the first trainable layer.  Same kernels, same order per tensor: bit-identical.
+                pset, views = self._stage(host_inputs)
+                main, side = torch.cuda.current_stream(), _prefix_stream()
+                side.wait_event(self._frozen_ready)         # the frozen layers' packed filters (lowered on the build stream)
+                with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws_prefix):
+                    dev = [p.to("cuda", non_blocking=True) for p in views]
+                    pset.mark_uploaded()
+                    pre = self._frozen_prefix(dev)
+                self._finish_update()
+                main.wait_stream(side)
+                for t in dev + ([pre] if pre is not None else []):
+                    t.record_stream(main)                   # allocated on the side stream, read (and released) under the main one
+                with ops.conv_workspace(self._conv_ws):
+                    self._device_step(dev, out, pre)
+        finally:
+            # a step that died half way (OOM, FrcnnError) must not leave its queued weight-gradient jobs to the next
+            # step -- possibly another model's -- to launch into this step's buffers
+            _PENDING_WGRAD.clear()
+            _PENDING_BIAS.clear()
+            self._cur = None
         pending = PendingLosses(slot[0], slot[1], self.l2, self.frozen_sumsq)
         slot[2] = weakref.ref(pending)
         return pending if defer else pending.result()
 
 
+class _PinnedSet:
+    """One flat, grow-only pinned float32 staging area; ``views(shapes)`` hands out one view per input."""
+
+    def __init__(self):
+        self.buf, self.uploaded = None, None
+
+    def views(self, shapes):
+        sizes = [int(np.prod(s)) for s in shapes]
+        offs = np.cumsum([0] + [-(-n // 64) * 64 for n in sizes])       # 256-byte aligned pieces
+        if self.uploaded is not None:
+            self.uploaded.synchronize()                 # the last upload out of this area has left
+        if self.buf is None or self.buf.numel() < int(offs[-1]):
+            self.buf = torch.empty(int(offs[-1] * 1.25) + 64, dtype=torch.float32).pin_memory()
+        return [self.buf[int(o):int(o) + n].view(*s) for o, n, s in zip(offs, sizes, shapes)]
+
+    def mark_uploaded(self):
+        if self.uploaded is None:
+            self.uploaded = torch.cuda.Event()
+        self.uploaded.record()
+
+
+_CAST_POOL = None
+CAST_THREADS = int(__import__("os").environ.get("FRCNN_CAST_THREADS", "4"))
+
+
+def _cast_into(dst, src):
+    """dst[...] = src cast to float32 (numpy 'unsafe' casting: bool / float64 / int inputs).  Large arrays go over a
+    small thread pool in contiguous bands of the leading non-unit axis."""
+    global _CAST_POOL
+    if src.size < (1 << 18) or CAST_THREADS <= 1:
+        np.copyto(dst, src, casting="unsafe")
+        return
+    if _CAST_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _CAST_POOL = ThreadPoolExecutor(CAST_THREADS)
+    d2, s2 = dst.reshape(-1, dst.shape[-1]), src.reshape(-1, src.shape[-1])
+    rows = d2.shape[0]
+    step = -(-rows // CAST_THREADS)
+    futs = [_CAST_POOL.submit(np.copyto, d2[i:i + step], s2[i:i + step], "unsafe") for i in range(0, rows, step)]
+    for f in futs:
+        f.result()
+
+
 LOSS_RING = 8
+_LIVE_DRIVERS = weakref.WeakSet()
+
+
+def finish_pending_updates():
+    """Enqueue the optimiser of every trainer whose data-parallel all-reduce is still pending (timing loops call this
+    before their final synchronisation so the last step's update is inside the timed region)."""
+    for d in list(_LIVE_DRIVERS):
+        d._finish_update()
+
 _PREFIX_STREAM = None
 _LOSS_STREAM = None
 
@@ -630,6 +738,7 @@ class RpnTrainer(_StepDriver):
         self._init_driver()
 
     def compile(self, optimizer, loss=None):
+        self._finish_update()                   # a pending data-parallel update belongs to the old slots
         self.optimizer = optimizer
         self.params.reset_optimizer()
 
@@ -679,9 +788,11 @@ class RpnTrainer(_StepDriver):
         self._update()
 
     def sync_weights(self):
-        """Write the trained master weights back into the model's Keras-keyed weight dict."""
+        """Write the trained master weights back into the model's Keras-keyed weight dict.  Only the layers that train
+        are re-lowered: the frozen layers' packed filters stay (the prefix stream may be reading them)."""
+        self._finish_update()
         self.params.export(self.model.weights)
-        self.model.invalidate()
+        self.model.invalidate(only=set(self.params.names))
 
 
 # ----------------------------------------------------------------------------- detector steps 2 and 4
@@ -777,6 +888,7 @@ class DetTrainer(_StepDriver):
         self._init_driver()
 
     def compile(self, optimizer, loss=None):
+        self._finish_update()                   # a pending data-parallel update belongs to the old slots
         self.optimizer = optimizer
         self.params.reset_optimizer()
 
@@ -830,11 +942,12 @@ class DetTrainer(_StepDriver):
         self._update()
 
     def sync_weights(self):
+        self._finish_update()
         w = self.model.weights
         self.params.export(w)                                    # per-layer entries (+ the merged "dense")
         dense = w.pop("dense")
         C = self.C
         w["dense_class_%d" % C] = [dense[0][:, :C].copy(), dense[1][:C].copy()]
         w["dense_reg_%d" % C] = [dense[0][:, C:].copy(), dense[1][C:].copy()]
-        self.model.invalidate()
+        self.model.invalidate(only=set(self.params.names))
         self.model.head.dense = nets._MergedDense(w, C)

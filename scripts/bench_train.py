@@ -53,6 +53,7 @@ def timed(fn, steps, warmup):
         prev = cur
     if hasattr(prev, "result"):
         prev.result()
+    train.finish_pending_updates()
     torch.cuda.synchronize()
     if dp.world() > 1:
         torch.distributed.barrier()
@@ -99,7 +100,7 @@ def main():
            "workload": "ResNet-50 600x1000, 1 image per GPU per step, SGD momentum 0.9, l2 1e-4, synthetic data",
            "losses_read": "after every step" if args.sync_each_step else "one step late (train_util's loops), all inside the timed region"}
 
-    def report(tag, ms, params, ms_sync=None):
+    def report(tag, ms, params, ms_sync=None, step=None):
         ar = allreduce_ms(params)
         tf = GFLOP[tag] * world / ms                   # GFLOP / ms = TFLOP/s, whole job
         out[tag] = {"ms_per_step": round(ms, 3), "img_s": round(world * 1e3 / ms, 2), "grad_payload_MB": round(params.total * 4 / 1e6, 1),
@@ -108,6 +109,16 @@ def main():
                                  "frac": round(tf / world / PEAK[DT], 4), "gflop_per_step": round(GFLOP[tag], 1)}}
         if ms_sync is not None:
             out[tag]["ms_per_step_losses_read_every_step"] = round(ms_sync, 3)
+        if world > 1 and step is not None:
+            # the same steps with the collective left out: what the all-reduce adds to a step once the next image's host
+            # staging, upload and frozen stages run beside it (train._StepDriver._update / _finish_update)
+            train.DP_SYNC = False
+            try:
+                ms_local = timed(step, args.steps, 1)
+            finally:
+                train.DP_SYNC = True
+            out[tag]["ms_per_step_without_allreduce"] = round(ms_local, 3)
+            out[tag]["exposed_allreduce_ms"] = round(max(ms - ms_local, 0.0), 3)
 
     if args.only in (None, "rpn"):
         w = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=1)
@@ -119,9 +130,10 @@ def main():
         y_bbreg = np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32),
                                   (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
         rpn.compile(train.SGD(1e-3, 0.9))
-        ms = timed(lambda: rpn.train_on_batch(x, [y_class, y_bbreg], defer=not args.sync_each_step), args.steps, args.warmup)
+        step = lambda: rpn.train_on_batch(x, [y_class, y_bbreg], defer=not args.sync_each_step)
+        ms = timed(step, args.steps, args.warmup)
         ms_sync = None if args.sync_each_step else timed(lambda: rpn.train_on_batch(x, [y_class, y_bbreg]), args.steps, 2)
-        report("rpn_step1", ms, rpn._trainer.params, ms_sync)
+        report("rpn_step1", ms, rpn._trainer.params, ms_sync, step)
         del rpn, base
     if args.only in (None, "det"):
         dw = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=2)
@@ -142,9 +154,10 @@ def main():
                 tg[i, 4 * c:4 * c + 4] = rs.randn(4)
         yb = np.concatenate([lab, tg], axis=1)[None]
         det.compile(train.SGD(1e-3, 0.9))
-        ms = timed(lambda: det.train_on_batch([x, rois], [yc, yb], defer=not args.sync_each_step), args.steps, args.warmup)
+        step = lambda: det.train_on_batch([x, rois], [yc, yb], defer=not args.sync_each_step)
+        ms = timed(step, args.steps, args.warmup)
         ms_sync = None if args.sync_each_step else timed(lambda: det.train_on_batch([x, rois], [yc, yb]), args.steps, 2)
-        report("det_step2", ms, det._trainer.params, ms_sync)
+        report("det_step2", ms, det._trainer.params, ms_sync, step)
     # flat keys kept for the round-1 readers of this line
     for tag, short in (("rpn_step1", "rpn_step1"), ("det_step2", "det_step2")):
         if tag in out:

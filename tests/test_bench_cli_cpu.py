@@ -1,0 +1,34 @@
+"""bench.py's launcher half, which runs before any GPU call and therefore here: `--gpus N` without a rank environment
+must start N ranks, and must REFUSE (exit code != 0, a message that says why) when fewer than N devices are visible
+instead of quietly measuring one GPU and printing n_gpus: 1."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FRCNN_BENCH_BACKEND")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_gpus_flag_refuses_without_enough_devices():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two devices visible: the refusal path needs fewer")
+    r = _run({})
+    assert r.returncode == 2 and "refusing" in r.stderr and "--gpus 2" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert "{" not in r.stdout                       # no JSON line that could be mistaken for a measurement
+
+
+def test_gpus_flag_gloo_still_needs_a_device():
+    import torch
+    if torch.cuda.device_count() >= 1:
+        import pytest
+        pytest.skip("a device is visible")
+    r = _run({"FRCNN_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 2 and "no HIP device" in r.stderr

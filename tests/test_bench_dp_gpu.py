@@ -87,3 +87,28 @@ def test_bench_train_two_ranks_on_one_gpu():
     assert r["allreduce_ms"] > 0 and 0 < r["allreduce_share"] < 10
     assert r["roofline"]["gflop_per_step"] > 200 and 0 < r["roofline"]["frac"] < 1
     assert abs(r["img_s"] - 2 * 1e3 / r["ms_per_step"]) < 0.02 * r["img_s"]
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with NO rank environment (how a plain driver command line reads): bench.py starts the
+    two ranks itself -- here both on the one GPU over gloo -- relays ONE line with n_gpus 2, and that line carries the
+    data-parallel training steps whose gradient went through the collective on both ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FRCNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "2", "--no-cpu-baseline", "--no-io"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "replicas x2" in line["config"]["parallelism"]
+    assert abs(line["value"] - 2 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
+    t = line["train_dp"]
+    assert "error" not in t, t
+    assert t["ranks_seen"] == 2 and t["backend"] == "gloo" and t["collectives_per_step"] == 1
+    assert abs(t["grad_payload_MB"] - 47.3) < 0.2
+    assert t["allreduce_ms"] > 0 and t["exposed_allreduce_ms"] >= 0 and t["ms_per_step"] >= t["ms_per_step_without_allreduce"] * 0.9
+    assert abs(t["img_s"] - 2 * 1e3 / t["ms_per_step"]) < 0.02 * t["img_s"]
+    # --gpus 1 stays a plain single-process run: no train_dp object
+    one = _launch(["bench.py", "--steps", "2", "--warmup", "1", "--streams", "2", "--no-cpu-baseline", "--no-io", "--gpus", "1"], 1)
+    assert one["n_gpus"] == 1 and "train_dp" not in one
