@@ -113,6 +113,8 @@ def test_config2_rpn_step1_600x1000_training_step_fp32():
     names = kt.conv_layer_names(50, [4]) + ["rpn_conv1", "rpn_out_cls", "rpn_out_bbreg"]
     stats = _update_stats(w0, {n: rpn.get_layer(n).get_weights() for n in names}, ref_w, names)
     worst = max(stats.items(), key=lambda kv: kv[1][0])
+    worst_m = max(stats.items(), key=lambda kv: kv[1][1]); worst_c = min(stats.items(), key=lambda kv: kv[1][2])
+    print("config2 fp32 step: losses", losses, ref_losses, "worst fro", worst, "worst max", worst_m, "worst cos", worst_c)
     # f32 gradient sums over 2 394 pixels x up to 9 taps vs f64; a ReLU pre-activation within rounding of 0 may take the other
     # branch (tests/test_train_gpu.py check_updates): Frobenius 3e-2 / max 0.2 are the bars of the reduced-size tests
     assert worst[1][0] < 3e-2 and max(v[1] for v in stats.values()) < 0.2, worst

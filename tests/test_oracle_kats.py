@@ -258,6 +258,114 @@ def test_product_host_preprocess_is_bgr_minus_mean():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# 7. Kernel ORIENTATION (the all-ones kernels above cannot tell a convolution from a cross-correlation, a
+#    transposed (r, t) or swapped (in, out) axes).  Keras Conv2D with a (kh, kw, in, out) kernel -> tf.nn.conv2d (NHWC,
+#    HWIO) is a CROSS-CORRELATION: y[h, w, o] = sum_{r,t,i} x[h*s + r - p, w*s + t - q, i] * k[r, t, i, o]
+#    (resnet.py:150, 229, 408; vgg.py:96).  Asymmetric everything: 5x6 input with 2 channels, 3x3x2x2 kernel with 36
+#    distinct entries, stride 2 SAME -> rows pad (1, 1), columns pad (0, 1) (pad_along 2 and 1), output 3x3x2.
+#        x[h, w, i]    = 1 + 12 h + 2 w + i                                (1 .. 60)
+#        k[r, t, i, 0] = 1 + 2 ((3 r + t) 2 + i)                          (odd numbers 1 .. 35)
+#        k[r, t, i, 1] = -(2 + 2 ((3 r + t) 2 + i)),  except k[1, 2, 0, 1] = 7
+#    y[0, 0, 0] worked by hand: rows -1, 0, 1 -> taps r = 1, 2 on image rows 0, 1; columns 0, 1, 2 -> t = 0, 1, 2:
+#        r=1: (1, 2).(13, 15) + (3, 4).(17, 19) + (5, 6).(21, 23) = 43 + 127 + 243
+#        r=2: (13, 14).(25, 27) + (15, 16).(29, 31) + (17, 18).(33, 35) = 703 + 931 + 1191        sum = 3238
+#    The other 17 literals come from the same formula evaluated with explicit Python loops (below, not the code under test).
+#    What the plausible WRONG orientations give at y[0, 0] / y[1, 1]:
+#        true                      [3238, -3207] / [12039, -11649]
+#        kernel flipped (true convolution)      [878, -963] / [8391, -8117]
+#        (r, t) transposed                      [2622, -2301] / [11079, -10399]
+#        (in, out) swapped                      [-24, -210] / [545, -459]
+#        column padding (1, 0) instead of (0, 1)  y[0, 0] = [2076, -2057]
+ORIENT_WANT = [[[3238, -3207], [4390, -4291], [3212, -3344]],
+               [[10743, -10397], [12039, -11649], [7806, -8220]],
+               [[7054, -6063], [7630, -6571], [4508, -4928]]]
+ORIENT_WRONG = {"flipped": ([878, -963], [8391, -8117]), "rt_transposed": ([2622, -2301], [11079, -10399]),
+                "io_swapped": ([-24, -210], [545, -459])}
+
+
+def _orient_case():
+    x = np.zeros((5, 6, 2), np.float32)
+    k = np.zeros((3, 3, 2, 2), np.float32)
+    for h in range(5):
+        for w in range(6):
+            for i in range(2):
+                x[h, w, i] = 1 + 12 * h + 2 * w + i
+    for r in range(3):
+        for t in range(3):
+            for i in range(2):
+                k[r, t, i, 0] = 1 + 2 * ((3 * r + t) * 2 + i)
+                k[r, t, i, 1] = -(2 + 2 * ((3 * r + t) * 2 + i))
+    k[1, 2, 0, 1] = 7
+    return x, k
+
+
+def _xcorr_loops(x, k, stride, pad_top, pad_left, ho, wo):
+    y = np.zeros((ho, wo, k.shape[3]), np.float64)
+    for h in range(ho):
+        for w in range(wo):
+            for o in range(k.shape[3]):
+                for r in range(k.shape[0]):
+                    for t in range(k.shape[1]):
+                        hh, ww = h * stride + r - pad_top, w * stride + t - pad_left
+                        if 0 <= hh < x.shape[0] and 0 <= ww < x.shape[1]:
+                            y[h, w, o] += float(np.dot(x[hh, ww].astype(np.float64), k[r, t, :, o].astype(np.float64)))
+    return y
+
+
+def test_oracle_conv_orientation_asymmetric_kernel():
+    x, k = _orient_case()
+    want = np.array(ORIENT_WANT, np.float64)
+    assert want[0, 0, 0] == 43 + 127 + 243 + 703 + 931 + 1191                    # the element worked out above
+    assert np.array_equal(_xcorr_loops(x, k, 2, 1, 0, 3, 3), want)              # the literals follow the stated formula
+    y = np.asarray(kr.conv2d(x[None], k, None, 2, "same", torch.float64))[0]
+    assert np.array_equal(y, want)
+    # and each wrong orientation is a DIFFERENT answer on this case (so agreement above means something)
+    for name, kk in (("flipped", k[::-1, ::-1]), ("rt_transposed", k.transpose(1, 0, 2, 3)), ("io_swapped", k.transpose(0, 1, 3, 2))):
+        bad = _xcorr_loops(x, np.ascontiguousarray(kk), 2, 1, 0, 3, 3)
+        assert bad[0, 0].tolist() == ORIENT_WRONG[name][0] and bad[1, 1].tolist() == ORIENT_WRONG[name][1]
+        assert not np.array_equal(bad, want)
+
+
+# 8. Dense after the VGG head's Flatten (vgg.py:233-247: TimeDistributed(Flatten()) on the (7, 7, C) crop, channels last
+#    -> flat index j = (h*7 + w)*C + c, then Dense kernels are (in, out): y = x @ K + b).  A 7x7 RoI makes RoiResizeConv
+#    the identity (scale 1), so crop[h, w, c] = feat[y1 + h, x1 + w, c] with feat[y, x, c] = 100 y + 10 x + c, roi
+#    (x1, y1, x2, y2) = (2, 1, 9, 8): crop[h, w, c] = 100 (1 + h) + 10 (2 + w) + c.  fc1 column 0 is one-hot at
+#    (h, w, c) = (2, 5, 1) -> j = 77 -> 371; column 1 at (6, 0, 3) -> j = 171 -> 723.
+#    A channels-first flatten (j = c*49 + h*7 + w) would read crop[4, 0, 1] = 521 and crop[3, 3, 3] = 453; a (w, h)
+#    transposed one crop[5, 2, 1] = 641; a Dense kernel used as (out, in) does not even have the right shape.
+#    fc2 = identity on the first two features; dense_reg_2 = [x0, x1, x0 - x1, 2 x0]; dense_class_2 logits = x / 128.
+FLAT_REG_WANT = [371.0, 723.0, -352.0, 742.0]
+
+
+def _flatten_case():
+    C = 4
+    feat = np.zeros((1, 9, 10, C), np.float32)
+    for y in range(9):
+        for xx in range(10):
+            for c in range(C):
+                feat[0, y, xx, c] = 100 * y + 10 * xx + c
+    rois = np.array([[2, 1, 9, 8]], np.float32)
+    fc1 = np.zeros((49 * C, 4), np.float32)
+    fc1[(2 * 7 + 5) * C + 1, 0] = 1.0
+    fc1[(6 * 7 + 0) * C + 3, 1] = 1.0
+    fc2 = np.zeros((4, 4), np.float32)
+    fc2[0, 0] = fc2[1, 1] = 1.0
+    kreg = np.array([[1, 0, 1, 2], [0, 1, -1, 0], [0, 0, 0, 0], [0, 0, 0, 0]], np.float32)
+    kcls = np.array([[1 / 128, 0], [0, 1 / 128], [0, 0], [0, 0]], np.float32)      # exact in f32
+    z = lambda n: np.zeros(n, np.float32)
+    w = {"fc1": [fc1, z(4)], "fc2": [fc2, z(4)], "dense_class_2": [kcls, z(2)], "dense_reg_2": [kreg, z(4)]}
+    p1 = 1.0 / (1.0 + math.exp((371 - 723) / 128))
+    return feat, rois, w, [1.0 - p1, p1]
+
+
+def test_oracle_dense_after_hwc_flatten():
+    feat, rois, w, cls_want = _flatten_case()
+    cls, reg = kr.KerasGraphs(w, torch.float64).vgg_classifier(torch.as_tensor(feat), rois, 2)
+    assert np.array_equal(np.asarray(reg)[0], FLAT_REG_WANT)
+    assert np.abs(np.asarray(cls)[0] - cls_want).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # GPU twins: the same hand-derived answers through the C ABI.
 gpu = pytest.mark.gpu
 
@@ -413,3 +521,39 @@ def test_gpu_optimiser_known_answers():
     d4b, _, _ = _adam_update(gv, lr, 4, m3, v3)
     assert opt.iterations == 4
     assert abs(float(ps.w[0]) - (1 + d1 + d2 + d3b + d4b)) < 4e-7
+
+
+@gpu
+def test_gpu_conv_orientation_asymmetric_kernel():
+    """The hand-derived orientation vectors through frcnn_pack_conv_weights + frcnn_conv2d_fwd: once on the 2-channel
+    shape itself (per-element k decode) and once embedded in 32 input / 4 output channels (the MFMA main loop with its
+    [channel chunk][tap][32 channels] filter packing), the unused input channels carrying non-zero data under zero weights."""
+    from faster_rcnn_amd import ops
+    x, k = _orient_case()
+    want = np.array(ORIENT_WANT, np.float32)
+    y = ops.conv2d(torch.from_numpy(x[None]).cuda(), ops.PackedConv(k), 2, "same").cpu().numpy()[0]
+    assert np.array_equal(y, want)
+    x32 = np.full((1, 5, 6, 32), 7.0, np.float32)
+    x32[0, :, :, 5], x32[0, :, :, 20] = x[:, :, 0], x[:, :, 1]
+    k32 = np.zeros((3, 3, 32, 4), np.float32)
+    k32[:, :, 5, 1], k32[:, :, 20, 1] = k[:, :, 0, 0], k[:, :, 1, 0]
+    k32[:, :, 5, 3], k32[:, :, 20, 3] = k[:, :, 0, 1], k[:, :, 1, 1]
+    y = ops.conv2d(torch.from_numpy(x32).cuda(), ops.PackedConv(k32), 2, "same").cpu().numpy()[0]
+    assert np.array_equal(y[:, :, 1], want[:, :, 0]) and np.array_equal(y[:, :, 3], want[:, :, 1]) and not y[:, :, (0, 2)].any()
+    # the bf16 engine (64-channel chunks): small integers are exact in bf16 operands with f32 accumulation
+    x64 = np.full((1, 5, 6, 64), 3.0, np.float32)
+    x64[0, :, :, 9], x64[0, :, :, 40] = x[:, :, 0], x[:, :, 1]
+    k64 = np.zeros((3, 3, 64, 64), np.float32)
+    k64[:, :, 9, 2], k64[:, :, 40, 2] = k[:, :, 0, 0], k[:, :, 1, 0]
+    k64[:, :, 9, 33], k64[:, :, 40, 33] = k[:, :, 0, 1], k[:, :, 1, 1]
+    yb = ops.conv2d_bf16(torch.from_numpy(x64).cuda().to(torch.bfloat16), ops.PackedConvBf16(k64), 2, "same", out_f32=True).cpu().numpy()[0]
+    assert np.array_equal(yb[:, :, 2], want[:, :, 0]) and np.array_equal(yb[:, :, 33], want[:, :, 1])
+
+
+@gpu
+def test_gpu_dense_after_hwc_flatten():
+    from faster_rcnn_amd import nets
+    feat, rois, w, cls_want = _flatten_case()
+    cls, reg = nets.VggHead(w, 2)(torch.from_numpy(feat).cuda(), torch.from_numpy(rois).cuda())
+    assert np.array_equal(reg.cpu().numpy()[0], FLAT_REG_WANT)
+    assert np.abs(cls.cpu().numpy()[0].astype(np.float64) - cls_want).max() < 1e-6

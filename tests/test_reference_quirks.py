@@ -218,3 +218,26 @@ def test_training_loop_prints_the_reference_lines_in_order_with_deferred_losses(
     # iteration 1's losses are read only after iteration 2 has been enqueued; a save reads its own iteration first
     ev = m.events
     assert ev.index(("enqueue", 2)) < ev.index(("read", 1)) and ev.index(("read", 2)) < ev.index(("save", 2))
+
+
+def test_jpeg_decode_is_stable_and_recorded():
+    """f2 leftover: ``shapes.Image.data`` decodes with Pillow (libjpeg-turbo 6.2-API build here: ISLOW IDCT + "fancy"
+    triangle chroma upsampling, libjpeg's defaults), the reference with cv2.imread (shapes.py:19-29 of the reference;
+    its environment pins IJG ``jpeg=9b`` / ``8d``, environment.yml:27, environment-ec2.yml:33).  VOC_test/000005.jpg is
+    4:2:0 (sampling index 2): IJG releases >= 7 upsample chroma inside the IDCT (scaled DCT) while libjpeg-turbo keeps the
+    6b triangle filter, so the two decoders may differ by a few grey levels in chroma on such files -- the decode is
+    therefore NOT claimed bit-equal to the reference's.  What IS pinned: the decode this build performs, by the sha1 of
+    the BGR array (recorded with Pillow 12.2.0 / libjpeg-turbo), so a change of decoder shows up as a failure here
+    instead of as silent drift in every downstream golden; and that decoding twice gives the same bytes."""
+    import hashlib
+    from PIL import Image as PilImage
+    from faster_rcnn_amd.data import voc_data_helpers
+    path = os.path.join(GOLD, "VOC_test", "JPEGImages", "000005.jpg")
+    a = np.ascontiguousarray(np.asarray(PilImage.open(path).convert("RGB"))[:, :, ::-1])
+    b = np.ascontiguousarray(np.asarray(PilImage.open(path).convert("RGB"))[:, :, ::-1])
+    assert a.shape == (375, 500, 3) and a.dtype == np.uint8 and np.array_equal(a, b)
+    assert a[0, 0].tolist() == [10, 10, 10] and a[100, 200].tolist() == [110, 147, 173] and int(a.sum()) == 51838662
+    assert hashlib.sha1(a.tobytes()).hexdigest() == "19d26cc86b4f4f981de77496b6817c2ae29f50f0"
+    # and the product's Image.data hands exactly these pixels over at the native size
+    img = voc_data_helpers.extract_img_data(os.path.join(GOLD, "VOC_test"), "000005")
+    assert (img.height, img.width) == (375, 500) and np.array_equal(img.data, a)
