@@ -223,6 +223,39 @@ def backbone_in_flight(pipe, n_images, base_gflop, steps=20):
             "what": "one hipGraph of the base network per image, %d replaying concurrently on their own streams, wall clock over %d rounds" % (n_images, steps)}
 
 
+def real_voc_image():
+    """tests/golden/VOC_test/000005 (375x500 JPEG, 5 annotated chairs) the way voc_dets.main feeds it: resized within
+    600/1000 (util.resize_imgs), resnet.preprocess.  -> (x (1,600,800,3) f32, resize_ratio, (width, height) of the original)."""
+    from faster_rcnn_amd import resnet, util
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+    img = extract_img_data(os.path.join(ROOT, "tests", "golden", "VOC_test"), "000005")
+    (resized,), (ratio,) = util.resize_imgs([img], min_size=600, max_size=1000)
+    return resnet.preprocess(resized.data)[None].astype(np.float32), ratio, (img.width, img.height)
+
+
+def e2e_parity(pipe, weights, anchors, oracle_runs):
+    """SURVEY 8(d) "box mAP delta": the oracle END TO END on its own (image -> detections) beside the device END TO END
+    on its own, over the synthetic 600x1000 images the cpu_baseline leg has just run through the oracle plus the real
+    VOC_test/000005 frame, compared directly and through voc_dets.write_dets + eval_dets.voc_eval (oracle/e2e.py)."""
+    from oracle import e2e
+    from oracle.keras_ref import KerasGraphs
+    from faster_rcnn_amd.data.voc_data_helpers import VOC_CLASS_MAPPING
+    items = []
+    for seed, kept, dets in oracle_runs:
+        items.append({"name": "synth%03d" % seed, "size": (WIDTH, HEIGHT), "oracle": (kept, dets), "device": e2e.device_detect(pipe, synth_image(seed))})
+    x, ratio, size = real_voc_image()
+    g = KerasGraphs(weights, torch.float32)
+    items.append({"name": "000005", "size": size, "oracle": e2e.oracle_detect(g, x, anchors, NUM_CLASSES, DEPTH, PROPOSALS, ratio),
+                  "device": e2e.device_detect(pipe, x, ratio)})
+    res = e2e.compare(items, VOC_CLASS_MAPPING)
+    res["bar"] = "map_pair_delta <= %g" % E2E_MAP_BAR
+    res["ok"] = bool(res["map_pair_delta"] <= E2E_MAP_BAR)
+    return res
+
+
+E2E_MAP_BAR = 2e-2
+
+
 def full_size_parity(pipe, weights, anchors):
     """The oracle as CHECKER at the benchmark's own size (configs[1] only): one synthetic 600x1000 image through the
     HIP pipeline (eager) and, stage by stage, through the CPU restatement fed with the SAME stage inputs -- float
@@ -263,8 +296,9 @@ def full_size_parity(pipe, weights, anchors):
     return res
 
 
-def cpu_baseline(weights, anchors, budget_s=20.0):
-    """The oracle ("port" of the Keras CPU path) on this host: full path on whole images."""
+def cpu_baseline(weights, anchors, budget_s=20.0, runs=None):
+    """The oracle ("port" of the Keras CPU path) on this host: full path on whole images.  ``runs``: a list that receives
+    (seed, kept proposals, detections) of every image, for the end-to-end pair comparison (e2e_parity)."""
     from oracle import np_ref
     from oracle.keras_ref import KerasGraphs
     g = KerasGraphs(weights, torch.float32)
@@ -278,8 +312,10 @@ def cpu_baseline(weights, anchors, budget_s=20.0):
             kept = np_ref.proposals(reg.numpy(), cls.numpy(), anchors, 16, 8000, PROPOSALS)[0]
             rois = np_ref.pad_rois(kept.astype(np.float32), 64)
             out_cls, out_reg = g.resnet_classifier(feat, rois, NUM_CLASSES, DEPTH)
-            np_ref.detections(kept, out_cls.numpy(), out_reg.numpy(), NUM_CLASSES - 1, 1.0)
+            dets = np_ref.detections(kept, out_cls.numpy(), out_reg.numpy(), NUM_CLASSES - 1, 1.0)
             t_total += time.perf_counter() - t0
+            if runs is not None:
+                runs.append((100 + n, kept, dets))
             n += 1
     return {"value": round(n / t_total, 4), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d synthetic %dx%d image(s), ResNet-%d, full RPN+detector path, torch-CPU fp32 restatement of the Keras graph "
@@ -706,12 +742,17 @@ def main():
             except Exception as e:
                 line["parity"] = {"ok": False, "error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline and args.config == "c2":
-            line["cpu_baseline"] = cpu_baseline(weights, anchors)
+            oracle_runs = []
+            line["cpu_baseline"] = cpu_baseline(weights, anchors, runs=oracle_runs)
             if DTYPE == "f32":
                 try:
                     line["parity"] = full_size_parity(pipe, weights, anchors)
                 except Exception as e:                              # the checker must not cost the bench line
                     line["parity"] = {"ok": False, "error": repr(e)[:200]}
+                try:
+                    line["parity"]["e2e"] = e2e_parity(pipe, weights, anchors, oracle_runs)
+                except Exception as e:
+                    line["parity"]["e2e"] = {"ok": False, "error": repr(e)[:300]}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()                  # rank 0 is still measuring the roofline: leave the group together

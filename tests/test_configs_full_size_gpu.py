@@ -62,6 +62,47 @@ def test_config1_resnet50_600x1000_inference_fp32():
         assert res[k] < 1e-4, res
 
 
+def test_config1_end_to_end_pair_and_map_delta():
+    """configs[1], oracle END TO END vs device END TO END (SURVEY 8(d) "box mAP delta"): two synthetic 600x1000 frames and
+    the real VOC_test/000005 (600x800 after util.resize_imgs) each run through the CPU restatement on its own and through
+    the HIP pipeline on its own; both detection sets written with voc_dets.write_dets and scored with eval_dets.voc_eval.
+    bench.py reports the same object over 8 synthetic frames + the real one (`parity.e2e`)."""
+    import bench
+    from faster_rcnn_amd import voc_dets
+    from faster_rcnn_amd.data.voc_data_helpers import VOC_CLASS_MAPPING
+    from faster_rcnn_amd.det_util import DetTrainingManager
+    from faster_rcnn_amd import resnet
+    from oracle import e2e
+    from oracle.keras_ref import KerasGraphs
+    pipe, weights, anchors = bench.build_pipeline()
+    g = KerasGraphs(weights, torch.float32)
+    runs = [(seed,) + e2e.oracle_detect(g, bench.synth_image(seed), anchors, bench.NUM_CLASSES) for seed in (100, 101)]
+    res = bench.e2e_parity(pipe, weights, anchors, runs)
+    print("config1 e2e pair:", res)
+    assert res["images"] == 3 and res["ok"] and res["map_pair_delta"] <= bench.E2E_MAP_BAR, res
+    same, total = (int(v) for v in res["detections_identical"].split("/"))
+    assert same >= 0.9 * total, res
+    same, total = (int(v) for v in res["proposals_identical"].split("/"))
+    assert same >= 0.9 * total, res
+    assert res["max_score_diff"] < 1e-4, res
+    # the reference's own entry point (voc_dets.get_dets over the managers) emits what the fused pipeline emits
+    x, ratio, size = bench.real_voc_image()
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+    from faster_rcnn_amd import util
+    import os
+    img = extract_img_data(os.path.join(bench.ROOT, "tests", "golden", "VOC_test"), "000005")
+    (resized,), _ = util.resize_imgs([img], min_size=600, max_size=1000)
+    mgr = DetTrainingManager(rpn_model=pipe.rpn, class_mapping=VOC_CLASS_MAPPING, preprocess_func=resnet.preprocess, anchor_dims=anchors)
+    dets = voc_dets.get_dets(mgr, pipe.det, resized, ratio, num_rois=64, stride=16)
+    _, dd = e2e.device_detect(pipe, x, ratio)
+    rev = {v: k for k, v in VOC_CLASS_MAPPING.items()}
+    # (get_dets scores the reference's PADDED RoI list, 320 rows: a different GEMM height may pick another split-K
+    #  partition, so scores are held to 1e-6, classes and boxes exactly)
+    a = sorted((d["cls_name"], tuple(int(v) for v in d["bbox"]), float(d["prob"])) for d in dets)
+    b = sorted((rev[c], tuple(int(v) for v in bb), float(p)) for c, p, bb in dd)
+    assert [t[:2] for t in a] == [t[:2] for t in b] and max(abs(s[2] - t[2]) for s, t in zip(a, b)) < 1e-6
+
+
 def _rpn_targets_full(rows, cols, A, seed):
     """y_class / y_bbreg at the density the real target generator produces (256 sampled anchors, <= 128 positive)."""
     rs = np.random.RandomState(seed)
