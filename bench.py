@@ -123,9 +123,16 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
         pipe.forward_dev(x)
         torch.cuda.synchronize()
         ops.CONV_PROFILE = []
+        pipe.rpn.base.net(x)                        # the base network on its own: which launches are "the backbone"
+        torch.cuda.synchronize()
+        base_prof, ops.CONV_PROFILE = ops.CONV_PROFILE, []
         pipe.forward_dev(x)
         torch.cuda.synchronize()
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+    n_base = len(base_prof)
+    # the pass starts with exactly those launches (same kernels, same shapes): anything else would shift FLOP and time
+    # between "backbone" and "head" silently
+    assert [(r["kernel"],) + r["shape"] for r in prof[:n_base]] == [(r["kernel"],) + r["shape"] for r in base_prof], "backbone launches are not the head of the pass"
     groups = {}
     for rec in prof:
         g = groups.setdefault((rec["kernel"],) + rec["shape"], {"count": 0, "rec": rec})
@@ -151,7 +158,6 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
         tot_ms += g["ms"] * g["count"]
     # the backbone alone (conv1 .. res4f: the layers the north star's ">= 60 % of the MFMA roofline on the ResNet-50
     # backbone conv" speaks of): the first launches of the pass, one per ConvUnit of the base network
-    n_base = len(list(pipe.rpn.base.net.units()))
     base_flops = sum(rec["flops"] for rec in prof[:n_base])
     base_ms = sum(groups[(rec["kernel"],) + rec["shape"]]["ms"] for rec in prof[:n_base])
     dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1][1])
@@ -175,7 +181,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
                               "ms_per_image": round(tot_ms, 3),
                               "achieved": round(tot_flops / (tot_ms * 1e-3) / 1e12, 2),
                               "frac": round(tot_flops / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)},
-        "backbone_conv": {"launches_per_image": n_base, "gflop_per_image": round(base_flops / 1e9, 2), "ms_per_image": round(base_ms, 3),
+        "backbone_conv": {"launches_per_image": n_base, "layers_per_image": len(list(pipe.rpn.base.net.units())), "gflop_per_image": round(base_flops / 1e9, 2), "ms_per_image": round(base_ms, 3),
                           "achieved": round(base_flops / (base_ms * 1e-3) / 1e12, 2),
                           "frac": round(base_flops / (base_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
                           "note": "conv1..res4f, each launch alone on the chip (single image, no other stream): the latency view; "
@@ -253,7 +259,7 @@ def e2e_parity(pipe, weights, anchors, oracle_runs):
     return res
 
 
-E2E_MAP_BAR = 2e-2
+E2E_MAP_BAR = 1e-3        # measured on MI355X: 0.0 (2700/2700 proposals, 2382/2382 detections identical over 9 frames)
 
 
 def full_size_parity(pipe, weights, anchors):

@@ -50,6 +50,9 @@ struct ConvArgs {
     int group_m;            // tile order inside an XCD's run of ids: 0 = all row tiles of one column tile, then the next column;
                             // g > 0 = groups of g row tiles, every column tile of a group before the next group (L2 working set)
     int vec_epi;            // 1: y / residual / mask rows are 16-byte addressable (set by frcnn_conv2d_fwd_ws): the v2 / balanced kernels use epilogue_vec
+    // Two layers in one launch (frcnn_conv2d_fwd_dual): columns [0, n_split) are layer 1 -> y (ldy, act), columns
+    // [n_split, Cout) are layer 2 -> y2 (ldy2, act2).  n_split == 0: one layer.  No residual / mask in this form.
+    int n_split; float* y2; int ldy2, act2;
 };
 
 constexpr int BK = 32;
@@ -76,6 +79,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& 
         if (n >= p.Cout) continue;
         const float sc = p.scale ? p.scale[n] : 1.0f;
         const float sh = p.shift ? p.shift[n] : 0.0f;
+        const bool second = p.n_split && n >= p.n_split;        // this lane's column belongs to the launch's second layer
+        float* const yb = second ? p.y2 : p.y;
+        const int ld = second ? p.ldy2 : p.ldy, act = second ? p.act2 : p.act, nn = second ? n - p.n_split : n;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
@@ -86,7 +92,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& 
                     float v = acc[i][j][e] * sc + sh;
                     if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
                     if (p.mask && !(p.mask[(size_t)m * p.Cout + n] > 0.0f)) v = 0.0f;
-                    p.y[(size_t)m * p.ldy + n] = activate(v, p.act);
+                    yb[(size_t)m * ld + nn] = activate(v, act);
                 }
             }
         }
@@ -292,7 +298,13 @@ template <int TM, int TN, int WM, int WN, bool HAVE_PRE>
 __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh,
                                              float* smem, const f32x4* rpre) {
     using E = EpiVec<TM, TN, WM, WN>;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * p.ldy * 4), 0x00020000);
+    // two layers in one launch: n_split is a multiple of the tile width here (the host falls back to the scalar epilogue
+    // otherwise), so the whole tile belongs to ONE of them -- workgroup-uniform choice of output, stride, activation
+    const bool second = p.n_split && n0 >= p.n_split;
+    float* const yb = second ? p.y2 : p.y;
+    const int y_ld = second ? p.ldy2 : p.ldy, y_act = second ? p.act2 : p.act, y_n0 = second ? p.n_split : 0;
+    const int y_cols = p.n_split ? (second ? p.Cout - p.n_split : p.n_split) : p.Cout;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((size_t)p.M * y_ld * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -347,9 +359,11 @@ __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], const ConvAr
                 float t = a[c] * sc[c] + sh[c];
                 if (p.residual) t += HAVE_PRE ? rpre[q][c] : rres[q][c];
                 if (p.mask && !(rmask[q][c] > 0.0f)) t = 0.0f;
-                v[c] = activate(t, p.act);
+                v[c] = activate(t, y_act);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, epi_piece_off<TM, TN, WM, WN>(p, m0, n0, tid, pass, p.ldy), 0, 0);
+            const int ym = m0 + pass * E::RPP + tid / E::C4, yn = n0 - y_n0 + (tid % E::C4) * 4;
+            const unsigned yoff = (ym < p.M && yn < y_cols) ? (unsigned)(((size_t)ym * y_ld + yn) * 4) : OOB_OFFSET;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, yoff, 0, 0);
         }
     }
 }
@@ -1961,9 +1975,41 @@ size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d) {
     return SPLITK_TICKET_BYTES + tiles * splits * 64 * 64 * sizeof(float);
 }
 
+struct DualOut { int n1; int act1; float* y2; int act2; };      // frcnn_conv2d_fwd_dual: the launch's second layer
+
+static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                         const float* scale, const float* shift, const float* residual, const float* mask, float* y,
+                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream);
+
 int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                         const float* scale, const float* shift, const float* residual, const float* mask, float* y,
                         void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_fwd_impl(d, x, w_packed, scale, shift, residual, mask, y, nullptr, workspace, workspace_bytes, stream);
+}
+
+// Split-K workspace of the two-layer launch: the balanced (stream-K) form is not used there.
+size_t frcnn_conv2d_dual_workspace_bytes(const frcnn_conv_desc* d) {
+    if (!d || d->cin <= 0 || (d->cin % BK) != 0) return 0;
+    const int splits = choose_splits(d, choose_config(d));
+    if (splits <= 1) return 0;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const size_t tiles = (size_t)((M + 63) / 64) * ((d->cout + 63) / 64);
+    return SPLITK_TICKET_BYTES + tiles * splits * 64 * 64 * sizeof(float);
+}
+
+int frcnn_conv2d_fwd_dual(const frcnn_conv_desc* d, const float* x, const float* w_packed, const float* scale, const float* shift,
+                          float* y1, int n1, int act1, float* y2, int act2,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !y2 || n1 <= 0 || n1 >= d->cout) return fail(FRCNN_E_ARG, "conv2d_fwd_dual: need 0 < n1 < cout and two outputs");
+    if (d->ldy > 0 || d->ldres > 0) return fail(FRCNN_E_ARG, "conv2d_fwd_dual: dense outputs only (ldy = ldres = 0)");
+    if ((d->cin % BK) != 0 || d->kh * d->kw > 32) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_dual: cin %% 32 == 0 and at most 32 taps");
+    const DualOut dual = {n1, act1, y2, act2};
+    return conv_fwd_impl(d, x, w_packed, scale, shift, nullptr, nullptr, y1, &dual, workspace, workspace_bytes, stream);
+}
+
+static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                         const float* scale, const float* shift, const float* residual, const float* mask, float* y,
+                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !x || !w_packed || !y) return fail(FRCNN_E_ARG, "conv2d_fwd: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->ho <= 0 || d->wo <= 0)
         return fail(FRCNN_E_ARG, "conv2d_fwd: bad shape");
@@ -1975,6 +2021,8 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     if (M > 0x7fffffffLL) return fail(FRCNN_E_ARG, "conv2d_fwd: too many output pixels");
     a.M = (int)M; a.K = d->kh * d->kw * d->cin; a.Kpad = frcnn_conv_packed_k(d->kh, d->kw, d->cin);
     a.act = d->act; a.ldy = d->ldy > 0 ? d->ldy : d->cout; a.ldres = d->ldres > 0 ? d->ldres : d->cout;
+    a.n_split = 0; a.y2 = nullptr; a.ldy2 = 0; a.act2 = 0;
+    if (dual) { a.n_split = dual->n1; a.act = dual->act1; a.ldy = dual->n1; a.y2 = dual->y2; a.ldy2 = d->cout - dual->n1; a.act2 = dual->act2; }
     a.tiles_m = a.tiles_n = 0;
     a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
     a.layout = d->layout ? 1 : 0;
@@ -1989,12 +2037,26 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
     int cfg = choose_config(d);
+    if (dual) {
+        if (cfg >= 61) cfg -= 40;                               // no balanced form for the two-layer launch
+        if (cfg < 11 || (cfg >= 41 && cfg <= 43)) cfg = 23;     // v2 main loops with the 2x2-wave tiles only
+        // the 16-byte epilogue picks the output per TILE: the boundary between the layers must be a tile boundary and
+        // both outputs 16-byte addressable; otherwise every lane picks per column (the 4-byte epilogue)
+        const int bn = (cfg == 21 || cfg == 26 || cfg == 11 || cfg == 24 || cfg == 14) ? 128 : 64;
+        a.vec_epi = a.vec_epi && dual->n1 % bn == 0 && (a.ldy2 & 3) == 0 && al16(dual->y2) && (size_t)M * a.ldy2 * 4 < 0x7fffffffull;
+    }
     // tile order (ConvArgs.group_m): multi-round 64x64 launches with many column tiles walk groups of four row tiles
     // (1x1 512->2048 on 14 700 rows: 276 -> 261 us, scripts/micro/conv_lab.hip under FRCNN_GROUP_M); single-round
     // grids and the big tiles measured no difference and keep the plain order
     {
         const long long t64 = ((M + 63) / 64) * ((d->cout + 63) / 64);
         a.group_m = g_group_m >= 0 ? g_group_m : ((cfg == 22 || cfg == 23) && t64 > 1024 && d->cout >= 512 ? 4 : 0);
+        // round 3 (scripts/group_m_sweep.sh, rocprofv3 --pmc FETCH_SIZE): the plain 128x128 launches gave the column tiles
+        // of one row tile to DIFFERENT XCDs (an XCD's run of ids was ~57 row tiles of one column tile), so every A row
+        // tile crossed the fabric once per column tile.  With groups of ONE row tile the column tiles that share A rows are
+        // neighbours on one XCD: 2048->512 on 14 700 rows fetches 105 instead of 259 MB (raw counter) at 287 vs 291 us, the
+        // 3x3 181 instead of 203 MB (its nine taps reach the neighbouring positions' rows, which live on other XCDs).
+        if (g_group_m < 0 && (cfg == 21 || cfg == 26) && d->cout > 128) a.group_m = 1;
     }
     if (cfg == 21 && !workspace && d->tile % 100 == 0 && a.layout && d->kh * d->kw > 1)
         cfg = 23;                                               // the 128x128 choice there counted on the balanced form
@@ -2006,10 +2068,10 @@ int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w
         return launch_conv_cin3(a, s, d->tile % 100 != 32);      // the mid-chunk-barrier loop (conv1 50.6 -> 49.4 us); 32: dev code, the late-store loop
     }
     if (!generic && workspace) {
-        const size_t need = frcnn_conv2d_workspace_bytes(d);
+        const size_t need = dual ? frcnn_conv2d_dual_workspace_bytes(d) : frcnn_conv2d_workspace_bytes(d);
         if (need) {
             if (workspace_bytes < need) return fail(FRCNN_E_WORKSPACE, "conv2d_fwd: workspace needs %zu bytes", need);
-            if (const int G = choose_streamk(d, cfg)) {
+            if (const int G = dual ? 0 : choose_streamk(d, cfg)) {
                 a.tickets = (unsigned*)workspace;
                 a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
                 return (cfg == 21 || cfg == 26 || cfg == 61) ? launch_conv_sk<2, 2>(a, G, s) : launch_conv_sk<1, 1>(a, G, s);

@@ -60,6 +60,59 @@ class ConvUnit:
         return ops.conv2d(x, self.pc, self.stride, self.padding, act, residual, out, self.tile, layout)
 
 
+class DualUnit:
+    """Two ConvUnits that read the SAME input with the same kernel size, stride and padding, as ONE launch
+    (frcnn_conv2d_fwd_dual): the filters concatenated along the output axis, each layer with its own folded
+    BatchNorm / bias vector slice, activation and output tensor.  conv_block's ``branch2a`` + shortcut ``branch1``
+    (resnet.py:218-241) and rpn_out_cls + rpn_out_bbreg (resnet.py:464-474).  f32 path only; per output element the
+    arithmetic is that of the two single-layer launches (same k order), so the results are bit-identical to them
+    whenever those make the same split-K choice (tests/test_conv_gpu.py)."""
+
+    def __init__(self, first, second):
+        assert first.dtype == second.dtype == "f32" and (first.stride, first.padding) == (second.stride, second.padding)
+        self.a, self.b, self.pc, self.n1 = first, second, None, None
+        self._src = None
+
+    def lower(self):
+        a, b = self.a, self.b
+        for u in (a, b):
+            if u.pc is None:
+                u.lower()
+        # (the single-layer lowerings are kept: training and the reference-order paths launch the layers one by one)
+        wa, wb = a.pc.w, b.pc.w
+        pc = ops.PackedConv.__new__(ops.PackedConv)
+        pc.kh, pc.kw, pc.cin, pc.cout = a.pc.kh, a.pc.kw, a.pc.cin, a.pc.cout + b.pc.cout
+        assert (a.pc.kh, a.pc.kw, a.pc.cin) == (b.pc.kh, b.pc.kw, b.pc.cin)
+        pc.w = torch.cat([wa, wb], dim=0).contiguous()                  # packed rows are per output channel: [cout][Kpad]
+        pc.scale = torch.cat([a.pc.scale, b.pc.scale]).contiguous()
+        pc.shift = torch.cat([a.pc.shift, b.pc.shift]).contiguous()
+        self.pc, self.n1, self._src = pc, a.pc.cout, (a.pc, b.pc)
+        return self
+
+    def __call__(self, x, act1="unit", act2="unit", layout=0):
+        if self.pc is None or self._src[0] is not self.a.pc or self._src[1] is not self.b.pc:
+            self.lower()                                                # (a re-lowered or invalidated layer invalidates the pair)
+        act1 = self.a.act if act1 == "unit" else act1
+        act2 = self.b.act if act2 == "unit" else act2
+        return ops.conv2d_dual(x, self.pc, self.n1, self.a.stride, self.a.padding, act1, act2, layout, self.a.tile)
+
+
+FUSE_PAIRS = True       # dev knob (tests): False launches every layer on its own
+
+
+def _pair(first, second):
+    """The DualUnit of two f32 ConvUnits (cached on the first), or None when the pair cannot share a launch."""
+    if not FUSE_PAIRS or first.dtype != "f32" or second.dtype != "f32":
+        return None
+    d = getattr(first, "_dual", None)
+    if d is None or d.b is not second:
+        w = first.weights[first.conv][0]
+        if np.ndim(w) != 4 or np.shape(w)[2] % 32 != 0:
+            return None
+        d = first._dual = DualUnit(first, second)
+    return d
+
+
 def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dtype="f32"):
     def unit(suffix, **kw):
         tag = "%d%s_branch%s" % (stage, block, suffix)
@@ -74,8 +127,12 @@ def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dt
 
 def run_block(u, x, layout=0):
     """identity_block / conv_block (resnet.py:114-247) and their TimeDistributed twins (:250-392)."""
-    shortcut = u["1"](x, layout=layout) if "1" in u else x
-    t = u["2a"](x, layout=layout)
+    pair = _pair(u["2a"], u["1"]) if "1" in u else None
+    if pair is not None:                                    # branch2a and the shortcut conv read x: one launch
+        t, shortcut = pair(x, layout=layout)
+    else:
+        shortcut = u["1"](x, layout=layout) if "1" in u else x
+        t = u["2a"](x, layout=layout)
     t = u["2b"](t, layout=layout)
     return u["2c"](t, residual=shortcut, layout=layout)
 
@@ -144,6 +201,9 @@ class RpnHead:
 
     def __call__(self, feat):
         t = self.conv(feat)
+        pair = _pair(self.cls, self.reg)
+        if pair is not None and t.dtype == torch.float32:   # sigmoid scores and linear deltas from one N = 5A launch
+            return pair(t)
         return self.cls(t), self.reg(t)
 
 
@@ -195,8 +255,12 @@ class ResNetHead:
     def _first_block_hoisted(self, feat, rois, resize):
         a = self.blocks[0]
         fmap = feat.reshape(1, feat.shape[-3], feat.shape[-2], feat.shape[-1])
-        u = a["2a"](fmap, act=None)                         # conv + BN on the map; its ReLU follows the resampling
-        v = a["1"](fmap)                                    # shortcut conv + BN
+        pair = _pair(a["2a"], a["1"])
+        if pair is not None:
+            u, v = pair(fmap, act1=None)                    # one launch: conv + BN of both on the map
+        else:
+            u = a["2a"](fmap, act=None)                     # conv + BN on the map; its ReLU follows the resampling
+            v = a["1"](fmap)                                # shortcut conv + BN
         # an invalid (empty) RoI crops to zeros in the reference order, which these layers map to their BN shift
         L = self.layout
         t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)

@@ -388,6 +388,31 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
     return out
 
 
+def conv2d_dual(x, pc, n1, stride=1, padding="valid", act1=None, act2=None, layout=0, tile=0):
+    """Two layers on the same input in one launch (frcnn_conv2d_fwd_dual): ``pc`` packs the two filters concatenated along
+    the output axis, the first ``n1`` output channels are layer 1.  -> (y1 (n,ho,wo,n1), y2 (n,ho,wo,cout-n1))."""
+    _require_gpu()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == pc.cin and 0 < n1 < pc.cout
+    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, 0, layout)
+    d.tile = tile or AUTO_TILE
+    lead = (d.ho, d.wo, d.n) if layout else (d.n, d.ho, d.wo)
+    y1 = torch.empty(lead + (n1,), dtype=torch.float32, device="cuda")
+    y2 = torch.empty(lead + (pc.cout - n1,), dtype=torch.float32, device="cuda")
+    ws = _split_k_ws(_lib.load().frcnn_conv2d_dual_workspace_bytes(ctypes.byref(d)))
+    args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(y1), n1, ACT[act1], _p(y2), ACT[act2],
+            _p(ws), ws.numel() if ws is not None else 0)
+    _lib.call("frcnn_conv2d_fwd_dual", *args, _stream())
+    if CONV_PROFILE is not None:
+        flops = 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin
+        cfg = _lib.load().frcnn_conv2d_config(ctypes.byref(d))
+        cfg = cfg - 40 if cfg >= 61 else cfg
+        kname = CONV_KERNEL_NAMES.get(cfg, "?") + (" split-K" if ws is not None else "")
+        keep = (d, x, pc, y1, y2, ws)
+        CONV_PROFILE.append({"kernel": kname, "flops": flops, "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
+                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_dual", *args, _stream())})
+    return y1, y2
+
+
 def pool2d(x, k, stride, is_max=True):
     _require_gpu()
     n, h, w, c = x.shape

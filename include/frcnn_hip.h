@@ -227,6 +227,20 @@ size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                         const float* scale, const float* shift, const float* residual, const float* mask,
                         float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* TWO layers that read the SAME input with the same geometry in ONE launch: the output channels of the two filters
+ * concatenated, [0, n1) = layer 1 -> y1 [M][n1] with activation act1, [n1, cout) = layer 2 -> y2 [M][cout - n1] with act2.
+ * Replaces the pairs conv_block's `branch2a` + shortcut `branch1` (both 1x1, strides (s, s), resnet.py:218-241, the
+ * TimeDistributed twins :353-386 and the hoisted res5a pair) and rpn_out_cls (sigmoid) + rpn_out_bbreg (linear)
+ * (resnet.py:464-474; vgg.py:172-185): the shared input is read once and one launch boundary disappears.
+ * d->cout = n1 + n2, d->act is ignored, ldy / ldres must be 0; w_packed / scale / shift are those of the concatenated
+ * filter (frcnn_pack_conv_weights on np.concatenate([k1, k2], axis=3)).  Per output element the arithmetic is that of
+ * the single-layer launch with the same tile and split-K choice (the k order does not depend on cout): bit-identical to
+ * two frcnn_conv2d_fwd_ws calls whenever those would have made the same split-K choice (always without a workspace).
+ * cin % 32 == 0, at most 32 taps.  Workspace contract as frcnn_conv2d_fwd_ws (split-K only, never the balanced form). */
+size_t frcnn_conv2d_dual_workspace_bytes(const frcnn_conv_desc* d);
+int frcnn_conv2d_fwd_dual(const frcnn_conv_desc* d, const float* x, const float* w_packed, const float* scale, const float* shift,
+                          float* y1, int n1, int act1, float* y2, int act2,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* Filter of the input-gradient convolution: transposed (cin <-> cout), flipped in both taps, input
  * channel co scaled by scale[co] (the forward epilogue scale = folded BatchNorm; NULL = 1).
  * packed: [cin][frcnn_conv_packed_k(kh, kw, cout)]. */

@@ -67,7 +67,8 @@ def test_bench_two_ranks_on_one_gpu():
         assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
         assert line["with_host_io"]["value"] > 0
         bb = line["roofline"]["backbone_conv"]
-        assert bb["launches_per_image"] == 43 and 0 < bb["frac"] < 1 and abs(bb["gflop_per_image"] - 75.25) < 0.1
+        # (three conv_block pairs -- branch2a + shortcut -- share a launch: 43 layers, 40 launches)
+        assert bb["layers_per_image"] == 43 and bb["launches_per_image"] == 40 and 0 < bb["frac"] < 1 and abs(bb["gflop_per_image"] - 75.25) < 0.1
         # the backbone with the images in flight is measured on one-rank runs only (rank 0 alone would skew a 2-rank job)
         assert ("in_flight" in bb) == (n == 1) and (n != 1 or (bb["in_flight"]["images_in_flight"] == 2 and 0 < bb["in_flight"]["frac"] < 1))
     # two ranks share ONE GPU here, so the aggregate stays in the neighbourhood of the single-rank figure

@@ -286,3 +286,98 @@ def test_balanced_launch_is_chosen_for_the_head_shapes(ops):
     assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=50, **head) == 21       # beside other images' launches: plain
     assert cfg(cin=512, cout=2048, kh=1, kw=1, pad_top=0, pad_left=0, tile=0, **head) == 23       # 16 chunks: too short
     assert cfg(cin=512, cout=512, kh=3, kw=3, pad_top=1, pad_left=1, tile=100, **head) == 23      # "never split" turns it off
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Two layers on one input in ONE launch (frcnn_conv2d_fwd_dual): conv_block's branch2a + shortcut (resnet.py:218-241)
+# and rpn_out_cls + rpn_out_bbreg (resnet.py:464-474).  The bar is bit-identity with the two single-layer launches.
+DUAL_CASES = [
+    # n, h, w, cin, n1, n2, k, stride, padding, act1, act2, tile, layout
+    (1, 40, 50, 64, 64, 256, 1, 1, "valid", "relu", None, 0, 0),          # res2a: 64x64 tiles, boundary on a tile edge (16-byte epilogue)
+    (1, 37, 50, 256, 128, 512, 1, 2, "valid", "relu", None, 0, 0),        # res3a: stride 2
+    (1, 38, 63, 512, 256, 1024, 1, 1, "valid", "relu", None, 0, 0),       # res4a shapes
+    (1, 38, 63, 1024, 512, 2048, 1, 1, "valid", None, None, 0, 0),        # the hoisted res5a pair on the conv4 map
+    (1, 38, 63, 512, 9, 36, 1, 1, "valid", "sigmoid", None, 0, 0),        # RPN outputs: boundary INSIDE a tile (4-byte epilogue), split-K
+    (1, 38, 63, 512, 18, 72, 1, 1, "valid", "sigmoid", None, 0, 0),       # 18 anchors (configs[3])
+    (1, 21, 33, 64, 64, 72, 3, 1, "same", "relu", "relu", 23, 0),         # a 3x3 pair, second layer with a partial column tile
+    (1, 21, 33, 64, 128, 128, 1, 1, "valid", "relu", None, 26, 0),        # 128x128 tiles, boundary on a tile edge
+    (1, 21, 33, 64, 64, 192, 1, 1, "valid", "relu", None, 26, 0),         # 128x128 tiles, boundary inside a tile -> 4-byte epilogue
+    (1, 21, 33, 64, 64, 192, 1, 1, "valid", "relu", None, 21, 0),
+    (20, 7, 7, 1024, 512, 2048, 1, 1, "valid", "relu", None, 0, 1),       # position-major (the TimeDistributed res5a pair, reference order)
+]
+
+
+@pytest.mark.parametrize("case", DUAL_CASES, ids=[str(c) for c in DUAL_CASES])
+@pytest.mark.parametrize("split_k", [False, True])
+def test_dual_launch_equals_two_launches(ops, case, split_k):
+    n, h, w, cin, n1, n2, k, stride, padding, act1, act2, tile, layout = case
+    rs = np.random.RandomState(n1 + n2 + h)
+    shape = (h, w, n, cin) if layout else (n, h, w, cin)
+    x = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    wa = (rs.randn(k, k, cin, n1) / np.sqrt(k * k * cin)).astype(np.float32)
+    wb = (rs.randn(k, k, cin, n2) / np.sqrt(k * k * cin)).astype(np.float32)
+    sa, ha, sb, hb = (rs.rand(n1) + 0.5).astype(np.float32), rs.randn(n1).astype(np.float32), (rs.rand(n2) + 0.5).astype(np.float32), rs.randn(n2).astype(np.float32)
+    pa, pb = ops.PackedConv(wa, sa, ha), ops.PackedConv(wb, sb, hb)
+    pcat = ops.PackedConv(np.concatenate([wa, wb], axis=3), np.concatenate([sa, sb]), np.concatenate([ha, hb]))
+    assert torch.equal(pcat.w, torch.cat([pa.w, pb.w]))                   # packed rows are per output channel
+    ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
+    with ops.conv_workspace(ws):
+        ya = ops.conv2d(x, pa, stride, padding, act1, tile=tile, layout=layout)
+        yb = ops.conv2d(x, pb, stride, padding, act2, tile=tile, layout=layout)
+        for _ in range(3):                                                # (repeat: split-K tickets must come back to zero)
+            y1, y2 = ops.conv2d_dual(x, pcat, n1, stride, padding, act1, act2, layout, tile)
+    torch.cuda.synchronize()
+    assert y1.shape == ya.shape and y2.shape == yb.shape
+    same_split = not split_k or (n1 + n2 <= 64)       # tiny grids: one column tile, the same slices either way
+    if same_split:
+        assert torch.equal(y1, ya) and torch.equal(y2, yb)
+    else:
+        # a single-layer launch on a small grid may have cut K into slices where the pair's larger grid does not:
+        # same products, another summation tree
+        for got, want in ((y1, ya), (y2, yb)):
+            assert float(((got - want).abs() / want.abs().clamp(min=1)).max()) < 1e-5
+
+
+def test_dual_rejects_bad_arguments(ops):
+    from faster_rcnn_amd import _lib
+    x = torch.zeros((1, 8, 8, 64), dtype=torch.float32, device="cuda")
+    pc = ops.PackedConv(np.zeros((1, 1, 64, 96), np.float32), np.ones(96, np.float32), np.zeros(96, np.float32))
+    with pytest.raises(AssertionError):
+        ops.conv2d_dual(x, pc, 96)
+    x48 = torch.zeros((1, 8, 8, 48), dtype=torch.float32, device="cuda")
+    pc48 = ops.PackedConv(np.zeros((1, 1, 48, 96), np.float32), np.ones(96, np.float32), np.zeros(96, np.float32))
+    with pytest.raises(_lib.FrcnnError):
+        ops.conv2d_dual(x48, pc48, 32)                                    # cin % 32 != 0
+
+
+def test_networks_with_paired_launches_equal_unpaired(ops):
+    """ResNet-50 base + RPN head + hoisted detector head with the pairs in one launch == every layer on its own launch,
+    bit for bit (plain launches), and to rounding with split-K on (the pair's grid is larger: other slice counts)."""
+    from faster_rcnn_amd import nets, resnet, util
+    from faster_rcnn_amd.weights import synthetic_resnet
+    anchors = util.get_anchors([128, 256, 512])
+    w = synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=11)
+    x = torch.from_numpy((np.random.RandomState(1).randint(0, 256, (1, 160, 224, 3)) - 110.0).astype(np.float32)).cuda()
+    rois = torch.tensor([[0, 0, 5, 4], [2, 1, 9, 8], [3, 3, 13, 9], [0, 2, 4, 9]], dtype=torch.float32, device="cuda")
+
+    def run(fuse, ws):
+        nets.FUSE_PAIRS = fuse
+        try:
+            base = resnet.resnet50_base(weights=w)
+            rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=9)
+            det = resnet.resnet50_classifier(4, 21, weights=w)
+            with ops.conv_workspace(ws):
+                cls, reg, feat = rpn.forward_dev(x)
+                dc, dr = det.forward_dev(feat, rois)
+            torch.cuda.synchronize()
+            return cls, reg, feat, dc, dr
+        finally:
+            nets.FUSE_PAIRS = True
+    a = run(True, ops.NO_SPLIT_K)
+    b = run(False, ops.NO_SPLIT_K)
+    for s, t in zip(a, b):
+        assert torch.equal(s, t)
+    c = run(True, ops.ConvWorkspace())
+    d = run(False, ops.ConvWorkspace())
+    for s, t in zip(c, d):
+        assert float(((s - t).abs() / t.abs().clamp(min=1)).max()) < 1e-5
