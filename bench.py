@@ -111,7 +111,7 @@ def build_pipeline():
     return InferencePipeline(rpn, det, anchors, max_proposals=PROPOSALS), w, anchors
 
 
-def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
+def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1):
     """Per-launch duration of every conv launch of one image, measured with HIP events on the launch
     stream.  An event pair around ONE short kernel also measures the event packets themselves
     (tens of microseconds on this stack), so each distinct launch (kernel instantiation x shape) is
@@ -154,12 +154,12 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
         g["ms"] = e0.elapsed_time(e1) / reps
         a = per_kernel.setdefault(rec["kernel"], [0.0, 0.0, 0])
         a[0] += rec["flops"] * g["count"]; a[1] += g["ms"] * g["count"]; a[2] += g["count"]
-        tot_flops += rec["flops"] * g["count"]
-        tot_ms += g["ms"] * g["count"]
+        tot_flops += rec["flops"] * g["count"] / images          # "per image" figures: a pass is `images` images (batched pipeline)
+        tot_ms += g["ms"] * g["count"] / images
     # the backbone alone (conv1 .. res4f: the layers the north star's ">= 60 % of the MFMA roofline on the ResNet-50
     # backbone conv" speaks of): the first launches of the pass, one per ConvUnit of the base network
-    base_flops = sum(rec["flops"] for rec in prof[:n_base])
-    base_ms = sum(groups[(rec["kernel"],) + rec["shape"]]["ms"] for rec in prof[:n_base])
+    base_flops = sum(rec["flops"] for rec in prof[:n_base]) / images
+    base_ms = sum(groups[(rec["kernel"],) + rec["shape"]]["ms"] for rec in prof[:n_base]) / images
     dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1][1])
     achieved = dom[0] / (dom[1] * 1e-3) / 1e12
     heavy_key, heavy = max(((k, v) for k, v in groups.items() if k[0] == dom_name), key=lambda kv: kv[1]["ms"] * kv[1]["count"])
@@ -171,7 +171,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
         "bound": "mfma", "kernel": dom_name,
         "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
-        "launches_per_image": dom[2], "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
+        "launches_per_image": dom[2], "images_per_launch": images, "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
         "gflop_per_launch_avg": round(dom[0] / dom[2] / 1e9, 3),
         "share_of_conv_time": round(dom[1] / tot_ms, 3),
         "heaviest_shape_MNK": list(heavy_key[1:4]),
@@ -191,7 +191,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False):
     return roof, groups
 
 
-def backbone_in_flight(pipe, n_images, base_gflop, steps=20):
+def backbone_in_flight(pipe, n_images, base_gflop, steps=20, batch=1):
     """The backbone (conv1 .. last base stage, with its pools) of `n_images` images at once, one hipGraph per image on its
     own stream -- how the timed pipeline keeps the chip busy -- timed as a whole: ms per image and the conv TFLOP/s that
     is.  The per-launch sum in `backbone_conv` is the latency view of the same launches."""
@@ -200,14 +200,15 @@ def backbone_in_flight(pipe, n_images, base_gflop, steps=20):
     streams = [torch.cuda.Stream() for _ in range(n_images)]
     graphs = []
     for i, st in enumerate(streams):
-        x = torch.from_numpy(synth_image(200 + i)).cuda()
-        ws = ops.ConvWorkspace()
+        x = torch.from_numpy(np.concatenate([synth_image(200 + i * batch + j) for j in range(batch)])).cuda()
+        ws = ops.ConvWorkspace() if batch == 1 else ops.NO_SPLIT_K
+        shared = n_images > 1 or batch > 1
         st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st), ops.conv_workspace(ws), ops.tile_policy(n_images > 1):
+        with torch.cuda.stream(st), ops.conv_workspace(ws), ops.tile_policy(shared):
             net(x); net(x)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"), ops.conv_workspace(ws), ops.tile_policy(n_images > 1):
+        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"), ops.conv_workspace(ws), ops.tile_policy(shared):
             y = net(x)
         graphs.append((g, x, y, ws))
 
@@ -222,9 +223,9 @@ def backbone_in_flight(pipe, n_images, base_gflop, steps=20):
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / (steps * n_images)
+    ms = 1e3 * (time.perf_counter() - t0) / (steps * n_images * batch)
     tf = base_gflop / ms
-    return {"images_in_flight": n_images, "ms_per_image": round(ms, 3), "achieved": round(tf, 2),
+    return {"images_in_flight": n_images * batch, "graphs_in_flight": n_images, "images_per_graph": batch, "ms_per_image": round(ms, 3), "achieved": round(tf, 2),
             "frac": round(tf / (PEAK_BF16_TFLOPS if DTYPE == "bf16" else PEAK_F32_MATRIX_TFLOPS), 4),
             "what": "one hipGraph of the base network per image, %d replaying concurrently on their own streams, wall clock over %d rounds" % (n_images, steps)}
 
@@ -346,7 +347,17 @@ def full_size_parity_bf16(pipe, weights, anchors):
         return float(((a - b) ** 2).mean().sqrt() / b.pow(2).mean().sqrt().clamp(min=1e-12)), float((a - b).abs().max()) / scale
 
     with torch.no_grad():
-        out = pipe.forward_dev(torch.from_numpy(x).cuda())
+        batch = getattr(pipe, "batch", 1)
+        if batch > 1:
+            # the batched pipeline (what the timed graphs replay): the checked image rides as image 0 of a batch of different
+            # images; its slice of every output is what the oracle is compared with
+            from faster_rcnn_amd import ops
+            xb = np.concatenate([x] + [synth_image(300 + j) for j in range(batch - 1)])
+            with ops.conv_workspace(ops.NO_SPLIT_K), ops.tile_policy(True):
+                out = pipe.forward_dev(torch.from_numpy(xb).cuda())
+            out = {k: (v[0] if isinstance(v, list) else v[0:1] if k in ("rpn_cls", "rpn_reg", "feat") else v[0]) for k, v in out.items()}
+        else:
+            out = pipe.forward_dev(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
         host = {k: (v.float() if v.dtype == torch.bfloat16 else v).cpu() for k, v in out.items()}
         res = {}
@@ -537,14 +548,23 @@ def main():
                     help="skip the second, I/O-inclusive timing (fresh uint8 images from pinned host memory in, detections out)")
     ap.add_argument("--streams", type=int, default=0,
                     help="images in flight per GPU (one hipGraph + HIP stream each); default: 8 for the fp32 config, 4 for bf16")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="images per hipGraph (BatchedInferencePipeline: trunk at batch B, one detector-head pass over B x 300 RoIs); "
+                         "default: 8 for configs[3] (bf16), 1 otherwise")
+    ap.add_argument("--conv-table", action="store_true", help="print every distinct conv launch's duration alone on the chip to stderr")
     ap.add_argument("--no-train-dp", action="store_true", help="N > 1: leave the data-parallel training steps (`train_dp`) out of the line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)                      # does not return
     global HOIST, DTYPE, WORKLOAD
     select_config(args.config)
+    bf16_run = not (DTYPE == "f32" and args.dtype in ("config", "f32"))
+    if args.batch <= 0:
+        args.batch = 8 if (bf16_run and args.config != "c1" and not args.no_graph) else 1
+    if args.batch > 1 and (not bf16_run or args.config == "c1" or args.no_graph):
+        ap.error("--batch needs the bf16 conv path and hipGraph replay")
     if args.streams <= 0:
-        args.streams = 8 if (DTYPE == "f32" and args.dtype in ("config", "f32")) else 4
+        args.streams = 8 if not bf16_run else (3 if args.batch > 1 else 4)       # configs[3] sweep (round 3): 8 x 3 940 img/s, 8 x 4 911, 4 x 4 876, 12 x 3 917
     # ROCm maps a process's streams onto 4 hardware queues unless told otherwise; more than four images in flight need
     # a queue each or they queue behind one another (measured on MI355X: 8 streams on 8 queues 245.6 img/s, 8 streams on
     # 4 queues 241.4, 4 on 4 240.7, 4 on 8 217.0; configs[3] (bf16) is fastest with 4 on 4).  Read when the HIP runtime
@@ -565,21 +585,28 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count() if world > 1 else 0)
 
     pipe, weights, anchors = build_pipeline()
-    x = torch.from_numpy(synth_image(rank)).cuda()
+    B = args.batch                                  # images per hipGraph (1 = InferencePipeline, one image per graph)
+    synth_batch = lambda first: torch.from_numpy(np.concatenate([synth_image(first + j) for j in range(B)])).cuda()
+    if B > 1:
+        from faster_rcnn_amd.pipeline import BatchedInferencePipeline
+        pipe = BatchedInferencePipeline(pipe.rpn, pipe.det, anchors, B, max_proposals=PROPOSALS)
+    x = synth_batch(rank)
     S = max(1, args.streams)
     # split-K is a latency tool: measured on MI355X it gains 6-9 % with one image in flight, nothing (f32) or -4 % (bf16)
     # with four, and costs 1.2 % (f32: 246.1 vs 249.0 img/s, `--split-k off`) with eight, where concurrency already
     # fills the small grids.  The fp32 default keeps it on: the graphs then hold the same launch forms the roofline
     # section times one at a time (the small-grid layers alone on the chip are what split-K is for).
-    split_k = args.split_k == "on" or (args.split_k == "auto" and (S == 1 or DTYPE == "f32"))
+    split_k = args.split_k == "on" or (args.split_k == "auto" and B == 1 and (S == 1 or DTYPE == "f32"))
     if not args.no_graph:
         from faster_rcnn_amd.pipeline import InferencePipeline
-        pipes = [pipe] + [RpnOnlyPipeline(pipe.rpn) if DEPTH == 16 else InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS)
-                          for _ in range(S - 1)]
+        more = lambda: (RpnOnlyPipeline(pipe.rpn) if DEPTH == 16 else
+                        BatchedInferencePipeline(pipe.rpn, pipe.det, anchors, B, max_proposals=PROPOSALS) if B > 1 else
+                        InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS))
+        pipes = [pipe] + [more() for _ in range(S - 1)]
         streams = [torch.cuda.Stream() for _ in range(S)]
         for i, (pl, st) in enumerate(zip(pipes, streams)):
-            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1)
-            pl._static_in.copy_(torch.from_numpy(synth_image(rank * S + i)).cuda())
+            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1 or B > 1)
+            pl._static_in.copy_(synth_batch((rank * S + i) * B))
         torch.cuda.synchronize()
 
         def step():
@@ -636,22 +663,26 @@ def main():
     if not args.no_graph and not args.no_io:
         from faster_rcnn_amd import ops
         rs = np.random.RandomState(1000 + rank)
-        frames = [torch.from_numpy(rs.randint(0, 256, (HEIGHT, WIDTH, 3)).astype(np.uint8)).pin_memory() for _ in range(4 * S)]
-        dev_u8 = [torch.empty((HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda") for _ in range(S)]
+        frames = [torch.from_numpy(rs.randint(0, 256, (HEIGHT, WIDTH, 3)).astype(np.uint8)).pin_memory() for _ in range(4 * S * B)]
+        dev_u8 = [torch.empty((HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda") for _ in range(S * B)]
         # (the detector's outputs are views into ONE buffer, `det_packed`: n_dets / det_bbox / det_cls / det_prob / det_roi
         #  reach the host in a single copy and ops.split_detections() carves them out of it)
         det_keys = [k for k in ("det_packed", "n_rois") if k in pipes[0]._static_out] or ["rpn_cls", "rpn_reg"]
-        host_out = [{k: torch.empty(pl._static_out[k].shape, dtype=pl._static_out[k].dtype).pin_memory() for k in det_keys} for pl in pipes]
+        per_image = lambda v: v if isinstance(v, list) else [v]       # the batched pipeline returns per-image lists of the small outputs
+        host_out = [{k: [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in per_image(pl._static_out[k])] for k in det_keys} for pl in pipes]
         mean = (103.939, 116.779, 123.68)
 
         def step_io(it):
             for i, (pl, st) in enumerate(zip(pipes, streams)):
                 with torch.cuda.stream(st):
-                    dev_u8[i].copy_(frames[(it * S + i) % len(frames)], non_blocking=True)
-                    ops.preprocess_u8(dev_u8[i], mean, out=pl._static_in)
+                    for j in range(B):
+                        u8 = dev_u8[i * B + j]
+                        u8.copy_(frames[((it * S + i) * B + j) % len(frames)], non_blocking=True)
+                        ops.preprocess_u8(u8, mean, out=pl._static_in[j:j + 1])
                     pl._graph.replay()
                     for k in det_keys:
-                        host_out[i][k].copy_(pl._static_out[k], non_blocking=True)
+                        for h, d in zip(host_out[i][k], per_image(pl._static_out[k])):
+                            h.copy_(d, non_blocking=True)
 
         for it in range(args.warmup):
             step_io(it)
@@ -671,13 +702,13 @@ def main():
             t = torch.tensor([elapsed_io], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed_io = float(t.item())
-        io = {"value": round(world * S * args.steps / elapsed_io, 3), "unit": "img/s", "ms_per_step": round(1e3 * elapsed_io / args.steps, 4),
-              "distinct_frames": len(frames), "n_detections_last": int(host_out[0]["det_packed"][0].item()) if "det_packed" in det_keys else None,
+        io = {"value": round(world * S * B * args.steps / elapsed_io, 3), "unit": "img/s", "ms_per_step": round(1e3 * elapsed_io / args.steps, 4),
+              "distinct_frames": len(frames), "n_detections_last": int(host_out[0]["det_packed"][0][0].item()) if "det_packed" in det_keys else None,
               "what": "per image: uint8 BGR frame from pinned host memory -> H2D -> device preprocess -> hipGraph replay -> D2H of "
                       "%s into pinned host memory" % " / ".join("n_dets + det_cls + det_prob + det_bbox + det_roi (one packed copy)" if k == "det_packed" else k for k in det_keys)}
         # leave the graphs' inputs as the resident-input run had them (the roofline / parity sections below use pipe._static_out)
         for i, pl in enumerate(pipes):
-            pl._static_in.copy_(torch.from_numpy(synth_image(rank * S + i)).cuda())
+            pl._static_in.copy_(synth_batch((rank * S + i) * B))
             pl._graph.replay()
         torch.cuda.synchronize()
 
@@ -689,25 +720,31 @@ def main():
             train_dp = {"error": "%s: %s" % (type(e).__name__, e)}
 
     out = pipe._static_out if not args.no_graph else pipe.forward_dev(x)
-    n_rois = int(out["n_rois"].item()) if "n_rois" in out else None
-    n_dets = int(out["n_dets"].item()) if "n_dets" in out else None
+    first = lambda v: v[0] if isinstance(v, list) else v                # (the batched pipeline returns per-image lists)
+    n_rois = int(first(out["n_rois"]).item()) if "n_rois" in out else None
+    n_dets = int(first(out["n_dets"]).item()) if "n_dets" in out else None
 
     if rank == 0:
         try:
-            roof, _ = conv_roofline(pipe, x, split_k=split_k, throughput=S > 1)
+            roof, groups = conv_roofline(pipe, x, split_k=split_k, throughput=S > 1 or B > 1, images=B)
+            if args.conv_table:                     # per distinct launch: shape, count, duration alone on the chip, rate (stderr)
+                for key, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["count"]):
+                    fl = g["rec"]["flops"]
+                    sys.stderr.write("conv %-44s M=%-7d N=%-5d K=%-5d s=%d  x%-3d %8.1f us %7.1f TFLOP/s  (%.3f ms per image)\n" % (
+                        key[0], key[1], key[2], key[3], key[4], g["count"], 1e3 * g["ms"], fl / (g["ms"] * 1e-3) / 1e12, g["ms"] * g["count"] / B))
         except Exception as e:                          # the throughput line must survive a failed per-kernel pass
             roof = None
             roof_error = "%s: %s" % (type(e).__name__, e)
         line = {
             "metric": ("images/sec RPN-only forward VGG16 %dx%d" % (HEIGHT, WIDTH)) if DEPTH == 16
                       else "images/sec end-to-end (RPN+det) ResNet-%d %dx%d" % (DEPTH, HEIGHT, WIDTH),
-            "value": round(world * S * args.steps / elapsed, 3), "unit": "img/s",
+            "value": round(world * S * B * args.steps / elapsed, 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": WORKLOAD,
-                       "images_per_step_per_gpu": S, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "images_per_step_per_gpu": S * B, "graphs_in_flight": S, "images_per_graph": B, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "proposals": PROPOSALS, "classes": NUM_CLASSES,
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
                        "head_order": "no detector head" if DEPTH == 16 else
@@ -722,15 +759,15 @@ def main():
         if roof is None:
             line["roofline"] = {"bound": "mfma", "error": roof_error}
         if roof is not None and HOIST and DEPTH != 16:   # what the same image costs in the reference's layer order (res5a_branch2a / branch1 on every crop)
-            rows_cols = int(out["rpn_cls"].shape[1] * out["rpn_cls"].shape[2])
+            rows_cols = int(out["rpn_cls"].shape[-3] * out["rpn_cls"].shape[-2])
             saved = 2.0 * 1024 * (512 + 2048) * (PROPOSALS * 49 - rows_cols) / 1e9
             roof["all_conv_launches"]["gflop_per_image_reference_order"] = round(roof["all_conv_launches"]["gflop_per_image"] + saved, 2)
         # conv FLOP actually executed per second by the whole job (all images in flight)
         if roof is not None:
             line["roofline"]["end_to_end_conv_tflops"] = round(roof["all_conv_launches"]["gflop_per_image"] * line["value"] / 1e3, 2)
-        if roof is not None and S > 1 and world == 1:
+        if roof is not None and (S > 1 or B > 1) and world == 1:
             try:
-                roof["backbone_conv"]["in_flight"] = backbone_in_flight(pipe, S, roof["backbone_conv"]["gflop_per_image"])
+                roof["backbone_conv"]["in_flight"] = backbone_in_flight(pipe, S, roof["backbone_conv"]["gflop_per_image"], batch=B)
             except Exception as e:
                 roof["backbone_conv"]["in_flight"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if roof is not None and DTYPE == "bf16":

@@ -34,6 +34,7 @@ struct ConvArgsBf16 {
     int splits;             // split-K (see conv_igemm.hip): K-slices per tile, f32 partial slabs, arrival tickets
     float* slabs;
     unsigned* tickets;
+    int res_pre;            // 1: the kernel may request its residual pieces BEFORE the main loop (16-byte addressable, tensor under 2 GiB)
 };
 
 constexpr int BKH = 64;                 // channels per k-chunk (128 B)
@@ -187,6 +188,34 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // Round 3: the residual pieces this lane adds in the epilogue are requested HERE, before the main loop (the f32 kernel's
+    // EPI_PRE).  The short-k, wide-output layers -- every block's 2c: 256 -> 1024 over 28 576 rows of a batch of eight
+    // (4 chunks), 512 -> 2048 over 117 600 RoI rows (8 chunks) -- moved their bytes at 2.2-3.7 TB/s: the main loop is over in
+    // 1-2 us, and only then did each half tile issue its 16-byte residual load and wait for it, four round trips in a row per
+    // wave.  One or two 32x32 tiles per wave: 2 or 4 pieces of 16 bytes per lane (8-16 registers; the 128x128 eight-wave
+    // tile has 69 of its 128 in use).  Same values added in the same order: bit-identical.
+    constexpr bool RES_PRE = !SPLITK && !MASKED && (TM * TN == 1 || (VARIANT == 3 && TM * TN == 2));   // (the register-staged 128x128 tile has no room: 118 + 18 registers)
+    i32x4 rpre[RES_PRE ? TM * TN * 2 : 1];
+    bool pre = false;
+    if constexpr (RES_PRE) {
+        pre = p.res_pre && p.residual != nullptr;
+        if (pre) {
+            const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<__bf16*>(p.residual), 0, (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int m = m0 + wm * TM * 32 + i * 32 + half * 16 + (lane >> 2);
+                        const int n = n0 + wn * TN * 32 + j * 32 + (lane & 3) * 8;
+                        const unsigned off = (m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * p.Cout + n) * 2) : OOB_OFFSET_B;
+                        rpre[(j * TM + i) * 2 + half] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+                    }
+        }
+    }
 
     constexpr int MF = TM * TN;            // MFMAs per k-step (k = 16)
     constexpr int NL = PA + PB;
@@ -478,7 +507,9 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                         const size_t o = (size_t)m * p.Cout + n;
                         if (p.residual) {
-                            const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.residual + o);
+                            bf16x8 r;
+                            if (RES_PRE && pre) r = __builtin_bit_cast(bf16x8, rpre[RES_PRE ? (j * TM + i) * 2 + half : 0]);
+                            else r = *reinterpret_cast<const bf16x8*>(p.residual + o);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] += (float)r[q];
                         }
@@ -676,6 +707,51 @@ __global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int ro
     }
 }
 
+// The same for the RoIs of SEVERAL images in one launch (batched inference): RoI r belongs to image r / n_per_img, whose map
+// starts at feat + image * rows * cols * C; the output is ONE tensor over all RoIs ([7][7][all RoIs][C] position-major, or
+// [all RoIs][7][7][C]), so the detector head runs one GEMM pass over every image's RoIs.  Eight channels (16 bytes) per lane;
+// per element the arithmetic is k_roi_fwd_bf16's (f32 lerp in the same order, one rounding): bit-identical per RoI.
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+__global__ void __launch_bounds__(256) k_roi_fwd_bf16_batch(const __bf16* feat, int rows, int cols, int C, const float4* rois, int n_per_img, int pool,
+                                                            const float* fill, int relu, int pos_major, __bf16* out) {
+    const int pix = blockIdx.x;
+    const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    const size_t orow = pos_major ? (size_t)(py * pool + px) * (gridDim.x / (pool * pool)) + r : (size_t)pix;
+    const float4 roi = rois[r];
+    const int x1 = (int)roi.x, y1 = (int)roi.y, x2 = (int)roi.z, y2 = (int)roi.w;
+    const int h = y2 - y1, w = x2 - x1;
+    __bf16* o = out + orow * C;
+    const bool ok = h > 0 && w > 0 && x1 >= 0 && y1 >= 0 && x2 <= cols && y2 <= rows;
+    if (!ok) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { const float v = fill ? fill[c] : 0.0f; o[c] = (__bf16)(relu ? fmaxf(v, 0.0f) : v); }
+        return;
+    }
+    const __bf16* f = feat + (size_t)(r / n_per_img) * rows * cols * C;
+    const float sy = (float)h / (float)pool, sx = (float)w / (float)pool;
+    const float fy = (float)py * sy, fx = (float)px * sx;
+    const int ly = (int)fy, lx = (int)fx;
+    const float ty = fy - (float)ly, tx = fx - (float)lx;
+    const int ylo = y1 + ly, yhi = y1 + min(ly + 1, h - 1), xlo = x1 + lx, xhi = x1 + min(lx + 1, w - 1);
+    const u16x8* tl = reinterpret_cast<const u16x8*>(f + ((size_t)ylo * cols + xlo) * C);
+    const u16x8* tr = reinterpret_cast<const u16x8*>(f + ((size_t)ylo * cols + xhi) * C);
+    const u16x8* bl = reinterpret_cast<const u16x8*>(f + ((size_t)yhi * cols + xlo) * C);
+    const u16x8* br = reinterpret_cast<const u16x8*>(f + ((size_t)yhi * cols + xhi) * C);
+    u16x8* o8 = reinterpret_cast<u16x8*>(o);
+    for (int c = threadIdx.x; c < C / 8; c += blockDim.x) {
+        const u16x8 va = tl[c], vb = tr[c], vd = bl[c], ve = br[c];
+        u16x8 res;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float a = bf16_bits_to_f32(va[k]), b = bf16_bits_to_f32(vb[k]), d = bf16_bits_to_f32(vd[k]), e = bf16_bits_to_f32(ve[k]);
+            const float top = a + (b - a) * tx, bot = d + (e - d) * tx;
+            const float v = top + (bot - top) * ty;
+            res[k] = __builtin_bit_cast(unsigned short, (__bf16)(relu ? fmaxf(v, 0.0f) : v));
+        }
+        o8[c] = res;
+    }
+}
+
 static int g_bf16_variant = getenv("FRCNN_BF16_VARIANT") ? atoi(getenv("FRCNN_BF16_VARIANT")) : 2;   // dev knob: 0 = the round-1 loop
 
 template <int TM, int TN, int WM, int WN, bool MASKED, int VARIANT>
@@ -758,6 +834,12 @@ static int choose_config_bf16(const frcnn_conv_desc* d) {
         const long long t256 = ((M + 255) / 256) * nt256, t128x256 = ((M + 127) / 128) * nt256;
         if (wide && (d->cout % 256) == 0 && t256 >= 256) return 45;
         if (wide && (d->cout % 256) == 0 && t128x256 >= 200) return 46;
+        // round 3, batched passes (M = 8 x 14 700 RoI rows / 8 x 3 572 map rows; bench.py --config c4 --conv-table): with
+        // several ROUNDS of 256x256 tiles the wide form wins on the long-k layers -- 2048->512 311 -> 264 us, the head 3x3
+        // 465 -> 440, rpn_conv1 281 -> 264 -- and loses on the short-k, wide-output ones (512->2048 446 -> 505 us, 256->1024
+        // 36.8 -> 46.4: those are bound by their output / residual bytes, and the 128x128 tile requests its residual
+        // pieces before the main loop), so: long k, two or more rounds of whole tiles
+        if ((d->cout % 256) == 0 && t256 >= 512 && d->kh * d->kw * d->cin >= 1024) return 45;
         static const bool dma64 = getenv("FRCNN_BF16_DMA64") && atoi(getenv("FRCNN_BF16_DMA64")) != 0;   // dev knob
         static const int big = getenv("FRCNN_BF16_BIG") ? atoi(getenv("FRCNN_BF16_BIG")) : 47;            // dev knob: 42 = register-staged
         // 47 (direct-to-LDS 128x128) on long row ranges -- the detector head over 300 RoIs: 1024->2048 103 -> 81 us, 3x3
@@ -821,6 +903,9 @@ int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, c
     a.M = d->n * d->ho * d->wo; a.Kpad = d->kh * d->kw * d->cin; a.act = d->act; a.out_f32 = y_is_f32;
     a.tiles_m = a.tiles_n = 0;
     a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
+    static const bool no_pre = getenv("FRCNN_BF16_NO_RES_PRE") != nullptr;               // dev knob (A/B)
+    a.res_pre = !no_pre && residual_bf16 && (d->cout & 7) == 0 && (reinterpret_cast<uintptr_t>(residual_bf16) & 15) == 0
+             && (size_t)a.M * d->cout * 2 < 0x7fffffffull;
     a.layout = d->layout ? 1 : 0;
     a.pix_stride = a.layout ? d->n * d->cin : d->cin;
     a.img_stride = a.layout ? d->cin : d->h * d->w * d->cin;
@@ -938,6 +1023,19 @@ int frcnn_roi_crop_resize_fwd_bf16_ex(const void* feat_bf16, int rows, int cols,
     k_roi_fwd_bf16<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const __bf16*)feat_bf16, rows, cols, C, (const float4*)rois, pool,
                                                                    fill, relu, layout, (__bf16*)out_bf16);
     return check_launch("roi_crop_resize_fwd_bf16");
+}
+
+int frcnn_roi_crop_resize_fwd_bf16_batch(const void* feat_bf16, int n_img, int rows, int cols, int C, const float* rois, int n_per_img, int pool,
+                                         const float* fill, int relu, int layout, void* out_bf16, void* stream) {
+    if (n_img <= 0 || n_per_img <= 0 || rows <= 0 || cols <= 0 || C <= 0 || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16_batch: bad shape");
+    if (C % 8) return fail(FRCNN_E_UNSUPPORTED, "roi_crop_resize_fwd_bf16_batch: C must be a multiple of 8");
+    if (!feat_bf16 || !rois || !out_bf16) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16_batch: null pointer");
+    if ((reinterpret_cast<uintptr_t>(feat_bf16) | reinterpret_cast<uintptr_t>(out_bf16)) & 15) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16_batch: 16-byte aligned tensors");
+    const long long blocks = (long long)n_img * n_per_img * pool * pool;
+    if (blocks > 0x7fffffffLL) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16_batch: too many RoIs");
+    k_roi_fwd_bf16_batch<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>((const __bf16*)feat_bf16, rows, cols, C, (const float4*)rois, n_per_img, pool,
+                                                                          fill, relu, layout, (__bf16*)out_bf16);
+    return check_launch("roi_crop_resize_fwd_bf16_batch");
 }
 
 }  // extern "C"

@@ -286,6 +286,22 @@ class ResNetHead:
         return self.dense(x.reshape(x.shape[0], -1))
 
 
+    def forward_batched(self, feat, rois, n_per_img):
+        """The head over the RoIs of a BATCH of images in one pass: feat (B,R,C,Cf) bf16, rois (B*n_per_img,4) (RoI r belongs
+        to image r // n_per_img) -> (class probabilities (B*n,C), regressions).  Same layers, same per-row arithmetic as
+        ``__call__`` per image; the GEMMs are B times taller (one launch per layer for the whole batch)."""
+        assert self.dtype == "bf16" and self.hoist, "batched head: bf16, hoisted order"
+        L, a = self.layout, self.blocks[0]
+        u = a["2a"](feat, act=None)                         # conv + BN on every image's map (M = B * rows * cols)
+        v = a["1"](feat)
+        t = ops.roi_crop_resize_bf16_batch(u, rois, n_per_img, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)
+        s = ops.roi_crop_resize_bf16_batch(v, rois, n_per_img, self.pool, fill=a["1"].pc.shift, layout=L)
+        x = a["2c"](a["2b"](t, layout=L), residual=s, layout=L)
+        for b in self.blocks[1:]:
+            x = run_block(b, x, L)
+        return self.dense(ops.avgpool_bf16(x, 7, L))
+
+
 class VggHead:
     """RoiResizeConv -> Flatten (h,w,c order) -> fc1, fc2 (ReLU) -> dense x2 (vgg.py:226-255)."""
     pool = 7

@@ -183,9 +183,13 @@ def nms_sorted(boxes, n, thresh, max_boxes):
     return keep, n_keep
 
 
-def gather_rois(cand, keep, n_keep, batch, out_rows):
+def gather_rois(cand, keep, n_keep, batch, out_rows, out=None):
+    """``out``: write into this (out_rows,4) f32 tensor (a slice of a batch's RoI list) instead of a new one."""
     _require_gpu()
-    out = torch.empty((out_rows, 4), dtype=torch.float32, device="cuda")
+    if out is None:
+        out = torch.empty((out_rows, 4), dtype=torch.float32, device="cuda")
+    else:
+        assert out.dtype == torch.float32 and tuple(out.shape) == (out_rows, 4) and out.is_contiguous()
     _lib.call("frcnn_gather_rois", _p(cand), _p(keep), _p(n_keep), batch, out_rows, _p(out), _stream())
     return out
 
@@ -684,4 +688,18 @@ def roi_crop_resize_bf16(feat, rois, pool, fill=None, relu=False, layout=0):
     n = rois.shape[0]
     out = torch.empty((pool, pool, n, C) if layout else (n, pool, pool, C), dtype=torch.bfloat16, device="cuda")
     _lib.call("frcnn_roi_crop_resize_fwd_bf16_ex", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, _p(out), _stream())
+    return out
+
+
+def roi_crop_resize_bf16_batch(feat, rois, n_per_img, pool, fill=None, relu=False, layout=0):
+    """RoiResizeConv for the RoIs of several images in one launch: feat (B,R,C,Cf) bf16, rois (B*n_per_img,4) f32 (image =
+    row // n_per_img) -> (B*n,pool,pool,Cf) bf16, or (pool,pool,B*n,Cf) with layout=1."""
+    _require_gpu()
+    assert feat.dtype == torch.bfloat16 and feat.dim() == 4 and feat.is_contiguous()
+    B, rows, cols, C = feat.shape
+    rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
+    n = rois.shape[0]
+    assert n == B * n_per_img
+    out = torch.empty((pool, pool, n, C) if layout else (n, pool, pool, C), dtype=torch.bfloat16, device="cuda")
+    _lib.call("frcnn_roi_crop_resize_fwd_bf16_batch", _p(feat), B, rows, cols, C, _p(rois), n_per_img, pool, _p(fill), 1 if relu else 0, layout, _p(out), _stream())
     return out

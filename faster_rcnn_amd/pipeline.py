@@ -34,14 +34,14 @@ class InferencePipeline:
         self._graph = None
 
     # ------------------------------------------------------------------ stages
-    def proposals_dev(self, cls, reg):
+    def proposals_dev(self, cls, reg, rois_out=None):
         """RPN outputs (device) -> (rois (n_rois,4) f32, n_keep (1,) i32, cand, keep)."""
         rois_all, valid = ops.decode_proposals(reg, self.anchor_conv)
         scores = cls.reshape(-1)
         order, n = ops.topk_order(scores, valid, self.pre)
         cand, cand_scores = ops.gather_candidates(rois_all, scores, order, n, self.pre)
         keep, n_keep = ops.nms_sorted(cand, n, 0.7, self.post)
-        rois = ops.gather_rois(cand, keep, n_keep, self.roi_batch, self.n_rois)
+        rois = ops.gather_rois(cand, keep, n_keep, self.roi_batch, self.n_rois, out=rois_out)
         return rois, n_keep, cand, keep
 
     def forward_dev(self, x, resize_ratio=1.0):
@@ -95,3 +95,79 @@ class InferencePipeline:
             self._static_in.copy_(x)
         self._graph.replay()
         return self._static_out
+
+
+import os as _os
+# dev knob: False keeps the per-image stages of a batched pass on the pass's own stream
+PARALLEL_BRANCHES = _os.environ.get("FRCNN_PAR_BRANCHES", "0") != "0"
+
+
+class BatchedInferencePipeline(InferencePipeline):
+    """B images per pass (bf16 conv path, configs[3]): the backbone and the RPN heads run at batch B (GEMMs B times taller),
+    proposal selection and the detection post-process stay per image (the same kernels on each image's slice), and the
+    detector head makes ONE pass over all B x n_rois RoIs (frcnn_roi_crop_resize_fwd_bf16_batch puts every image's crops in
+    one position-major tensor).  One hipGraph replay = B images; several such graphs may replay concurrently.
+
+    Why: one 600x1500 image gives the ResNet-101 trunk 94 launches of 28-56 row tiles (M = 3 572) for 256 CUs and the head
+    GEMMs 115 row tiles; batched, every launch fills the chip and the big direct-to-LDS tiles apply everywhere
+    (scripts/c4_stage_times.py: trunk 1.47 -> 0.63 ms per image at B = 8, head 0.66 -> 0.56).  Per output row the arithmetic is
+    that of the per-image pipeline launched without split-K (a row's k order does not depend on the GEMM's height)."""
+
+    def __init__(self, rpn_model, det_model, anchor_dims, batch, **kw):
+        super().__init__(rpn_model, det_model, anchor_dims, **kw)
+        self.batch = int(batch)
+        assert getattr(det_model.head, "dtype", "f32") == "bf16" and hasattr(det_model.head, "forward_batched"), "batched pipeline: bf16 ResNet head"
+        # the per-image stages (proposal selection: ~10 short dependent launches; detection post-process: one workgroup) of the
+        # B images are independent chains.  FRCNN_PAR_BRANCHES=1 runs each on its own stream, forked from and joined into the
+        # pass's stream, so a captured graph holds them as B parallel branches: ONE graph in flight gains (B = 8: 663 -> 740
+        # img/s on configs[3]) but several such graphs replaying concurrently lose (B = 4 x 4 graphs: 856 -> 627: the runtime
+        # serialises branchy graphs against each other), and 3-4 plain graphs in flight hide the chains behind each other's
+        # convolutions anyway (856-878 img/s).  Off by default.
+        self._side = [torch.cuda.Stream() for _ in range(self.batch)] if self.batch > 1 and PARALLEL_BRANCHES else None
+
+    def _fan_out(self, fn):
+        """fn(i) for every image, image i on its own side stream between a fork from and a join into the current stream."""
+        if self._side is None:
+            return [fn(i) for i in range(self.batch)]
+        main = torch.cuda.current_stream()
+        outs = []
+        for i, st in enumerate(self._side):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(fn(i))
+        for st in self._side:
+            main.wait_stream(st)
+        return outs
+
+    def forward_dev(self, x, resize_ratio=1.0):
+        """x: (B,H,W,3) f32 device tensor.  Returns a dict: batch tensors with a leading image axis (rpn_cls, rpn_reg, feat,
+        rois (B,n_rois,4), cls (B,n_rois,C), reg) and per-image LISTS of the small outputs (n_rois, n_dets, det_packed, det_bbox,
+        det_cls, det_prob, det_roi: entry i is image i's tensor, exactly what InferencePipeline returns for one image)."""
+        B = self.batch
+        assert x.shape[0] == B
+        cls, reg, feat = self.rpn.forward_dev(x)
+        rois = torch.empty((B * self.n_rois, 4), dtype=torch.float32, device="cuda")
+        n_keep = self._fan_out(lambda i: self.proposals_dev(cls[i], reg[i], rois_out=rois[i * self.n_rois:(i + 1) * self.n_rois])[1])
+        out_cls, out_reg = self.det.head.forward_batched(feat, rois, self.n_rois)
+        res = {"rpn_cls": cls, "rpn_reg": reg, "feat": feat, "rois": rois.view(B, self.n_rois, 4), "n_rois": n_keep,
+               "cls": out_cls.view(B, self.n_rois, -1), "reg": out_reg.view(B, self.n_rois, -1)}
+        dets = self._fan_out(lambda i: ops.detections(rois[i * self.n_rois:(i + 1) * self.n_rois], n_keep[i], res["cls"][i], res["reg"][i], self.roi_batch,
+                                                      self.bg_idx, self.det_threshold, float(self.stride), float(resize_ratio)))
+        for k in dets[0]:
+            res[k] = [d[k] for d in dets]
+        return res
+
+    def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=False, throughput=True):
+        self._static_in = torch.zeros((self.batch, height, width, 3), dtype=torch.float32, device="cuda")
+        self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+            for _ in range(warmup):
+                self.forward_dev(self._static_in, resize_ratio)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+            self._static_out = self.forward_dev(self._static_in, resize_ratio)
+        return self

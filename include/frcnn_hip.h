@@ -414,6 +414,12 @@ int frcnn_roi_crop_resize_fwd_bf16(const void* feat_bf16, int rows, int cols, in
                                    void* out_bf16, void* stream);
 int frcnn_roi_crop_resize_fwd_bf16_ex(const void* feat_bf16, int rows, int cols, int c, const float* rois, int n, int pool,
                                       const float* fill, int relu, int layout, void* out_bf16, void* stream);
+/* The same for the RoIs of n_img images in ONE launch (batched inference: the detector head then makes one GEMM pass over
+ * every image's RoIs): feat [n_img][rows][cols][C] bf16, rois [n_img * n_per_img][4] f32 (RoI r reads image r / n_per_img),
+ * out over all RoIs in the chosen layout.  C % 8 == 0.  Per RoI bit-identical to frcnn_roi_crop_resize_fwd_bf16_ex
+ * (custom_layers.py:35-56). */
+int frcnn_roi_crop_resize_fwd_bf16_batch(const void* feat_bf16, int n_img, int rows, int cols, int C, const float* rois, int n_per_img, int pool,
+                                         const float* fill, int relu, int layout, void* out_bf16, void* stream);
 
 #ifdef __cplusplus
 }

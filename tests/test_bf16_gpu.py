@@ -295,3 +295,67 @@ def test_mixed_precision_training_step_against_the_bf16_storage_oracle(which):
     assert min(r[1] for r in report) >= 0.999, min(report, key=lambda r: r[1])
     assert max(r[2] for r in report) <= 0.05, max(report, key=lambda r: r[2])
     assert tot_dot / np.sqrt(tot_g * tot_w) >= 0.9995
+
+
+def test_batched_pipeline_equals_per_image_pipeline():
+    """BatchedInferencePipeline (B images per pass: trunk and RPN heads at batch B, ONE detector-head pass over all B x n RoIs)
+    against InferencePipeline on each image alone, both without split-K: a row's k order does not depend on how tall the GEMM
+    is, so every output is bit-identical -- RPN maps, proposals, detector outputs, detections."""
+    import numpy as np
+    from faster_rcnn_amd import ops, resnet, util
+    from faster_rcnn_amd.pipeline import BatchedInferencePipeline, InferencePipeline
+    from faster_rcnn_amd.weights import synthetic_resnet
+    anchors = util.get_anchors([32, 64, 128])
+    A, C, B, n = len(anchors), 10, 3, 40
+    w = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=9)
+    base = resnet.resnet50_base(weights=w, dtype="bf16")
+    rpn = resnet.resnet50_rpn(base, include_conv=True, anchors_per_loc=A)
+    det = resnet.resnet50_classifier(n, C, weights=w, dtype="bf16")
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy((rs.randint(0, 256, (B, 176, 240, 3)) - 110.0).astype(np.float32)).cuda()
+    with ops.conv_workspace(ops.NO_SPLIT_K):
+        bp = BatchedInferencePipeline(rpn, det, anchors, B, max_proposals=n)
+        out = bp.forward_dev(x)
+        single = InferencePipeline(rpn, det, anchors, max_proposals=n)
+        per = [single.forward_dev(x[i:i + 1].contiguous()) for i in range(B)]
+    torch.cuda.synchronize()
+    for i, o in enumerate(per):
+        assert torch.equal(out["rpn_cls"][i], o["rpn_cls"][0]) and torch.equal(out["rpn_reg"][i], o["rpn_reg"][0]) and torch.equal(out["feat"][i], o["feat"][0])
+        assert int(out["n_rois"][i]) == int(o["n_rois"]) > 0 and torch.equal(out["rois"][i], o["rois"])
+        assert torch.equal(out["cls"][i], o["cls"]) and torch.equal(out["reg"][i], o["reg"])
+        assert int(out["n_dets"][i]) == int(o["n_dets"])
+        for k in ("det_bbox", "det_cls", "det_prob", "det_roi"):                     # (det_packed also holds three pad words)
+            assert torch.equal(out[k][i], o[k]), k
+    # and from a captured graph (what bench.py --config c4 replays), fed another batch
+    bp.capture(176, 240)
+    x2 = torch.from_numpy((rs.randint(0, 256, (B, 176, 240, 3)) - 110.0).astype(np.float32)).cuda()
+    bp._static_in.copy_(x2)
+    bp._graph.replay()
+    torch.cuda.synchronize()
+    with ops.conv_workspace(ops.NO_SPLIT_K):
+        want = bp.forward_dev(x2)
+    torch.cuda.synchronize()
+    for i in range(B):
+        assert torch.equal(bp._static_out["det_bbox"][i], want["det_bbox"][i]) and torch.equal(bp._static_out["det_prob"][i], want["det_prob"][i])
+        assert torch.equal(bp._static_out["cls"][i], want["cls"][i])
+
+
+def test_batched_roi_resize_equals_per_image():
+    import numpy as np
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(2)
+    B, R, Cc, Cf, n = 3, 9, 13, 64, 7
+    feat = torch.from_numpy(rs.randn(B, R, Cc, Cf).astype(np.float32)).cuda().to(torch.bfloat16)
+    x1, y1 = rs.randint(0, Cc - 2, B * n), rs.randint(0, R - 2, B * n)
+    rois = np.stack([x1, y1, x1 + 1 + rs.randint(0, 6, B * n), y1 + 1 + rs.randint(0, 5, B * n)], 1).astype(np.float32)
+    rois[4] = [3, 3, 3, 8]                                             # an empty RoI -> the fill vector
+    rois[9] = [2, 1, Cc + 2, 4]                                        # out of the map -> fill
+    rois_d = torch.from_numpy(rois).cuda()
+    fill = torch.from_numpy(rs.randn(Cf).astype(np.float32)).cuda()
+    for layout in (0, 1):
+        for relu in (False, True):
+            got = ops.roi_crop_resize_bf16_batch(feat, rois_d, n, 7, fill=fill, relu=relu, layout=layout)
+            for i in range(B):
+                want = ops.roi_crop_resize_bf16(feat[i], rois_d[i * n:(i + 1) * n], 7, fill=fill, relu=relu, layout=layout)
+                part = got[:, :, i * n:(i + 1) * n] if layout else got[i * n:(i + 1) * n]
+                assert torch.equal(part, want)
