@@ -79,6 +79,9 @@ SIGNATURES = {
     "frcnn_sumsq_workspace_bytes": (c_size_t, []),
     "frcnn_sumsq": (I, [P, c_size_t, P, P, c_size_t, P]),
     "frcnn_fold_bias": (I, [P, P, P, P, I, P]),
+    "frcnn_stem_bf16_packed_elems": (I, []),
+    "frcnn_pack_stem_weights_bf16": (I, [P, P, P]),
+    "frcnn_stem_bf16_fwd": (I, [P, I, I, I, P, P, P, P, P]),
     "frcnn_conv_packed_k_bf16": (I, [I, I, I]),
     "frcnn_pack_conv_weights_bf16": (I, [P, I, I, I, I, P, P]),
     "frcnn_conv2d_fwd_bf16": (I, [P, P, P, P, P, P, P, I, P]),

@@ -27,7 +27,8 @@ class ConvUnit:
         self.dtype, self.out_f32 = dtype, out_f32           # "bf16": bf16 operands / activations (configs[3])
         self.pc = None
 
-    def lower(self):
+    def folded(self):
+        """(HWIO kernel f32, per-channel scale, shift) with bias, BatchNorm and Scale folded (numpy)."""
         w = self.weights[self.conv]
         kernel = np.asarray(w[0], dtype=np.float32)
         if kernel.ndim == 2:                               # Dense kernel (in, out) == 1x1 conv
@@ -45,8 +46,11 @@ class ConvUnit:
             g2, b2 = (np.asarray(a, dtype=np.float64) for a in self.weights[self.scale_name])
             scale = scale * g2
             shift = shift * g2 + b2
+        return kernel, scale.astype(np.float32), shift.astype(np.float32)
+
+    def lower(self):
         packer = ops.PackedConvBf16 if self.dtype == "bf16" else ops.PackedConv
-        self.pc = packer(kernel, scale.astype(np.float32), shift.astype(np.float32))
+        self.pc = packer(*self.folded())
         return self
 
     def __call__(self, x, residual=None, out=None, act="unit", layout=0):
@@ -98,6 +102,7 @@ class DualUnit:
 
 
 FUSE_PAIRS = True       # dev knob (tests): False launches every layer on its own
+FUSED_BF16_STEM = True  # dev knob (tests): False = f32 stem conv + f32 pool + cast in front of a bf16 trunk
 
 
 def _pair(first, second):
@@ -157,11 +162,20 @@ class ResNetBase:
         for b in self.blocks:
             yield from b.values()
 
+    def stem_pool(self, x):
+        """conv1 + BN (+ Scale) + ReLU + MaxPooling2D((3,3), strides=(2,2)) (resnet.py:408-412).  bf16 path: ONE launch on
+        the bf16 matrix cores with the pool and the bf16 store fused (frcnn_stem_bf16_fwd); ``FUSED_BF16_STEM = False``
+        keeps the round-1/2 form (f32 conv, f32 pool, cast)."""
+        if self.dtype == "bf16" and FUSED_BF16_STEM:
+            src = tuple(id(a) for name in (self.stem.conv, self.stem.bn, self.stem.scale_name) if name for a in self.weights[name])
+            if getattr(self, "_stem_bf16", None) is None or self._stem_src != src:      # (re-packed when conv1 / its BatchNorm were replaced)
+                self._stem_bf16, self._stem_src = ops.PackedStemBf16(*self.stem.folded()), src
+            return ops.stem_bf16(x, self._stem_bf16)
+        x = ops.pool2d(self.stem(x), 3, 2, True)
+        return ops.cast_bf16(x) if self.dtype == "bf16" else x
+
     def __call__(self, x):
-        x = self.stem(x)
-        x = ops.pool2d(x, 3, 2, True)                       # MaxPooling2D((3,3), strides=(2,2)) (resnet.py:412)
-        if self.dtype == "bf16":                            # the 3-channel stem and its pool stay f32
-            x = ops.cast_bf16(x)
+        x = self.stem_pool(x)
         for b in self.blocks:
             x = run_block(b, x)
         return x

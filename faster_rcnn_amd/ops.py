@@ -703,3 +703,28 @@ def roi_crop_resize_bf16_batch(feat, rois, n_per_img, pool, fill=None, relu=Fals
     out = torch.empty((pool, pool, n, C) if layout else (n, pool, pool, C), dtype=torch.bfloat16, device="cuda")
     _lib.call("frcnn_roi_crop_resize_fwd_bf16_batch", _p(feat), B, rows, cols, C, _p(rois), n_per_img, pool, _p(fill), 1 if relu else 0, layout, _p(out), _stream())
     return out
+
+
+class PackedStemBf16:
+    """The fused bf16 stem's parameters (frcnn_stem_bf16_fwd): conv1's 7x7x3x64 filter packed to bf16 [64][176] and the
+    folded f32 scale / shift of bias + BatchNorm (+ Scale)."""
+
+    def __init__(self, w_hwio, scale, shift):
+        _require_gpu()
+        w = _dev(w_hwio, torch.float32)
+        assert tuple(w.shape) == (7, 7, 3, 64), "the fused stem is conv1 of the ResNets: 7x7x3 -> 64"
+        self.w = torch.empty(_lib.load().frcnn_stem_bf16_packed_elems(), dtype=torch.bfloat16, device="cuda")
+        _lib.call("frcnn_pack_stem_weights_bf16", _p(w), _p(self.w), _stream())
+        self.scale, self.shift = _dev(scale, torch.float32), _dev(shift, torch.float32)
+        torch.cuda.current_stream().synchronize()            # w may be a temporary
+
+
+def stem_bf16(x, ps):
+    """(n,H,W,3) f32 preprocessed images -> (n,Hp,Wp,64) bf16: conv1 + BN (+Scale) + ReLU + 3x3/2 max-pool, one launch."""
+    _require_gpu()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[-1] == 3
+    n, h, w, _ = x.shape
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    out = torch.empty((n, (ho - 3) // 2 + 1, (wo - 3) // 2 + 1, 64), dtype=torch.bfloat16, device="cuda")
+    _lib.call("frcnn_stem_bf16_fwd", _p(x), n, h, w, _p(ps.w), _p(ps.scale), _p(ps.shift), _p(out), _stream())
+    return out

@@ -325,7 +325,7 @@ class ResNetBaseTrain:
         net = base_model.net
         freeze = set(base_model.freeze_blocks)
         self.bf16 = getattr(net, "dtype", "f32") == "bf16"
-        self.stem, self.frozen_blocks, self.blocks = net.stem, [], []
+        self.net, self.stem, self.frozen_blocks, self.blocks = net, net.stem, [], []
         first = True
         for (stage, block, _), units in zip(resnet_block_names(net.depth), net.blocks):
             if stage in freeze:
@@ -351,9 +351,7 @@ class ResNetBaseTrain:
     def forward_frozen(self, x):
         """Stem and the frozen stages: no trainable weight is read, so a step driver may run this for the NEXT image
         while the previous step is still in its backward pass (_StepDriver._run_step)."""
-        t = ops.pool2d(self.stem(x), 3, 2, True)
-        if self.bf16:                                           # the 3-channel stem and its pool stay f32 (nets.ResNetBase)
-            t = ops.cast_bf16(t)
+        t = self.net.stem_pool(x)                               # (bf16: conv1 + BN + ReLU + pool + bf16 store in one launch)
         for units in self.frozen_blocks:
             t = nets.run_block(units, t)
         return t

@@ -374,6 +374,16 @@ int frcnn_sumsq(const float* w, size_t n, float* out, void* workspace, size_t wo
  * activations/filters on v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 scale/shift, one RNE rounding
  * at the store.  cin % 64 == 0 (the 3-channel stem stays on the f32 kernel).  Layouts as the f32 path;
  * packed filter row length = kh*kw*cin, k = ((c/64)*kh*kw + tap)*64 + c%64. */
+/* The ResNet stem in ONE launch on the bf16 matrix cores: conv1 7x7 / 2 'same' (3 -> 64) + folded BatchNorm (+ Scale) + ReLU +
+ * MaxPooling2D(3x3, strides 2, VALID) + the bf16 store that opens the bf16 trunk (resnet.py:408-412; resnet101: :565-568).
+ * x [n][h][w][3] f32 (preprocessed image, rounded to bf16 once inside), packed filter from frcnn_pack_stem_weights_bf16
+ * (HWIO f32 [7][7][3][64] -> bf16 [64][176], k = r*24 + s*3 + c), scale / shift [64] f32 (folded bias + BatchNorm + Scale);
+ * out [n][hp][wp][64] bf16 with hp = ((h+1)/2 - 3)/2 + 1.  f32 accumulate, f32 epilogue, one rounding; the pool runs on the
+ * rounded values (rounding is monotonic: same bits as pooling first). */
+int frcnn_stem_bf16_packed_elems(void);
+int frcnn_pack_stem_weights_bf16(const float* w_hwio, void* packed_bf16, void* stream);
+int frcnn_stem_bf16_fwd(const float* x, int n, int h, int w, const void* w_packed_bf16, const float* scale, const float* shift,
+                        void* out_bf16, void* stream);
 int frcnn_conv_packed_k_bf16(int kh, int kw, int cin);
 int frcnn_pack_conv_weights_bf16(const float* w_hwio, int kh, int kw, int cin, int cout, void* packed_bf16, void* stream);
 /* y is bf16 [M][cout], or f32 when y_is_f32 != 0 (network outputs: RPN scores/regressions). */

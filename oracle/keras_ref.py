@@ -171,11 +171,15 @@ class KerasGraphs:
     the identity otherwise): the comparand for the product's bf16 / mixed-precision paths, so that what is left between
     the two is accumulation order, not storage precision."""
 
-    def __init__(self, weights, dtype=None, mixed=False):
+    def __init__(self, weights, dtype=None, mixed=False, bf16_stem=None):
         torch = _torch()
         self.w = weights
         self.dtype = dtype or torch.float32
         self.mixed = mixed
+        # round 3: on the bf16 paths the product's stem is a bf16 conv too (frcnn_stem_bf16_fwd: pixels and conv1's taps
+        # rounded to bf16, f32 accumulate, BatchNorm / ReLU in f32, one rounding, then the pool); False = the round-1/2
+        # f32 stem whose pooled output is cast once
+        self.bf16_stem = mixed if bf16_stem is None else bool(bf16_stem)
         if mixed:
             self.q, self.qw = _make_quantisers()
         else:
@@ -191,7 +195,7 @@ class KerasGraphs:
     def conv(self, x, name, stride=1, padding="valid"):
         w = self.w[name]
         k = w[0]
-        if self.mixed and self._bf16_layer(name):
+        if self.mixed and (self._bf16_layer(name) or (self.bf16_stem and name == "conv1")):
             k = self.qw(_t(k, self.dtype))
         return conv2d(x, k, w[1] if len(w) > 1 else None, stride, padding, self.dtype)
 
@@ -232,6 +236,8 @@ class KerasGraphs:
     def resnet_base(self, x, depth=50):
         """resnet50_base (resnet.py:395-448) / resnet101_base (:551-602). x: (1,H,W,3)."""
         r101 = depth == 101
+        if self.mixed and self.bf16_stem:
+            x = self.q(_t(x, self.dtype))                                   # the fused bf16 stem rounds the pixels once
         x = self.conv(x, "conv1", stride=2, padding="same")                 # :408
         x = self.bn(x, "bn_conv1", 1e-3)                                    # Keras default eps (:410)
         if r101:

@@ -359,3 +359,55 @@ def test_batched_roi_resize_equals_per_image():
                 want = ops.roi_crop_resize_bf16(feat[i], rois_d[i * n:(i + 1) * n], 7, fill=fill, relu=relu, layout=layout)
                 part = got[:, :, i * n:(i + 1) * n] if layout else got[i * n:(i + 1) * n]
                 assert torch.equal(part, want)
+
+
+@pytest.mark.parametrize("shape", [(1, 37, 53), (2, 160, 224), (1, 75, 131), (1, 600, 1500)])
+def test_fused_bf16_stem(shape):
+    """frcnn_stem_bf16_fwd (conv1 7x7/2 'same' + BN + Scale + ReLU + 3x3/2 max-pool + bf16 store in one launch, resnet.py:408-412)
+    against f64 arithmetic on the SAME bf16-rounded pixels and filter taps: what is left is the f32 accumulation order, i.e. at
+    most one bf16 rounding step on the stored value.  Sizes: odd and even, pooled extents that do not fill the last 4 x 16
+    workgroup patch, a batch of two, and configs[3]'s own 600x1500."""
+    import numpy as np
+    import torch.nn.functional as F
+    from faster_rcnn_amd import nets, ops
+    n, h, w = shape
+    rs = np.random.RandomState(h)
+    x = (rs.randint(0, 256, (n, h, w, 3)) - np.array([103.939, 116.779, 123.68])).astype(np.float32)
+    wts = {"conv1": [(rs.randn(7, 7, 3, 64) * 0.05).astype(np.float32), (rs.randn(64) * 0.1).astype(np.float32)],
+           "bn_conv1": [(rs.rand(64) + 0.5).astype(np.float32), (rs.randn(64) * 0.2).astype(np.float32), (rs.randn(64) * 0.5).astype(np.float32), (rs.rand(64) + 0.5).astype(np.float32)],
+           "scale_conv1": [(rs.rand(64) + 0.5).astype(np.float32), (rs.randn(64) * 0.1).astype(np.float32)]}
+    unit = nets.ConvUnit(wts, "conv1", "bn_conv1", "scale_conv1", nets.BN_EPS_STEM, stride=2, padding="same", act="relu")
+    kernel, scale, shift = unit.folded()
+    got = ops.stem_bf16(torch.from_numpy(x).cuda(), ops.PackedStemBf16(kernel, scale, shift)).float().cpu()
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    assert tuple(got.shape) == (n, (ho - 3) // 2 + 1, (wo - 3) // 2 + 1, 64)
+    q = lambda t: t.to(torch.bfloat16).to(torch.float64)
+    xq, kq = q(torch.from_numpy(x)).permute(0, 3, 1, 2), q(torch.from_numpy(kernel)).permute(3, 2, 0, 1)
+    pt, pl = max((ho - 1) * 2 + 7 - h, 0), max((wo - 1) * 2 + 7 - w, 0)
+    y = F.conv2d(F.pad(xq, (pl // 2, pl - pl // 2, pt // 2, pt - pt // 2)), kq, stride=2)
+    y = (y * torch.from_numpy(scale).double().view(1, -1, 1, 1) + torch.from_numpy(shift).double().view(1, -1, 1, 1)).clamp(min=0)
+    want = F.max_pool2d(y, 3, 2).permute(0, 2, 3, 1)
+    err = (got.double() - want).abs()
+    bar = want.abs() * 2.0 ** -8 + 1e-6                       # one bf16 rounding step (8 significant bits) of the exact value
+    assert bool((err <= bar).all()), float((err / bar).max())
+    assert float((got.double() == want.to(torch.bfloat16).double()).double().mean()) > 0.97     # nearly all values: the very same bf16
+
+
+def test_fused_stem_network_close_to_f32_stem_network():
+    """The bf16 trunk behind the fused bf16 stem against the same trunk behind the round-2 f32 stem (FUSED_BF16_STEM off): the two
+    differ by the stem's operand rounding only -- relative RMS of the conv4 map well under the bf16 parity bars."""
+    import numpy as np
+    from faster_rcnn_amd import nets, resnet
+    from faster_rcnn_amd.weights import synthetic_resnet
+    w = synthetic_resnet(50, anchors_per_loc=9, seed=3)
+    x = torch.from_numpy((np.random.RandomState(0).randint(0, 256, (1, 160, 224, 3)) - 110.0).astype(np.float32)).cuda()
+    outs = []
+    for fused in (True, False):
+        nets.FUSED_BF16_STEM = fused
+        try:
+            outs.append(resnet.resnet50_base(weights=w, dtype="bf16").net(x).float())
+        finally:
+            nets.FUSED_BF16_STEM = True
+    a, b = outs
+    rms = float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
+    assert rms < 1e-2, rms
