@@ -35,6 +35,7 @@ struct ConvArgsBf16 {
     float* slabs;
     unsigned* tickets;
     int res_pre;            // 1: the kernel may request its residual pieces BEFORE the main loop (16-byte addressable, tensor under 2 GiB)
+    int epi_rows;           // 1: the workgroup-wide "row pieces" epilogue (cout % 8 == 0); 0: the per-wave patches (dev knob / fallback)
 };
 
 constexpr int BKH = 64;                 // channels per k-chunk (128 B)
@@ -67,11 +68,12 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     constexpr int RPP = NT / 8;                          // tile rows staged per pass (8 lanes x 16 B per row)
     constexpr int PA = BM / RPP, PB = BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-    static_assert(VARIANT != 3 || !SPLITK, "the direct-to-LDS form takes whole-K tiles");
-    constexpr int LSTR = VARIANT == 3 ? 128 : LDS_STRIDE_B;   // VARIANT 3: unpadded rows, XOR-swizzled 16-byte slots
+    static_assert(VARIANT < 3 || !SPLITK, "the direct-to-LDS forms take whole-K tiles");
+    constexpr int LSTR = VARIANT >= 3 ? 128 : LDS_STRIDE_B;   // VARIANTs 3 / 4: unpadded rows, XOR-swizzled 16-byte slots
+    constexpr int RING = VARIANT == 4 ? 4 : 2;                 // LDS operand buffers (VARIANT 4: a ring of four, three chunks in flight)
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    char* As = smem_b;                                   // [2][BM][LSTR]
-    char* Bs = smem_b + 2 * BM * LSTR;                   // [2][BN][LSTR]
+    char* As = smem_b;                                   // [RING][BM][LSTR]
+    char* Bs = smem_b + RING * BM * LSTR;                // [RING][BN][LSTR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -85,8 +87,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     // VARIANT 3 (256-wide column tiles, a handful per row tile): the column tiles of ONE row tile are adjacent, so an XCD's
     // resident workgroups share their A rows in L2 and the whole filter (<= 4 MB on the head) stays there; the other forms
     // walk row tiles first (their column tile's filter slice is what the neighbours share)
-    const int tile_n = VARIANT == 3 ? tile % p.tiles_n : tile / p.tiles_m;
-    const int tile_m = VARIANT == 3 ? tile / p.tiles_n : tile - tile_n * p.tiles_m;
+    const int tile_n = VARIANT >= 3 ? tile % p.tiles_n : tile / p.tiles_m;
+    const int tile_m = VARIANT >= 3 ? tile / p.tiles_n : tile - tile_n * p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     // byte column inside the 128-B chunk row this thread stages.  VARIANT 3: the LDS slot is the lane's position in the
     // wave instruction (tid & 7); slot g' of row r holds granule g' ^ ((r >> 1) & 7), so THAT is what the lane fetches
     // (rows advance by 64 per pass: the XOR term is the same for all of a thread's rows)
-    const int lrow = tid >> 3, lcolb = VARIANT == 3 ? (((tid & 7) ^ ((lrow >> 1) & 7)) * 16) : (tid & 7) * 16;
+    const int lrow = tid >> 3, lcolb = VARIANT >= 3 ? (((tid & 7) ^ ((lrow >> 1) & 7)) * 16) : (tid & 7) * 16;
     int a_h[PA], a_w[PA], a_off[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -195,32 +197,40 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     // 1-2 us, and only then did each half tile issue its 16-byte residual load and wait for it, four round trips in a row per
     // wave.  One or two 32x32 tiles per wave: 2 or 4 pieces of 16 bytes per lane (8-16 registers; the 128x128 eight-wave
     // tile has 69 of its 128 in use).  Same values added in the same order: bit-identical.
-    constexpr bool RES_PRE = !SPLITK && !MASKED && (TM * TN == 1 || (VARIANT == 3 && TM * TN == 2));   // (the register-staged 128x128 tile has no room: 118 + 18 registers)
-    i32x4 rpre[RES_PRE ? TM * TN * 2 : 1];
+    // Round 3, epilogue through ONE workgroup-wide LDS tile ("row pieces"): the per-wave patch above hands every lane 8
+    // channels of a 32-column tile, so a wave's store instruction covers sixteen 64-BYTE row segments -- half cache lines,
+    // the other half written by the neighbouring wave some time later.  With the whole BM x BN f32 tile in LDS (it fits in
+    // the dead operand buffers of every tile up to 128x128) thread t owns 16-byte pieces of WHOLE rows: piece q is row
+    // q * RPPE + t / PPR, channels 8 (t % PPR) .., a wave instruction writes four full 256-byte row segments.  Same
+    // arithmetic per element in the same order as the per-wave form: bit-identical (tests compare the two).
+    constexpr int PPR = BN / 8, RPPE = NT / PPR, EP = BM / RPPE;
+    constexpr bool EPI_ROWS = (size_t)BM * BN * 4 <= (size_t)RING * (BM + BN) * LSTR && NT % PPR == 0 && BM % RPPE == 0;
+    // The residual pieces this lane adds in the epilogue are requested HERE, before the main loop (the f32 kernel's EPI_PRE).
+    // The short-k, wide-output layers -- every block's 2c: 256 -> 1024 over 28 576 rows of a batch of eight (4 chunks),
+    // 512 -> 2048 over 117 600 RoI rows (8 chunks) -- have a main loop of 1-2 us, after which each piece issued its 16-byte
+    // residual load and waited for it.  2-4 pieces of 16 bytes per lane (8-16 registers; the 128x128 eight-wave direct-to-LDS
+    // tile has 69 of its 128 in use, the register-staged one 118: no room there).  Same values, same order: bit-identical.
+    constexpr bool RES_PRE = !SPLITK && !MASKED && EPI_ROWS && (TM * TN == 1 || (VARIANT >= 3 && TM * TN == 2));
+    i32x4 rpre[RES_PRE ? EP : 1];
     bool pre = false;
     if constexpr (RES_PRE) {
-        pre = p.res_pre && p.residual != nullptr;
+        pre = p.res_pre && p.residual != nullptr && p.epi_rows;
         if (pre) {
             const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<__bf16*>(p.residual), 0, (int)((size_t)p.M * p.Cout * 2), 0x00020000);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int m = m0 + wm * TM * 32 + i * 32 + half * 16 + (lane >> 2);
-                        const int n = n0 + wn * TN * 32 + j * 32 + (lane & 3) * 8;
-                        const unsigned off = (m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * p.Cout + n) * 2) : OOB_OFFSET_B;
-                        rpre[(j * TM + i) * 2 + half] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
-                    }
+            for (int q = 0; q < EP; ++q) {
+                const int m = m0 + q * RPPE + tid / PPR, n = n0 + (tid % PPR) * 8;
+                const unsigned off = (m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * p.Cout + n) * 2) : OOB_OFFSET_B;
+                rpre[q] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+            }
         }
     }
 
     constexpr int MF = TM * TN;            // MFMAs per k-step (k = 16)
     constexpr int NL = PA + PB;
     constexpr int NF = TM + TN;
-    if constexpr (VARIANT == 3) {
+    if constexpr (VARIANT >= 3) {
         // Direct global -> LDS staging (buffer_load ... lds) for the 256-wide tiles of the detector head (round 2).
         // The 128x128 tile reads 1.5 fragments per MFMA and moves 32 KB of operands per 512 CU-cycles of matrix work; a
         // 128x64 (256x256 tile) or 64x64 (128x256) patch per wave reads 0.75 / 1.0 and halves the operand traffic.  What
@@ -270,14 +280,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         };
         const int arow = wm * TM * 32 + li, brow = wn * TN * 32 + li;
         const int sw = (li >> 1) & 7;                             // (row >> 1) & 7 of every fragment row of this lane (tiles are 32 rows apart)
-        prep();
-        issue(0);
-        prep();                                                   // chunk kb + 1 (never issued if the range has one chunk)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int kc = kb; kc < ke; ++kc) {
-            const int buf = (kc - kb) & 1;
-            if (kc + 1 < ke) issue(buf ^ 1);
+        auto multiply = [&](int buf) {
             const char* a = As + buf * BM * LSTR + arow * LSTR;
             const char* b = Bs + buf * BN * LSTR + brow * LSTR;
 #pragma unroll
@@ -294,9 +297,46 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
+        };
+        if constexpr (VARIANT == 4) {
+            // Round 3: a RING of four operand buffers, three chunks in flight.  On the short-k, wide-output layers of a batched
+            // pass (512 -> 2048 over 117 600 RoI rows: 8 chunks; 256 -> 1024 over 28 576: 4) a chunk is 256 MFMA cycles per
+            // wave, while its operands take 1-2 us to arrive (the first column tile of a row tile misses the L2): with ONE
+            // chunk of lead and two workgroups per CU the matrix pipe idled 78 % of the time (553 TFLOP/s, 2.4 TB/s).  Here
+            // chunk t + 3 is requested as chunk t starts; `s_waitcnt vmcnt(n)` waits for the OLDEST chunk only (a chunk is NL
+            // wave instructions per thread, requests complete in order), then one barrier makes it visible to all waves and
+            // frees the buffer chunk t - 1 was read from.  128 KB of LDS: one workgroup per CU.  Same k order: bit-identical.
+            const int nk = ke - kb;
+            prep(); issue(0);
+            prep(); if (nk > 1) issue(1);
+            prep(); if (nk > 2) issue(2);
+            prep();                                               // chunk kb + 3
+            for (int t = 0; t < nk; ++t) {
+                const int later = min(2, nk - 1 - t);             // chunks requested behind chunk t (wave-uniform)
+                if (later == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * NL) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 3 < nk) issue((t + 3) & 3);               // into the buffer of chunk t - 1: every wave is past its reads
+                multiply(t & 3);
+                prep();                                           // chunk t + 4, behind this chunk's MFMAs
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // the epilogue reuses the buffers
+        } else {
+        prep();
+        issue(0);
+        prep();                                                   // chunk kb + 1 (never issued if the range has one chunk)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kc = kb; kc < ke; ++kc) {
+            const int buf = (kc - kb) & 1;
+            if (kc + 1 < ke) issue(buf ^ 1);
+            multiply(buf);
             prep();                                               // chunk kc + 2, behind this chunk's MFMAs
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        }
         }
     } else if constexpr (VARIANT == 2) {
         // The mid-chunk-barrier schedule of conv_igemm.hip's VARIANT 2.  A bf16 chunk is only 4 x MF MFMAs of 32 cycles
@@ -477,6 +517,65 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     }
 
     // epilogue: C/D map col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    if constexpr (EPI_ROWS) {
+        if (p.epi_rows) {
+            float* stg = reinterpret_cast<float*>(smem_b);               // [BM][BN] f32, unpadded (see the read order below)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ncl = wn * TN * 32 + j * 32 + li, nc = n0 + ncl;
+                const float sc = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
+                const float sh = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float* dst = stg + (wm * TM * 32 + i * 32 + 4 * lh) * BN + ncl;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[i][j][e] * sc + sh;
+                }
+            }
+            __syncthreads();
+            const int prow = tid / PPR, pcol = (tid % PPR) * 8;
+            // a row is BN floats, unpadded: lanes c and c + 8 of a row would meet on the same banks, so the upper eight read
+            // their second 16 bytes first
+            const int swap = (tid % PPR) & 8 ? 4 : 0;
+#pragma unroll
+            for (int q = 0; q < EP; ++q) {
+                const int row = q * RPPE + prow, m = m0 + row, n = n0 + pcol;
+                const float* src = stg + row * BN + pcol;
+                const f32x4 va = *reinterpret_cast<const f32x4*>(src + swap);
+                const f32x4 vb = *reinterpret_cast<const f32x4*>(src + (swap ^ 4));
+                const f32x4 v0 = swap ? vb : va, v1 = swap ? va : vb;
+                if (m < p.M && n < p.Cout) {
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    const size_t o = (size_t)m * p.Cout + n;
+                    if (p.residual) {
+                        bf16x8 r;
+                        if (RES_PRE && pre) r = __builtin_bit_cast(bf16x8, rpre[RES_PRE ? q : 0]);
+                        else r = *reinterpret_cast<const bf16x8*>(p.residual + o);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += (float)r[k];
+                    }
+                    if constexpr (MASKED) {
+                        const bf16x8 mk = *reinterpret_cast<const bf16x8*>(p.mask + o);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) if (!((float)mk[k] > 0.0f)) v[k] = 0.0f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = activate_b(v[k], p.act);
+                    if (p.out_f32) {
+                        float* y = reinterpret_cast<float*>(p.y) + o;
+                        *reinterpret_cast<f32x4*>(y) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(y + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    } else {
+                        bf16x8 ob;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) ob[k] = (__bf16)v[k];
+                        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(p.y) + o) = ob;
+                    }
+                }
+            }
+            return;
+        }
+    }
     if ((p.Cout & 7) == 0) {
         // Vectorised form.  In the accumulator layout a lane owns ONE column, so storing from it means 2-byte stores
         // (and 2-byte residual / mask loads) -- 16 memory instructions per 32x32 tile, each moving 128 B.  Instead
@@ -507,9 +606,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                         const size_t o = (size_t)m * p.Cout + n;
                         if (p.residual) {
-                            bf16x8 r;
-                            if (RES_PRE && pre) r = __builtin_bit_cast(bf16x8, rpre[RES_PRE ? (j * TM + i) * 2 + half : 0]);
-                            else r = *reinterpret_cast<const bf16x8*>(p.residual + o);
+                            const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.residual + o);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] += (float)r[q];
                         }
@@ -675,6 +772,25 @@ __global__ void k_avgpool_bf16_f32(const __bf16* x, int n, int hw, int C, int po
     }
 }
 
+// The same, eight channels (16 bytes) per lane: the scalar form above moves 2 bytes per lane per load (1.85 TB/s over the
+// 482 MB of a batch of eight's res5c output); per channel the additions are the same, in the same order: bit-identical.
+__global__ void k_avgpool_bf16_f32_v8(const __bf16* x, int n, int hw, int C, int pos_major, float* y) {
+    const size_t total8 = (size_t)n * C / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 8;                               // first of this lane's eight (img, c) outputs: same img (C % 8 == 0)
+        const int c = (int)(e % C);
+        const size_t img = e / C;
+        float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q = 0; q < hw; ++q) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(pos_major ? x + (size_t)q * n * C + e : x + (img * hw + q) * C + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];
+        }
+        *reinterpret_cast<f32x4*>(y + e) = f32x4{acc[0] / (float)hw, acc[1] / (float)hw, acc[2] / (float)hw, acc[3] / (float)hw};
+        *reinterpret_cast<f32x4*>(y + e + 4) = f32x4{acc[4] / (float)hw, acc[5] / (float)hw, acc[6] / (float)hw, acc[7] / (float)hw};
+    }
+}
+
 // RoiResizeConv on a bf16 feature map (custom_layers.py:35-56): f32 lerp, bf16 output
 __global__ void __launch_bounds__(256) k_roi_fwd_bf16(const __bf16* feat, int rows, int cols, int C, const float4* rois, int pool,
                                                       const float* fill, int relu, int pos_major, __bf16* out) {
@@ -760,7 +876,7 @@ static int launch_bf16_v(const ConvArgsBf16& a, hipStream_t s) {
     ConvArgsBf16 p = a;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * (VARIANT == 3 ? 128 : LDS_STRIDE_B);
+    const size_t lds = VARIANT == 4 ? (size_t)4 * (BM + BN) * 128 : (size_t)2 * (BM + BN) * (VARIANT == 3 ? 128 : LDS_STRIDE_B);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -906,6 +1022,8 @@ int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, c
     static const bool no_pre = getenv("FRCNN_BF16_NO_RES_PRE") != nullptr;               // dev knob (A/B)
     a.res_pre = !no_pre && residual_bf16 && (d->cout & 7) == 0 && (reinterpret_cast<uintptr_t>(residual_bf16) & 15) == 0
              && (size_t)a.M * d->cout * 2 < 0x7fffffffull;
+    static const bool wave_epi = getenv("FRCNN_BF16_WAVE_EPILOGUE") != nullptr;          // dev knob (A/B, bit-identity tests)
+    a.epi_rows = !wave_epi && (d->cout & 7) == 0;
     a.layout = d->layout ? 1 : 0;
     a.pix_stride = a.layout ? d->n * d->cin : d->cin;
     a.img_stride = a.layout ? d->cin : d->h * d->w * d->cin;
@@ -944,6 +1062,8 @@ int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, c
                  return launch_bf16<2, 1, 2, 4>(a, s);
         // (the masked launches -- training's input gradients, 2-3 k rows -- stay on the register-staged forms)
         case 47: if (!a.mask) return launch_bf16_v<2, 1, 2, 4, false, 3>(a, s);     // 128x128, 8 waves, direct-to-LDS staging (two workgroups per CU)
+                 return launch_bf16<2, 1, 2, 4>(a, s);
+        case 49: if (!a.mask) return launch_bf16_v<2, 1, 2, 4, false, 4>(a, s);     // 128x128, 8 waves, direct-to-LDS RING of four buffers (one workgroup per CU)
                  return launch_bf16<2, 1, 2, 4>(a, s);
         case 48: if (!a.mask) return launch_bf16_v<1, 1, 2, 2, false, 3>(a, s);     // 64x64, 4 waves, direct-to-LDS staging
                  return launch_bf16<1, 1>(a, s);
@@ -1007,7 +1127,10 @@ int frcnn_avgpool_bf16_to_f32(const void* x_bf16, int n, int k, int c, float* y,
 
 int frcnn_avgpool_bf16_to_f32_ex(const void* x_bf16, int n, int k, int c, int layout, float* y, void* stream) {
     if (!x_bf16 || !y || n <= 0 || k <= 0 || c <= 0) return fail(FRCNN_E_ARG, "avgpool_bf16_to_f32: bad argument");
-    k_avgpool_bf16_f32<<<ew_grid_b((size_t)n * c), 256, 0, as_stream(stream)>>>((const __bf16*)x_bf16, n, k * k, c, layout, y);
+    if ((c & 7) == 0 && ((reinterpret_cast<uintptr_t>(x_bf16) | reinterpret_cast<uintptr_t>(y)) & 15) == 0)
+        k_avgpool_bf16_f32_v8<<<ew_grid_b((size_t)n * c / 8), 256, 0, as_stream(stream)>>>((const __bf16*)x_bf16, n, k * k, c, layout, y);
+    else
+        k_avgpool_bf16_f32<<<ew_grid_b((size_t)n * c), 256, 0, as_stream(stream)>>>((const __bf16*)x_bf16, n, k * k, c, layout, y);
     return check_launch("avgpool_bf16_to_f32");
 }
 
@@ -1033,7 +1156,9 @@ int frcnn_roi_crop_resize_fwd_bf16_batch(const void* feat_bf16, int n_img, int r
     if ((reinterpret_cast<uintptr_t>(feat_bf16) | reinterpret_cast<uintptr_t>(out_bf16)) & 15) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16_batch: 16-byte aligned tensors");
     const long long blocks = (long long)n_img * n_per_img * pool * pool;
     if (blocks > 0x7fffffffLL) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_bf16_batch: too many RoIs");
-    k_roi_fwd_bf16_batch<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>((const __bf16*)feat_bf16, rows, cols, C, (const float4*)rois, n_per_img, pool,
+    // one workgroup per output pixel, one lane per 8 channels: 64 lanes for the 512-channel map, 256 for the 2048-channel one
+    const int threads = C / 8 >= 256 ? 256 : (C / 8 > 64 ? 128 : 64);
+    k_roi_fwd_bf16_batch<<<(unsigned)blocks, threads, 0, as_stream(stream)>>>((const __bf16*)feat_bf16, rows, cols, C, (const float4*)rois, n_per_img, pool,
                                                                           fill, relu, layout, (__bf16*)out_bf16);
     return check_launch("roi_crop_resize_fwd_bf16_batch");
 }
