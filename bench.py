@@ -173,7 +173,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1):
         "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
         "launches_per_image": dom[2], "images_per_launch": images, "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
         "gflop_per_launch_avg": round(dom[0] / dom[2] / 1e9, 3),
-        "share_of_conv_time": round(dom[1] / tot_ms, 3),
+        "share_of_conv_time": round(dom[1] / images / tot_ms, 3),
         "heaviest_shape_MNK": list(heavy_key[1:4]),
         "heaviest_shape_tflops": round(heavy["rec"]["flops"] / (heavy["ms"] * 1e-3) / 1e12, 2),
         "all_conv_launches": {"launches_per_image": sum(v[2] for v in per_kernel.values()),

@@ -88,3 +88,17 @@ for k in sorted(acc):
     if "TCC_HIT_sum" in c:
         print("    -> L2 hit rate = %.3f" % (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
 json.dump(traffic, open(os.path.join(root, "traffic.json"), "w"), indent=1)
+# whole-pass totals per PMC directory (all kernels): HBM-side bytes of everything a pass launched
+print("\n== PMC totals per pass directory (all kernels summed; KB as the counters report them)")
+for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
+    if not os.path.isdir(d):
+        continue
+    tot = collections.defaultdict(float)
+    nd = 0
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+            nd += 1
+    log = d + ".log"
+    note = open(log).read().strip().splitlines()[-1][:120] if os.path.exists(log) else ""
+    print(os.path.basename(d), {k: "%.4g" % v for k, v in tot.items()}, "rows", nd, "|", note)
