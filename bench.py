@@ -551,6 +551,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="images per hipGraph (BatchedInferencePipeline: trunk at batch B, one detector-head pass over B x 300 RoIs); "
                          "default: 8 for configs[3] (bf16), 1 otherwise")
+    ap.add_argument("--unit-tiles", default="", help="dev: tile codes for named conv layers, e.g. res5a_branch2c=26,res5b_branch2c=26")
     ap.add_argument("--conv-table", action="store_true", help="print every distinct conv launch's duration alone on the chip to stderr")
     ap.add_argument("--no-train-dp", action="store_true", help="N > 1: leave the data-parallel training steps (`train_dp`) out of the line")
     args = ap.parse_args()
@@ -585,6 +586,12 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count() if world > 1 else 0)
 
     pipe, weights, anchors = build_pipeline()
+    if args.unit_tiles:
+        want = dict(kv.split("=") for kv in args.unit_tiles.split(","))
+        for m in (pipe.rpn.base.net, pipe.rpn.head) + ((pipe.det.head,) if hasattr(pipe, "det") else ()):
+            for u in m.units():
+                if u.conv in want:
+                    u.tile = int(want[u.conv])
     B = args.batch                                  # images per hipGraph (1 = InferencePipeline, one image per graph)
     synth_batch = lambda first: torch.from_numpy(np.concatenate([synth_image(first + j) for j in range(B)])).cuda()
     if B > 1:

@@ -1908,7 +1908,8 @@ static int choose_streamk(const frcnn_conv_desc* d, int cfg) {
         // eligible (3x3 575 -> 483 us, 2048->512 276 -> 263, 1024->512 154 -> 149); on the 64x64 tile the partial-tile
         // traffic eats the gain (506 -> 520, 280 -> 294), and beside other images' launches (tile 50) the idle slots
         // are already taken: four images in flight run 3 % slower with it
-        if (!big || d->tile % 100 == 50) return 0;
+        static const bool sk_shared = getenv("FRCNN_SK_SHARED") != nullptr;       // dev knob: the balanced form beside other images' launches too
+        if (!big || (d->tile % 100 == 50 && !sk_shared)) return 0;
         if (nk_max < 32 || tiles * 100 > G * 94 || tiles * 2 < G) return 0;
     }
     long long U = 0;

@@ -40,5 +40,19 @@ def main():
         print("%-18s stem kernel %.1f us (%.1f TF)   generic on 4 channels %.1f us" % (name, t3, gf / t3 * 1e3, t4))
 
 
+def fused_bf16():
+    """The fused bf16 stem (conv1 + BN + ReLU + 3x3/2 max-pool + bf16 store, one launch) against the three launches it replaces."""
+    rs = np.random.RandomState(1)
+    wt = (rs.randn(7, 7, 3, 64) * 0.05).astype(np.float32)
+    sc, sh = (rs.rand(64) + 0.5).astype(np.float32), rs.randn(64).astype(np.float32)
+    ps, pc = ops.PackedStemBf16(wt, sc, sh), ops.PackedConv(wt, sc, sh)
+    for n, h, w in ((1, 600, 1000), (1, 600, 1500), (8, 600, 1500)):
+        x = torch.from_numpy(rs.randn(n, h, w, 3).astype(np.float32) * 50).cuda()
+        t_f = timed(lambda: ops.stem_bf16(x, ps))
+        t_o = timed(lambda: ops.cast_bf16(ops.pool2d(ops.conv2d(x, pc, 2, "same", "relu"), 3, 2, True)))
+        print("stem %dx%dx%d: fused bf16 %.1f us (%.1f per image)   f32 conv + pool + cast %.1f us" % (n, h, w, t_f, t_f / n, t_o))
+
+
 if __name__ == "__main__":
     main()
+    fused_bf16()
