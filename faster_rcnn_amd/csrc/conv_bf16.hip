@@ -658,6 +658,156 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Row-STRIP form for the short-k, wide-output 1x1 layers of a batched pass (round 3): every ResNet block's branch2c --
+// 512 -> 2048 over 117 600 RoI rows, 256 -> 1024 over 28 576 map rows -- and the stride-1 shortcuts.
+//
+// PMC on the tiled kernel (scripts/pmc_bf16_one.sh, 512 -> 2048): matrix pipe 25 % busy, waves waiting 54 % of their cycles,
+// 5.3 GB through the L2 for 1.1 GB of algorithmic bytes, at ~47 GB/s per CU -- the per-CU vector-memory path, not HBM
+// (3.3 TB/s) and not the MFMAs, sets the time: a 128x128 tile pulls 32 KB of operands per 64-deep chunk and its A rows are
+// pulled again by each of the 16 column tiles.  Here a workgroup owns a STRIP of BM rows and walks ALL column tiles itself:
+// the strip's A operand (BM x K bf16 <= 64 KB) is brought into LDS ONCE and stays, only the filter streams (two 16 KB ring
+// buffers, chunk t + 1 requested while chunk t multiplies -- across column-tile boundaries, so it also flies during a
+// column tile's epilogue), the residual pieces of a column tile are requested when its first chunk starts, and the stores of
+// tile j drain under the chunks of tile j + 1.  Operand bytes through the CU: K x (BM + N) instead of K x (BM + 128) x N / 128.
+// 1x1, stride 1, no padding (a GEMM: Y[m] = X[m] . W^T in either row layout), bf16 output, cin % 64 == 0, BM x K x 2 <= 64 KB.
+// Same k order, same epilogue arithmetic as the tiled forms: bit-identical.
+template <int BM>
+__global__ void __launch_bounds__(512) k_gemm_strip_bf16(const ConvArgsBf16 p) {
+    constexpr int NT = 512, BN = 128, RPP = 64, LSTR = 128;
+    constexpr int TM = BM / 64;                            // 32-row tiles per wave (2 x 4 waves: wm owns BM / 2 rows, wn 32 columns)
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int PPR = BN / 8, RPPE = NT / PPR, EP = BM / RPPE;
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    char* Al = smem_s;                                     // [nk][BM][128 B], the strip's whole A operand (<= 64 KB)
+    char* Wl = smem_s + 65536;                             // [2][128][128 B] filter ring
+    float* stg = reinterpret_cast<float*>(smem_s + 65536 + 2 * BN * LSTR);       // [BM][128] f32 epilogue tile
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int nk = p.Kpad / BKH, tiles_n = (p.Cout + BN - 1) / BN, T = nk * tiles_n;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x), 0, (int)((size_t)p.M * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.Cout * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<__bf16*>(p.y), 0, (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+    const int lrow = tid >> 3, lcolb = ((tid & 7) ^ ((lrow >> 1) & 7)) * 16;       // source granule of this lane's LDS slot (the XOR swizzle)
+    unsigned a_off[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + RPP * i;
+        a_off[i] = m < p.M ? (unsigned)((size_t)m * p.Cin * 2 + lcolb) : OOB_OFFSET_B;
+    }
+    auto issue_w = [&](int t) {                            // chunk t of the strip's (column tile, k chunk) sequence -> ring buffer t & 1
+        const int j = t / nk, c = t - j * nk;
+        char* b = Wl + (t & 1) * BN * LSTR + wave * 8 * LSTR;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int n = j * BN + lrow + RPP * i;
+            const unsigned off = n < p.Cout ? (unsigned)((size_t)n * p.Kpad * 2 + lcolb) : OOB_OFFSET_B;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(b + i * RPP * LSTR), 16, off, c * (BKH * 2), 0, 0);
+        }
+#endif
+    };
+    const bool pre = p.residual != nullptr;
+    i32x4 rpre[EP];
+    auto issue_res = [&](int j) {
+#pragma unroll
+        for (int q = 0; q < EP; ++q) {
+            const int m = m0 + q * RPPE + tid / PPR, n = j * BN + (tid % PPR) * 8;
+            const unsigned off = (m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * p.Cout + n) * 2) : OOB_OFFSET_B;
+            rpre[q] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+        }
+    };
+    // ---- the strip's A operand, once
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int c = 0; c < nk; ++c) {
+        char* a = Al + c * BM * LSTR + wave * 8 * LSTR;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(a + i * RPP * LSTR), 16, a_off[i], c * (BKH * 2), 0, 0);
+    }
+#endif
+    issue_w(0);
+    if (pre) issue_res(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int arow = wm * TM * 32 + li, brow = wn * 32 + li, sw = (li >> 1) & 7;
+    const int prow = tid / PPR, pcol = (tid % PPR) * 8, swap = (tid % PPR) & 8 ? 4 : 0;
+    int t = 0;
+    for (int j = 0; j < tiles_n; ++j) {
+        f32x16 acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+        for (int c = 0; c < nk; ++c, ++t) {
+            if (t + 1 < T) issue_w(t + 1);                 // into the buffer chunk t - 1 was read from: everyone passed the last barrier
+            if (c == 0 && j > 0 && pre) issue_res(j);
+            const char* a = Al + c * BM * LSTR + arow * LSTR;
+            const char* b = Wl + (t & 1) * BN * LSTR + brow * LSTR;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int slot = ((2 * st + lh) ^ sw) * 16;
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(b + slot);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(a + i * 32 * LSTR + slot);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+                }
+            }
+            const bool last = c == nk - 1;
+            if (last) {
+                // ---- epilogue of column tile j (the row-piece form of k_conv_igemm_bf16): scale / shift per column in the
+                // accumulator layout -> f32 tile in LDS -> 16-byte pieces of whole rows + residual + activation -> bf16
+                const int n0 = j * BN, ncl = wn * 32 + li, nc = n0 + ncl;
+                const float sc = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
+                const float sh = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float* dst = stg + (wm * TM * 32 + i * 32 + 4 * lh) * BN + ncl;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[i][e] * sc + sh;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int q = 0; q < EP; ++q) {
+                    const int row = q * RPPE + prow, m = m0 + row, n = n0 + pcol;
+                    const float* src = stg + row * BN + pcol;
+                    const f32x4 va = *reinterpret_cast<const f32x4*>(src + swap);
+                    const f32x4 vb = *reinterpret_cast<const f32x4*>(src + (swap ^ 4));
+                    const f32x4 v0 = swap ? vb : va, v1 = swap ? va : vb;
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (pre) {
+                        const bf16x8 r = __builtin_bit_cast(bf16x8, rpre[q]);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] += (float)r[k];
+                    }
+                    bf16x8 ob;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ob[k] = (__bf16)activate_b(v[k], p.act);
+                    // branch-free: EVERY wave issues exactly EP store instructions per column tile (pieces outside the tensor
+                    // ride on the buffer descriptor) -- the vmcnt arithmetic at the end of the iteration counts on it
+                    const unsigned yoff = (m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * p.Cout + n) * 2) : OOB_OFFSET_B;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, ob), yrsrc, yoff, 0, 0);
+                }
+            }
+            // chunk t + 1 must have landed before the next iteration reads it; what this iteration issued BEHIND it may stay in
+            // flight: the residual pieces of tile j (c == 0), the stores of tile j (last chunk) -- requests complete in order
+            const int later = ((c == 0 && j > 0 && pre) ? EP : 0) + (last ? EP : 0);
+            if (later == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else if (later == EP) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(EP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * EP) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
 // f32 HWIO [R][S][Cin][Cout] -> bf16 packed [Cout][Kpad], k = ((c/64)*R*S + tap)*64 + c%64 (Cin % 64 == 0)
 __global__ void k_pack_hwio_bf16(const float* w, int RS, int Cin, int Cout, int Kpad, __bf16* out) {
     const size_t total = (size_t)Cout * Kpad;
@@ -915,6 +1065,29 @@ static int launch_bf16_splitk(const ConvArgsBf16& a, hipStream_t s) {
 }
 
 // K-slices per tile for the 64x64 bf16 kernel: same policy as the f32 engine (conv_igemm.hip choose_splits)
+// the row-strip GEMM form (k_gemm_strip_bf16): eligibility of a descriptor, and the strip height it takes
+static int strip_rows_bf16(const frcnn_conv_desc* d, bool has_mask, int y_is_f32) {
+    if (has_mask || y_is_f32 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad_top || d->pad_left) return 0;
+    if ((d->cin % BKH) || (d->cout & 7) || d->ho != d->h || d->wo != d->w) return 0;
+    const int K = d->cin;
+    if (128 * K * 2 <= 65536) return 128;
+    if (64 * K * 2 <= 65536) return 64;
+    return 0;
+}
+
+template <int BM>
+static int launch_strip_bf16(const ConvArgsBf16& a, hipStream_t s) {
+    const size_t lds = 65536 + 2 * 128 * 128 + (size_t)BM * 128 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)k_gemm_strip_bf16<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS to %zu", lds);
+        attr_done = true;
+    }
+    k_gemm_strip_bf16<BM><<<(a.M + BM - 1) / BM, 512, lds, s>>>(a);
+    return check_launch("conv2d_fwd_bf16 (row strips)");
+}
+
 static int choose_splits_bf16(const frcnn_conv_desc* d, int cfg) {
     if (cfg != 2 && cfg != 12) return 1;
     const long long M = (long long)d->n * d->ho * d->wo;
@@ -1048,7 +1221,13 @@ int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, c
             return launch_bf16_splitk(a, s);
         }
     }
-    switch (cfg) {
+    if (cfg == 60) {                                                 // row strips (explicit code; auto: choose_config_bf16)
+        const int bm = strip_rows_bf16(d, mask_bf16 != nullptr, y_is_f32);
+        if (bm && (!residual_bf16 || (reinterpret_cast<uintptr_t>(residual_bf16) & 15) == 0) && (reinterpret_cast<uintptr_t>(y) & 15) == 0
+            && (size_t)a.M * d->cout * 2 < 0x7fffffffull && (size_t)a.M * d->cin * 2 < 0x7fffffffull)
+            return bm == 128 ? launch_strip_bf16<128>(a, s) : launch_strip_bf16<64>(a, s);
+    }
+    switch (cfg == 60 ? 47 : cfg) {                                  // (60 on a shape that is not a strip shape: the 128x128 direct-to-LDS tile)
         case 1: case 11: return launch_bf16<2, 2>(a, s);
         case 2: case 12: return launch_bf16<1, 1>(a, s);
         case 3: case 13: return launch_bf16<2, 1>(a, s);

@@ -28,7 +28,13 @@ torch = pytest.importorskip("torch")
                                   (1, 30, 41, 256, 320, 1, 2, "valid", 45), (1, 30, 41, 256, 320, 1, 2, "valid", 46),
                                   (6, 14, 14, 1024, 512, 1, 1, "valid", 46), (6, 14, 14, 256, 1024, 3, 1, "same", 45),
                                   (2, 15, 22, 128, 192, 3, 1, "same", 47), (6, 14, 14, 256, 1024, 3, 1, "same", 47),     # 128x128 (the auto pick)
-                                  (1, 30, 41, 256, 320, 1, 2, "valid", 48), (3, 7, 7, 512, 200, 3, 1, "same", 48)])     # 64x64
+                                  (1, 30, 41, 256, 320, 1, 2, "valid", 48), (3, 7, 7, 512, 200, 3, 1, "same", 48),      # 64x64
+                                  # round 3 dev codes: 49 = the 128x128 tile on a RING of four LDS buffers (three chunks in flight),
+                                  # 60 = row strips (A resident in LDS, the workgroup walks all column tiles; 1x1 stride 1 only:
+                                  # other shapes fall back to 47): one / two / many k chunks, ragged rows and columns
+                                  (2, 15, 22, 128, 192, 3, 1, "same", 49), (6, 14, 14, 256, 1024, 3, 1, "same", 49), (1, 19, 23, 64, 136, 1, 1, "valid", 49),
+                                  (1, 19, 23, 64, 136, 1, 1, "valid", 60), (3, 37, 41, 256, 1024, 1, 1, "valid", 60), (2, 33, 35, 512, 328, 1, 1, "valid", 60),
+                                  (1, 30, 41, 256, 320, 1, 2, "valid", 60)])
 def test_conv2d_bf16(case):
     from faster_rcnn_amd import ops
     from oracle import keras_ref
@@ -48,10 +54,10 @@ def test_conv2d_bf16(case):
     assert got.dtype == torch.bfloat16 and tuple(got.shape) == tuple(want.shape)
     err = ((got.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
     assert err < 1e-2, err
-    got32 = ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), out_f32=True, tile=tile)
+    got32 = ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), out_f32=True, tile=tile)     # (60 with an f32 output: the tiled form)
     err32 = ((got32.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
     assert err32 < 1e-4, err32                      # f32 accumulate on identical operands
-    if tile in (45, 46, 47, 48):                    # same k order, same MFMA: bit for bit the 128x128 tile's result,
+    if tile in (45, 46, 47, 48, 49, 60):            # same k order, same MFMA: bit for bit the 128x128 tile's result,
         ref42 = ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), tile=42)
         for _ in range(8):                          # every time (the staging is asynchronous: a race would come and go)
             assert torch.equal(ops.conv2d_bf16(x.cuda(), pc, stride, padding, "relu", res.cuda(), tile=tile), ref42)
