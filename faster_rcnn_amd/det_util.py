@@ -29,6 +29,20 @@ class DetTrainingManager:
         self.anchor_dims = anchor_dims
         self._cache = {}
         self.conv_only = True if len(rpn_model.output) == 3 else False
+        self._stream = None
+
+    def _own_stream(self):
+        """The manager's device work (RPN forward, decode, ordering, NMS, RoI -> truth, the copies back to numpy) runs on a
+        stream of its own.  In the detector loops (train_util._train_detector) it is called while the PREVIOUS detector step
+        is still enqueued on the caller's stream; on that stream the `.cpu()` at the end of this work would make the host wait
+        for the whole step before it could stage the next image.  The RPN model here is never the model being
+        trained (steps 2 / 4 freeze it: train_det_step2.py / step4), and a detector trainer writes only its own master
+        and packed buffers, so nothing this stream reads is written by the step beside it."""
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        if getattr(self.rpn_model, "_trainer", None) is not None and getattr(self.rpn_model, "_dirty", False):
+            self._stream.wait_stream(torch.cuda.current_stream())       # (a trained RPN model: order behind its last step)
+        return torch.cuda.stream(self._stream)
 
     def batched_image(self, image):
         return np.expand_dims(self.preprocess_func(image.data), axis=0)
@@ -51,11 +65,12 @@ class DetTrainingManager:
         return rois, (feat if self.conv_only else None)
 
     def _process(self, image):
-        rois, feat = self._proposals_dev(image, 12000, 2000)
-        filtered_rois, y_class_num, y_transform = _rois_to_truth(rois, image, self.class_mapping, stride=self.stride)
-        cache_obj = {"rois": filtered_rois, "y_class_num": y_class_num, "y_transform": y_transform}
-        if feat is not None:
-            cache_obj["conv_out"] = feat.cpu().numpy()
+        with self._own_stream():
+            rois, feat = self._proposals_dev(image, 12000, 2000)
+            filtered_rois, y_class_num, y_transform = _rois_to_truth(rois, image, self.class_mapping, stride=self.stride)
+            cache_obj = {"rois": filtered_rois, "y_class_num": y_class_num, "y_transform": y_transform}
+            if feat is not None:
+                cache_obj["conv_out"] = feat.cpu().numpy()
         self._cache[image.cache_key] = cache_obj
 
     def get_training_input(self, image):
@@ -76,8 +91,9 @@ class DetTrainingManager:
 
     def get_det_inputs(self, image):
         """det_util.py:136-158: (conv feature map (1,R,C,Cf) or None, nms_rois (n,4) int16)."""
-        rois, feat = self._proposals_dev(image, 8000, 300)
-        return (feat.cpu().numpy() if feat is not None else None), rois.cpu().numpy()
+        with self._own_stream():
+            rois, feat = self._proposals_dev(image, 8000, 300)
+            return (feat.cpu().numpy() if feat is not None else None), rois.cpu().numpy()
 
 
 def _get_anchor_coords(conv_rows, conv_cols, anchor_dims, multiplier=1):

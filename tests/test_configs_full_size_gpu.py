@@ -156,10 +156,12 @@ def test_config2_rpn_step1_600x1000_training_step_fp32():
     worst = max(stats.items(), key=lambda kv: kv[1][0])
     worst_m = max(stats.items(), key=lambda kv: kv[1][1]); worst_c = min(stats.items(), key=lambda kv: kv[1][2])
     print("config2 fp32 step: losses", losses, ref_losses, "worst fro", worst, "worst max", worst_m, "worst cos", worst_c)
-    # f32 gradient sums over 2 394 pixels x up to 9 taps vs f64; a ReLU pre-activation within rounding of 0 may take the other
-    # branch (tests/test_train_gpu.py check_updates): Frobenius 3e-2 / max 0.2 are the bars of the reduced-size tests
-    assert worst[1][0] < 3e-2 and max(v[1] for v in stats.values()) < 0.2, worst
-    assert min(v[2] for v in stats.values()) > 0.9995, min(stats.items(), key=lambda kv: kv[1][2])
+    # f32 gradient sums over 2 394 pixels x up to 9 taps vs f64.  Measured on MI355X (round 3, this seed; the step is bitwise
+    # reproducible): worst relative Frobenius error 1.19e-3 and worst max error 4.96e-3 of the largest update (both
+    # res4c_branch2a), worst cosine 0.999999 (res4a_branch2c).  Bars at ~2.5x the measured values (round 2 held 3e-2 / 0.2 /
+    # 0.9995, the slack of the reduced-size tests, where a ReLU pre-activation within rounding of 0 may take the other branch).
+    assert worst[1][0] < 3e-3 and max(v[1] for v in stats.values()) < 1.2e-2, (worst, worst_m)
+    assert min(v[2] for v in stats.values()) > 0.99999, worst_c
 
 
 def _det_inputs(rows, cols, C, n, seed):
