@@ -33,11 +33,13 @@ int main() {
         d.pad_top = same ? ((d.ho - 1) * d.stride + d.kh - d.h > 0 ? ((d.ho - 1) * d.stride + d.kh - d.h) / 2 : 0) : 0;
         d.pad_left = same ? ((d.wo - 1) * d.stride + d.kw - d.w > 0 ? ((d.wo - 1) * d.stride + d.kw - d.w) / 2 : 0) : 0;
         d.act = rnd() % 3;
-        d.tile = pick({0, 0, 0, 50, 2, 21, 22, 23, 26, 61, 62, 123, 302, 42, 45, 46, 47, 48, 999});
+        d.tile = pick({0, 0, 0, 50, 2, 21, 22, 23, 26, 61, 62, 123, 302, 42, 45, 46, 47, 48, 49, 60, 999});
         d.layout = (d.n > 5 && (d.cin % 32) == 0) ? (rnd() & 1) : 0;
         const size_t a = frcnn_conv2d_workspace_bytes(&d);
         const size_t b = frcnn_conv2d_workspace_bytes_bf16(&d);
         const size_t c = frcnn_conv2d_wgrad_workspace_bytes(&d);
+        const size_t dual = frcnn_conv2d_dual_workspace_bytes(&d);          // round 3: the two-layer launch's split-K workspace
+        if (dual > ((size_t)1 << 33) || (dual && (d.cin % 32))) { printf("implausible dual workspace %zu\n", dual); ++failures; }
         const int k = frcnn_conv_packed_k(d.kh, d.kw, d.cin);
         if (k < d.kh * d.kw * d.cin) { printf("packed_k too small for %dx%dx%d\n", d.kh, d.kw, d.cin); ++failures; }
         if (a > ((size_t)1 << 33) || b > ((size_t)1 << 33) || c > ((size_t)1 << 36)) { printf("implausible workspace %zu %zu %zu\n", a, b, c); ++failures; }
@@ -70,7 +72,18 @@ int main() {
     if (frcnn_loss_rpn_cls_ws(nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr) == FRCNN_OK) { printf("loss accepted nulls\n"); ++failures; }
     if (frcnn_loss_workspace_bytes() < 1024) { printf("loss workspace too small\n"); ++failures; }
     if (frcnn_refresh_packed(nullptr, 3, nullptr) == FRCNN_OK) { printf("refresh_packed accepted a null table\n"); ++failures; }
-    checked += 6;
+    // round 3 entry points: refused before any launch
+    float dummy = 0.0f;
+    if (frcnn_conv2d_fwd_dual(&d, &dummy, &dummy, nullptr, nullptr, &dummy, 64, 1, &dummy, 0, nullptr, 0, nullptr) == FRCNN_OK) { printf("dual accepted n1 == cout\n"); ++failures; }
+    if (frcnn_conv2d_fwd_dual(&d, &dummy, &dummy, nullptr, nullptr, &dummy, 32, 1, nullptr, 0, nullptr, 0, nullptr) == FRCNN_OK) { printf("dual accepted a null second output\n"); ++failures; }
+    d.cin = 48;
+    if (frcnn_conv2d_fwd_dual(&d, &dummy, &dummy, nullptr, nullptr, &dummy, 32, 1, &dummy, 0, nullptr, 0, nullptr) == FRCNN_OK) { printf("dual accepted cin %% 32 != 0\n"); ++failures; }
+    if (frcnn_stem_bf16_fwd(nullptr, 1, 600, 1000, nullptr, nullptr, nullptr, nullptr, nullptr) == FRCNN_OK) { printf("stem accepted nulls\n"); ++failures; }
+    if (frcnn_stem_bf16_fwd(&dummy, 1, 5, 5, &dummy, &dummy, &dummy, &dummy, nullptr) == FRCNN_OK) { printf("stem accepted a 5x5 image\n"); ++failures; }
+    if (frcnn_stem_bf16_packed_elems() != 64 * 176) { printf("stem packed size\n"); ++failures; }
+    if (frcnn_roi_crop_resize_fwd_bf16_batch(&dummy, 2, 38, 94, 12, &dummy, 300, 7, nullptr, 0, 1, &dummy, nullptr) == FRCNN_OK) { printf("roi batch accepted C %% 8 != 0\n"); ++failures; }
+    if (frcnn_roi_crop_resize_fwd_bf16_batch(nullptr, 2, 38, 94, 16, nullptr, 300, 7, nullptr, 0, 1, nullptr, nullptr) == FRCNN_OK) { printf("roi batch accepted nulls\n"); ++failures; }
+    checked += 14;
     printf("host sanitizer driver: %d checks, %d failures\n", checked, failures);
     return failures ? 1 : 0;
 }
