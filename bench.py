@@ -171,6 +171,8 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1):
         "bound": "mfma", "kernel": dom_name,
         "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+        "traffic_source": "profiles/traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch of this kernel, from the committed rocprofv3 --pmc "
+                          "passes of scripts/profile_round3.sh (counters cannot be read from inside this process; null if the kernel is not in the file)",
         "launches_per_image": dom[2], "images_per_launch": images, "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
         "gflop_per_launch_avg": round(dom[0] / dom[2] / 1e9, 3),
         "share_of_conv_time": round(dom[1] / images / tot_ms, 3),
