@@ -33,6 +33,13 @@ def _worker(rank, world, port, out):
     scale = dp.allreduce_sum_(g)
     assert scale == 0.5
     assert torch.allclose(g * scale, torch.arange(1000, dtype=torch.float32) * 0.5)
+    # the asynchronous form the training step uses (started behind the last gradient kernel, waited for when the optimiser
+    # is enqueued): same sum, same scale
+    g2 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    handle, scale2 = dp.allreduce_sum_begin(g2)
+    assert handle is not None and scale2 == 0.5
+    handle.wait()
+    assert torch.equal(g2, torch.arange(1000, dtype=torch.float32) * 3)
     # schedule: the two ranks cover consecutive images of the reference schedule, no overlap
     idx = [dp.image_index(i, 1, 10, 7) for i in range(10)]
     out[rank] = idx
@@ -56,6 +63,7 @@ def test_single_process_is_identity():
     assert dp.world() == 1 and dp.rank() == 0
     g = torch.ones(5)
     assert dp.allreduce_sum_(g) == 1.0 and bool((g == 1).all())
+    assert dp.allreduce_sum_begin(g) == (None, 1.0)                      # nothing to wait for: the step updates at once
     # world 1 reproduces the reference schedule exactly (train_util.py:39)
     assert [dp.image_index(i, 2, 10, 7) for i in range(10)] == [(i + 10 * 2) % 7 for i in range(10)]
 
