@@ -76,8 +76,8 @@ def allreduce_ms(params, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bf16", action="store_true", help="mixed precision: bf16 activations / gradients / packed filters, f32 masters")
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=40, help="untimed steps first: ~0.1 s of work, enough for the clocks to leave their idle state (with 3 the first config timed read 2.6-4.6 ms from box to box)")
     ap.add_argument("--big-tiles", action="store_true")
     ap.add_argument("--only", choices=("rpn", "det"), default=None)
     ap.add_argument("--sync-each-step", action="store_true", help="time only the plain Keras call (losses read back after every step); by default "
