@@ -464,7 +464,7 @@ def spawn_ranks(n):
     sys.exit(0)
 
 
-def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=3):
+def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=10):
     """BASELINE configs[2] inside the N > 1 line: ResNet-50 RPN step-1 training steps at 600x1000, one image per GPU
     per step (train_util.py:38-54 under data parallelism), the flat gradient buffer through the path's ONE collective
     (dp.allreduce_sum_begin -> RCCL all-reduce over xGMI).  Every rank runs this; returns the object rank 0 prints.
