@@ -601,10 +601,12 @@ def main():
         pipe = BatchedInferencePipeline(pipe.rpn, pipe.det, anchors, B, max_proposals=PROPOSALS)
     x = synth_batch(rank)
     S = max(1, args.streams)
-    # split-K is a latency tool: measured on MI355X it gains 6-9 % with one image in flight, nothing (f32) or -4 % (bf16)
-    # with four, and costs 1.2 % (f32: 246.1 vs 249.0 img/s, `--split-k off`) with eight, where concurrency already
-    # fills the small grids.  The fp32 default keeps it on: the graphs then hold the same launch forms the roofline
-    # section times one at a time (the small-grid layers alone on the chip are what split-K is for).
+    # split-K is a latency tool: measured on MI355X it gains 6-9 % with one image in flight, and with eight (f32) it costs
+    # 1.2-1.4 % (round 3: 266.2 / 267.2 img/s with it, 269.9 / 270.0 with `--split-k off`: concurrency already fills the small
+    # grids and the plain launches do less total work); bf16 with four in flight loses 4 %.  The fp32 default keeps it on: the
+    # graphs then hold the same launch forms the roofline section times one at a time (the small-grid layers alone on the chip
+    # are what split-K is for; without it every 64x64 launch also falls under ONE instantiation name, which then outweighs the
+    # 3x3 head kernel as "dominant kernel" at 0.53 of peak alone -- a bookkeeping change, not a slower pipeline).
     split_k = args.split_k == "on" or (args.split_k == "auto" and B == 1 and (S == 1 or DTYPE == "f32"))
     if not args.no_graph:
         from faster_rcnn_amd.pipeline import InferencePipeline
