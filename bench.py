@@ -453,10 +453,32 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
+    # rank 0's stdout is drained on a thread; the ranks are polled so that ONE rank dying (before the process group is up
+    # the others would sit in the rendezvous until its timeout) takes the rest down at once -- by the PIDs started here
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    reader.join(timeout=10)
+    if not failed:
+        sys.stdout.write(b"".join(chunks).decode())
+        sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
