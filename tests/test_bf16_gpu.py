@@ -417,3 +417,25 @@ def test_fused_stem_network_close_to_f32_stem_network():
     a, b = outs
     rms = float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
     assert rms < 1e-2, rms
+
+
+def test_fused_bf16_stem_random_sizes():
+    """The fused stem on random image sizes (odd / even, down to the smallest the pool accepts, pooled extents on and off the
+    4 x 16 workgroup patch) against the three launches it replaces fed the SAME bf16-rounded pixels and taps: f32 conv of
+    bf16-exact operands accumulates the same products in another order, so the stored bf16 values agree to one rounding step."""
+    import numpy as np
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(77)
+    wt = (rs.randn(7, 7, 3, 64) * 0.05).astype(np.float32)
+    sc, sh = (rs.rand(64) + 0.5).astype(np.float32), rs.randn(64).astype(np.float32)
+    q = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+    ps, pc = ops.PackedStemBf16(wt, sc, sh), ops.PackedConv(q(wt), sc, sh)
+    for it in range(12):
+        n, h, w = int(rs.randint(1, 3)), int(rs.randint(11, 140)), int(rs.randint(11, 200))
+        x = (rs.randint(0, 256, (n, h, w, 3)) - 110.0).astype(np.float32)
+        got = ops.stem_bf16(torch.from_numpy(x).cuda(), ps).float()
+        ref = ops.cast_bf16(ops.pool2d(ops.conv2d(torch.from_numpy(q(x)).cuda(), pc, 2, "same", "relu"), 3, 2, True)).float()
+        assert got.shape == ref.shape, (n, h, w)
+        err = (got - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -7 + 1e-6).all()), ((n, h, w), float(err.max()))
+        assert float((got == ref).float().mean()) > 0.95, (n, h, w)

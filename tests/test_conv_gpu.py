@@ -381,3 +381,33 @@ def test_networks_with_paired_launches_equal_unpaired(ops):
     d = run(False, ops.ConvWorkspace())
     for s, t in zip(c, d):
         assert float(((s - t).abs() / t.abs().clamp(min=1)).max()) < 1e-5
+
+
+def test_dual_launch_random_shapes(ops):
+    """Randomised sweep of the two-layer launch against the two single-layer launches (plain launches: bit-identical):
+    channel counts off and on tile boundaries, strides, kernel sizes, both row layouts, tile codes."""
+    rs = np.random.RandomState(2024)
+    for it in range(40):
+        k = int(rs.choice([1, 1, 3]))
+        stride = int(rs.choice([1, 2])) if k == 1 else 1
+        padding = "valid" if k == 1 else "same"
+        cin = int(rs.choice([32, 64, 96, 160]))
+        n1 = int(rs.choice([4, 9, 36, 64, 72, 128, 200]))
+        n2 = int(rs.choice([4, 16, 45, 64, 128, 136, 256]))
+        layout = int(rs.rand() < 0.3)
+        n, h, w = (int(rs.randint(3, 9)), 7, 7) if layout else (1, int(rs.randint(5, 40)), int(rs.randint(5, 50)))
+        tile = int(rs.choice([0, 0, 23, 26, 21, 50]))
+        act1, act2 = rs.choice([None, "relu", "sigmoid"]), rs.choice([None, "relu"])
+        x = torch.from_numpy(rs.randn(*((h, w, n, cin) if layout else (n, h, w, cin))).astype(np.float32)).cuda()
+        wa = (rs.randn(k, k, cin, n1) / np.sqrt(k * k * cin)).astype(np.float32)
+        wb = (rs.randn(k, k, cin, n2) / np.sqrt(k * k * cin)).astype(np.float32)
+        sa, ha, sb, hb = (rs.rand(n1) + 0.5).astype(np.float32), rs.randn(n1).astype(np.float32), (rs.rand(n2) + 0.5).astype(np.float32), rs.randn(n2).astype(np.float32)
+        pa, pb = ops.PackedConv(wa, sa, ha), ops.PackedConv(wb, sb, hb)
+        pcat = ops.PackedConv(np.concatenate([wa, wb], axis=3), np.concatenate([sa, sb]), np.concatenate([ha, hb]))
+        with ops.conv_workspace(ops.NO_SPLIT_K):
+            ya = ops.conv2d(x, pa, stride, padding, act1, tile=tile, layout=layout)
+            yb = ops.conv2d(x, pb, stride, padding, act2, tile=tile, layout=layout)
+            y1, y2 = ops.conv2d_dual(x, pcat, n1, stride, padding, act1, act2, layout, tile)
+        torch.cuda.synchronize()
+        case = (it, k, stride, cin, n1, n2, layout, n, h, w, tile, act1, act2)
+        assert torch.equal(y1, ya) and torch.equal(y2, yb), case
