@@ -248,6 +248,20 @@ __global__ void k_sgd_momentum(float* w, const float* g, float* v, size_t n, flo
         w[i] += vi;
     }
 }
+// the same update, four parameters per lane (16-byte loads and stores: the 4-byte form moved the flat buffers of an RPN
+// step -- 47 MB of parameters, five passes -- at 2.7 TB/s, 88 us); per element the arithmetic is k_sgd_momentum's: bit-identical
+__global__ void k_sgd_momentum_v4(float4* w, const float4* g, float4* v, size_t n4, float lr, float momentum, float l2, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 wi = w[i], vi = v[i];
+        const float4 gg = g[i];
+        const float g0 = gg.x * gscale + 2.0f * l2 * wi.x, g1 = gg.y * gscale + 2.0f * l2 * wi.y;
+        const float g2 = gg.z * gscale + 2.0f * l2 * wi.z, g3 = gg.w * gscale + 2.0f * l2 * wi.w;
+        vi.x = momentum * vi.x - lr * g0; vi.y = momentum * vi.y - lr * g1; vi.z = momentum * vi.z - lr * g2; vi.w = momentum * vi.w - lr * g3;
+        wi.x += vi.x; wi.y += vi.y; wi.z += vi.z; wi.w += vi.w;
+        v[i] = vi;
+        w[i] = wi;
+    }
+}
 
 // Keras Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m/(sqrt(v)+eps)
 __global__ void k_adam(float* w, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps, float l2, float gscale) {
@@ -350,7 +364,10 @@ int frcnn_maxpool_bwd(const float* x, const float* y, const float* gy, int n, in
 int frcnn_sgd_momentum(float* w, const float* g, float* v, size_t n, float lr, float momentum, float l2, float grad_scale, void* stream) {
     if (!w || !g || !v) return fail(FRCNN_E_ARG, "sgd_momentum: null pointer");
     if (n == 0) return FRCNN_OK;
-    k_sgd_momentum<<<ew_grid(n), 256, 0, as_stream(stream)>>>(w, g, v, n, lr, momentum, l2, grad_scale);
+    const size_t n4 = ((((uintptr_t)w | (uintptr_t)g | (uintptr_t)v) & 15) == 0) ? n / 4 : 0;
+    if (n4) k_sgd_momentum_v4<<<ew_grid(n4), 256, 0, as_stream(stream)>>>((float4*)w, (const float4*)g, (float4*)v, n4, lr, momentum, l2, grad_scale);
+    if (n > 4 * n4)                                              // the tail -- or all of it when a buffer is not 16-byte aligned
+        k_sgd_momentum<<<n4 ? 1 : ew_grid(n), n4 ? 64 : 256, 0, as_stream(stream)>>>(w + 4 * n4, g + 4 * n4, v + 4 * n4, n - 4 * n4, lr, momentum, l2, grad_scale);
     return check_launch("sgd_momentum");
 }
 int frcnn_adam(float* w, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, int t, float l2, float grad_scale, void* stream) {
