@@ -39,10 +39,12 @@ def _stream():
 
 
 def _p(t):
+    """Device pointer of a tensor as the plain integer ctypes' c_void_p argtype accepts (None = NULL).  (Building a c_void_p
+    object per argument cost ~0.2 us x ~470 pointers per training step, whose mixed-precision form is bound by this host path.)"""
     if t is None:
-        return ctypes.c_void_p(0)
+        return None
     assert t.is_cuda and t.is_contiguous(), "device-contiguous tensor required"
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def _anchor_arg(anchor_hw):
@@ -350,7 +352,7 @@ def _split_k_ws(need):
 
 def _conv_launch(d, x, w, scale, shift, residual, mask, out):
     """frcnn_conv2d_fwd_ws with the right workspace; returns the ctypes argument tuple for re-launches."""
-    ws = _split_k_ws(_lib.load().frcnn_conv2d_workspace_bytes(ctypes.byref(d)))
+    ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_workspace_bytes"))
     args = (ctypes.byref(d), _p(x), _p(w), _p(scale), _p(shift), _p(residual), _p(mask), _p(out), _p(ws), ws.numel() if ws is not None else 0)
     _lib.call("frcnn_conv2d_fwd_ws", *args, _stream())
     return args, ws
@@ -361,15 +363,8 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
     layout=1: position-major tensors, x (h,w,n,cin) -> (ho,wo,n,cout) (frcnn_conv_desc.layout)."""
     _require_gpu()
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == pc.cin, (x.shape, pc.cin)
-    if layout:
-        h, w, n, _ = x.shape
-    else:
-        n, h, w, _ = x.shape
-    if padding == "same":
-        ho, pt = same_pad(h, pc.kh, stride)
-        wo, pl = same_pad(w, pc.kw, stride)
-    else:
-        ho, wo, pt, pl = valid_out(h, pc.kh, stride), valid_out(w, pc.kw, stride), 0, 0
+    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act], layout, tile or AUTO_TILE)
+    n, ho, wo = d.n, d.ho, d.wo
     oshape = (ho, wo, n, pc.cout) if layout else (n, ho, wo, pc.cout)
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device="cuda")
@@ -377,8 +372,6 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
         assert out.shape == oshape and out.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
-    d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc.cin, cout=pc.cout, kh=pc.kh, kw=pc.kw, stride=stride, pad_top=pt, pad_left=pl,
-                      ho=ho, wo=wo, act=ACT[act], ldy=0, ldres=0, tile=tile or AUTO_TILE, layout=layout)
     args, ws = _conv_launch(d, x, pc.w, pc.scale, pc.shift, residual, None, out)
     if CONV_PROFILE is not None:
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
@@ -397,12 +390,11 @@ def conv2d_dual(x, pc, n1, stride=1, padding="valid", act1=None, act2=None, layo
     the output axis, the first ``n1`` output channels are layer 1.  -> (y1 (n,ho,wo,n1), y2 (n,ho,wo,cout-n1))."""
     _require_gpu()
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == pc.cin and 0 < n1 < pc.cout
-    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, 0, layout)
-    d.tile = tile or AUTO_TILE
+    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, 0, layout, tile or AUTO_TILE)
     lead = (d.ho, d.wo, d.n) if layout else (d.n, d.ho, d.wo)
     y1 = torch.empty(lead + (n1,), dtype=torch.float32, device="cuda")
     y2 = torch.empty(lead + (pc.cout - n1,), dtype=torch.float32, device="cuda")
-    ws = _split_k_ws(_lib.load().frcnn_conv2d_dual_workspace_bytes(ctypes.byref(d)))
+    ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_dual_workspace_bytes"))
     args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(y1), n1, ACT[act1], _p(y2), ACT[act2],
             _p(ws), ws.numel() if ws is not None else 0)
     _lib.call("frcnn_conv2d_fwd_dual", *args, _stream())
@@ -471,7 +463,18 @@ def split_detections(packed, rows=None):
 
 
 # ----------------------------------------------------------------------------- conv backward
-def _conv_desc(x_shape, kh, kw, cout, stride, padding, act=0, layout=0):
+_DESC_CACHE = {}
+
+
+def _conv_desc(x_shape, kh, kw, cout, stride, padding, act=0, layout=0, tile=0):
+    """frcnn_conv_desc of a launch.  Descriptors are CACHED by their defining tuple and shared between calls (a training step
+    builds ~90 of them from the same few dozen shapes; constructing the 17-field ctypes structure and asking the library for
+    its workspace size cost ~4 us per launch of a host path that bounds the mixed-precision step): callers must not write
+    to the returned object.  ``d._ws`` memoises the workspace-size queries made with it."""
+    key = (x_shape, kh, kw, cout, stride, padding, act, layout, tile)
+    d = _DESC_CACHE.get(key)
+    if d is not None:
+        return d
     if layout:
         h, w, n, cin = x_shape
     else:
@@ -481,8 +484,24 @@ def _conv_desc(x_shape, kh, kw, cout, stride, padding, act=0, layout=0):
         wo, pl = same_pad(w, kw, stride)
     else:
         ho, wo, pt, pl = valid_out(h, kh, stride), valid_out(w, kw, stride), 0, 0
-    return _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride, pad_top=pt, pad_left=pl,
-                         ho=ho, wo=wo, act=act, ldy=0, ldres=0, tile=0, layout=layout)
+    d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride, pad_top=pt, pad_left=pl,
+                      ho=ho, wo=wo, act=act, ldy=0, ldres=0, tile=tile, layout=layout)
+    d._ws = {}
+    if len(_DESC_CACHE) > 4096:
+        _DESC_CACHE.clear()
+    _DESC_CACHE[key] = d
+    return d
+
+
+def _ws_need(d, query):
+    """Workspace bytes of descriptor ``d`` under the library query ``query`` (memoised on cached descriptors)."""
+    memo = getattr(d, "_ws", None)
+    if memo is None:
+        return getattr(_lib.load(), query)(ctypes.byref(d))
+    need = memo.get(query)
+    if need is None:
+        need = memo[query] = getattr(_lib.load(), query)(ctypes.byref(d))
+    return need
 
 
 class PackedDgrad:
@@ -513,8 +532,8 @@ def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
     assert padding == "same" or (pd.kh == 1 and pd.kw == 1), "dgrad supports 1x1 valid and odd 'same' kernels"
     if out is None:
         out = torch.empty((n, ho, wo, pd.cout), dtype=torch.float32, device="cuda")
-    d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=pd.cin, cout=pd.cout, kh=pd.kh, kw=pd.kw, stride=1, pad_top=pt, pad_left=pl,
-                      ho=ho, wo=wo, act=0, ldy=0, ldres=0, tile=0)
+    d = _conv_desc((n, ho, wo, pd.cin), pd.kh, pd.kw, pd.cout, 1, padding, 0, 0, 0)      # (see conv2d_dgrad_bf16)
+    assert (d.pad_top, d.pad_left, d.ho, d.wo) == (pt, pl, ho, wo)
     _conv_launch(d, gy.contiguous(), pd.w, None, None, residual, mask, out)
     return out
 
@@ -600,9 +619,10 @@ def conv2d_dgrad_bf16(gy, pd, padding="valid", residual=None, mask=None):
     pl = (pd.kw - 1) // 2 if padding == "same" else 0
     assert padding == "same" or (pd.kh == 1 and pd.kw == 1), "dgrad supports 1x1 valid and odd 'same' kernels"
     out = torch.empty((n, ho, wo, pd.cout), dtype=torch.bfloat16, device="cuda")
-    d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=pd.cin, cout=pd.cout, kh=pd.kh, kw=pd.kw, stride=1, pad_top=pt, pad_left=pl,
-                      ho=ho, wo=wo, act=0, ldy=0, ldres=0, tile=AUTO_TILE)
-    ws = _split_k_ws(_lib.load().frcnn_conv2d_workspace_bytes_bf16(ctypes.byref(d)))
+    # (stride 1 with 'same' padding of an odd kernel, or 1x1 'valid': the forward descriptor of that geometry IS the dgrad one)
+    d = _conv_desc((n, ho, wo, pd.cin), pd.kh, pd.kw, pd.cout, 1, padding, 0, 0, AUTO_TILE)
+    assert (d.pad_top, d.pad_left, d.ho, d.wo) == (pt, pl, ho, wo)
+    ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_workspace_bytes_bf16"))
     _lib.call("frcnn_conv2d_fwd_bf16_masked", ctypes.byref(d), _p(gy.contiguous()), _p(pd.w), None, None, _p(residual), _p(mask), _p(out), 0,
               _p(ws), ws.numel() if ws is not None else 0, _stream())
     return out
@@ -646,13 +666,12 @@ def conv2d_bf16(x, pc, stride=1, padding="valid", act=None, residual=None, out_f
     """x: (n,h,w,cin) bf16 NHWC -> (n,ho,wo,cout) bf16 (or f32 when out_f32); layout=1: (h,w,n,cin) -> (ho,wo,n,cout)."""
     _require_gpu()
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == pc.cin
-    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act], layout)
-    d.tile = tile or AUTO_TILE
+    d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act], layout, tile or AUTO_TILE)
     oshape = (d.ho, d.wo, d.n, pc.cout) if layout else (d.n, d.ho, d.wo, pc.cout)
     out = torch.empty(oshape, dtype=torch.float32 if out_f32 else torch.bfloat16, device="cuda")
     if residual is not None:
         assert residual.dtype == torch.bfloat16 and residual.shape == out.shape and residual.is_contiguous()
-    ws = _split_k_ws(_lib.load().frcnn_conv2d_workspace_bytes_bf16(ctypes.byref(d)))
+    ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_workspace_bytes_bf16"))
     args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(residual), _p(out), 1 if out_f32 else 0,
             _p(ws), ws.numel() if ws is not None else 0)
     _lib.call("frcnn_conv2d_fwd_bf16_ws", *args, _stream())
