@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40, help="untimed steps first: ~0.1 s of work, enough for the clocks to leave their idle state (with 3 the first config timed read 2.6-4.6 ms from box to box)")
     ap.add_argument("--big-tiles", action="store_true")
     ap.add_argument("--only", choices=("rpn", "det"), default=None)
+    ap.add_argument("--no-split-k", action="store_true", help="dev: plain conv launches only (no split-K workspace) in the training steps")
     ap.add_argument("--sync-each-step", action="store_true", help="time only the plain Keras call (losses read back after every step); by default "
                     "the loop reads them one step late, the way train_util's loops do, and the per-step figure is reported beside it")
     args = ap.parse_args()
@@ -130,6 +131,8 @@ def main():
         y_bbreg = np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32),
                                   (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
         rpn.compile(train.SGD(1e-3, 0.9))
+        if args.no_split_k:
+            rpn._trainer._conv_ws = rpn._trainer._conv_ws_prefix = ops.NO_SPLIT_K
         step = lambda: rpn.train_on_batch(x, [y_class, y_bbreg], defer=not args.sync_each_step)
         ms = timed(step, args.steps, args.warmup)
         ms_sync = None if args.sync_each_step else timed(lambda: rpn.train_on_batch(x, [y_class, y_bbreg]), args.steps, 2)
@@ -154,6 +157,8 @@ def main():
                 tg[i, 4 * c:4 * c + 4] = rs.randn(4)
         yb = np.concatenate([lab, tg], axis=1)[None]
         det.compile(train.SGD(1e-3, 0.9))
+        if args.no_split_k:
+            det._trainer._conv_ws = det._trainer._conv_ws_prefix = ops.NO_SPLIT_K
         step = lambda: det.train_on_batch([x, rois], [yc, yb], defer=not args.sync_each_step)
         ms = timed(step, args.steps, args.warmup)
         ms_sync = None if args.sync_each_step else timed(lambda: det.train_on_batch([x, rois], [yc, yb]), args.steps, 2)
