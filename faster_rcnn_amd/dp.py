@@ -55,9 +55,15 @@ def allreduce_sum_begin(flat):
     (handle, 1/world scale).  ``handle.wait()`` orders the CURRENT stream behind the collective (RCCL: stream-wise, the
     host does not block; gloo: the host blocks until the exchange has happened).  world == 1: (None, 1.0)."""
     w = world()
-    if w == 1:
+    if w == 1 and not (FORCE_COLLECTIVE and dist.is_available() and dist.is_initialized()):
         return None, 1.0
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), 1.0 / w
+
+
+# test hook: run the collective even in a one-rank process group (tests/test_dp_gpu.py drives the step's asynchronous
+# all-reduce through REAL RCCL on a one-GPU box that way: the sum over one rank is the identity, so the step must stay
+# bit-identical to the plain single-process step)
+FORCE_COLLECTIVE = os.environ.get("FRCNN_DP_FORCE_COLLECTIVE", "0") != "0"
 
 
 def broadcast_(flat, src=0):

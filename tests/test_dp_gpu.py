@@ -95,3 +95,36 @@ def test_dp_different_images_agree_across_ranks():
         for s, x, y in zip(single[n], a[n], b[n]):
             assert np.array_equal(x, y), n                     # one gradient, one update, everywhere
     assert any(not np.array_equal(single[n][0], a[n][0]) for n in single)       # and it is not rank 0's own step
+
+
+def _rccl_world1_worker(port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      FRCNN_DP_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    from faster_rcnn_amd import dp
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+    assert dp.FORCE_COLLECTIVE and dp.world() == 1
+    out["w"] = _train([3, 4, 5], steps=3)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_step_through_real_rccl_in_a_one_rank_group():
+    """The data-parallel step's asynchronous all-reduce (started behind the last weight-gradient batch; the optimiser enqueued
+    behind it once the next step's upload + frozen stages are out) through the REAL RCCL backend: a one-rank "nccl" process
+    group on this box's one GPU with the collective forced on (dp.FORCE_COLLECTIVE).  The sum over one rank is the identity,
+    so three steps must end bit-identical to the plain single-process steps -- a mis-ordering between RCCL's stream and the
+    step's streams (the gradient buffer reduced too early, the optimiser run too early) would show in the weights."""
+    single = _train([3, 4, 5], steps=3)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    p = mp.get_context("spawn").Process(target=_rccl_world1_worker, args=(_free_port(), out))
+    p.start()
+    p.join(900)
+    assert p.exitcode == 0, p.exitcode
+    got = out["w"]
+    for n in single:
+        for s_, g_ in zip(single[n], got[n]):
+            assert np.array_equal(s_, g_), n
