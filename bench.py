@@ -660,7 +660,16 @@ def main():
         else:
             step = lambda: pipe.forward_dev(x)
 
-    if world > 1:
+    # FRCNN_BENCH_FORCE_DIST=1 (dev / tests): take the multi-rank code path with ONE rank -- process group over the real "nccl"
+    # backend, barriers, max-over-ranks timing, the `train_dp` leg with its collective forced on -- on a one-GPU box
+    force_dist = world == 1 and os.environ.get("FRCNN_BENCH_FORCE_DIST", "0") != "0"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        from faster_rcnn_amd import dp as _dp
+        _dp.FORCE_COLLECTIVE = True
+    if world > 1 or force_dist:
         # the process group comes up AFTER the hipGraph captures: its watchdog thread must not touch the HIP
         # runtime while a capture is open
         import torch.distributed as dist

@@ -113,3 +113,20 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     # --gpus 1 stays a plain single-process run: no train_dp object
     one = _launch(["bench.py", "--steps", "2", "--warmup", "1", "--streams", "2", "--no-cpu-baseline", "--no-io", "--gpus", "1"], 1)
     assert one["n_gpus"] == 1 and "train_dp" not in one
+
+
+def test_bench_multi_rank_path_over_real_rccl():
+    """bench.py's multi-rank code path -- process group brought up after the hipGraph captures, barrier-bracketed timing with the
+    max over ranks taken on a device tensor, the `train_dp` leg with its asynchronous all-reduce -- over the REAL "nccl" (RCCL)
+    backend, with one rank on this box's one GPU (FRCNN_BENCH_FORCE_DIST=1): what a node run does per rank, minus the peers."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FRCNN_BENCH_BACKEND")}
+    env.update(FRCNN_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--streams", "2", "--no-cpu-baseline", "--no-io"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    t = line["train_dp"]
+    assert "error" not in t, t
+    assert t["backend"] == "nccl" and t["ranks_seen"] == 1 and abs(t["grad_payload_MB"] - 47.3) < 0.2
+    assert t["allreduce_ms"] > 0 and t["ms_per_step"] > 0 and t["exposed_allreduce_ms"] >= 0
