@@ -477,7 +477,9 @@ def spawn_ranks(n):
             rcs.append(p.wait())
     reader.join(timeout=10)
     if not failed:
-        sys.stdout.write(b"".join(chunks).decode())
+        for ln in b"".join(chunks).decode().splitlines():
+            if ln.startswith("{"):                          # rank 0's line (anything else a library printed is dropped)
+                sys.stdout.write(ln + "\n")
         sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
@@ -552,6 +554,21 @@ def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=10):
                        "host staging, upload and frozen stages (stem..res3) run beside it"}
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to fd 1 when
+    its communicator goes away; eval_dets prints progress): from here on fd 1 IS stderr for everybody, and the JSON line goes
+    to the original stdout through the handle kept here."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _JSON_OUT
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -581,6 +598,7 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)                      # does not return
+    json_out = claim_stdout()
     global HOIST, DTYPE, WORKLOAD
     select_config(args.config)
     bf16_run = not (DTYPE == "f32" and args.dtype in ("config", "f32"))
@@ -838,7 +856,8 @@ def main():
                     line["parity"]["e2e"] = e2e_parity(pipe, weights, anchors, oracle_runs)
                 except Exception as e:
                     line["parity"]["e2e"] = {"ok": False, "error": repr(e)[:300]}
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if dist is not None:
         dist.barrier()                  # rank 0 is still measuring the roofline: leave the group together
         dist.destroy_process_group()

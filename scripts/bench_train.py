@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--sync-each-step", action="store_true", help="time only the plain Keras call (losses read back after every step); by default "
                     "the loop reads them one step late, the way train_util's loops do, and the per-step figure is reported beside it")
     args = ap.parse_args()
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")             # ONE JSON line on stdout: RCCL's version banner and anything else written
+    os.dup2(2, 1)                                    # to fd 1 goes to stderr from here on
     backend = os.environ.get("FRCNN_BENCH_BACKEND")
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env > 1 and backend == "gloo":
@@ -170,7 +173,8 @@ def main():
             out[short + "_img_s"] = out[tag]["img_s"]
             out[short + "_params_MB"] = out[tag]["grad_payload_MB"]
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
