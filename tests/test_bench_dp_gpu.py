@@ -124,7 +124,9 @@ def test_bench_multi_rank_path_over_real_rccl():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--streams", "2", "--no-cpu-baseline", "--no-io"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    out_lines = r.stdout.strip().splitlines()
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), r.stdout[-1500:]     # RCCL's version banner (written to fd 1) must not reach stdout
+    line = json.loads(out_lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0
     t = line["train_dp"]
     assert "error" not in t, t
