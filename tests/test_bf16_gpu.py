@@ -332,6 +332,11 @@ def test_batched_pipeline_equals_per_image_pipeline():
         assert int(out["n_dets"][i]) == int(o["n_dets"])
         for k in ("det_bbox", "det_cls", "det_prob", "det_roi"):                     # (det_packed also holds three pad words)
             assert torch.equal(out[k][i], o[k]), k
+    # a "batch" of one is the per-image pipeline too
+    with ops.conv_workspace(ops.NO_SPLIT_K):
+        one = BatchedInferencePipeline(rpn, det, anchors, 1, max_proposals=n).forward_dev(x[1:2].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(one["cls"][0], per[1]["cls"]) and torch.equal(one["det_bbox"][0], per[1]["det_bbox"]) and int(one["n_dets"][0]) == int(per[1]["n_dets"])
     # and from a captured graph (what bench.py --config c4 replays), fed another batch
     bp.capture(176, 240)
     x2 = torch.from_numpy((rs.randint(0, 256, (B, 176, 240, 3)) - 110.0).astype(np.float32)).cuda()

@@ -344,6 +344,21 @@ def test_dual_rejects_bad_arguments(ops):
     pc = ops.PackedConv(np.zeros((1, 1, 64, 96), np.float32), np.ones(96, np.float32), np.zeros(96, np.float32))
     with pytest.raises(AssertionError):
         ops.conv2d_dual(x, pc, 96)
+    # raw C ABI: strided outputs and an undersized workspace are refused before any launch
+    import ctypes
+    d = _lib.ConvDesc(n=1, h=38, w=63, cin=512, cout=45, kh=1, kw=1, stride=1, pad_top=0, pad_left=0, ho=38, wo=63, act=0, ldy=0, ldres=0, tile=0, layout=0)
+    need = _lib.load().frcnn_conv2d_dual_workspace_bytes(ctypes.byref(d))
+    assert need > 0                                                        # 38 tiles, 16 chunks: split-K
+    xs = torch.zeros((1, 38, 63, 512), dtype=torch.float32, device="cuda")
+    pcs = ops.PackedConv(np.zeros((1, 1, 512, 45), np.float32), np.ones(45, np.float32), np.zeros(45, np.float32))
+    y1, y2 = torch.empty((2394, 9), device="cuda"), torch.empty((2394, 36), device="cuda")
+    small = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    rc = _lib.load().frcnn_conv2d_fwd_dual(ctypes.byref(d), xs.data_ptr(), pcs.w.data_ptr(), pcs.scale.data_ptr(), pcs.shift.data_ptr(),
+                                           y1.data_ptr(), 9, 2, y2.data_ptr(), 0, small.data_ptr(), small.numel(), None)
+    assert rc == -2 and b"workspace" in _lib.load().frcnn_last_error()       # FRCNN_E_WORKSPACE
+    d.ldy = 64
+    rc = _lib.load().frcnn_conv2d_fwd_dual(ctypes.byref(d), xs.data_ptr(), pcs.w.data_ptr(), None, None, y1.data_ptr(), 9, 2, y2.data_ptr(), 0, None, 0, None)
+    assert rc == -1                                                         # FRCNN_E_ARG: dense outputs only
     x48 = torch.zeros((1, 8, 8, 48), dtype=torch.float32, device="cuda")
     pc48 = ops.PackedConv(np.zeros((1, 1, 48, 96), np.float32), np.ones(96, np.float32), np.zeros(96, np.float32))
     with pytest.raises(_lib.FrcnnError):
