@@ -73,7 +73,7 @@ def _worker(rank, world, port, same_image, out):
 
 
 def _run_world2(same_image):
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()         # (a forked manager would inherit this process's initialised HIP runtime: it has crashed)
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), same_image, out), nprocs=2, join=True)
     return out[0], out[1]
@@ -118,9 +118,10 @@ def test_step_through_real_rccl_in_a_one_rank_group():
     so three steps must end bit-identical to the plain single-process steps -- a mis-ordering between RCCL's stream and the
     step's streams (the gradient buffer reduced too early, the optimiser run too early) would show in the weights."""
     single = _train([3, 4, 5], steps=3)
-    mgr = mp.Manager()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
     out = mgr.dict()
-    p = mp.get_context("spawn").Process(target=_rccl_world1_worker, args=(_free_port(), out))
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), out))
     p.start()
     p.join(900)
     assert p.exitcode == 0, p.exitcode
