@@ -554,6 +554,58 @@ def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=10):
                        "host staging, upload and frozen stages (stem..res3) run beside it"}
 
 
+def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images=8):
+    """The reference's own inference entry point, timed: ``voc_dets.get_dets_by_cls`` (voc_dets.py:91-111) over a
+    ``DetTrainingManager`` (det_util.py:136-158) on a list of ``n_images`` distinct synthetic uint8 frames of the
+    benchmark's size -- host frame in, list of detection dicts out, everything the call does included (staging copy,
+    H2D, captured pass, D2H, building the dicts).  The captured path (entry.DetectionEntry) is what a caller of that
+    function gets; the eager path (`voc_dets.FAST_ENTRY = False`: the reference's own sequencing with its two host round
+    trips) is timed beside it on ``eager_images`` frames so the gain is visible."""
+    import contextlib
+    import io as _io
+    from faster_rcnn_amd import entry, resnet, shapes, voc_dets
+    from faster_rcnn_amd.data.voc_data_helpers import KITTI_CLASS_MAPPING, VOC_CLASS_MAPPING
+    from faster_rcnn_amd.det_util import DetTrainingManager
+    mapping = VOC_CLASS_MAPPING if NUM_CLASSES == len(VOC_CLASS_MAPPING) else KITTI_CLASS_MAPPING
+    mgr = DetTrainingManager(rpn_model=pipe.rpn, class_mapping=mapping, preprocess_func=resnet.preprocess, anchor_dims=anchors)
+    rs = np.random.RandomState(2000 + rank)
+    images = [shapes.Image(shapes.Metadata("synth%03d" % i, WIDTH, HEIGHT, [], "none"), rs.randint(0, 256, (HEIGHT, WIDTH, 3)).astype(np.uint8))
+              for i in range(n_images)]
+    ratios = [1.0] * n_images
+    sink = _io.StringIO()
+
+    def run(imgs):
+        with contextlib.redirect_stdout(sink):                  # the reference's per-image progress lines
+            t0 = time.perf_counter()
+            dets = voc_dets.get_dets_by_cls(mgr, pipe.det, ratios[:len(imgs)], imgs)
+            return time.perf_counter() - t0, dets
+    t_first, _ = run(images)                                    # first sighting of the size: captures its passes
+    run(images)
+    torch.cuda.synchronize()
+    t = 0.0
+    for _ in range(passes):
+        dt, dets = run(images)
+        t += dt
+    n_dets = sum(len(v) for per_img in dets.values() for v in per_img.values())
+    dtype = getattr(pipe.det.head, "dtype", "f32")
+    eng = entry.for_models(mgr, pipe.det, 64, 16, entry.default_in_flight(dtype))
+    voc_dets.FAST_ENTRY = False
+    try:
+        run(images[:2])
+        t_eager, dets_eager = run(images[:eager_images])
+    finally:
+        voc_dets.FAST_ENTRY = True
+    same = all(k in dets and all(len(v[i]) == len(dets[k][i]) for i in v) for k, v in dets_eager.items())
+    return {"value": round(n_images * passes / t, 3), "unit": "img/s", "images": n_images, "passes": passes,
+            "detections_per_image": round(n_dets / n_images, 1), "first_pass_s": round(t_first, 3), "graph_cache": eng.stats(),
+            "eager": {"value": round(eager_images / t_eager, 3), "unit": "img/s", "images": eager_images,
+                      "what": "the same call with voc_dets.FAST_ENTRY = False: get_det_inputs returns the conv map and the RoIs as numpy "
+                              "(det_util.py:136-158), the detector takes them back (voc_dets.py:49), one image at a time"},
+            "same_detection_counts_as_eager": bool(same),
+            "what": "voc_dets.get_dets_by_cls(DetTrainingManager, detector, ratios, images) over %d distinct %dx%d uint8 frames in host memory, "
+                    "%d images in flight, list of detection dicts out; wall clock of the whole call" % (n_images, HEIGHT, WIDTH, eng.in_flight)}
+
+
 _JSON_OUT = None
 
 
@@ -772,6 +824,13 @@ def main():
             pl._graph.replay()
         torch.cuda.synchronize()
 
+    via_entry = None
+    if world == 1 and not force_dist and not args.no_graph and not args.no_io and DEPTH != 16 and B == 1 and "FRCNN_BENCH_NO_ENTRY" not in os.environ:
+        try:
+            via_entry = reference_entry_leg(pipe, anchors, rank)
+        except Exception as e:
+            via_entry = {"error": "%s: %s" % (type(e).__name__, e)}
+
     train_dp = None
     if dist is not None and args.config == "c2" and not args.no_train_dp:
         try:
@@ -814,6 +873,8 @@ def main():
         }
         if io is not None:
             line["with_host_io"] = io
+        if via_entry is not None:
+            line["via_reference_entry"] = via_entry
         if train_dp is not None:
             line["train_dp"] = train_dp
         if roof is None:

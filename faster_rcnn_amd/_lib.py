@@ -100,7 +100,8 @@ SIGNATURES = {
     "frcnn_roi_crop_resize_fwd_bf16": (I, [P, I, I, I, P, I, I, P, P]),
     "frcnn_roi_crop_resize_fwd_bf16_ex": (I, [P, I, I, I, P, I, I, P, I, I, P, P]),
     "frcnn_roi_crop_resize_fwd_bf16_batch": (I, [P, I, I, I, I, P, I, I, P, I, I, P, P]),
-    "frcnn_detections": (I, [P, P, I, P, P, I, I, ctypes.c_float, c_double, c_double, c_double, P, P, P, P, P, P]),
+    "frcnn_detections": (I, [P, P, I, P, P, I, I, c_double, c_double, c_double, c_double, P, P, P, P, P, P]),
+    "frcnn_detections_dyn": (I, [P, P, I, I, P, P, I, I, c_double, c_double, P, P, P, P, P, P, P]),
 }
 
 

@@ -8,6 +8,8 @@
 //
 // dtype flow = the reference under its pinned numpy 1.13 (legacy scalar promotion):
 //   cxa = f64(f32(x1+x2))/2, wa = f32(x2-x1), cx = f64(f32(tx*wa)) + cxa, w = exp(f64(tw))*f64(wa)
+//   `confidence < det_threshold` (voc_dets.py:57): np.float32 scalar against a Python float = an f64 comparison there
+//   (checked under numpy 1.26's legacy rules: np.float32(0.7) < 0.7 is True; NEP 50 compares in f32 and says False)
 // Compiled with -ffp-contract=off.
 #include "common.h"
 #include <stdlib.h>
@@ -37,8 +39,9 @@ __device__ __forceinline__ bool det_suppresses(const double4 a, const double4 b,
 
 __global__ void __launch_bounds__(DET_MAX) k_detections(
         const float4* rois, const int32_t* n_rois_ptr, int max_rows, const float* out_cls, const float* out_reg, int C,
-        int bg_idx, float det_threshold, double stride, double resize_ratio, double nms_thresh,
-        int32_t* det_cls, float* det_prob, int32_t* det_bbox, int32_t* det_roi, int32_t* n_dets) {
+        int bg_idx, double det_threshold, double stride, double resize_ratio, double nms_thresh,
+        int32_t* det_cls, float* det_prob, int32_t* det_bbox, int32_t* det_roi, int32_t* n_dets,
+        const double* dyn, int roi_batch) {
     __shared__ double4 s_box[DET_MAX];      // sorted by score
     __shared__ float s_prob[DET_MAX];
     __shared__ int s_cls[DET_MAX];
@@ -53,7 +56,13 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
     int* u_cls = reinterpret_cast<int*>(u_prob + DET_MAX);
 
     const int r = threadIdx.x;
-    const int n = min(min(*n_rois_ptr, max_rows), DET_MAX);
+    // frcnn_detections_dyn: the two per-image scalars live in device memory (a captured graph serves every image of its size)
+    // and the reference's padded duplicates (voc_dets.py:42-46: the last batch filled with copies of ITS first RoI, which
+    // frcnn_gather_rois has laid out) are scored like any other row (:51 loops over all num_rois rows of every batch)
+    if (dyn) { resize_ratio = dyn[0]; det_threshold = dyn[1]; }
+    const int n_live = *n_rois_ptr;
+    const int n_scored = (roi_batch > 0 && n_live > 0) ? (n_live + roi_batch - 1) / roi_batch * roi_batch : n_live;
+    const int n = min(min(n_scored, max_rows), DET_MAX);
     if (r < DET_MAX_CLASSES) s_first[r] = 0x7fffffff;
     if (r == 0) s_nvalid = 0;
     if (r < DET_WORDS) s_kept[r] = 0;
@@ -66,7 +75,7 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
         int best = 0; float bv = pc[0];
 #pragma unroll 8
         for (int c = 1; c < C; ++c) { const float v = pc[c]; if (v > bv) { bv = v; best = c; } }   // np.argmax: first max
-        if (best != bg_idx && !(bv < det_threshold)) {
+        if (best != bg_idx && !((double)bv < det_threshold)) {
             cls = best; conf = bv;
             const float4 roi = rois[r];
             const float* pr = out_reg + (size_t)r * 4 * (C - 1) + 4 * best;
@@ -188,7 +197,10 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
         det_cls[i] = -1; det_prob[i] = 0.0f; det_roi[i] = -1;
         det_bbox[4 * i + 0] = det_bbox[4 * i + 1] = det_bbox[4 * i + 2] = det_bbox[4 * i + 3] = 0;
     }
-    if (r == 0) *n_dets = s_total;
+    if (r == 0) {
+        n_dets[0] = s_total;
+        if (dyn) n_dets[1] = n_live;          // counts[1]: what voc_dets.get_dets prints as "num rois"
+    }
 }
 
 }  // namespace frcnn
@@ -196,13 +208,28 @@ __global__ void __launch_bounds__(DET_MAX) k_detections(
 using namespace frcnn;
 
 extern "C" int frcnn_detections(const float* rois, const int32_t* n_rois, int max_rows, const float* out_cls, const float* out_reg,
-                                int num_classes, int bg_idx, float det_threshold, double stride, double resize_ratio, double nms_thresh,
+                                int num_classes, int bg_idx, double det_threshold, double stride, double resize_ratio, double nms_thresh,
                                 int32_t* det_cls, float* det_prob, int32_t* det_bbox, int32_t* det_roi, int32_t* n_dets, void* stream) {
     if (!rois || !n_rois || !out_cls || !out_reg || !det_cls || !det_prob || !det_bbox || !det_roi || !n_dets)
         return fail(FRCNN_E_ARG, "detections: null pointer");
     if (max_rows <= 0 || max_rows > DET_MAX) return fail(FRCNN_E_ARG, "detections: max_rows=%d exceeds %d", max_rows, DET_MAX);
     if (num_classes < 2 || num_classes > DET_MAX_CLASSES) return fail(FRCNN_E_ARG, "detections: num_classes=%d out of range", num_classes);
     k_detections<<<1, DET_MAX, 0, as_stream(stream)>>>((const float4*)rois, n_rois, max_rows, out_cls, out_reg, num_classes, bg_idx,
-                                                       det_threshold, stride, resize_ratio, nms_thresh, det_cls, det_prob, det_bbox, det_roi, n_dets);
+                                                       det_threshold, stride, resize_ratio, nms_thresh, det_cls, det_prob, det_bbox, det_roi, n_dets,
+                                                       nullptr, 0);
     return check_launch("detections");
+}
+
+extern "C" int frcnn_detections_dyn(const float* rois, const int32_t* n_rois, int roi_batch, int max_rows, const float* out_cls, const float* out_reg,
+                                    int num_classes, int bg_idx, double stride, double nms_thresh, const double* dyn,
+                                    int32_t* det_cls, float* det_prob, int32_t* det_bbox, int32_t* det_roi, int32_t* counts, void* stream) {
+    if (!rois || !n_rois || !out_cls || !out_reg || !dyn || !det_cls || !det_prob || !det_bbox || !det_roi || !counts)
+        return fail(FRCNN_E_ARG, "detections_dyn: null pointer");
+    if (max_rows <= 0 || max_rows > DET_MAX) return fail(FRCNN_E_ARG, "detections_dyn: max_rows=%d exceeds %d", max_rows, DET_MAX);
+    if (roi_batch < 0) return fail(FRCNN_E_ARG, "detections_dyn: roi_batch=%d", roi_batch);
+    if (num_classes < 2 || num_classes > DET_MAX_CLASSES) return fail(FRCNN_E_ARG, "detections_dyn: num_classes=%d out of range", num_classes);
+    if (((uintptr_t)dyn & 7) != 0) return fail(FRCNN_E_ARG, "detections_dyn: dyn must be 8-byte aligned");
+    k_detections<<<1, DET_MAX, 0, as_stream(stream)>>>((const float4*)rois, n_rois, max_rows, out_cls, out_reg, num_classes, bg_idx,
+                                                       0.0, stride, 1.0, nms_thresh, det_cls, det_prob, det_bbox, det_roi, counts, dyn, roi_batch);
+    return check_launch("detections_dyn");
 }

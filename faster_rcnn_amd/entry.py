@@ -1,0 +1,272 @@
+"""The reference's INFERENCE ENTRY POINTS on the captured device pipeline.
+
+``voc_dets.get_dets`` / ``get_dets_by_cls`` (voc_dets.py:20-111) reach the device through
+``DetTrainingManager.get_det_inputs`` (det_util.py:136-158) and ``detector.predict`` (voc_dets.py:49), crossing to
+numpy twice per image (det_util.py:41, 49-55).  When the manager's ``rpn_model`` and the ``detector`` are this package's
+models, the same call runs here as ONE captured pass per image:
+
+    image.data (uint8 BGR)  ->  one H2D copy [pixels | resize_ratio, det_threshold]
+                            ->  hipGraph: resnet.preprocess on the device, backbone, RPN heads, decode, top-8000,
+                                NMS to 300, the reference's padded RoI list, RoI crop-resize, detector head, post-process
+                            ->  one packed D2H copy [n_dets, n_rois | boxes | classes | scores]
+
+* A captured pass is specific to an image SIZE (VOC has dozens after ``util.resize_imgs``): ``GraphCache`` keeps them per
+  (height, width), least-recently-used first out under a byte budget; a size is captured at its first sighting.
+  ``resize_ratio`` and ``det_threshold`` are per-image VALUES, read from device memory by the post-process
+  (frcnn_detections_dyn), so they are not part of the key.
+* ``get_dets_by_cls`` keeps several images in flight (one HIP stream each; a size seen several times in a row gets as
+  many captured instances as are in flight) and hands results back in submission order, so the returned dict is the
+  reference's, entry for entry.
+* A foreign ``preprocess_func`` (anything but resnet.preprocess / vgg.preprocess) is called on the host, as the reference
+  does (det_util.py:36), and its float image is uploaded instead of the bytes; a foreign ``detector`` (any other object
+  with Keras' ``predict``) keeps voc_dets' eager path.
+* Weights that change (load_weights, a training step, set_weights) bump ``models.weights_epoch()``; every captured pass
+  holds pointers to packed filters, so the cache is dropped and re-captured on the next call.
+"""
+import collections
+import os
+
+import numpy as np
+import torch
+
+from . import models, ops
+from .pipeline import InferencePipeline
+
+MEAN_BGR = (103.939, 116.779, 123.68)           # resnet.preprocess / vgg.preprocess (resnet.py:64-75, vgg.py:52-57)
+PRE_NMS_TOP_N, MAX_PROPOSALS = 8000, 300        # det_util.py:151-156
+
+
+def _default_budget():
+    env = os.environ.get("FRCNN_GRAPH_CACHE_BYTES")
+    if env:
+        return int(float(env))
+    total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+    return total // 4                           # 72 GB of an MI355X's 288: ~150 captured 600x1000 fp32 passes
+
+
+def default_in_flight(dtype="f32"):
+    """Images in flight for get_dets_by_cls: one per hardware queue (fp32 wants 8 streams on 8 queues, the
+    power-limited bf16 path 4 on 4); ROCm gives a process 4 queues unless GPU_MAX_HW_QUEUES says otherwise."""
+    env = int(os.environ.get("FRCNN_ENTRY_IN_FLIGHT", "0"))
+    if env > 0:
+        return env
+    queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    return 8 if (queues >= 8 and dtype == "f32") else 4
+
+
+class _Slot:
+    """One captured pass for one image size, with its staging on both sides of PCIe."""
+    __slots__ = ("key", "pipe", "graph", "out", "io_dev", "io_pin", "pix_host", "dyn_host", "out_pin", "event", "busy", "nbytes",
+                 "x_f32", "ws", "seq")
+
+
+class GraphCache:
+    """Captured passes by image size, least-recently-used first out under a byte budget.  ``acquire(key, make)`` hands out
+    an idle slot of that size or captures a new one; busy slots (an image in flight) are never evicted."""
+
+    def __init__(self, byte_budget):
+        self.byte_budget = int(byte_budget)
+        self._slots = collections.OrderedDict()          # key -> [slots]; order = recency
+        self.nbytes = 0
+        self.captures = self.evictions = self.hits = 0
+
+    def __len__(self):
+        return sum(len(v) for v in self._slots.values())
+
+    def keys(self):
+        return list(self._slots)
+
+    def acquire(self, key, make):
+        slots = self._slots.get(key)
+        if slots is not None:
+            self._slots.move_to_end(key)
+            for s in slots:
+                if not s.busy:
+                    self.hits += 1
+                    return s
+        slot = make()
+        self.captures += 1
+        self._slots.setdefault(key, []).append(slot)
+        self._slots.move_to_end(key)
+        self.nbytes += slot.nbytes
+        self._evict(keep=slot)
+        return slot
+
+    def _evict(self, keep):
+        if self.nbytes <= self.byte_budget:
+            return
+        dropped = False
+        for key in list(self._slots):                    # oldest size first
+            slots = self._slots[key]
+            for s in list(slots):
+                if self.nbytes <= self.byte_budget:
+                    break
+                if s.busy or s is keep:
+                    continue
+                slots.remove(s)
+                self.nbytes -= s.nbytes
+                self.evictions += 1
+                dropped = True
+            if not slots:
+                del self._slots[key]
+            if self.nbytes <= self.byte_budget:
+                break
+        if dropped:
+            torch.cuda.empty_cache()                     # a dropped graph's private pool goes back to the device
+
+    def clear(self):
+        assert not any(s.busy for v in self._slots.values() for s in v), "graph cache cleared with images in flight"
+        self._slots.clear()
+        self.nbytes = 0
+        torch.cuda.empty_cache()
+
+
+class Ticket:
+    __slots__ = ("slot", "image")
+
+    def __init__(self, slot, image):
+        self.slot, self.image = slot, image
+
+
+class DetectionEntry:
+    """voc_dets.get_dets for one (manager, detector) pair: ``submit(image, resize_ratio, det_threshold)`` enqueues an image,
+    ``collect(ticket)`` returns ``(num_rois, dets)`` with ``dets`` the reference's list of
+    ``{'bbox': int array [x1,y1,x2,y2], 'cls_name', 'prob'}`` in its order (voc_dets.py:73-86)."""
+
+    def __init__(self, manager, detector, num_rois=64, stride=16, in_flight=1, byte_budget=None):
+        self.manager, self.detector = manager, detector
+        self.num_rois, self.stride, self.in_flight = int(num_rois), stride, max(1, int(in_flight))
+        from . import resnet, vgg
+        self.device_preprocess = manager.preprocess_func in (resnet.preprocess, vgg.preprocess)
+        self.rev_class_mapping = dict((v, k) for k, v in manager.class_mapping.items())
+        self.cache = GraphCache(_default_budget() if byte_budget is None else byte_budget)
+        self._streams = [torch.cuda.Stream() for _ in range(self.in_flight)]
+        self._seq = 0
+        self._epoch = models.weights_epoch()
+        self.capture_seconds = 0.0
+
+    # ------------------------------------------------------------------ eligibility
+    @staticmethod
+    def usable(manager, detector, num_rois):
+        rpn = getattr(manager, "rpn_model", None)
+        if not (isinstance(rpn, models.RpnModel) and isinstance(detector, models.DetModel)):
+            return False                                # a foreign Keras-style model: voc_dets keeps the eager path
+        if not manager.conv_only or detector.base is not None:
+            return False                                # the detector must take the RPN's conv map (voc_dets.py:177-183)
+        n_rows = -(-MAX_PROPOSALS // int(num_rois)) * int(num_rois)
+        return 0 < n_rows <= 512                        # frcnn_detections: one workgroup, <= 512 scored rows
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self, H, W):
+        import time
+        t0 = time.perf_counter()
+        m = self.manager
+        pipe = InferencePipeline(m.rpn_model, self.detector, m.anchor_dims, stride=self.stride, pre_nms_top_n=PRE_NMS_TOP_N,
+                                 max_proposals=MAX_PROPOSALS, roi_batch=self.num_rois, pad_to_batch=True, bg_idx=m.class_mapping["bg"])
+        reserved0 = torch.cuda.memory_reserved()
+        npix = H * W * 3
+        pix_bytes = npix if self.device_preprocess else 4 * npix
+        off = (pix_bytes + 15) // 16 * 16
+        s = _Slot()
+        s.key, s.pipe, s.busy, s.seq = (H, W), pipe, False, 0
+        s.io_dev = torch.zeros(off + 16, dtype=torch.uint8, device="cuda")
+        s.io_pin = torch.zeros(off + 16, dtype=torch.uint8).pin_memory()
+        host = s.io_pin.numpy()
+        s.pix_host = host[:npix].reshape(H, W, 3) if self.device_preprocess else host[:pix_bytes].view(np.float32).reshape(H, W, 3)
+        s.dyn_host = host[off:off + 16].view(np.float64)
+        s.dyn_host[:] = (1.0, 0.0)
+        dyn_dev = s.io_dev[off:off + 16].view(torch.float64)
+        if self.device_preprocess:
+            u8 = s.io_dev[:npix].view(H, W, 3)
+            s.x_f32 = torch.empty((1, H, W, 3), dtype=torch.float32, device="cuda")
+        else:
+            s.x_f32 = s.io_dev[:pix_bytes].view(torch.float32).view(1, H, W, 3)
+
+        def run():
+            if self.device_preprocess:
+                ops.preprocess_u8(u8, MEAN_BGR, out=s.x_f32)        # resnet.preprocess + the f32 feed cast, bit for bit
+            return pipe.forward_dev(s.x_f32, dyn=dyn_dev)
+
+        shared = self.in_flight > 1
+        # one image in flight: split-K on the small grids (a latency tool); several: plain launches, tiles for a shared chip
+        s.ws = ops.NO_SPLIT_K if shared else ops.ConvWorkspace()
+        s.io_dev.copy_(s.io_pin)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared):
+            for _ in range(2):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        s.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(s.graph, capture_error_mode="thread_local"), ops.conv_workspace(s.ws), ops.tile_policy(shared):
+            s.out = run()
+        s.out_pin = torch.empty(s.out["det_packed"].shape, dtype=torch.int32).pin_memory()
+        s.event = torch.cuda.Event()
+        torch.cuda.synchronize()
+        s.nbytes = max(int(torch.cuda.memory_reserved() - reserved0), int(s.io_dev.numel() + s.x_f32.numel() * 4))
+        self.capture_seconds += time.perf_counter() - t0
+        return s
+
+    # ------------------------------------------------------------------ the call
+    def _check_epoch(self):
+        self.manager.rpn_model._flush_trainer()
+        self.detector._flush_trainer()
+        if models.weights_epoch() != self._epoch:
+            self.cache.clear()
+            self._epoch = models.weights_epoch()
+
+    def submit(self, image, resize_ratio, det_threshold=0.0):
+        self._check_epoch()
+        data = image.data
+        if self.device_preprocess:
+            data = np.asarray(data)
+            if data.dtype != np.uint8:
+                raise TypeError("image.data must be uint8 BGR (shapes.py:19-29), got %s" % data.dtype)
+        else:
+            data = self.manager.preprocess_func(data)               # det_util.py:36 (float64 on the host, cast on feed)
+        H, W = int(data.shape[0]), int(data.shape[1])
+        s = self.cache.acquire((H, W), lambda: self._capture(H, W))
+        np.copyto(s.pix_host, data, casting="same_kind")            # into pinned memory (f64 -> f32 cast for a foreign preprocess)
+        s.dyn_host[0], s.dyn_host[1] = float(resize_ratio), float(det_threshold)
+        st = self._streams[self._seq % self.in_flight]
+        self._seq += 1
+        with torch.cuda.stream(st):
+            s.io_dev.copy_(s.io_pin, non_blocking=True)
+            s.graph.replay()
+            s.out_pin.copy_(s.out["det_packed"], non_blocking=True)
+            s.event.record(st)
+        s.busy = True
+        return Ticket(s, image)
+
+    def collect(self, ticket):
+        s = ticket.slot
+        s.event.synchronize()
+        packed = s.out_pin.numpy()
+        nd, n_rois = int(packed[0]), int(packed[1])
+        rows = (packed.size - 4) // 7
+        bbox = packed[4:4 + 4 * nd].reshape(nd, 4).astype(np.int64)
+        cls = packed[4 + 4 * rows:4 + 4 * rows + nd].copy()
+        prob = packed[4 + 5 * rows:4 + 5 * rows + nd].view(np.float32).copy()
+        s.busy = False
+        rev = self.rev_class_mapping
+        return n_rois, [{"bbox": bbox[i], "cls_name": rev[int(cls[i])], "prob": prob[i]} for i in range(nd)]
+
+    def stats(self):
+        c = self.cache
+        return {"graphs": len(c), "sizes": len(c.keys()), "bytes": c.nbytes, "byte_budget": c.byte_budget, "captures": c.captures,
+                "hits": c.hits, "evictions": c.evictions, "capture_seconds": round(self.capture_seconds, 3), "in_flight": self.in_flight,
+                "device_preprocess": self.device_preprocess}
+
+
+def for_models(manager, detector, num_rois=64, stride=16, in_flight=1):
+    """The DetectionEntry of this (manager, detector, num_rois, stride, in_flight), built on first use and kept on the
+    manager; None when the pair cannot take the captured path (voc_dets then runs the eager one)."""
+    if not torch.cuda.is_available() or not DetectionEntry.usable(manager, detector, num_rois):
+        return None
+    table = manager.__dict__.setdefault("_entries", {})
+    key = (id(detector), int(num_rois), stride, int(in_flight))
+    eng = table.get(key)
+    if eng is None or eng.detector is not detector:
+        eng = table[key] = DetectionEntry(manager, detector, num_rois, stride, in_flight)
+    return eng

@@ -10,15 +10,27 @@ from . import nets
 from .weights import load_npz, save_weights_file
 
 
+_WEIGHTS_EPOCH = 0
+
+
+def weights_epoch():
+    """Bumped whenever ANY model re-lowers a layer (load_weights, a flushed training step, set_weights).  Captured passes
+    hold pointers to packed filters, so whoever keeps hipGraphs across calls (entry.DetectionEntry) compares epochs and
+    re-captures; one process-wide counter because models share base networks and weight dicts."""
+    return _WEIGHTS_EPOCH
+
+
 class _Layer:
-    def __init__(self, weights, name):
-        self._w, self.name = weights, name
+    def __init__(self, weights, name, model=None):
+        self._w, self.name, self._model = weights, name, model
 
     def get_weights(self):
         return [np.array(a) for a in self._w[self.name]]
 
     def set_weights(self, arrs):
         self._w[self.name] = [np.asarray(a, dtype=np.float32) for a in arrs]
+        if self._model is not None:
+            self._model.invalidate(only={self.name})
 
 
 class _Model:
@@ -62,14 +74,19 @@ class _Model:
         self._flush_trainer()
         if name not in self.weights:
             raise ValueError("No such layer: " + name)
-        return _Layer(self.weights, name)
+        return _Layer(self.weights, name, self)
 
     def invalidate(self, only=None):
-        """Re-lower (re-pack / re-fold) after weights changed; ``only``: the conv layer names that changed."""
+        """Re-lower (re-pack / re-fold) after weights changed; ``only``: the layer names that changed (a conv layer or the
+        BatchNormalization / Scale folded into its launch)."""
+        global _WEIGHTS_EPOCH
+        _WEIGHTS_EPOCH += 1
         for m in self._modules():
             for u in m.units():
-                if only is None or u.conv in only:
+                if only is None or u.conv in only or u.bn in only or u.scale_name in only or any(n in only for n in getattr(u, "names", ())):
                     u.pc = None
+            if hasattr(m, "invalidate_fused"):
+                m.invalidate_fused(only)
 
     def load_weights(self, path, by_name=False):
         """Keras ``load_weights``: ``path`` is a Keras 2.0.x .h5 (weights or full model) or this package's .npz."""

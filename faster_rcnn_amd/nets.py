@@ -162,6 +162,12 @@ class ResNetBase:
         for b in self.blocks:
             yield from b.values()
 
+    def invalidate_fused(self, only=None):
+        """models._Model.invalidate: drop the fused bf16 stem with conv1's lowering (the cache below is keyed on the weight
+        arrays' id(), which a freed-and-reallocated generation of arrays can repeat: ADVICE r3)."""
+        if only is None or self.stem.conv in only or self.stem.bn in only or self.stem.scale_name in only:
+            self._stem_bf16 = None
+
     def stem_pool(self, x):
         """conv1 + BN (+ Scale) + ReLU + MaxPooling2D((3,3), strides=(2,2)) (resnet.py:408-412).  bf16 path: ONE launch on
         the bf16 matrix cores with the pool and the bf16 store fused (frcnn_stem_bf16_fwd); ``FUSED_BF16_STEM = False``
@@ -221,16 +227,27 @@ class RpnHead:
         return self.cls(t), self.reg(t)
 
 
+class _MergedDenseUnit(ConvUnit):
+    """The two dense layers as one 1x1 "conv": the kernels are concatenated from the LIVE weight dict whenever the unit is
+    (re-)lowered, so load_weights / set_weights on either layer reach the launch like any other layer's."""
+
+    def __init__(self, weights, num_classes):
+        super().__init__(weights, "dense")
+        self.names = ("dense_class_%d" % num_classes, "dense_reg_%d" % num_classes)
+
+    def folded(self):
+        (kc, bc), (kr, br) = (self.weights[n] for n in self.names)
+        merged = {"dense": [np.concatenate([kc, kr], axis=1), np.concatenate([bc, br])]}
+        return ConvUnit(merged, "dense").folded()
+
+
 class _MergedDense:
     """dense_class_C (softmax) and dense_reg_C (linear) share their input, so they run as ONE
     GEMM with the two kernels concatenated along the output axis (resnet.py:522-533)."""
 
     def __init__(self, weights, num_classes):
         self.C = num_classes
-        kc, bc = weights["dense_class_%d" % num_classes]
-        kr, br = weights["dense_reg_%d" % num_classes]
-        merged = {"dense": [np.concatenate([kc, kr], axis=1), np.concatenate([bc, br])]}
-        self.unit = ConvUnit(merged, "dense")
+        self.unit = _MergedDenseUnit(weights, num_classes)
 
     def __call__(self, x2d):
         n, cin = x2d.shape

@@ -455,6 +455,21 @@ def detections(rois, n_rois, out_cls, out_reg, roi_batch, bg_idx, det_threshold,
     return {"det_cls": det_cls, "det_prob": det_prob, "det_bbox": det_bbox, "det_roi": det_roi, "n_dets": n_dets, "det_packed": packed}
 
 
+def detections_dyn(rois, n_rois, out_cls, out_reg, roi_batch, bg_idx, stride, dyn, nms_thresh=0.5):
+    """`detections` for a captured pass that serves every image of one size: resize_ratio and det_threshold are read from
+    the device tensor ``dyn`` (2 x f64), the reference's padded RoI list is scored when ``roi_batch`` > 0, and word 1 of
+    `det_packed` carries the number of proposals the NMS kept (frcnn_detections_dyn)."""
+    _require_gpu()
+    rows, C = out_cls.shape
+    assert dyn.dtype == torch.float64 and dyn.numel() >= 2 and dyn.is_cuda
+    packed = torch.empty(4 + 7 * rows, dtype=torch.int32, device="cuda")
+    n_dets, det_bbox, det_cls, det_prob, det_roi = split_detections(packed, rows)
+    _lib.call("frcnn_detections_dyn", _p(rois), _p(n_rois), int(roi_batch), rows, _p(out_cls.contiguous()), _p(out_reg.contiguous()), C,
+              int(bg_idx), float(stride), float(nms_thresh), dyn.data_ptr(),
+              _p(det_cls), _p(det_prob), _p(det_bbox), _p(det_roi), _p(packed), _stream())
+    return {"det_cls": det_cls, "det_prob": det_prob, "det_bbox": det_bbox, "det_roi": det_roi, "n_dets": n_dets, "det_packed": packed}
+
+
 def split_detections(packed, rows=None):
     """Views (n_dets, det_bbox, det_cls, det_prob, det_roi) into a `det_packed` buffer (device tensor or its host copy)."""
     rows = (packed.numel() - 4) // 7 if rows is None else rows

@@ -28,6 +28,7 @@ class InferencePipeline:
         self.stride, self.pre, self.post = stride, pre_nms_top_n, max_proposals
         self.roi_batch = roi_batch
         # strict mode scores the reference's padded duplicates too (voc_dets.py:42-46)
+        self.pad_to_batch = bool(pad_to_batch)
         self.n_rois = -(-max_proposals // roi_batch) * roi_batch if pad_to_batch else max_proposals
         self.bg_idx = det_model.num_classes - 1 if bg_idx is None else bg_idx
         self.det_threshold = det_threshold
@@ -44,14 +45,20 @@ class InferencePipeline:
         rois = ops.gather_rois(cand, keep, n_keep, self.roi_batch, self.n_rois, out=rois_out)
         return rois, n_keep, cand, keep
 
-    def forward_dev(self, x, resize_ratio=1.0):
-        """x: (1,H,W,3) f32 device tensor (already preprocessed).  Returns a dict of device tensors."""
+    def forward_dev(self, x, resize_ratio=1.0, dyn=None):
+        """x: (1,H,W,3) f32 device tensor (already preprocessed).  Returns a dict of device tensors.
+        ``dyn``: device tensor [resize_ratio, det_threshold] (f64) read by the post-process INSTEAD of the two host scalars
+        (entry.DetectionEntry: one captured pass serves every image of its size); the reference's padded RoI rows are then
+        scored too when the pipeline was built with ``pad_to_batch`` (voc_dets.py:42-51)."""
         cls, reg, feat = self.rpn.forward_dev(x)
         rois, n_keep, cand, keep = self.proposals_dev(cls, reg)
         out_cls, out_reg = self.det.forward_dev(feat, rois)
         res = {"rpn_cls": cls, "rpn_reg": reg, "feat": feat, "rois": rois, "n_rois": n_keep,
                "cls": out_cls, "reg": out_reg}
-        if hasattr(ops, "detections"):
+        if dyn is not None:
+            res.update(ops.detections_dyn(rois, n_keep, out_cls, out_reg, self.roi_batch if self.pad_to_batch else 0, self.bg_idx,
+                                          float(self.stride), dyn))
+        else:
             res.update(ops.detections(rois, n_keep, out_cls, out_reg, self.roi_batch, self.bg_idx, self.det_threshold,
                                       float(self.stride), float(resize_ratio)))
         return res

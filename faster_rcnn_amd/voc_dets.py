@@ -2,20 +2,29 @@
 
 ``get_dets(training_manager, detector, image, resize_ratio, num_rois, stride, det_threshold)``
 returns the same list of ``{'bbox': int array [x1,y1,x2,y2], 'cls_name', 'prob'}`` dicts in the
-same order.  The detector runs once over all (padded) RoIs and the arg-max / decode /
-per-class NMS / rescale tail runs in one device kernel (frcnn_detections) instead of the
-reference's Python loops.
+same order.
+
+Two paths behind the same call:
+* **captured** (entry.DetectionEntry; taken whenever the manager's RPN model and the detector are this package's
+  models): one H2D copy of the uint8 frame, ONE hipGraph per image from preprocess to post-process, one packed D2H
+  copy; graphs cached per image size; ``get_dets_by_cls`` keeps several images in flight.  No host round trip between
+  the RPN and the detector (the reference makes two per image: det_util.py:41, 49-55).
+* **eager** (``FAST_ENTRY = False``, or a foreign Keras-style ``detector``): ``get_det_inputs`` exactly as the reference
+  sequences it (conv map and RoIs come back as numpy), the detector once over all padded RoIs, and the arg-max / decode /
+  per-class NMS / rescale tail in one device kernel (frcnn_detections) instead of the reference's Python loops.
 """
+import collections
 import os
 import timeit
 
 import numpy as np
 import torch
 
-from . import nets, ops
+from . import entry, nets, ops
 from .det_util import DetTrainingManager, nms  # noqa: F401  (re-exported like the reference module)
 
 DEFAULT_DET_THRESHOLD = 0.0
+FAST_ENTRY = os.environ.get("FRCNN_ENTRY_EAGER", "0") == "0"      # False: always the eager path (tests and bench.py compare the two)
 
 
 def _pad_rois(rois, num_rois):
@@ -30,6 +39,15 @@ def _pad_rois(rois, num_rois):
 
 def get_dets(training_manager, detector, image, resize_ratio, num_rois=64, stride=16,
              det_threshold=DEFAULT_DET_THRESHOLD):
+    eng = entry.for_models(training_manager, detector, num_rois, stride, in_flight=1) if FAST_ENTRY else None
+    if eng is not None:
+        num_boxes, dets = eng.collect(eng.submit(image, resize_ratio, det_threshold))
+        print("num rois: {}".format(num_boxes))
+        return dets
+    return _get_dets_eager(training_manager, detector, image, resize_ratio, num_rois, stride, det_threshold)
+
+
+def _get_dets_eager(training_manager, detector, image, resize_ratio, num_rois, stride, det_threshold):
     conv_out, rois = training_manager.get_det_inputs(image)
     class_mapping = training_manager.class_mapping
     rev_class_mapping = dict((v, k) for k, v in class_mapping.items())
@@ -59,14 +77,46 @@ def get_dets(training_manager, detector, image, resize_ratio, num_rois=64, strid
 
 
 def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=16, det_threshold=DEFAULT_DET_THRESHOLD):
-    """voc_dets.py:91-111."""
+    """voc_dets.py:91-111.  On the captured path the images are pipelined: up to ``entry.default_in_flight()`` are enqueued
+    (own HIP stream each) before the oldest one's detections are read, and results are folded into the dict in list order,
+    so the dict -- keys, per-image lists, their order -- is the one the reference's one-by-one loop builds."""
     dets_by_cls = {}
-    for image, resized_ratio in zip(images, resized_ratios):
-        start_time = timeit.default_timer()
-        dets = get_dets(training_manager, detector, image, resized_ratio, stride=stride, det_threshold=det_threshold)
+
+    def fold(image, dets, start_time):
         for det in dets:
             dets_by_cls.setdefault(det["cls_name"], {}).setdefault(image.name, []).append(det)
         print("image {} ran in {} seconds".format(image.name, timeit.default_timer() - start_time))
+
+    eng = None
+    if FAST_ENTRY:
+        dtype = getattr(getattr(detector, "head", None), "dtype", "f32")
+        eng = entry.for_models(training_manager, detector, 64, stride, in_flight=entry.default_in_flight(dtype))
+    if eng is None:
+        for image, resized_ratio in zip(images, resized_ratios):
+            start_time = timeit.default_timer()
+            dets = get_dets(training_manager, detector, image, resized_ratio, stride=stride, det_threshold=det_threshold)
+            fold(image, dets, start_time)
+        return dets_by_cls
+    window = collections.deque()
+
+    def finish():
+        image, ticket, start_time = window.popleft()
+        num_boxes, dets = eng.collect(ticket)
+        print("num rois: {}".format(num_boxes))
+        fold(image, dets, start_time)
+
+    try:
+        for image, resized_ratio in zip(images, resized_ratios):
+            start_time = timeit.default_timer()
+            window.append((image, eng.submit(image, resized_ratio, det_threshold), start_time))
+            if len(window) >= eng.in_flight:
+                finish()
+        while window:
+            finish()
+    finally:
+        for _, ticket, _ in window:                    # an exception mid-list: no slot stays marked busy
+            ticket.slot.event.synchronize()
+            ticket.slot.busy = False
     return dets_by_cls
 
 
@@ -106,6 +156,8 @@ def main(argv=None):
     from .data.voc_data_helpers import KITTI_CLASS_MAPPING, VOC_CLASS_MAPPING
     from .util import get_anchors, resize_imgs
     args = build_parser().parse_args(argv)
+    # eight images in flight want eight hardware queues; read when the HIP runtime starts, an explicit setting wins
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     test_imgs = base_paths_to_imgs(args.voc_path, img_set=args.img_set, do_flip=False)
     anchors = get_anchors(anchor_scales_from_str(args.anchor_scales))
     print("num test_imgs: ", len(test_imgs))

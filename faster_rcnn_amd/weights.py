@@ -95,6 +95,24 @@ def synthetic_resnet(depth=50, anchors_per_loc=9, num_classes=21, seed=1):
     return w
 
 
+def calibrate_classifier(weights, num_classes, probs, spread=2.0):
+    """Synthetic-weight helper: make an UNTRAINED ``dense_class_C`` layer fire many classes.
+
+    Random-init heads are degenerate: the pooled stage-5 features of all RoIs share a large common component, so one class
+    wins every arg-max and detection-set comparisons (mAP deltas, per-class NMS) exercise a single class.  Given the class
+    probabilities ``probs`` (n, C) the CURRENT weights produce on a calibration image, the logits are known up to a per-row
+    constant (log p); this returns new ``[kernel, bias]`` with each class's logit centred over the RoIs and the whole layer
+    scaled so a class's logit varies by ``spread`` (standard deviation) from RoI to RoI:  W' = g W,  b' = g (b - mean_r L).
+    A linear re-parametrisation of the same layer -- nothing about the kernels under test changes."""
+    name = "dense_class_%d" % num_classes
+    kernel, bias = (np.asarray(a, dtype=np.float64) for a in weights[name])
+    logits = np.log(np.clip(np.asarray(probs, dtype=np.float64), 1e-30, None))
+    logits -= logits.mean(axis=1, keepdims=True)                  # drop the per-row softmax constant
+    centre = logits.mean(axis=0)
+    gain = spread / max(float((logits - centre).std(axis=0).mean()), 1e-6)
+    return [(gain * kernel).astype(f32), (gain * (bias - centre)).astype(f32)]
+
+
 VGG_CONVS = [("block1_conv1", 3, 64), ("block1_conv2", 64, 64), ("block2_conv1", 64, 128), ("block2_conv2", 128, 128),
              ("block3_conv1", 128, 256), ("block3_conv2", 256, 256), ("block3_conv3", 256, 256),
              ("block4_conv1", 256, 512), ("block4_conv2", 512, 512), ("block4_conv3", 512, 512),

@@ -315,7 +315,8 @@ int frcnn_dense_heads_split(const float* x, int rows, int cols, int tail, int ld
 
 /* ------------------------------------------------------------------ detections */
 /* voc_dets.get_dets, everything after detector.predict (voc_dets.py:51-88): per scored RoI
- * arg-max class and confidence, skip background / confidence < det_threshold, decode the class's
+ * arg-max class and confidence, skip background / f64(confidence) < det_threshold (the reference's pinned numpy compares an
+ * np.float32 scalar with a Python float in f64), decode the class's
  * regression with util.transform (util.py:55-74) x stride, per-class det_util.nms(thresh, 2000)
  * on the float boxes, divide by resize_ratio and round half-to-even.
  * rois [max_rows][4] f32 (conv units), *n_rois live rows (<= max_rows <= 512),
@@ -326,8 +327,19 @@ int frcnn_dense_heads_split(const float* x, int rows, int cols, int tail, int ld
  * det_prob = 0, det_bbox = 0), so the caller need not clear the buffers.  The reference's padded duplicate RoIs
  * (voc_dets.py:42-46) are suppressed by its own NMS (IoU 1), so only live rows are scored. */
 int frcnn_detections(const float* rois, const int32_t* n_rois, int max_rows, const float* out_cls, const float* out_reg,
-                     int num_classes, int bg_idx, float det_threshold, double stride, double resize_ratio, double nms_thresh,
+                     int num_classes, int bg_idx, double det_threshold, double stride, double resize_ratio, double nms_thresh,
                      int32_t* det_cls, float* det_prob, int32_t* det_bbox, int32_t* det_roi, int32_t* n_dets, void* stream);
+/* The same post-process for a CAPTURED pass that serves every image of one size (voc_dets.get_dets_by_cls, voc_dets.py:91-111,
+ * walks a list of images whose resize ratios differ): the two per-image scalars are read from DEVICE memory,
+ * dyn[0] = resize_ratio, dyn[1] = det_threshold (f64, 8-byte aligned; the comparison `confidence < det_threshold` is made in
+ * f64, numpy 1.13's promotion of an np.float32 scalar against a Python float, voc_dets.py:57).  roi_batch > 0: the rows
+ * scored are the reference's PADDED list -- *n_rois rounded up to a multiple of roi_batch, the fill rows being the copies of
+ * the last batch's first RoI that frcnn_gather_rois laid out (voc_dets.py:42-46, :51) -- so det_roi indexes that list;
+ * roi_batch = 0 scores the live rows only.  counts[0] = detections emitted, counts[1] = *n_rois (the "num rois" line,
+ * voc_dets.py:26): both reach the host in the one copy that carries the detections. */
+int frcnn_detections_dyn(const float* rois, const int32_t* n_rois, int roi_batch, int max_rows, const float* out_cls, const float* out_reg,
+                         int num_classes, int bg_idx, double stride, double nms_thresh, const double* dyn,
+                         int32_t* det_cls, float* det_prob, int32_t* det_bbox, int32_t* det_roi, int32_t* counts, void* stream);
 
 /* ------------------------------------------------------------------ training: losses, optimisers */
 /* The reference's four Keras loss functions (loss_functions.py:15-76) as Keras 2.0.8 evaluates them

@@ -407,7 +407,9 @@ def detections(rois, out_cls, out_reg, bg_idx, resize_ratio, stride=16, det_thre
     for r in range(len(padded)):
         c = int(np.argmax(out_cls[r]))
         conf = out_cls[r, c]
-        if c == bg_idx or conf < np.float32(det_threshold):
+        # np.float32 scalar < Python float: an f64 comparison under the reference's pinned numpy 1.13 (legacy promotion;
+        # np.float32(0.7) < 0.7 is True there, False under NEP 50)
+        if c == bg_idx or float(conf) < float(det_threshold):
             continue
         t = out_reg[r, 4 * c:4 * c + 4] / BBREG_MULTIPLIERS
         p = transform_legacy(padded[r], t)

@@ -368,7 +368,7 @@ def test_detections_device(ops):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dets_legacy.npz"))
     rois = g["rois"].astype(np.float32)
     n = len(rois)
-    for tag in ("t0", "t5", "t0r"):
+    for tag in ("t0", "t5", "t0r", "tb"):     # tb: threshold one f64 step above a row's f32 score (the f64 comparison of the pinned numpy)
         thr, ratio = g[tag + "_args"]
         for rows in (n, 320):                 # unpadded (fast path) and with the reference's padded duplicates
             r = np.zeros((rows, 4), np.float32)
@@ -385,6 +385,16 @@ def test_detections_device(ops):
             assert np.array_equal(out["det_cls"].cpu().numpy()[:nd], g[tag + "_cls"])
             assert np.array_equal(out["det_prob"].cpu().numpy()[:nd], g[tag + "_prob"])
             assert np.array_equal(out["det_bbox"].cpu().numpy()[:nd], g[tag + "_bbox"])
+            # the captured-pass form: the two scalars from device memory; roi_batch 64 scores the padded list out of the live count
+            dyn = dev(np.array([ratio, thr], np.float64))
+            for n_live, batch in ((rows, 0), (n, 64)):
+                if n_live + (-n_live % max(batch, 1)) > rows:
+                    continue
+                dirty(rows * 4, rows * 4, rows * 16, rows * 4, 4)
+                o2 = ops.detections_dyn(dev(r), dev(np.array([n_live], np.int32)), dev(g["out_cls"][:rows]), dev(g["out_reg"][:rows]), batch, 20, 16.0, dyn)
+                assert o2["det_packed"][:2].tolist() == [nd, n_live]
+                for k in ("det_cls", "det_prob", "det_bbox", "det_roi"):
+                    assert torch.equal(o2[k], out[k]), (tag, rows, batch, k)
     # nothing above threshold
     out = ops.detections(dev(rois), dev(np.array([n], np.int32)), dev(g["out_cls"][:n]), dev(g["out_reg"][:n]), 64, 20, 2.0, 16.0, 1.0)
     assert int(out["n_dets"].item()) == 0 and (out["det_cls"].cpu().numpy() == -1).all()

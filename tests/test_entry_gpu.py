@@ -1,0 +1,220 @@
+"""The reference's inference entry points (voc_dets.get_dets / get_dets_by_cls, voc_dets.py:20-111) on the captured
+device pipeline (faster_rcnn_amd/entry.py) against the same calls on the eager path, which sequences the stages exactly
+as the reference does (get_det_inputs -> numpy -> detector.predict) and is itself held to the oracle / the goldens in
+test_pipeline_gpu.py and test_configs_full_size_gpu.py.
+
+Bar: classes and boxes identical, list order identical, scores within 1e-6 (a captured pass replays the launch forms
+chosen for its in-flight depth: another split-K partition of a small-grid layer rounds differently; with the same launch
+forms the two paths are bit-identical, which the determinism test checks)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def models():
+    from faster_rcnn_amd import resnet, util
+    from faster_rcnn_amd.data.voc_data_helpers import VOC_CLASS_MAPPING
+    from faster_rcnn_amd.det_util import DetTrainingManager
+    from faster_rcnn_amd.pipeline import InferencePipeline
+    from faster_rcnn_amd.weights import calibrate_classifier, synthetic_resnet
+    anchors = util.get_anchors([128, 256, 512])
+    w = synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=1)
+    rpn = resnet.resnet50_rpn(resnet.resnet50_base(weights=w), include_conv=True, anchors_per_loc=9)
+    det = resnet.resnet50_classifier(64, 21, weights=w)
+    # random-init heads put every RoI in one class: re-centre dense_class on a calibration frame so that many classes fire
+    x = resnet.preprocess(synth_pixels(320, 480, 99))[None].astype(np.float32)
+    out = InferencePipeline(rpn, det, anchors).forward_dev(torch.from_numpy(x).cuda())
+    n = int(out["n_rois"].item())
+    det.get_layer("dense_class_21").set_weights(calibrate_classifier(w, 21, out["cls"][:n].cpu().numpy()))
+    mgr = DetTrainingManager(rpn_model=rpn, class_mapping=VOC_CLASS_MAPPING, preprocess_func=resnet.preprocess, anchor_dims=anchors)
+    return mgr, det, rpn, w
+
+
+def named_image(name, pixels):
+    from faster_rcnn_amd import shapes
+    h, w = pixels.shape[:2]
+    return shapes.Image(shapes.Metadata(name, w, h, [], "none"), pixels)
+
+
+def synth_pixels(h, w, seed):
+    return np.random.RandomState(seed).randint(0, 256, (h, w, 3)).astype(np.uint8)
+
+
+def voc_frame(resized):
+    from faster_rcnn_amd import util
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+    img = extract_img_data(os.path.join(ROOT, "tests", "golden", "VOC_test"), "000005")
+    if not resized:
+        return img, 1.0
+    (r,), (ratio,) = util.resize_imgs([img], min_size=600, max_size=1000)
+    return r, ratio
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        res = fn(*a, **k)
+    return res, buf.getvalue()
+
+
+def both_paths(fn, *a, **k):
+    from faster_rcnn_amd import voc_dets
+    fast, out_fast = quiet(fn, *a, **k)
+    voc_dets.FAST_ENTRY = False
+    try:
+        eager, out_eager = quiet(fn, *a, **k)
+    finally:
+        voc_dets.FAST_ENTRY = True
+    return fast, eager, out_fast, out_eager
+
+
+def same_dets(a, b, tol=1e-6):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x["cls_name"] == y["cls_name"] and np.array_equal(x["bbox"], y["bbox"]), (x, y)
+        assert x["bbox"].dtype == y["bbox"].dtype and type(x["prob"]) is type(y["prob"])
+        assert abs(float(x["prob"]) - float(y["prob"])) <= tol, (x, y)
+
+
+def test_get_dets_three_sizes_match_the_eager_path(models):
+    """600x1000 synthetic, the real VOC frame resized to 600x800, the same frame un-resized (375x500)."""
+    from faster_rcnn_amd import entry, voc_dets
+    mgr, det, _, _ = models
+    cases = [(named_image("synth", synth_pixels(600, 1000, 7)), 1.0)]
+    cases += [voc_frame(True), voc_frame(False)]
+    for image, ratio in cases:
+        for thr in (0.0, 0.3):
+            fast, eager, out_fast, out_eager = both_paths(voc_dets.get_dets, mgr, det, image, ratio, det_threshold=thr)
+            assert len(eager) > 0 or thr > 0
+            same_dets(fast, eager)
+            assert out_fast == out_eager and out_fast.startswith("num rois: ")           # the reference's progress line, same count
+    eng = entry.for_models(mgr, det, 64, 16, 1)
+    st = eng.stats()
+    assert st["captures"] == 3 and st["sizes"] == 3 and st["hits"] == 3 and st["device_preprocess"]
+    assert len({d["cls_name"] for d in eager}) >= 5                # the calibrated head is not degenerate
+
+
+def test_get_dets_by_cls_pipelined_equals_one_by_one(models):
+    """A list of mixed sizes with several images in flight: the same dict, keys and per-image lists in the same order."""
+    from faster_rcnn_amd import entry, voc_dets
+    mgr, det, _, _ = models
+    frame, ratio = voc_frame(True)
+    images, ratios = [], []
+    for i in range(11):
+        if i % 4 == 3:
+            images.append(named_image("voc%02d" % i, frame.data)); ratios.append(ratio)
+        elif i % 4 == 1:
+            images.append(named_image("small%02d" % i, synth_pixels(352, 480, 40 + i))); ratios.append(0.8)
+        else:
+            images.append(named_image("synth%02d" % i, synth_pixels(600, 1000, 20 + i))); ratios.append(1.0 + 0.05 * i)
+    fast, eager, out_fast, out_eager = both_paths(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.1)
+    assert list(fast) == list(eager) and len(fast) >= 2
+    for cls_name in eager:
+        assert list(fast[cls_name]) == list(eager[cls_name])
+        for img_name in eager[cls_name]:
+            same_dets(fast[cls_name][img_name], eager[cls_name][img_name])
+    strip = lambda s: [ln.split(" ran in ")[0] for ln in s.splitlines()]
+    assert strip(out_fast) == strip(out_eager)
+    depth = entry.default_in_flight("f32")
+    eng = entry.for_models(mgr, det, 64, 16, depth)
+    st = eng.stats()
+    assert st["sizes"] == 3 and st["in_flight"] == depth >= 4
+    assert st["captures"] <= 3 * depth and st["hits"] + st["captures"] == 11
+    # a second walk over the list re-uses every captured pass and returns the same bits
+    again, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.1)
+    assert eng.stats()["captures"] == st["captures"]
+    for cls_name in fast:
+        for img_name in fast[cls_name]:
+            same_dets(again[cls_name][img_name], fast[cls_name][img_name], tol=0.0)
+
+
+def test_graph_cache_budget_evicts_least_recently_used(models):
+    from faster_rcnn_amd import entry
+    mgr, det, _, _ = models
+    eng = entry.DetectionEntry(mgr, det, 64, 16, in_flight=1, byte_budget=1)        # nothing fits: every new size evicts the idle ones
+    sizes = [(160, 224), (176, 240), (160, 224), (192, 256)]
+    ref = {}
+    for k, (h, w) in enumerate(sizes):
+        img = named_image("s%d" % k, synth_pixels(h, w, 90 + h))
+        n, dets = eng.collect(eng.submit(img, 1.0, 0.0))
+        if (h, w) in ref:
+            same_dets(dets, ref[(h, w)], tol=0.0)                                   # a re-captured size returns the same bits
+        ref[(h, w)] = dets
+        assert len(eng.cache) == 1 and eng.cache.keys() == [(h, w)]
+    st = eng.stats()
+    assert st["captures"] == 4 and st["evictions"] == 3 and st["hits"] == 0
+    big = entry.DetectionEntry(mgr, det, 64, 16, in_flight=1, byte_budget=1 << 40)
+    for k, (h, w) in enumerate(sizes):
+        big.collect(big.submit(named_image("s%d" % k, synth_pixels(h, w, 90 + h)), 1.0, 0.0))
+    assert big.stats()["captures"] == 3 and big.stats()["hits"] == 1 and big.stats()["evictions"] == 0
+    assert 0 < big.stats()["bytes"] < 8 << 30
+
+
+def test_changed_weights_drop_the_captured_passes(models):
+    from faster_rcnn_amd import voc_dets
+    from faster_rcnn_amd import entry
+    mgr, det, rpn, w = models
+    image = named_image("w", synth_pixels(192, 256, 5))
+    before, _ = quiet(voc_dets.get_dets, mgr, det, image, 1.0)
+    eng = entry.for_models(mgr, det, 64, 16, 1)
+    caps = eng.stats()["captures"]
+    name = "dense_class_21"
+    old = det.get_layer(name).get_weights()
+    try:
+        det.get_layer(name).set_weights([old[0][:, ::-1].copy(), old[1][::-1].copy()])     # classes reversed
+        fast, eager, _, _ = both_paths(voc_dets.get_dets, mgr, det, image, 1.0)
+        same_dets(fast, eager)
+        assert eng.stats()["captures"] == caps + 1
+        assert [d["cls_name"] for d in fast] != [d["cls_name"] for d in before]
+    finally:
+        det.get_layer(name).set_weights(old)
+    after, _ = quiet(voc_dets.get_dets, mgr, det, image, 1.0)
+    same_dets(after, before, tol=0.0)
+
+
+def test_foreign_preprocess_and_foreign_detector(models):
+    from faster_rcnn_amd import entry, resnet, voc_dets
+    from faster_rcnn_amd.det_util import DetTrainingManager
+    mgr, det, rpn, _ = models
+    image = named_image("f", synth_pixels(192, 256, 6))
+    want, _ = quiet(voc_dets.get_dets, mgr, det, image, 1.25)
+    # a preprocess function the entry does not know: called on the host (det_util.py:36), its float image uploaded
+    mgr2 = DetTrainingManager(rpn_model=rpn, class_mapping=mgr.class_mapping, preprocess_func=lambda d: resnet.preprocess(d), anchor_dims=mgr.anchor_dims)
+    got, _ = quiet(voc_dets.get_dets, mgr2, det, image, 1.25)
+    same_dets(got, want, tol=0.0)
+    assert not entry.for_models(mgr2, det, 64, 16, 1).stats()["device_preprocess"]
+
+    class Foreign:                                  # the Keras predict() contract only: the eager path serves it
+        def __init__(self):
+            self.calls = 0
+
+        def predict(self, inputs):
+            self.calls += 1
+            return det.predict(inputs)
+
+    f = Foreign()
+    assert entry.for_models(mgr, f, 64, 16, 1) is None
+    got, _ = quiet(voc_dets.get_dets, mgr, f, image, 1.25)
+    assert f.calls == 5                              # ceil(300 / 64) batches (voc_dets.py:31)
+    same_dets(got, want)
+
+
+def test_a_failed_image_leaves_no_slot_busy(models):
+    from faster_rcnn_amd import entry, voc_dets
+    mgr, det, _, _ = models
+    good = named_image("g", synth_pixels(160, 224, 1))
+    bad = named_image("b", synth_pixels(160, 224, 2).astype(np.float32))           # not uint8: submit refuses
+    with pytest.raises(TypeError):
+        quiet(voc_dets.get_dets_by_cls, mgr, det, [1.0, 1.0, 1.0], [good, good, bad])
+    eng = entry.for_models(mgr, det, 64, 16, entry.default_in_flight("f32"))
+    assert not any(s.busy for v in eng.cache._slots.values() for s in v)
+    res, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, [1.0, 1.0], [good, good])
+    assert res
