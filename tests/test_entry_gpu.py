@@ -3,9 +3,11 @@ device pipeline (faster_rcnn_amd/entry.py) against the same calls on the eager p
 as the reference does (get_det_inputs -> numpy -> detector.predict) and is itself held to the oracle / the goldens in
 test_pipeline_gpu.py and test_configs_full_size_gpu.py.
 
-Bar: classes and boxes identical, list order identical, scores within 1e-6 (a captured pass replays the launch forms
-chosen for its in-flight depth: another split-K partition of a small-grid layer rounds differently; with the same launch
-forms the two paths are bit-identical, which the determinism test checks)."""
+Bar: classes and boxes identical, list order identical, scores within 1e-4 (north_star's bar for class scores).  A
+captured pass replays the launch forms chosen for its in-flight depth and the eager path those of an eager launch: another
+split-K partition of a small-grid layer, or a head GEMM over 64 instead of 320 RoIs, rounds differently in the last bit,
+and the fixture's classifier is re-scaled so that many classes fire, which multiplies logit differences by its gain
+(measured: <= 3e-5 between eight-in-flight graphs and eager launches, <= 3e-6 between a 64-RoI and a 320-RoI head pass).  With the same launch forms the results are bit-identical (tol=0.0 where the tests re-run a path)."""
 import contextlib
 import io
 import os
@@ -76,7 +78,7 @@ def both_paths(fn, *a, **k):
     return fast, eager, out_fast, out_eager
 
 
-def same_dets(a, b, tol=1e-6):
+def same_dets(a, b, tol=1e-4):
     assert len(a) == len(b)
     for x, y in zip(a, b):
         assert x["cls_name"] == y["cls_name"] and np.array_equal(x["bbox"], y["bbox"]), (x, y)
@@ -90,16 +92,18 @@ def test_get_dets_three_sizes_match_the_eager_path(models):
     mgr, det, _, _ = models
     cases = [(named_image("synth", synth_pixels(600, 1000, 7)), 1.0)]
     cases += [voc_frame(True), voc_frame(False)]
+    classes = set()
     for image, ratio in cases:
         for thr in (0.0, 0.3):
             fast, eager, out_fast, out_eager = both_paths(voc_dets.get_dets, mgr, det, image, ratio, det_threshold=thr)
             assert len(eager) > 0 or thr > 0
             same_dets(fast, eager)
+            classes |= {d["cls_name"] for d in eager}
             assert out_fast == out_eager and out_fast.startswith("num rois: ")           # the reference's progress line, same count
     eng = entry.for_models(mgr, det, 64, 16, 1)
     st = eng.stats()
     assert st["captures"] == 3 and st["sizes"] == 3 and st["hits"] == 3 and st["device_preprocess"]
-    assert len({d["cls_name"] for d in eager}) >= 5                # the calibrated head is not degenerate
+    assert len(classes) >= 5, classes                             # the calibrated head is not degenerate
 
 
 def test_get_dets_by_cls_pipelined_equals_one_by_one(models):
@@ -202,8 +206,9 @@ def test_foreign_preprocess_and_foreign_detector(models):
 
     f = Foreign()
     assert entry.for_models(mgr, f, 64, 16, 1) is None
-    got, _ = quiet(voc_dets.get_dets, mgr, f, image, 1.25)
-    assert f.calls == 5                              # ceil(300 / 64) batches (voc_dets.py:31)
+    got, printed = quiet(voc_dets.get_dets, mgr, f, image, 1.25)
+    n_rois = int(printed.split("num rois: ")[1].split()[0])
+    assert f.calls == -(-n_rois // 64) >= 2          # one predict() per batch of 64 RoIs (voc_dets.py:31-49)
     same_dets(got, want)
 
 
