@@ -460,9 +460,14 @@ def spawn_ranks(n):
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     failed = False
+    # an overall deadline: ranks stuck in a collective nobody else joins would otherwise wait for the RCCL watchdog
+    deadline = time.monotonic() + float(os.environ.get("FRCNN_BENCH_DEADLINE_S", "3600"))
     while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):
+        late = time.monotonic() > deadline
+        if late or any(p.poll() not in (None, 0) for p in procs):
             failed = True
+            if late:
+                sys.stderr.write("bench.py: ranks still running at the deadline (FRCNN_BENCH_DEADLINE_S): terminating them\n")
             for p in procs:
                 if p.poll() is None:
                     p.terminate()
@@ -482,7 +487,7 @@ def spawn_ranks(n):
                 sys.stdout.write(ln + "\n")
         sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
+    if bad or failed:
         sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
         sys.exit(1)
     sys.exit(0)
@@ -543,7 +548,14 @@ def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=10):
     finally:
         train.DP_SYNC = True
     buf = torch.zeros_like(params.g)
-    ar = timed(lambda: (dp.allreduce_sum_(buf), torch.cuda.synchronize()), 10, 2)
+    # (the begin / wait pair is the form a training step uses and the one dp.FORCE_COLLECTIVE applies to: a forced one-rank run
+    #  times a real RCCL all-reduce here, not a no-op)
+    def one_allreduce():
+        handle, _ = dp.allreduce_sum_begin(buf)
+        if handle is not None:
+            handle.wait()
+        torch.cuda.synchronize()
+    ar = timed(one_allreduce, 10, 2)
     return {"workload": "configs[2]: ResNet-50 RPN step-1 training, 600x1000, 1 image per GPU per step, SGD momentum, l2 1e-4, fp32, synthetic",
             "ranks_seen": int(seen.item()), "backend": dist.get_backend(), "steps": steps,
             "ms_per_step": round(ms, 3), "img_s": round(world * 1e3 / ms, 2),
@@ -835,8 +847,15 @@ def main():
     if dist is not None and args.config == "c2" and not args.no_train_dp:
         try:
             train_dp = train_dp_leg(weights, anchors, rank, world)
-        except Exception as e:                              # (a rank that fails here fails the collective for all: report, do not hang)
-            train_dp = {"error": "%s: %s" % (type(e).__name__, e)}
+        except Exception as e:
+            # a rank that fails inside the leg has left its peers inside a collective it will never join: going on to the
+            # final barrier would mismatch collectives (an RCCL hang).  Say why and leave with a non-zero code:
+            # the launcher (spawn_ranks' poll loop, or torch.distributed.run) takes the other ranks down at once.
+            import traceback
+            traceback.print_exc()
+            sys.stderr.write("bench.py: rank %d failed in the train_dp leg (%s: %s); exiting so the job fails instead of hanging\n" % (rank, type(e).__name__, e))
+            sys.stderr.flush()
+            os._exit(3)
 
     out = pipe._static_out if not args.no_graph else pipe.forward_dev(x)
     first = lambda v: v[0] if isinstance(v, list) else v                # (the batched pipeline returns per-image lists)

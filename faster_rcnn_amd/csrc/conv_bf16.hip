@@ -1027,12 +1027,8 @@ static int launch_bf16_v(const ConvArgsBf16& a, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const size_t lds = VARIANT == 4 ? (size_t)4 * (BM + BN) * 128 : (size_t)2 * (BM + BN) * (VARIANT == 3 ? 128 : LDS_STRIDE_B);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS to %zu", lds);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED, VARIANT>, lds, "conv2d_bf16")) return e;
     k_conv_igemm_bf16<TM, TN, false, WM, WN, MASKED, VARIANT><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
     return check_launch("conv2d_fwd_bf16");
 }
@@ -1078,12 +1074,8 @@ static int strip_rows_bf16(const frcnn_conv_desc* d, bool has_mask, int y_is_f32
 template <int BM>
 static int launch_strip_bf16(const ConvArgsBf16& a, hipStream_t s) {
     const size_t lds = 65536 + 2 * 128 * 128 + (size_t)BM * 128 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_gemm_strip_bf16<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS to %zu", lds);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_gemm_strip_bf16<BM>, lds, "conv2d_bf16")) return e;
     k_gemm_strip_bf16<BM><<<(a.M + BM - 1) / BM, 512, lds, s>>>(a);
     return check_launch("conv2d_fwd_bf16 (row strips)");
 }
@@ -1204,17 +1196,12 @@ int frcnn_conv2d_fwd_bf16_masked(const frcnn_conv_desc* d, const void* x_bf16, c
     if (d->kh * d->kw > 32) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_bf16: at most 32 filter taps");
     hipStream_t s = as_stream(stream);
     const int cfg = choose_config_bf16(d);
-    static bool attr_done = false;
+    static std::atomic<uint64_t> lds_seen{0};
     if (workspace) {
         const size_t need = frcnn_conv2d_workspace_bytes_bf16(d);
         if (need) {
             if (workspace_bytes < need) return fail(FRCNN_E_WORKSPACE, "conv2d_fwd_bf16: workspace needs %zu bytes", need);
-            if (!attr_done) {
-                if (hipFuncSetAttribute((const void*)k_conv_igemm_bf16<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(2 * 128 * LDS_STRIDE_B)) != hipSuccess)
-                    return fail(FRCNN_E_HIP, "conv2d_bf16: cannot raise dynamic LDS");
-                attr_done = true;
-            }
+            if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_bf16<1, 1, true>, (size_t)2 * 128 * LDS_STRIDE_B, "conv2d_bf16")) return e;
             a.splits = choose_splits_bf16(d, cfg);
             a.tickets = (unsigned*)workspace;
             a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES_B);

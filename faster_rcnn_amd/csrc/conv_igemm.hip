@@ -1732,12 +1732,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32<TM, TN, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_f32<TM, TN, G>, lds, "conv2d")) return e;
     k_conv_igemm_f32<TM, TN, G><<<p.tiles_m * p.tiles_n, 256, lds, s>>>(p);
     return check_launch("conv2d_fwd");
 }
@@ -1749,12 +1745,8 @@ static int launch_conv_v2(const ConvArgs& a, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN>, lds, "conv2d")) return e;
     k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
     return check_launch("conv2d_fwd");
 }
@@ -1778,12 +1770,8 @@ static int launch_conv_v2_splitk(const ConvArgs& a, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN, true>, lds, "conv2d")) return e;
     k_conv_igemm_f32_v2<TM, TN, VARIANT, WM, WN, true><<<p.tiles_m * p.tiles_n * p.splits, 64 * WM * WN, lds, s>>>(p);
     return check_launch("conv2d_fwd (split-K)");
 }
@@ -1797,6 +1785,13 @@ static int g_group_m = getenv("FRCNN_GROUP_M") ? atoi(getenv("FRCNN_GROUP_M")) :
 
 // tile / main-loop selection shared by frcnn_conv2d_fwd and frcnn_conv2d_config
 static int choose_streamk(const frcnn_conv_desc* d, int cfg);
+
+// what the two-layer launch (frcnn_conv2d_fwd_dual) makes of a single-layer tile choice
+static int dual_config(int cfg) {
+    if (cfg >= 61) cfg -= 40;                               // no balanced form for the two-layer launch
+    if (cfg < 11 || (cfg >= 41 && cfg <= 43)) cfg = 23;     // v2 main loops with the 2x2-wave tiles only
+    return cfg;
+}
 
 static int choose_config(const frcnn_conv_desc* d) {
     const long long M = (long long)d->n * d->ho * d->wo;
@@ -1926,11 +1921,13 @@ static int launch_conv_sk(const ConvArgs& a, int G, hipStream_t s) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float) + (size_t)(p.tiles_m + 1) * sizeof(int);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
+    static std::atomic<size_t> attr_lds[64];                 // per device ordinal (the limit is a per-device function attribute); grows with tiles_m
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(FRCNN_E_HIP, "conv2d: no current HIP device");
+    if (lds > attr_lds[dev & 63].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)k_conv_igemm_f32_sk<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return fail(FRCNN_E_HIP, "conv2d: cannot raise dynamic LDS to %zu", lds);
-        attr_lds = lds;
+        attr_lds[dev & 63].store(lds, std::memory_order_release);
     }
     k_conv_igemm_f32_sk<TM, TN><<<G, 256, lds, s>>>(p);
     return check_launch("conv2d_fwd (balanced)");
@@ -2039,8 +2036,7 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
     const bool generic = (d->cin % BK) != 0;
     int cfg = choose_config(d);
     if (dual) {
-        if (cfg >= 61) cfg -= 40;                               // no balanced form for the two-layer launch
-        if (cfg < 11 || (cfg >= 41 && cfg <= 43)) cfg = 23;     // v2 main loops with the 2x2-wave tiles only
+        cfg = dual_config(cfg);
         // the 16-byte epilogue picks the output per TILE: the boundary between the layers must be a tile boundary and
         // both outputs 16-byte addressable; otherwise every lane picks per column (the 4-byte epilogue)
         const int bn = (cfg == 21 || cfg == 26 || cfg == 11 || cfg == 24 || cfg == 14) ? 128 : 64;
@@ -2350,6 +2346,13 @@ int frcnn_conv2d_config(const frcnn_conv_desc* d) {
     const int cfg = choose_config(d);
     if (choose_streamk(d, cfg)) return (cfg == 21 || cfg == 26 || cfg == 61) ? 61 : 62;     // what a launch WITH a workspace runs
     return (cfg == 61 || cfg == 62) ? cfg - 40 : cfg;                           // asked for, but the shape is not eligible
+}
+
+int frcnn_conv2d_dual_config(const frcnn_conv_desc* d, int has_workspace) {
+    if (!d) return fail(FRCNN_E_ARG, "conv2d_dual_config: null descriptor");
+    int cfg = dual_config(choose_config(d));
+    if (cfg == 21 && !has_workspace && d->tile % 100 == 0 && d->layout && d->kh * d->kw > 1) cfg = 23;      // as conv_fwd_impl
+    return cfg;
 }
 
 int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream) {

@@ -160,12 +160,8 @@ int frcnn_stem_bf16_fwd(const float* x, int n, int h, int w, const void* w_packe
     const int ho = (h + 1) / 2, wo = (w + 1) / 2, hp = (ho - 3) / 2 + 1, wp = (wo - 3) / 2 + 1;
     if (hp <= 0 || wp <= 0) return fail(FRCNN_E_ARG, "stem_bf16_fwd: image too small for the 3x3 pool");
     if ((reinterpret_cast<uintptr_t>(w_packed_bf16) | reinterpret_cast<uintptr_t>(out_bf16)) & 15) return fail(FRCNN_E_ARG, "stem_bf16_fwd: 16-byte aligned tensors");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)k_stem_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ST_LDS) != hipSuccess)
-            return fail(FRCNN_E_HIP, "stem_bf16_fwd: cannot raise dynamic LDS to %zu", ST_LDS);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_stem_bf16, ST_LDS, "stem_bf16_fwd")) return e;
     const dim3 grid((wp + ST_PW - 1) / ST_PW, (hp + ST_PH - 1) / ST_PH, n);
     if (grid.y > 65535 || grid.z > 65535) return fail(FRCNN_E_ARG, "stem_bf16_fwd: image too large");
     k_stem_bf16<<<grid, 256, ST_LDS, as_stream(stream)>>>(x, (const __bf16*)w_packed_bf16, scale, shift, h, w, hp, wp, (__bf16*)out_bf16);

@@ -168,15 +168,21 @@ class ResNetBase:
         if only is None or self.stem.conv in only or self.stem.bn in only or self.stem.scale_name in only:
             self._stem_bf16 = None
 
+    def lower_fused_stem(self):
+        """The packed form frcnn_stem_bf16_fwd reads (None on an f32 base); built once, dropped by invalidate_fused."""
+        if self.dtype != "bf16" or not FUSED_BF16_STEM:
+            return None
+        src = tuple(id(a) for name in (self.stem.conv, self.stem.bn, self.stem.scale_name) if name for a in self.weights[name])
+        if getattr(self, "_stem_bf16", None) is None or self._stem_src != src:      # (re-packed when conv1 / its BatchNorm were replaced)
+            self._stem_bf16, self._stem_src = ops.PackedStemBf16(*self.stem.folded()), src
+        return self._stem_bf16
+
     def stem_pool(self, x):
         """conv1 + BN (+ Scale) + ReLU + MaxPooling2D((3,3), strides=(2,2)) (resnet.py:408-412).  bf16 path: ONE launch on
         the bf16 matrix cores with the pool and the bf16 store fused (frcnn_stem_bf16_fwd); ``FUSED_BF16_STEM = False``
         keeps the round-1/2 form (f32 conv, f32 pool, cast)."""
         if self.dtype == "bf16" and FUSED_BF16_STEM:
-            src = tuple(id(a) for name in (self.stem.conv, self.stem.bn, self.stem.scale_name) if name for a in self.weights[name])
-            if getattr(self, "_stem_bf16", None) is None or self._stem_src != src:      # (re-packed when conv1 / its BatchNorm were replaced)
-                self._stem_bf16, self._stem_src = ops.PackedStemBf16(*self.stem.folded()), src
-            return ops.stem_bf16(x, self._stem_bf16)
+            return ops.stem_bf16(x, self.lower_fused_stem())
         x = ops.pool2d(self.stem(x), 3, 2, True)
         return ops.cast_bf16(x) if self.dtype == "bf16" else x
 

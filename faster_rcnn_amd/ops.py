@@ -400,8 +400,7 @@ def conv2d_dual(x, pc, n1, stride=1, padding="valid", act1=None, act2=None, layo
     _lib.call("frcnn_conv2d_fwd_dual", *args, _stream())
     if CONV_PROFILE is not None:
         flops = 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin
-        cfg = _lib.load().frcnn_conv2d_config(ctypes.byref(d))
-        cfg = cfg - 40 if cfg >= 61 else cfg
+        cfg = _lib.load().frcnn_conv2d_dual_config(ctypes.byref(d), 1 if ws is not None else 0)     # the remapped code the launch ran
         kname = CONV_KERNEL_NAMES.get(cfg, "?") + (" split-K" if ws is not None else "")
         keep = (d, x, pc, y1, y2, ws)
         CONV_PROFILE.append({"kernel": kname, "flops": flops, "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),

@@ -492,6 +492,18 @@ class _StepDriver:
         for u in self._frozen_units():
             if u.pc is None:
                 u.lower()
+        # ... and the derived forms the frozen stages launch: a frozen conv_block runs branch2a + shortcut as ONE
+        # launch on a concatenated filter (nets.DualUnit), and a bf16 base runs conv1 as the fused stem -- both were still
+        # built lazily at first use, i.e. on the prefix stream
+        base = getattr(self, "base", None)
+        for units in getattr(base, "frozen_blocks", []) if base is not None else []:
+            if "1" in units:
+                pair = nets._pair(units["2a"], units["1"])
+                if pair is not None:
+                    pair.lower()
+        net = getattr(base, "net", None)
+        if net is not None and hasattr(net, "lower_fused_stem"):
+            net.lower_fused_stem()
         self._frozen_ready = torch.cuda.Event()
         self._frozen_ready.record()
 

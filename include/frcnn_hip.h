@@ -241,6 +241,9 @@ size_t frcnn_conv2d_dual_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_fwd_dual(const frcnn_conv_desc* d, const float* x, const float* w_packed, const float* scale, const float* shift,
                           float* y1, int n1, int act1, float* y2, int act2,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The tile / main-loop code frcnn_conv2d_fwd_dual runs for this descriptor (frcnn_conv2d_config's codes; the two-layer
+ * launch has no balanced form and only the 2x2-wave tiles): profiling tools name the kernel of a paired launch with it. */
+int frcnn_conv2d_dual_config(const frcnn_conv_desc* d, int has_workspace);
 /* Filter of the input-gradient convolution: transposed (cin <-> cout), flipped in both taps, input
  * channel co scaled by scale[co] (the forward epilogue scale = folded BatchNorm; NULL = 1).
  * packed: [cin][frcnn_conv_packed_k(kh, kw, cout)]. */

@@ -19,22 +19,25 @@ def roi_resize(feat, rois, pool=7):
     int32 truncation of the corners (:45-48), crop [y1:y2, x1:x2] (:50), then TF-1.3
     tf.image.resize_images bilinear, align_corners=False [3P: resize_bilinear_op.cc,
     compute_interpolation_weights + compute_lerp]: scale = in/out in f32, src = i*scale,
-    lo = int(src), hi = min(lo+1, in-1), lerp = src-lo; top/bottom lerp in x then y."""
+    lo = int(src), hi = min(lo+1, in-1), lerp = src-lo; top/bottom lerp in x then y.
+    ``pool`` may be (rows, cols) -- the reference only uses squares; the non-square form exists for TF's own published
+    resize vector (tests/test_oracle_kats.py)."""
     feat = np.asarray(feat, dtype=f32)
-    out = np.zeros((len(rois), pool, pool, feat.shape[2]), dtype=f32)
+    pool_h, pool_w = (pool, pool) if np.isscalar(pool) else pool
+    out = np.zeros((len(rois), pool_h, pool_w, feat.shape[2]), dtype=f32)
     for r, roi in enumerate(np.asarray(rois)):
         x1, y1, x2, y2 = (int(v) for v in roi)           # K.cast(., 'int32') truncates toward zero
         crop = feat[y1:y2, x1:x2, :]
         h, w = crop.shape[:2]
         if h == 0 or w == 0:
             continue
-        sy, sx = f32(h) / f32(pool), f32(w) / f32(pool)
-        for py in range(pool):
+        sy, sx = f32(h) / f32(pool_h), f32(w) / f32(pool_w)
+        for py in range(pool_h):
             fy = f32(py) * sy
             ylo = int(fy)
             yhi = min(ylo + 1, h - 1)
             ty = f32(fy - f32(ylo))
-            for px in range(pool):
+            for px in range(pool_w):
                 fx = f32(px) * sx
                 xlo = int(fx)
                 xhi = min(xlo + 1, w - 1)

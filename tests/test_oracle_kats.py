@@ -129,6 +129,31 @@ def test_oracle_legacy_bilinear_3x5_to_7x7():
     assert np.allclose(got[0, 0, :, 0], [0, 2, 4, 6, 8, 10, 12], atol=1e-5)
 
 
+# THIRD-PARTY vector (not derived here): TensorFlow 1.x's own unit test for the op the reference calls,
+# tensorflow/python/ops/image_ops_test.py ResizeImagesTest.testResizeUp -- a 3x2 single-channel image resized to 6x4 with
+# ResizeMethod.BILINEAR (align_corners=False, the legacy kernel without half-pixel centres that tf.image.resize_images
+# reaches from custom_layers.py:50).  The first number in the Keras half of the oracle that someone other than this
+# repository's author published.
+TF_RESIZE_UP_IN = [64, 32, 32, 64, 50, 100]                               # [3, 2] row-major
+TF_RESIZE_UP_BILINEAR = [64.0, 48.0, 32.0, 32.0,
+                         48.0, 48.0, 48.0, 48.0,
+                         32.0, 48.0, 64.0, 64.0,
+                         41.0, 61.5, 82.0, 82.0,
+                         50.0, 75.0, 100.0, 100.0,
+                         50.0, 75.0, 100.0, 100.0]                        # [6, 4]
+
+
+def test_oracle_tf_published_resize_up_vector():
+    feat = np.array(TF_RESIZE_UP_IN, np.float32).reshape(3, 2, 1)
+    got = kr.roi_resize(feat, np.array([[0, 0, 2, 3]], np.float32), (6, 4))
+    assert np.array_equal(got.reshape(-1), np.array(TF_RESIZE_UP_BILINEAR, np.float32))
+    # the wrong kernels give something else: half-pixel centres (TF2 / OpenCV convention) and align_corners=True
+    t = torch.tensor(TF_RESIZE_UP_IN, dtype=torch.float32).reshape(1, 1, 3, 2)
+    for kw in ({"align_corners": False}, {"align_corners": True}):
+        other = torch.nn.functional.interpolate(t, size=(6, 4), mode="bilinear", **kw).reshape(-1).numpy()
+        assert not np.allclose(other, TF_RESIZE_UP_BILINEAR)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # 3. BatchNormalization(training=False) with the two epsilons the reference uses: Keras default 1e-3 for bn_conv1
 #    (resnet.py:410) and 1e-5 inside the blocks (resnet.py:148, 216).  y = gamma*(x-mean)/sqrt(var+eps) + beta.
@@ -409,6 +434,24 @@ def test_gpu_legacy_bilinear_3x5_to_7x7():
     got = ops.roi_crop_resize(torch.from_numpy(f4).cuda(), torch.from_numpy(rois).cuda(), 7).cpu().numpy()
     assert np.abs(got[..., :2] - want).max() < 2e-5 and np.array_equal(got[..., :2], got[..., 2:])
     assert np.array_equal(got, kr.roi_resize(f4, rois, 7))        # and bit-for-bit the oracle's f32 lerp order
+
+
+@gpu
+def test_gpu_tf_published_resize_up_vector():
+    """The third-party vector through frcnn_roi_crop_resize_fwd.  The entry point resamples to a SQUARE grid (the reference
+    only asks for 7x7), so the 3x2 -> 6x4 resize is made of two calls, each the identity along one axis (in == out there:
+    scale 1, every lerp weight 0): 2 -> 4 columns on a 4-row strip, then 3 -> 6 rows on a 6-column strip.  That is TF's own
+    order -- x lerp inside each source row, then the y lerp between the two results -- and every value in this vector is
+    exact in f32, so the literals must come out bit for bit."""
+    from faster_rcnn_amd import ops
+    src = np.array(TF_RESIZE_UP_IN, np.float32).reshape(3, 2)
+    strip = np.zeros((4, 2, 4), np.float32)                         # (rows, cols, channels): a 4th row of padding, channel 0 carries the image
+    strip[:3, :, 0] = src
+    wide = ops.roi_crop_resize(torch.from_numpy(strip).cuda(), torch.tensor([[0., 0., 2., 4.]]).cuda(), 4).cpu().numpy()[0, :3, :, 0]     # (3,4)
+    strip2 = np.zeros((3, 6, 4), np.float32)
+    strip2[:, :4, 0] = wide
+    got = ops.roi_crop_resize(torch.from_numpy(strip2).cuda(), torch.tensor([[0., 0., 6., 3.]]).cuda(), 6).cpu().numpy()[0, :, :4, 0]     # (6,4)
+    assert np.array_equal(got.reshape(-1), np.array(TF_RESIZE_UP_BILINEAR, np.float32))
 
 
 @gpu
