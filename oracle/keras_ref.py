@@ -294,9 +294,10 @@ class KerasGraphs:
         reg = self._dense(x, "dense_reg_%d" % num_classes)
         return cls, reg
 
-    def resnet_classifier(self, feat, rois, num_classes, depth=50):
+    def resnet_classifier(self, feat, rois, num_classes, depth=50, return_pooled=False):
         """resnet50_classifier (resnet.py:489-548): RoiResizeConv, stage 5 with strides (1,1)
-        (:508), AveragePooling2D(7), flatten, dense softmax + dense linear."""
+        (:508), AveragePooling2D(7), flatten, dense softmax + dense linear.
+        ``return_pooled``: also the (n, 2048) input of the two dense layers."""
         torch = _torch()
         r101 = depth == 101
         crops = roi_resize(np.asarray(feat[0].to(torch.float32)), np.asarray(rois), 7)
@@ -307,7 +308,7 @@ class KerasGraphs:
         x = pool2d(x, 7, 7, False).reshape(x.shape[0], -1)
         cls = torch.softmax(self._dense(x, "dense_class_%d" % num_classes), dim=1)
         reg = self._dense(x, "dense_reg_%d" % num_classes)
-        return cls, reg
+        return (cls, reg, x) if return_pooled else (cls, reg)
 
     def vgg_classifier(self, feat, rois, num_classes):
         """vgg16_classifier (vgg.py:226-255)."""

@@ -283,3 +283,35 @@ def test_config3_resnet101_600x1500_bf16_inference():
         exp = [(int(d[0]), float(d[1]), tuple(int(v) for v in d[2])) for d in want]
         runs = lambda seq: [sorted(b for c, p, b in seq if (c, p) == key) for key in dict.fromkeys((c, p) for c, p, _ in seq)]
         assert nd == len(want) and [t[:2] for t in got] == [t[:2] for t in exp] and runs(got) == runs(exp)
+
+
+@pytest.mark.parametrize("config,dtype,frames", [("c4", "bf16", 4), ("c2", "bf16", 4)])
+def test_bf16_drift_from_the_fp32_reference_graph(config, dtype, frames):
+    """BASELINE's "box mAP delta vs ref" for the bf16 configs: the FP32 oracle END TO END (resnet.py:551-686 ->
+    det_util.py:136-158 -> voc_dets.py:20-88 restated, no storage model) against the bf16 device END TO END on the same
+    frames -- configs[3] (ResNet-101, 600x1500) and configs[1]'s shapes on the bf16 engine.  Bars (bench.DRIFT_BARS_*):
+    head as drawn >= 0.90 of the detections paired by class and IoU >= 0.5, mean score difference of the pairs <= 5e-3; the
+    calibrated head (~20 classes firing on margins below one bf16 rounding) is the stress case: >= 0.80, <= 2e-2.  The pair's
+    mAP delta is printed, not asserted (bench.py says why).  bench.py prints the same object (`parity.e2e_vs_fp32`)."""
+    import bench
+    saved = {k: getattr(bench, k) for k in ("HEIGHT", "WIDTH", "SCALES", "NUM_CLASSES", "DEPTH", "DTYPE", "WORKLOAD")}
+    try:
+        bench.select_config(config)
+        bench.DTYPE = dtype
+        pipe, weights, anchors = bench.build_pipeline()
+        assert pipe.raw_dense_class is not None
+        runs = []
+        bench.cpu_baseline(weights, anchors, budget_s=0.0, runs=runs, min_images=frames, alt_dense_class=pipe.raw_dense_class)
+        assert len(runs) == frames and all(len(r) == 4 for r in runs)
+        res = bench.e2e_drift_bf16(pipe, weights, anchors, runs)
+    finally:
+        for k, v in saved.items():
+            setattr(bench, k, v)
+    print("bf16 drift", config, res)
+    assert res["ok"], res
+    drawn, cal = res["head_as_drawn"], res["head_calibrated"]
+    assert drawn["matched_frac"] >= 0.90 and cal["matched_frac"] >= 0.80
+    assert cal["classes_detected_by_oracle"] >= 5                                  # the calibrated head is not degenerate
+    same, total = (int(v) for v in drawn["proposals_identical"].split("/"))
+    assert same >= 0.7 * total
+    assert drawn["matched_score_diff"]["mean"] < 5e-3 and cal["matched_score_diff"]["mean"] < 2e-2
