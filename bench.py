@@ -520,12 +520,14 @@ def vgg_rpn_cpu_and_parity(pipe, weights, budget_s=20.0):
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a rank environment: start N ranks of this same command line, one per GPU, the
     way torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), wait for them, print
-    rank 0's JSON line.  Runs BEFORE this process makes any HIP call (torch.cuda.device_count() does not initialise the
-    runtime on this stack; a process that has must never exec or fork GPU work)."""
+    rank 0's JSON line.  Runs BEFORE this process makes any HIP call: the devices are counted from the KFD topology in
+    sysfs (dp.count_gpus), and a process that has initialised the runtime must never exec or fork GPU work.  Each rank pins
+    itself to the cores next to its GPU when it starts (main: dp.pin_rank)."""
     import socket
     import subprocess
     backend = os.environ.get("FRCNN_BENCH_BACKEND", "nccl")
-    have = torch.cuda.device_count()
+    from faster_rcnn_amd import dp
+    have = dp.count_gpus()          # KFD topology + the *_VISIBLE_DEVICES variables, read from sysfs: no HIP call in this process
     if have < n and backend != "gloo":
         sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing (one rank per GPU over RCCL; "
                          "FRCNN_BENCH_BACKEND=gloo lets ranks share a GPU for a functional check)\n" % (n, have))
@@ -583,29 +585,57 @@ def spawn_ranks(n):
     sys.exit(0)
 
 
-def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=10):
-    """BASELINE configs[2] inside the N > 1 line: ResNet-50 RPN step-1 training steps at 600x1000, one image per GPU
-    per step (train_util.py:38-54 under data parallelism), the flat gradient buffer through the path's ONE collective
-    (dp.allreduce_sum_begin -> RCCL all-reduce over xGMI).  Every rank runs this; returns the object rank 0 prints.
+TRAIN_H, TRAIN_W = 600, 1000          # configs[2] / configs[4] are ResNet-50 at 600x1000 whatever inference config the line is for
+
+
+def train_dp_leg(anchors, rank, world, kind="rpn_step1", steps=10, warmup=10):
+    """One training config inside the N > 1 line, one image per GPU per step, the flat gradient buffer through the path's
+    ONE collective (dp.allreduce_sum_begin -> RCCL all-reduce over xGMI).  Every rank runs this; returns the object rank 0
+    prints.
+      kind "rpn_step1"  BASELINE configs[2]: ResNet-50 RPN step-1 steps (train_rpn_step1.py / train_util.py:38-54), fp32, 47.3 MB
+      kind "det_step2"  BASELINE configs[4]: ResNet-50 detector step-2 steps (train_det_step2.py:52-115), 64 RoIs, mixed bf16
+                        (bf16 activations / gradients / packed filters, f32 masters and an f32 89.0 MB gradient payload)
     `exposed_allreduce_ms` = step time with the collective - step time with the collective left out (same kernels)."""
     import torch.distributed as dist
     from faster_rcnn_amd import dp, resnet, train
-    A = len(anchors)
+    from faster_rcnn_amd.weights import synthetic_resnet
+    A, C = len(anchors), 21
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     seen = torch.ones(1, dtype=torch.float64, device=dev)
     dist.all_reduce(seen)                                           # what the collective library saw
-    base = resnet.resnet50_base(weights=dict(weights), weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
-    rpn = resnet.resnet50_rpn(base, anchors_per_loc=A)
     rs = np.random.RandomState(500 + rank)
-    x = synth_image(500 + rank).astype(np.float64)                  # the managers hand float64 (Keras casts on feed)
-    rows, cols = resnet.get_conv_rows_cols(HEIGHT, WIDTH)
-    can_use = rs.rand(1, rows, cols, A) < 0.012
-    is_pos = rs.rand(1, rows, cols, A) < 0.01
-    y_class = np.concatenate([can_use, is_pos], axis=3)
-    y_bbreg = np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32),
-                              (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
-    rpn.compile(train.SGD(1e-3, 0.9))
-    params = rpn._trainer.params
+    x = (rs.randint(0, 256, (TRAIN_H, TRAIN_W, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68]))[None]    # float64: what the managers hand (Keras casts on feed)
+    rows, cols = resnet.get_conv_rows_cols(TRAIN_H, TRAIN_W)
+    weights = synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=1 if kind == "rpn_step1" else 2)    # identical on every rank
+    if kind == "rpn_step1":
+        base = resnet.resnet50_base(weights=weights, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
+        model = resnet.resnet50_rpn(base, anchors_per_loc=A)
+        can_use = rs.rand(1, rows, cols, A) < 0.012
+        is_pos = rs.rand(1, rows, cols, A) < 0.01
+        y_class = np.concatenate([can_use, is_pos], axis=3)
+        y_bbreg = np.concatenate([np.repeat(can_use & is_pos, 4, axis=3).astype(np.float32),
+                                  (rs.randn(1, rows, cols, 4 * A) * is_pos.repeat(4, axis=3)).astype(np.float32)], axis=3)
+        inputs, targets = x, [y_class, y_bbreg]
+        workload = "configs[2]: ResNet-50 RPN step-1 training, 600x1000, 1 image per GPU per step, SGD momentum, l2 1e-4, fp32, synthetic"
+    else:
+        base = resnet.resnet50_base(weights=weights, weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER, dtype="bf16")
+        model = resnet.resnet50_classifier(64, C, base)
+        n = 64
+        x1, y1 = rs.randint(0, cols - 8, n), rs.randint(0, rows - 8, n)
+        rois = np.stack([x1, y1, x1 + 1 + rs.randint(0, 7, n), y1 + 1 + rs.randint(0, 7, n)], axis=1).astype(np.float32)[None]
+        ci = rs.randint(0, C, n)
+        yc = np.zeros((1, n, C), np.float32)
+        yc[0, np.arange(n), ci] = 1
+        lab, tg = np.zeros((n, 4 * (C - 1)), np.float32), np.zeros((n, 4 * (C - 1)), np.float32)
+        for i, c in enumerate(ci):
+            if c < C - 1:
+                lab[i, 4 * c:4 * c + 4] = 1
+                tg[i, 4 * c:4 * c + 4] = rs.randn(4)
+        inputs, targets = [x, rois], [yc, np.concatenate([lab, tg], axis=1)[None]]
+        workload = ("configs[4]: ResNet-50 detector step-2 training, 600x1000, 64 RoIs, 1 image per GPU per step, SGD momentum, l2 1e-4, "
+                    "mixed bf16 (f32 masters and gradient payload), synthetic")
+    model.compile(train.SGD(1e-3, 0.9))
+    params = model._trainer.params
 
     def timed(fn, k, w):
         prev = None
@@ -630,7 +660,7 @@ def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=10):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return 1e3 * float(t.item()) / k
 
-    step = lambda: rpn.train_on_batch(x, [y_class, y_bbreg], defer=True)
+    step = lambda: model.train_on_batch(inputs, targets, defer=True)
     ms = timed(step, steps, warmup)
     train.DP_SYNC = False
     try:
@@ -646,7 +676,8 @@ def train_dp_leg(weights, anchors, rank, world, steps=10, warmup=10):
             handle.wait()
         torch.cuda.synchronize()
     ar = timed(one_allreduce, 10, 2)
-    return {"workload": "configs[2]: ResNet-50 RPN step-1 training, 600x1000, 1 image per GPU per step, SGD momentum, l2 1e-4, fp32, synthetic",
+    train.finish_pending_updates()
+    return {"workload": workload,
             "ranks_seen": int(seen.item()), "backend": dist.get_backend(), "steps": steps,
             "ms_per_step": round(ms, 3), "img_s": round(world * 1e3 / ms, 2),
             "grad_payload_MB": round(params.total * 4 / 1e6, 1), "collectives_per_step": 1,
@@ -779,6 +810,12 @@ def main():
     dist = None
     # one rank per GPU; FRCNN_BENCH_BACKEND=gloo (dev) lets two ranks share one GPU to exercise this path on a 1-GPU box
     backend = os.environ.get("FRCNN_BENCH_BACKEND", "nccl")
+    # a rank of a node job keeps to the cores next to its GPU's PCIe slot (host staging, the launch thread and RCCL's proxy
+    # thread then stay off the other socket); sysfs + one syscall, before the HIP runtime starts
+    affinity = None
+    if world > 1 and backend == "nccl" and "FRCNN_BENCH_NO_PIN" not in os.environ:
+        from faster_rcnn_amd import dp as _dp
+        affinity = _dp.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     torch.cuda.set_device(local % torch.cuda.device_count() if world > 1 else 0)
 
     pipe, weights, anchors = build_pipeline()
@@ -936,9 +973,14 @@ def main():
             via_entry = {"error": "%s: %s" % (type(e).__name__, e)}
 
     train_dp = None
-    if dist is not None and args.config == "c2" and not args.no_train_dp:
+    if dist is not None and args.config in ("c2", "c4") and not args.no_train_dp:
         try:
-            train_dp = train_dp_leg(weights, anchors, rank, world)
+            from faster_rcnn_amd import util as _util
+            train_anchors = _util.get_anchors([128, 256, 512])
+            # configs[2] at the top level (the keys round 3's readers know), configs[4] under "det_step2"
+            train_dp = train_dp_leg(train_anchors, rank, world, "rpn_step1")
+            torch.cuda.empty_cache()
+            train_dp["det_step2"] = train_dp_leg(train_anchors, rank, world, "det_step2")
         except Exception as e:
             # a rank that fails inside the leg has left its peers inside a collective it will never join: going on to the
             # final barrier would mismatch collectives (an RCCL hang).  Say why and leave with a non-zero code:
@@ -979,7 +1021,8 @@ def main():
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
                        "head_order": "no detector head" if DEPTH == 16 else
                        "res5a 1x1 layers on the conv4 map, then RoI resampling (algebraically equal, see DESIGN 5)" if HOIST else "reference order",
-                       "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world},
+                       "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world,
+                       "rank0_cpu_affinity": affinity},
             "roofline": roof,
         }
         if io is not None:

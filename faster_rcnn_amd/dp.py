@@ -117,3 +117,132 @@ class ImageSchedule:
             self.rng.shuffle(self.images)
             self.applied += 1
         return self.images[pos % n]
+
+
+# ----------------------------------------------------------------------------- launch-side host logic (no HIP call anywhere below)
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def _kfd_gpu_nodes(root=KFD_NODES):
+    """The GPU nodes of the KFD topology in node order = the order the HIP runtime enumerates them: a list of property dicts
+    (CPU nodes have simd_count 0).  Reads sysfs only: a launcher must count devices WITHOUT initialising the HIP runtime (a
+    process that has must not start GPU children by exec/fork, and torch.cuda.device_count() is only runtime-free when
+    torch's amdsmi path is available: VERDICT r3)."""
+    nodes = []
+    try:
+        names = sorted((n for n in os.listdir(root) if n.isdigit()), key=int)
+    except OSError:
+        return None
+    for n in names:
+        props = {}
+        try:
+            with open(os.path.join(root, n, "properties")) as f:
+                for line in f:
+                    parts = line.split()
+                    if len(parts) == 2:
+                        props[parts[0]] = parts[1]
+        except OSError:
+            continue                                   # (a node this user may not read: not ours to use either)
+        if int(props.get("simd_count", "0")) > 0:
+            props["node"] = n
+            nodes.append(props)
+    return nodes
+
+
+def _apply_visibility(nodes, env):
+    """ROCR_VISIBLE_DEVICES filters the runtime's list, HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is its alias) indexes
+    what is left.  Integer lists only; anything else (UUIDs) -> None: the caller falls back to asking the runtime."""
+    for key in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES" if "HIP_VISIBLE_DEVICES" in env else "CUDA_VISIBLE_DEVICES"):
+        val = env.get(key)
+        if val is None:
+            continue
+        picked = []
+        for tok in (t.strip() for t in val.split(",")):
+            if tok == "":
+                continue
+            if not tok.lstrip("-").isdigit():
+                return None
+            i = int(tok)
+            if i < 0 or i >= len(nodes):
+                break                                   # the runtime stops at the first invalid index
+            picked.append(nodes[i])
+        nodes = picked
+    return nodes
+
+
+def visible_gpus(root=KFD_NODES, env=None):
+    """GPUs a child process of this one will see, as KFD property dicts in HIP device order; None when sysfs cannot tell."""
+    nodes = _kfd_gpu_nodes(root)
+    if nodes is None:
+        return None
+    return _apply_visibility(nodes, os.environ if env is None else env)
+
+
+def count_gpus(root=KFD_NODES, env=None):
+    """Number of HIP devices a child will see, without touching the runtime; falls back to torch's own count only when the
+    KFD topology is unreadable or the visibility variables name devices by UUID."""
+    nodes = visible_gpus(root, env)
+    return torch.cuda.device_count() if nodes is None else len(nodes)
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(props, pci_root="/sys/bus/pci/devices"):
+    """(cpus, numa_node) next to a GPU: KFD gives the PCI address (domain, location_id = bus << 8 | devfn), PCI sysfs the
+    CPUs local to that slot.  (None, None) when the platform does not say."""
+    try:
+        loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7)
+        with open(os.path.join(pci_root, bdf, "local_cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        try:
+            with open(os.path.join(pci_root, bdf, "numa_node")) as f:
+                numa = int(f.read().strip())
+        except OSError:
+            numa = -1
+        return (cpus or None), numa
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def rank_cpu_slice(local_rank, local_world, root=KFD_NODES, pci_root="/sys/bus/pci/devices", env=None, min_cpus=4):
+    """The cores rank `local_rank` of `local_world` should run on: the CPUs local to ITS GPU's PCIe slot, shared out evenly
+    among the ranks whose GPUs hang off the same set of CPUs (8 GPUs on 2 sockets: 4 ranks split each socket's cores).
+    Returns (sorted cpu list, numa node) or (None, None): no topology, a single rank, or fewer than `min_cpus` per rank (the
+    step's host side runs a handful of threads: staging casts, the RCCL proxy)."""
+    nodes = visible_gpus(root, env)
+    if not nodes or local_world <= 1 or local_rank >= len(nodes) or local_world > len(nodes):
+        return None, None
+    local = [gpu_local_cpus(nodes[r], pci_root) for r in range(local_world)]
+    mine, numa = local[local_rank]
+    if not mine:
+        return None, None
+    allowed = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set(mine)
+    mine = sorted(c for c in mine if c in allowed)
+    peers = [r for r in range(local_world) if local[r][0] and sorted(c for c in local[r][0] if c in allowed) == mine]
+    per = len(mine) // len(peers)
+    if per < min_cpus:
+        return None, None
+    k = peers.index(local_rank)
+    return mine[k * per:(k + 1) * per], numa
+
+
+def pin_rank(local_rank, local_world, **kw):
+    """sched_setaffinity to rank_cpu_slice(); returns a short description for logs (None = left alone).  A plain syscall:
+    safe before and after the HIP runtime starts; threads created later inherit the mask."""
+    try:
+        cpus, numa = rank_cpu_slice(local_rank, local_world, **kw)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return "cpus %d-%d (%d cores, numa node %s)" % (cpus[0], cpus[-1], len(cpus), numa)
+    except (OSError, AttributeError, ValueError):
+        return None

@@ -110,9 +110,39 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert abs(t["grad_payload_MB"] - 47.3) < 0.2
     assert t["allreduce_ms"] > 0 and t["exposed_allreduce_ms"] >= 0 and t["ms_per_step"] >= t["ms_per_step_without_allreduce"] * 0.9
     assert abs(t["img_s"] - 2 * 1e3 / t["ms_per_step"]) < 0.02 * t["img_s"]
+    _check_det_leg(t["det_step2"], ranks=2, backend="gloo")
     # --gpus 1 stays a plain single-process run: no train_dp object
     one = _launch(["bench.py", "--steps", "2", "--warmup", "1", "--streams", "2", "--no-cpu-baseline", "--no-io", "--gpus", "1"], 1)
     assert one["n_gpus"] == 1 and "train_dp" not in one
+
+
+def _check_det_leg(d, ranks, backend):
+    """BASELINE configs[4] inside `train_dp`: detector step-2 steps in mixed bf16, the 89.0 MB f32 gradient payload
+    (22.25 M trainable parameters) through the same ONE collective per step."""
+    assert "configs[4]" in d["workload"] and "mixed bf16" in d["workload"]
+    assert d["ranks_seen"] == ranks and d["backend"] == backend and d["collectives_per_step"] == 1
+    assert abs(d["grad_payload_MB"] - 89.0) < 0.2
+    assert d["allreduce_ms"] > 0 and d["ms_per_step"] > 0 and d["exposed_allreduce_ms"] >= 0
+    assert abs(d["img_s"] - ranks * 1e3 / d["ms_per_step"]) < 0.02 * d["img_s"]
+
+
+def test_bench_gpus_flag_config_c4_prints_the_same_contract():
+    """`python bench.py --gpus 2 --config c4`: configs[3]'s inference replicas (bf16, batched graphs) under the same launcher,
+    the same line keys, and the same two training legs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FRCNN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "c4", "--steps", "2", "--warmup", "1", "--streams", "1", "--batch", "2",
+                        "--no-cpu-baseline", "--no-io"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["dtype"] == "bf16" and "configs[3]" in line["config"]["workload"] and line["scaling"] == "weak"
+    assert line["config"]["images_per_graph"] == 2 and "replicas x2" in line["config"]["parallelism"]
+    assert abs(line["value"] - 2 * 2 * 2 / (line["ms_per_step"] * 2e-3)) < 0.02 * line["value"]            # ranks x images per step x steps / time
+    t = line["train_dp"]
+    assert "error" not in t and abs(t["grad_payload_MB"] - 47.3) < 0.2 and "configs[2]" in t["workload"]
+    _check_det_leg(t["det_step2"], ranks=2, backend="gloo")
 
 
 def test_bench_multi_rank_path_over_real_rccl():
@@ -132,3 +162,4 @@ def test_bench_multi_rank_path_over_real_rccl():
     assert "error" not in t, t
     assert t["backend"] == "nccl" and t["ranks_seen"] == 1 and abs(t["grad_payload_MB"] - 47.3) < 0.2
     assert t["allreduce_ms"] > 0 and t["ms_per_step"] > 0 and t["exposed_allreduce_ms"] >= 0
+    _check_det_leg(t["det_step2"], ranks=1, backend="nccl")
