@@ -130,7 +130,7 @@ def calibrate_head(pipe, w):
     assert pipe.det.weights is w
 
 
-def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1):
+def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1, engine="native"):
     """Per-launch duration of every conv launch of one image, measured with HIP events on the launch
     stream.  An event pair around ONE short kernel also measures the event packets themselves
     (tens of microseconds on this stack), so each distinct launch (kernel instantiation x shape) is
@@ -138,7 +138,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1):
     event pair brackets a replay; its average is the launch duration.  Returns the roofline object for the
     DOMINANT kernel instantiation (largest summed duration per image) plus the aggregate over all conv launches."""
     from faster_rcnn_amd import ops
-    with ops.conv_workspace(None if split_k else ops.NO_SPLIT_K), ops.tile_policy(throughput):     # the launch forms the timed graphs hold
+    with ops.conv_workspace(None if split_k else ops.NO_SPLIT_K), ops.tile_policy(throughput), ops.f32_engine(engine):     # the launch forms the timed graphs hold
         pipe.forward_dev(x)
         torch.cuda.synchronize()
         ops.CONV_PROFILE = []
@@ -779,6 +779,9 @@ def main():
                          "default: 8 for configs[3] (bf16), 1 otherwise")
     ap.add_argument("--unit-tiles", default="", help="dev: tile codes for named conv layers, e.g. res5a_branch2c=26,res5b_branch2c=26")
     ap.add_argument("--conv-table", action="store_true", help="print every distinct conv launch's duration alone on the chip to stderr")
+    ap.add_argument("--f32-engine", choices=("native", "bf16x6"), default="native",
+                    help="matrix path of the fp32 convolutions: native f32 MFMA, or the large launches on the bf16 matrix cores by exact "
+                         "three-way operand splitting (fp32-grade results, csrc/conv_x6.hip)")
     ap.add_argument("--no-train-dp", action="store_true", help="N > 1: leave the data-parallel training steps (`train_dp`) out of the line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -818,6 +821,10 @@ def main():
         affinity = _dp.pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     torch.cuda.set_device(local % torch.cuda.device_count() if world > 1 else 0)
 
+    # the engine policy of this PROCESS (captures, the per-launch roofline pass and the parity checkers below all see the same
+    # launch forms); the training legs of an N > 1 line run on the native engine
+    from faster_rcnn_amd import ops as _ops
+    _ops.F32_ENGINE = args.f32_engine
     pipe, weights, anchors = build_pipeline()
     if args.unit_tiles:
         want = dict(kv.split("=") for kv in args.unit_tiles.split(","))
@@ -849,7 +856,7 @@ def main():
         pipes = [pipe] + [more() for _ in range(S - 1)]
         streams = [torch.cuda.Stream() for _ in range(S)]
         for i, (pl, st) in enumerate(zip(pipes, streams)):
-            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1 or B > 1)
+            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1 or B > 1, **({"f32_engine": args.f32_engine} if DEPTH != 16 and B == 1 else {}))
             pl._static_in.copy_(synth_batch((rank * S + i) * B))
         torch.cuda.synchronize()
 
@@ -978,9 +985,10 @@ def main():
             from faster_rcnn_amd import util as _util
             train_anchors = _util.get_anchors([128, 256, 512])
             # configs[2] at the top level (the keys round 3's readers know), configs[4] under "det_step2"
-            train_dp = train_dp_leg(train_anchors, rank, world, "rpn_step1")
-            torch.cuda.empty_cache()
-            train_dp["det_step2"] = train_dp_leg(train_anchors, rank, world, "det_step2")
+            with _ops.f32_engine("native"):
+                train_dp = train_dp_leg(train_anchors, rank, world, "rpn_step1")
+                torch.cuda.empty_cache()
+                train_dp["det_step2"] = train_dp_leg(train_anchors, rank, world, "det_step2")
         except Exception as e:
             # a rank that fails inside the leg has left its peers inside a collective it will never join: going on to the
             # final barrier would mismatch collectives (an RCCL hang).  Say why and leave with a non-zero code:
@@ -998,7 +1006,7 @@ def main():
 
     if rank == 0:
         try:
-            roof, groups = conv_roofline(pipe, x, split_k=split_k, throughput=S > 1 or B > 1, images=B)
+            roof, groups = conv_roofline(pipe, x, split_k=split_k, throughput=S > 1 or B > 1, images=B, engine=args.f32_engine)
             if args.conv_table:                     # per distinct launch: shape, count, duration alone on the chip, rate (stderr)
                 for key, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"] * kv[1]["count"]):
                     fl = g["rec"]["flops"]
@@ -1019,6 +1027,7 @@ def main():
                        "images_per_step_per_gpu": S * B, "graphs_in_flight": S, "images_per_graph": B, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "proposals": PROPOSALS, "classes": NUM_CLASSES,
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
+                       "f32_matrix_path": args.f32_engine,
                        "head_order": "no detector head" if DEPTH == 16 else
                        "res5a 1x1 layers on the conv4 map, then RoI resampling (algebraically equal, see DESIGN 5)" if HOIST else "reference order",
                        "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world,

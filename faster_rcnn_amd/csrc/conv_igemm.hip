@@ -25,79 +25,9 @@
 //
 // Epilogue (fused, in registers): v = acc*scale[n] + shift[n] (folded bias+BN(+Scale)),
 // + residual[m][n], activation (none / relu / sigmoid), store NHWC.
-#include "common.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "conv_f32_common.h"
 
 namespace frcnn {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvArgs {
-    const float* x; const float* w; const float* scale; const float* shift; const float* residual; float* y;
-    const float* mask;      // optional [M][Cout]: output is zeroed where mask <= 0 (ReLU backward fused into dgrad)
-    int n_img, H, W, Cin, Cout, R, S, stride, pad_top, pad_left, Ho, Wo;
-    int M, K, Kpad, act, ldy, ldres;
-    int tiles_m, tiles_n;
-    int layout;             // 0: x[img][h][w][c], rows m = (img, ho, wo); 1 (v2 only): x[h][w][img][c], m = (ho, wo, img)
-    int pix_stride;         // elements between w-neighbours of one image (Cin, or n_img*Cin when layout == 1)
-    int img_stride;         // elements between images (H*W*Cin, or Cin when layout == 1)
-    int inv_S;              // ceil(65536 / S): tap / S without an integer division
-    int splits;             // split-K: K-slices per output tile (1 = none)
-    float* slabs;           // [tile][slice][BM*BN] f32 partial tiles
-    unsigned* tickets;      // [tile] arrival counters: zero on entry, left zero on exit
-    int group_m;            // tile order inside an XCD's run of ids: 0 = all row tiles of one column tile, then the next column;
-                            // g > 0 = groups of g row tiles, every column tile of a group before the next group (L2 working set)
-    int vec_epi;            // 1: y / residual / mask rows are 16-byte addressable (set by frcnn_conv2d_fwd_ws): the v2 / balanced kernels use epilogue_vec
-    // Two layers in one launch (frcnn_conv2d_fwd_dual): columns [0, n_split) are layer 1 -> y (ldy, act), columns
-    // [n_split, Cout) are layer 2 -> y2 (ldy2, act2).  n_split == 0: one layer.  No residual / mask in this form.
-    int n_split; float* y2; int ldy2, act2;
-};
-
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = BK + 4;     // floats per LDS row (144 B)
-
-__device__ __forceinline__ float activate(float v, int act) {
-    if (act == 1) return fmaxf(v, 0.0f);
-    if (act == 2) return 1.0f / (1.0f + __expf(-v));
-    return v;
-}
-
-// Bijective XCD remap (cdna guide T1): consecutive logical ids land on the same XCD.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// fused epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int wm, int wn, int li, int lh) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + li;
-        if (n >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[n] : 1.0f;
-        const float sh = p.shift ? p.shift[n] : 0.0f;
-        const bool second = p.n_split && n >= p.n_split;        // this lane's column belongs to the launch's second layer
-        float* const yb = second ? p.y2 : p.y;
-        const int ld = second ? p.ldy2 : p.ldy, act = second ? p.act2 : p.act, nn = second ? n - p.n_split : n;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < p.M) {
-                    float v = acc[i][j][e] * sc + sh;
-                    if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
-                    if (p.mask && !(p.mask[(size_t)m * p.Cout + n] > 0.0f)) v = 0.0f;
-                    yb[(size_t)m * ld + nn] = activate(v, act);
-                }
-            }
-        }
-    }
-}
 
 template <int TM, int TN, bool GENERIC_A>
 __global__ void __launch_bounds__(256) k_conv_igemm_f32(const ConvArgs p) {
@@ -239,12 +169,6 @@ __global__ void __launch_bounds__(256) k_conv_igemm_f32(const ConvArgs p) {
 //     for 64 cycles but the wave's issue port only briefly, so those VALU/VMEM/DS
 //     instructions issue in the shadow of the wave's own MFMAs instead of in a separate
 //     phase (v1: matrix pipe 79 % busy on a 2-wave SIMD, both waves stalling in lockstep).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x3 __attribute__((ext_vector_type(3)));
-constexpr unsigned OOB_OFFSET = 0x80000000u;     // >= num_records of any tensor we accept (< 2 GiB)
-
-#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-
 // Lab builds (scripts/micro/conv_lab.hip) compile this file with FRCNN_LAB_STAMPS: every workgroup then records
 // the 100 MHz wall clock at its phase boundaries.  The product library never defines it.
 #ifdef FRCNN_LAB_STAMPS
@@ -253,121 +177,6 @@ __device__ unsigned long long* g_lab_stamps = nullptr;
 #else
 #define LAB_STAMP(i) do { } while (0)
 #endif
-constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
-
-// ------------------------------------------------------------------------------------
-// Vectorised epilogue.  In the accumulator layout a lane owns ONE output column, so the plain epilogue above moves
-// 4 bytes per lane (sixteen residual loads and sixteen stores per 32x32 tile, each touching two 128-byte row pieces)
-// and, issued after the main loop, leaves their latency exposed: on the trunk's 64x64-tile launches it lasted as
-// long as the main loop itself (in-kernel timestamps, scripts/micro/conv_lab.hip: res3 2c 10.0 us against 9.0,
-// res2 2c 9.4 against 4.2, the head's 512->2048 layers 21.7 against 21.0).  Here the workgroup turns its BM x BN
-// tile through LDS (the operand buffers are dead by then) and every thread owns 16-byte pieces of whole rows:
-// scale / shift / residual / mask / y all move as b128, one wave instruction covers 1 KB of full row segments, and
-// out-of-range rows / columns ride on the buffer descriptors (no branches).  The residual pieces of a 64x64 tile
-// are fetched BEFORE the main loop (four registers' worth per thread) when the kernel has no split-K reducer.
-// Per element the arithmetic and its order are those of epilogue(): results are bit-identical.
-template <int TM, int TN, int WM, int WN>
-struct EpiVec {
-    static constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
-    static constexpr int LD = BN + 4;                    // floats per staged row (16-byte aligned rows)
-    static constexpr int C4 = BN / 4;                    // 16-byte pieces per row
-    static constexpr int RPP = NT / C4;                  // rows per pass
-    static constexpr int PASSES = BM / RPP;
-    static constexpr bool fits = (size_t)BM * LD <= (size_t)2 * (BM + BN) * LDS_STRIDE && BM % RPP == 0 && NT % C4 == 0;
-};
-
-// byte offsets of this thread's pieces in y (stride ldy) / residual (ldres) / mask (Cout); OOB_OFFSET outside the tensor
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ unsigned epi_piece_off(const ConvArgs& p, int m0, int n0, int tid, int q, int ld) {
-    using E = EpiVec<TM, TN, WM, WN>;
-    const int m = m0 + q * E::RPP + tid / E::C4, n = n0 + (tid % E::C4) * 4;
-    return (m < p.M && n < p.Cout) ? (unsigned)(((size_t)m * ld + n) * 4) : OOB_OFFSET;
-}
-
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void epi_prefetch_residual(const ConvArgs& p, int m0, int n0, int tid, f32x4 (&rpre)[EpiVec<TM, TN, WM, WN>::PASSES]) {
-    using E = EpiVec<TM, TN, WM, WN>;
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
-#pragma unroll
-    for (int q = 0; q < E::PASSES; ++q)
-        rpre[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, epi_piece_off<TM, TN, WM, WN>(p, m0, n0, tid, q, p.ldres), 0, 0));
-}
-
-template <int TM, int TN, int WM, int WN, bool HAVE_PRE>
-__device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh,
-                                             float* smem, const f32x4* rpre) {
-    using E = EpiVec<TM, TN, WM, WN>;
-    // two layers in one launch: n_split is a multiple of the tile width here (the host falls back to the scalar epilogue
-    // otherwise), so the whole tile belongs to ONE of them -- workgroup-uniform choice of output, stride, activation
-    const bool second = p.n_split && n0 >= p.n_split;
-    float* const yb = second ? p.y2 : p.y;
-    const int y_ld = second ? p.ldy2 : p.ldy, y_act = second ? p.act2 : p.act, y_n0 = second ? p.n_split : 0;
-    const int y_cols = p.n_split ? (second ? p.Cout - p.n_split : p.n_split) : p.Cout;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((size_t)p.M * y_ld * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.mask ? p.mask : p.x), 0, p.mask ? (int)((size_t)p.M * p.Cout * 4) : 0, 0x00020000);
-    // big tiles walk their passes in groups of four so the pieces in flight stay within ~32 registers: the 128x128
-    // kernels must keep (VGPR + AGPR) <= 256 for two waves per SIMD
-    constexpr int GP = E::PASSES < 4 ? E::PASSES : 4;
-    static_assert(E::PASSES % GP == 0, "passes must split into whole groups");
-    f32x4 rres[GP], rmask[GP];
-    auto fetch = [&](int g) {                               // the global reads of group g
-        if constexpr (!HAVE_PRE) {
-            if (p.residual) {
-#pragma unroll
-                for (int q = 0; q < GP; ++q)
-                    rres[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, epi_piece_off<TM, TN, WM, WN>(p, m0, n0, tid, g * GP + q, p.ldres), 0, 0));
-            }
-        }
-        if (p.mask) {
-#pragma unroll
-            for (int q = 0; q < GP; ++q)
-                rmask[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, epi_piece_off<TM, TN, WM, WN>(p, m0, n0, tid, g * GP + q, p.Cout), 0, 0));
-        }
-    };
-    fetch(0);                                               // in flight while the tile goes through LDS
-    const int n = n0 + (tid % E::C4) * 4;
-    f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (n < p.Cout) {
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-    }
-    __syncthreads();                                        // every wave is done with the operand buffers (and the split-K flag word)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float* dst = smem + (wm * TM * 32 + i * 32 + 4 * lh) * E::LD + wn * TN * 32 + j * 32 + li;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * E::LD] = acc[i][j][e];
-        }
-    __syncthreads();
-    const float* src = smem + (tid / E::C4) * E::LD + (tid % E::C4) * 4;
-#pragma unroll 1
-    for (int g = 0; g < E::PASSES / GP; ++g) {
-        if (g) fetch(g);
-#pragma unroll
-        for (int q = 0; q < GP; ++q) {
-            const int pass = g * GP + q;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src + pass * E::RPP * E::LD);
-            f32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float t = a[c] * sc[c] + sh[c];
-                if (p.residual) t += HAVE_PRE ? rpre[q][c] : rres[q][c];
-                if (p.mask && !(rmask[q][c] > 0.0f)) t = 0.0f;
-                v[c] = activate(t, y_act);
-            }
-            const int ym = m0 + pass * E::RPP + tid / E::C4, yn = n0 - y_n0 + (tid % E::C4) * 4;
-            const unsigned yoff = (ym < p.M && yn < y_cols) ? (unsigned)(((size_t)ym * y_ld + yn) * 4) : OOB_OFFSET;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, yoff, 0, 0);
-        }
-    }
-}
-
 //
 // SPLITK: small grids (stage 4, the RPN heads, the dense layers: <= 152 tiles for 256 CUs and a long k loop)
 // cut K into `splits` slices, one workgroup each.  Every slice writes its f32 partial tile to a slab, publishes
@@ -1977,7 +1786,20 @@ struct DualOut { int n1; int act1; float* y2; int act2; };      // frcnn_conv2d_
 
 static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                          const float* scale, const float* shift, const float* residual, const float* mask, float* y,
-                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream);
+                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream, bool x6 = false);
+
+int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16,
+                        const float* scale, const float* shift, const float* residual, const float* mask, float* y, void* stream) {
+    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_bf16), scale, shift, residual, mask, y, nullptr, nullptr, 0, stream, true);
+}
+
+int frcnn_conv2d_fwd_dual_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16, const float* scale, const float* shift,
+                             float* y1, int n1, int act1, float* y2, int act2, void* stream) {
+    if (!d || !y2 || n1 <= 0 || n1 >= d->cout) return fail(FRCNN_E_ARG, "conv2d_fwd_dual_x6: need 0 < n1 < cout and two outputs");
+    if (d->ldy > 0 || d->ldres > 0) return fail(FRCNN_E_ARG, "conv2d_fwd_dual_x6: dense outputs only (ldy = ldres = 0)");
+    const DualOut dual = {n1, act1, y2, act2};
+    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_bf16), scale, shift, nullptr, nullptr, y1, &dual, nullptr, 0, stream, true);
+}
 
 int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                         const float* scale, const float* shift, const float* residual, const float* mask, float* y,
@@ -2007,7 +1829,7 @@ int frcnn_conv2d_fwd_dual(const frcnn_conv_desc* d, const float* x, const float*
 
 static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                          const float* scale, const float* shift, const float* residual, const float* mask, float* y,
-                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream) {
+                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream, bool x6) {
     if (!d || !x || !w_packed || !y) return fail(FRCNN_E_ARG, "conv2d_fwd: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->ho <= 0 || d->wo <= 0)
         return fail(FRCNN_E_ARG, "conv2d_fwd: bad shape");
@@ -2034,6 +1856,19 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
              && (!mask || (al16(mask) && (size_t)M * d->cout * 4 < 0x7fffffffull)) && (!scale || al16(scale)) && (!shift || al16(shift));
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
+    if (x6) {
+        // the split-bf16 engine (conv_x6.hip): w_packed points at the three bf16 filter planes
+        if (generic || d->kh * d->kw > 32) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_x6: cin %% 32 == 0 and at most 32 taps");
+        if ((size_t)3 * d->cout * a.Kpad * 2 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_x6: filter planes over 2 GiB");
+        const int t = d->tile % 100;
+        const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
+        // auto: 128x128 tiles on eight waves (two workgroups per CU); under one tile per CU, 64x64
+        const int xcfg = (t >= 71 && t <= 75) ? t : (t128 >= 256 ? 71 : 74);
+        const int bn = x6_tile_width(xcfg);
+        if (dual) a.vec_epi = a.vec_epi && dual->n1 % bn == 0 && (a.ldy2 & 3) == 0 && al16(dual->y2) && (size_t)M * a.ldy2 * 4 < 0x7fffffffull;
+        a.group_m = g_group_m >= 0 ? g_group_m : (d->cout > bn ? 1 : 0);      // column tiles of a row tile adjacent on one XCD
+        return launch_conv_x6(a, xcfg, s);
+    }
     int cfg = choose_config(d);
     if (dual) {
         cfg = dual_config(cfg);

@@ -1,0 +1,367 @@
+// fp32 implicit-GEMM convolution on the bf16 matrix cores by EXACT three-way operand splitting ("bf16x6"), gfx950.
+//
+// Same contract, operands and layouts as k_conv_igemm_f32_v2 (conv_igemm.hip: f32 NHWC / position-major activations in,
+// f32 out, fused scale / shift / residual / mask / activation epilogue, filter taps walked per 32-channel chunk, padding
+// halo and ragged edges on the buffer descriptors) -- only the multiply differs:
+//
+//   every f32 value is the exact sum of three bf16 values,  a = a1 + a2 + a3  (8 + 8 + 8 significand bits: a1 = bf16(a),
+//   a2 = bf16(a - a1), a3 = a - a1 - a2, each subtraction exact), likewise b.  Of the nine partial products the six with
+//   i + j <= 4 are kept -- a1b1, a1b2, a2b1, a1b3, a2b2, a3b1 -- each EXACT in f32 (8 x 8 bits); the three dropped ones lie
+//   below 2^-24 |ab|, under one f32 rounding of the product.  The sum over k accumulates in f32 inside
+//   v_mfma_f32_32x32x16_bf16 exactly as it does inside v_mfma_f32_32x32x2_f32.
+//
+// Measured against fp64 (scripts/micro/x6_lab.hip, K = 512 / 4608, mixed-sign operands): max |err| / sum|ab| 2.19e-7 /
+// 1.83e-7 here against 2.69e-7 / 2.15e-7 for the native f32 MFMA -- the result is an fp32 GEMM, not a reduced-precision
+// one (the two-term "bf16x3" form measures 1.2e-6, plain bf16 5.6e-4).
+// Why: the bf16 MFMA issues 16x the FLOP of the f32 MFMA per cycle (MI355X_MICROARCH.md, matrix cores), so six of them per
+// product are 2.67x the native fp32 matrix rate on paper (416 vs 157 TFLOP/s), with HALF the LDS fragment reads per MFMA of
+// the plain bf16 kernel (nine 16-byte reads feed twelve MFMAs).
+//
+// Operands: the activation tile is split in the loader (global f32 -> registers -> three bf16 planes in LDS: ~7 VALU
+// operations per element, once per element per 128 output columns); the filter is split once at pack time into three
+// planes [3][Cout][Kpad] bf16 in the f32 kernel's k order (frcnn_pack_conv_weights_x6).
+// LDS: six planes of unpadded 64-byte rows; the 16-byte slot s of row r is stored at slot s ^ ((r >> 2) & 3), which puts the
+// sixteen rows of every ds_read_b128 lane group on sixteen distinct four-bank slots and keeps the two rows of a store group
+// on different halves of the 32 store banks (PMC: SQ_LDS_BANK_CONFLICT 28 % of the LDS cycles with padded 80-byte rows).
+// ONE buffer (48 KB for a 128x128 tile); the next two chunks wait in registers (requested two chunks ahead, so a load has a
+// whole chunk period to land); two workgroups per CU cover each other's split / store / barrier phase.  The 16-byte
+// epilogue turns the tile through the same LDS in wave-row passes (64 rows at a time), so the workgroup never holds more
+// than the operand planes: what is left of the CU's 160 KB stays available to other streams' workgroups.
+#include "conv_f32_common.h"
+
+namespace frcnn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int X6_ROWB = 64;           // LDS bytes per row per plane
+__device__ __forceinline__ int x6_swz(int row) { return (row >> 2) & 3; }
+
+__device__ __forceinline__ void x6_split(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 a1 = (__bf16)v[e];                       // round to nearest even (v_cvt_pk_bf16_f32)
+        const float r1 = v[e] - (float)a1;                    // exact
+        const __bf16 a2 = (__bf16)r1;
+        const float r2 = r1 - (float)a2;                      // exact; at most 8 significant bits are left
+        h[e] = a1; m[e] = a2; l[e] = (__bf16)r2;
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+struct X6Tile {
+    static constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static constexpr size_t planes = (size_t)3 * (BM + BN) * X6_ROWB;
+    static constexpr size_t epi = (size_t)(32 * TM) * (BN + 4) * 4;     // the 16-byte epilogue: one wave-row of the tile at a time
+    static constexpr size_t lds = planes > epi ? planes : epi;
+};
+
+// The 16-byte epilogue of conv_f32_common.h (epilogue_vec: same arithmetic per element, same order) with the tile turned through
+// LDS one WAVE-ROW at a time: pass h stages the 32 TM rows owned by the waves with wm == h, every thread then owns 16-byte pieces
+// of whole rows (scale / shift / residual / mask / y as b128, out-of-range pieces on the buffer descriptors).
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh, float* smem) {
+    constexpr int NT = 64 * WM * WN, BN = 32 * TN * WN, HB = 32 * TM, LD = BN + 4, C4 = BN / 4, RPP = NT / C4, PASSES = HB / RPP;
+    static_assert(HB % RPP == 0 && NT % C4 == 0 && PASSES >= 1 && PASSES <= 8, "epilogue passes");
+    const bool second = p.n_split && n0 >= p.n_split;       // two layers in one launch: the tile belongs to ONE of them (host guarantees it)
+    float* const yb = second ? p.y2 : p.y;
+    const int y_ld = second ? p.ldy2 : p.ldy, y_act = second ? p.act2 : p.act, y_n0 = second ? p.n_split : 0;
+    const int y_cols = p.n_split ? (second ? p.Cout - p.n_split : p.n_split) : p.Cout;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((size_t)p.M * y_ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.mask ? p.mask : p.x), 0, p.mask ? (int)((size_t)p.M * p.Cout * 4) : 0, 0x00020000);
+    const int prow = tid / C4, pcol = (tid % C4) * 4, n = n0 + pcol;
+    f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (n < p.Cout) {
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    }
+    f32x4 rres[PASSES], rmask[PASSES];
+    auto fetch = [&](int h) {                                // the global reads of wave-row h: in flight while it goes through LDS
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            const int m = m0 + h * HB + q * RPP + prow;
+            const bool in = m < p.M && n < p.Cout;
+            if (p.residual) rres[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, in ? (unsigned)(((size_t)m * p.ldres + n) * 4) : OOB_OFFSET, 0, 0));
+            if (p.mask) rmask[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, in ? (unsigned)(((size_t)m * p.Cout + n) * 4) : OOB_OFFSET, 0, 0));
+        }
+    };
+#pragma unroll 1
+    for (int h = 0; h < WM; ++h) {
+        fetch(h);
+        if (h) __syncthreads();                              // the previous wave-row has been read out (the caller synchronised before pass 0)
+        if (wm == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float* dst = smem + (i * 32 + 4 * lh) * LD + wn * TN * 32 + j * 32 + li;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * LD] = acc[i][j][e];
+                }
+        }
+        __syncthreads();
+        const float* src = smem + prow * LD + pcol;
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + q * RPP * LD);
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = a[c] * sc[c] + sh[c];
+                if (p.residual) t += rres[q][c];
+                if (p.mask && !(rmask[q][c] > 0.0f)) t = 0.0f;
+                v[c] = activate(t, y_act);
+            }
+            const int ym = m0 + h * HB + q * RPP + prow, yn = n0 - y_n0 + pcol;
+            const unsigned yoff = (ym < p.M && yn < y_cols) ? (unsigned)(((size_t)ym * y_ld + yn) * 4) : OOB_OFFSET;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, yoff, 0, 0);
+        }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p) {
+    using T = X6Tile<TM, TN, WM, WN>;
+    constexpr int NT = T::NT, BM = T::BM, BN = T::BN;
+    constexpr int RPP = NT / 8;                           // tile rows staged per pass of A (8 lanes x 16 B of f32 per row)
+    constexpr int PA = BM / RPP;
+    constexpr int RPB = NT / 4;                           // rows per pass of one B plane (4 lanes x 16 B of bf16 per row)
+    constexpr int PB = BN / RPB;
+    static_assert(BM % RPP == 0 && BN % RPB == 0 && PA >= 1 && PB >= 1, "tile rows must be a multiple of the staging pass");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* As = lds;                                       // [3][BM][X6_ROWB]
+    char* Bs = lds + 3 * BM * X6_ROWB;                    // [3][BN][X6_ROWB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    if (p.group_m > 0) {                                  // grouped order (see k_conv_igemm_f32_v2): g row tiles x all column tiles
+        const int per = p.group_m * p.tiles_n, g = tile / per, m_base = g * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - m_base), r = tile - g * per;
+        tile_n = r / gm;
+        tile_m = m_base + r - tile_n * gm;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const size_t plane_bytes = (size_t)p.Cout * p.Kpad * 2;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)(3 * plane_bytes), 0x00020000);         // p.w: the three bf16 planes
+
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;      // A: row within a pass, first of this lane's four channels
+    int a_h[PA], a_w[PA], a_off[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + RPP * i;
+        if (m < p.M) {
+            int wo, ho, img;
+            if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
+            else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
+            a_h[i] = ho * p.stride - p.pad_top;
+            a_w[i] = wo * p.stride - p.pad_left;
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * 4;     // may be "negative" in the halo
+        } else {
+            a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
+        }
+    }
+    const int brow = tid >> 2, bcol = (tid & 3) * 8;      // B: row within a pass, first of this lane's eight k
+    unsigned b_off[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + brow + RPB * i;
+        b_off[i] = n < p.Cout ? (unsigned)((n * p.Kpad + bcol) * 2) : OOB_OFFSET;
+    }
+
+    // filter taps this tile needs (position-major rows: taps that meet only zero padding for ALL rows of the tile are skipped)
+    const int RS = p.R * p.S;
+    const unsigned all_taps = RS >= 32 ? 0xffffffffu : (1u << RS) - 1u;
+    unsigned tap_mask = all_taps;
+    if (p.layout) {
+        const int pos_lo = m0 / p.n_img, pos_hi = (min(m0 + BM, p.M) - 1) / p.n_img;
+        if (pos_hi - pos_lo < 8) {
+            unsigned mk = 0;
+            for (int pos = pos_lo; pos <= pos_hi; ++pos) {
+                const int ho = pos / p.Wo, wo = pos - ho * p.Wo;
+                const int h0 = ho * p.stride - p.pad_top, w0 = wo * p.stride - p.pad_left;
+                for (int r = 0; r < p.R; ++r)
+                    for (int sx = 0; sx < p.S; ++sx)
+                        if ((unsigned)(h0 + r) < (unsigned)p.H && (unsigned)(w0 + sx) < (unsigned)p.W) mk |= 1u << (r * p.S + sx);
+            }
+            if (mk) tap_mask = mk;
+        }
+    }
+    const int n_taps = __popc(tap_mask);
+    const int nk = (p.Kpad / (BK * RS)) * n_taps;         // chunks of this tile: (channel group, needed tap) pairs
+
+    unsigned rem = tap_mask;                              // taps of the current channel group still to load
+    int c0 = 0, w_grp = 0;                                // channel offset / bf16 byte offset of the group's filter chunks
+    // the NEXT chunk of the sequence -> staging set S (calls walk the sequence in order; calls past its end fetch in-bounds
+    // or zero data that is never multiplied)
+    f32x4 ra[2][PA];
+    f32x4 rb[2][3][PB];
+    auto load_next = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+        const int tap = __builtin_ctz(rem);               // wave-uniform
+        const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 4;
+        const int w_off = w_grp + tap * (BK * 2);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[S][pl][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrsrc, b_off[i] == OOB_OFFSET ? OOB_OFFSET : b_off[i] + (unsigned)(pl * plane_bytes), w_off, 0));
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0));
+        }
+        rem &= rem - 1;                                   // branch-free walk to the next needed tap
+        const int wrap = (rem == 0);
+        rem |= wrap ? tap_mask : 0u;
+        c0 += wrap * BK;
+        w_grp += wrap * (RS * BK * 2);
+    };
+    auto store = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            bf16x4 h, m, l;
+            x6_split(ra[S][i], h, m, l);
+            const int row = lrow + RPP * i, g = tid & 7;
+            char* dst = As + row * X6_ROWB + 16 * ((g >> 1) ^ x6_swz(row)) + 8 * (g & 1);
+            *reinterpret_cast<bf16x4*>(dst) = h;
+            *reinterpret_cast<bf16x4*>(dst + BM * X6_ROWB) = m;
+            *reinterpret_cast<bf16x4*>(dst + 2 * BM * X6_ROWB) = l;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                *reinterpret_cast<f32x4*>(Bs + pl * BN * X6_ROWB + (brow + RPB * i) * X6_ROWB + 16 * ((tid & 3) ^ x6_swz(brow + RPB * i))) = rb[S][pl][i];
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const char* abase = As + (wm * TM * 32 + li) * X6_ROWB;
+    const char* bbase = Bs + (wn * TN * 32 + li) * X6_ROWB;
+    const int koff[2] = {16 * (lh ^ x6_swz(li)), 16 * ((2 + lh) ^ x6_swz(li))};       // k-step s reads logical slot 2 s + lh (tile bases are multiples of 32 rows)
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                     // two k-steps of 16 per 32-channel chunk
+            bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const bf16x8*>(abase + pl * BM * X6_ROWB + i * 32 * X6_ROWB + koff[s]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * BN * X6_ROWB + j * 32 * X6_ROWB + koff[s]);
+            }
+            // smallest terms first: (a3,b1) (a1,b3) (a2,b2) (a2,b1) (a1,b2) (a1,b1)
+            constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[IA[t]][i], fb[IB[t]][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // chunk c waits in set c & 1.  Iteration: MFMAs of chunk kt from LDS | barrier | split + store chunk kt+1 (requested one
+    // iteration earlier) and request chunk kt+3 into the registers just freed | barrier
+    load_next(I0{});                                      // chunk 0
+    load_next(I1{});                                      // chunk 1
+    store(I0{});
+    load_next(I0{});                                      // chunk 2
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        compute();
+        __syncthreads();
+        store(I1{});                                      // chunk kt+1
+        load_next(I1{});                                  // chunk kt+3
+        __syncthreads();
+        compute();
+        __syncthreads();
+        if (kt + 2 < nk) {
+            store(I0{});                                  // chunk kt+2
+            load_next(I0{});                              // chunk kt+4
+            __syncthreads();
+        }
+    }
+    if (kt < nk) {
+        compute();
+        __syncthreads();                                  // the epilogue reuses the buffer
+    }
+    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+}
+
+// f32 packed filter [Cout][Kpad] (frcnn_pack_conv_weights' k order) -> three bf16 planes [3][Cout][Kpad]
+__global__ void k_pack_x6(const float* w, size_t n, __bf16* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = w[i];
+        const __bf16 a1 = (__bf16)v;
+        const float r1 = v - (float)a1;
+        const __bf16 a2 = (__bf16)r1;
+        out[i] = a1; out[n + i] = a2; out[2 * n + i] = (__bf16)(r1 - (float)a2);
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_x6(const ConvArgs& a, hipStream_t s) {
+    using T = X6Tile<TM, TN, WM, WN>;
+    ConvArgs p = a;
+    p.tiles_m = (p.M + T::BM - 1) / T::BM;
+    p.tiles_n = (p.Cout + T::BN - 1) / T::BN;
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_x6<TM, TN, WM, WN>, T::lds, "conv2d_x6")) return e;
+    k_conv_igemm_x6<TM, TN, WM, WN><<<p.tiles_m * p.tiles_n, T::NT, T::lds, s>>>(p);
+    return check_launch("conv2d_fwd_x6");
+}
+
+// tile codes of the split-bf16 engine (frcnn_conv_desc.tile; 0 / 50 = auto)
+int launch_conv_x6(const ConvArgs& a, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case 71: return launch_x6<2, 1, 2, 4>(a, s);      // 128x128, 8 waves (64x32 per wave), two workgroups per CU
+        case 72: return launch_x6<2, 2, 4, 2>(a, s);      // 256x128, 8 waves (64x64 per wave), one workgroup per CU
+        case 73: return launch_x6<2, 2, 2, 2>(a, s);      // 128x128, 4 waves (64x64 per wave)
+        case 74: return launch_x6<1, 1, 2, 2>(a, s);      // 64x64, 4 waves
+        case 75: return launch_x6<1, 1, 2, 4>(a, s);      // 64x128, 8 waves
+        default: return fail(FRCNN_E_ARG, "conv2d_fwd_x6: unknown tile config %d", cfg);
+    }
+}
+
+int x6_tile_width(int cfg) { return cfg == 74 ? 64 : 128; }
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" int frcnn_pack_conv_weights_x6(const float* w_packed, int cout, int kpad, void* planes_bf16, void* stream) {
+    if (!w_packed || !planes_bf16 || cout <= 0 || kpad <= 0 || (kpad % 32)) return fail(FRCNN_E_ARG, "pack_conv_weights_x6: bad argument");
+    const size_t n = (size_t)cout * kpad;
+    if (3 * n * 2 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "pack_conv_weights_x6: filter planes over 2 GiB");
+    int grid = (int)((n + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    k_pack_x6<<<grid, 256, 0, as_stream(stream)>>>(w_packed, n, (__bf16*)planes_bf16);
+    return check_launch("pack_conv_weights_x6");
+}

@@ -268,6 +268,61 @@ class PackedConv:
         self.scale = None if scale is None else _dev(scale, torch.float32)
         self.shift = None if shift is None else _dev(shift, torch.float32)
 
+    def x6_planes(self):
+        """The filter as three bf16 planes [3][cout][packed_k] for the split-bf16 engine (frcnn_conv2d_fwd_x6), derived
+        once from the packed f32 filter (6 bytes per weight beside the 4 of the f32 form)."""
+        planes = getattr(self, "_x6", None)
+        if planes is None or getattr(self, "_x6_src", None) is not self.w:
+            planes = torch.empty((3,) + tuple(self.w.shape), dtype=torch.bfloat16, device="cuda")
+            _lib.call("frcnn_pack_conv_weights_x6", _p(self.w), self.w.shape[0], self.w.shape[1], _p(planes), _stream())
+            self._x6, self._x6_src = planes, self.w
+        return planes
+
+
+# ---- which matrix path an fp32 convolution takes.
+# "native": v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip).  "bf16x6": the same GEMM on the bf16 matrix cores by exact
+# three-way operand splitting (csrc/conv_x6.hip) for the launches where it measures faster -- large row counts, cin % 32 == 0;
+# everything else stays native.  fp32-grade either way (error against fp64 at or below the native kernel's), but a
+# different summation order: the two agree to f32 rounding, not bit for bit, so the library default stays "native" and a
+# caller opts in for a scope (``with f32_engine("bf16x6"):`` -- bench.py and entry.DetectionEntry do, around their captures).
+F32_ENGINE = "native"
+X6_MIN_ROWS = 8192              # GEMM rows (output pixels) from which the split engine's 128x128 tiles fill the chip
+X6_MIN_K = 256                  # kh * kw * cin
+
+
+class f32_engine:
+    def __init__(self, name):
+        assert name in ("native", "bf16x6")
+        self.name = name
+
+    def __enter__(self):
+        global F32_ENGINE
+        self.prev, F32_ENGINE = F32_ENGINE, self.name
+
+    def __exit__(self, *exc):
+        global F32_ENGINE
+        F32_ENGINE = self.prev
+
+
+def _use_x6(d, pc, tile):
+    if 71 <= tile % 100 <= 75:
+        return pc.cin % 32 == 0                                  # explicit tile code of the split engine
+    if F32_ENGINE != "bf16x6" or tile % 100 not in (0, 50):
+        return False
+    return pc.cin % 32 == 0 and d.n * d.ho * d.wo >= X6_MIN_ROWS and pc.kh * pc.kw * pc.cin >= X6_MIN_K and pc.cout >= 64
+
+
+X6_KERNEL_NAMES = {71: "k_conv_igemm_x6<2,1,2,4>", 72: "k_conv_igemm_x6<2,2,4,2>", 73: "k_conv_igemm_x6<2,2,2,2>", 74: "k_conv_igemm_x6<1,1,2,2>",
+                   75: "k_conv_igemm_x6<1,1,2,4>"}
+
+
+def _x6_name(d, tile):
+    t = tile % 100
+    if not 71 <= t <= 75:
+        m, n = d.n * d.ho * d.wo, d.cout
+        t = 71 if -(-m // 128) * -(-n // 128) >= 256 else 74
+    return X6_KERNEL_NAMES[t]
+
 
 # When set to a list, every conv2d launch appends {kernel, flops, shape, relaunch()} so bench.py can
 # re-issue each distinct launch back to back between one HIP-event pair on the launch stream.
@@ -372,6 +427,15 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
         assert out.shape == oshape and out.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
+    if _use_x6(d, pc, tile or AUTO_TILE):
+        args = (ctypes.byref(d), _p(x), _p(pc.x6_planes()), _p(pc.scale), _p(pc.shift), _p(residual), None, _p(out))
+        _lib.call("frcnn_conv2d_fwd_x6", *args, _stream())
+        if CONV_PROFILE is not None:
+            keep = (d, x, pc, residual, out)
+            CONV_PROFILE.append({"kernel": _x6_name(d, tile), "flops": 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin,
+                                 "shape": (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
+                                 "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_x6", *args, _stream())})
+        return out
     args, ws = _conv_launch(d, x, pc.w, pc.scale, pc.shift, residual, None, out)
     if CONV_PROFILE is not None:
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
@@ -394,6 +458,15 @@ def conv2d_dual(x, pc, n1, stride=1, padding="valid", act1=None, act2=None, layo
     lead = (d.ho, d.wo, d.n) if layout else (d.n, d.ho, d.wo)
     y1 = torch.empty(lead + (n1,), dtype=torch.float32, device="cuda")
     y2 = torch.empty(lead + (pc.cout - n1,), dtype=torch.float32, device="cuda")
+    if _use_x6(d, pc, tile or AUTO_TILE):
+        args = (ctypes.byref(d), _p(x), _p(pc.x6_planes()), _p(pc.scale), _p(pc.shift), _p(y1), n1, ACT[act1], _p(y2), ACT[act2])
+        _lib.call("frcnn_conv2d_fwd_dual_x6", *args, _stream())
+        if CONV_PROFILE is not None:
+            keep = (d, x, pc, y1, y2)
+            CONV_PROFILE.append({"kernel": _x6_name(d, tile), "flops": 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin,
+                                 "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
+                                 "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_dual_x6", *args, _stream())})
+        return y1, y2
     ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_dual_workspace_bytes"))
     args = (ctypes.byref(d), _p(x), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(y1), n1, ACT[act1], _p(y2), ACT[act2],
             _p(ws), ws.numel() if ws is not None else 0)

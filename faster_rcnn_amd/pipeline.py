@@ -64,8 +64,11 @@ class InferencePipeline:
         return res
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=True, throughput=False):
+    def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=True, throughput=False, f32_engine="native"):
         """Capture one full pass for a fixed image size into a hipGraph.
+
+        ``f32_engine``: "native" (v_mfma_f32_32x32x2_f32) or "bf16x6" (ops.f32_engine: the large fp32 launches on the bf16
+        matrix cores by exact operand splitting, fp32-grade results in a different summation order).
 
         ``split_k``: let small-grid convs cut K over several workgroups.  It shortens ONE image's pass (the
         stage-4 / RPN layers fill 60 % of the CUs otherwise); with several graphs replaying concurrently the
@@ -79,14 +82,15 @@ class InferencePipeline:
         self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.f32_engine(f32_engine):
             for _ in range(warmup):
                 self.forward_dev(self._static_in, resize_ratio)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         # thread_local: another thread of this process (e.g. an RCCL watchdog) may call into HIP during the capture
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), \
+                ops.f32_engine(f32_engine):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
 
