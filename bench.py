@@ -186,10 +186,13 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1, en
     tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC passes (rocprofv3 --pmc), committed
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
+    # the split-bf16 engine's ceiling is the bf16 matrix pipe: six v_mfma_f32_32x32x16_bf16 products per fp32 product
+    x6_dom = "x6" in dom_name
+    peak = PEAK_BF16_TFLOPS / 6.0 if x6_dom else PEAK_F32_MATRIX_TFLOPS
     roof = {
         "bound": "mfma", "kernel": dom_name,
-        "achieved": round(achieved, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+        "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic,
         "traffic_source": "profiles/traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch of this kernel, from the committed rocprofv3 --pmc "
                           "passes of scripts/profile_round3.sh (counters cannot be read from inside this process; null if the kernel is not in the file)",
         "launches_per_image": dom[2], "images_per_launch": images, "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
@@ -209,6 +212,10 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1, en
                                   "with several images in flight the same launches overlap"},
         "method": "HIP events on the launch stream around a hipGraph that holds each distinct launch %d x back to back" % reps,
     }
+    if x6_dom:
+        roof["peak_basis"] = ("fp32-equivalent FLOP/s: 2.5 PFLOP/s dense bf16 MFMA / 6 bf16 MFMAs per fp32 product; `achieved` counts each fp32 multiply-add once "
+                              "(the matrix pipe executes 6x that in bf16: %.0f TFLOP/s bf16); against the native fp32 matrix peak (157.3) the same launches read %.3f; "
+                              "all_conv_launches / backbone_conv stay relative to the native fp32 peak" % (6 * achieved, achieved / PEAK_F32_MATRIX_TFLOPS))
     return roof, groups
 
 
@@ -779,7 +786,7 @@ def main():
                          "default: 8 for configs[3] (bf16), 1 otherwise")
     ap.add_argument("--unit-tiles", default="", help="dev: tile codes for named conv layers, e.g. res5a_branch2c=26,res5b_branch2c=26")
     ap.add_argument("--conv-table", action="store_true", help="print every distinct conv launch's duration alone on the chip to stderr")
-    ap.add_argument("--f32-engine", choices=("native", "bf16x6"), default="native",
+    ap.add_argument("--f32-engine", choices=("native", "bf16x6"), default="bf16x6",
                     help="matrix path of the fp32 convolutions: native f32 MFMA, or the large launches on the bf16 matrix cores by exact "
                          "three-way operand splitting (fp32-grade results, csrc/conv_x6.hip)")
     ap.add_argument("--no-train-dp", action="store_true", help="N > 1: leave the data-parallel training steps (`train_dp`) out of the line")
@@ -914,6 +921,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same K steps on the NATIVE fp32 matrix instruction, when the timed graphs above run their large launches on the
+    # split-bf16 engine: both numbers in one line, same process, same inputs (one rank only)
+    native = None
+    if not args.no_graph and args.f32_engine == "bf16x6" and DTYPE == "f32" and DEPTH != 16 and B == 1 and world == 1 and not force_dist:
+        npipes = [more() for _ in range(S)]
+        for i, pl in enumerate(npipes):
+            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1, f32_engine="native")
+            pl._static_in.copy_(synth_batch((rank * S + i) * B))
+        torch.cuda.synchronize()
+
+        def nstep():
+            for pl, st in zip(npipes, streams):
+                with torch.cuda.stream(st):
+                    pl._graph.replay()
+        for _ in range(args.warmup):
+            nstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            nstep()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        native = {"value": round(S * args.steps / el, 3), "unit": "img/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+                  "what": "the same %d steps with every fp32 convolution on v_mfma_f32_32x32x2_f32 (--f32-engine native)" % args.steps}
+        same = all(torch.equal(a._static_out["det_bbox"], b._static_out["det_bbox"]) and torch.equal(a._static_out["det_cls"], b._static_out["det_cls"])
+                   for a, b in zip(pipes, npipes))
+        native["same_boxes_and_classes_as_value_run"] = bool(same)
+        del npipes
+        torch.cuda.empty_cache()
+
     # ---- the same K steps again with the host on both ends (voc_dets.get_dets' contract: image in, detections out,
     # voc_dets.py:20-88): per image a FRESH uint8 BGR frame leaves pinned host memory (1.8 MB over PCIe), resnet.preprocess
     # runs on the device into the graph's input, the graph replays, and the detection records come back to pinned host
@@ -1027,13 +1064,18 @@ def main():
                        "images_per_step_per_gpu": S * B, "graphs_in_flight": S, "images_per_graph": B, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "proposals": PROPOSALS, "classes": NUM_CLASSES,
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
-                       "f32_matrix_path": args.f32_engine,
+                       "f32_matrix_path": ("bf16x6: launches of >= %d rows, k >= %d, >= %d columns multiply on v_mfma_f32_32x32x16_bf16 with every f32 operand split EXACTLY "
+                                           "into three bf16 values, six exact partial products per product, f32 accumulate (csrc/conv_x6.hip; error against fp64 at the native "
+                                           "kernel's level); the rest on v_mfma_f32_32x32x2_f32" % (_ops.X6_MIN_ROWS, _ops.X6_MIN_K, _ops.X6_MIN_COUT))
+                                          if args.f32_engine == "bf16x6" and DTYPE == "f32" else "native: v_mfma_f32_32x32x2_f32",
                        "head_order": "no detector head" if DEPTH == 16 else
                        "res5a 1x1 layers on the conv4 map, then RoI resampling (algebraically equal, see DESIGN 5)" if HOIST else "reference order",
                        "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world,
                        "rank0_cpu_affinity": affinity},
             "roofline": roof,
         }
+        if native is not None:
+            line["native_f32_mfma"] = native
         if io is not None:
             line["with_host_io"] = io
         if via_entry is not None:

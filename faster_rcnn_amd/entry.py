@@ -133,8 +133,12 @@ class DetectionEntry:
     ``collect(ticket)`` returns ``(num_rois, dets)`` with ``dets`` the reference's list of
     ``{'bbox': int array [x1,y1,x2,y2], 'cls_name', 'prob'}`` in its order (voc_dets.py:73-86)."""
 
-    def __init__(self, manager, detector, num_rois=64, stride=16, in_flight=1, byte_budget=None):
+    def __init__(self, manager, detector, num_rois=64, stride=16, in_flight=1, byte_budget=None, f32_engine=None):
         self.manager, self.detector = manager, detector
+        # the matrix path of the fp32 convolutions inside the captured passes (ops.f32_engine): by default the large launches
+        # run on the bf16 matrix cores by exact three-way operand splitting -- fp32-grade results (csrc/conv_x6.hip), 1.2x the
+        # images per second; FRCNN_F32_ENGINE=native keeps v_mfma_f32_32x32x2_f32 everywhere
+        self.f32_engine = f32_engine or os.environ.get("FRCNN_F32_ENGINE", "bf16x6")
         self.num_rois, self.stride, self.in_flight = int(num_rois), stride, max(1, int(in_flight))
         from . import resnet, vgg
         self.device_preprocess = manager.preprocess_func in (resnet.preprocess, vgg.preprocess)
@@ -193,13 +197,13 @@ class DetectionEntry:
         s.io_dev.copy_(s.io_pin)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared):
+        with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine):
             for _ in range(2):
                 run()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         s.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(s.graph, capture_error_mode="thread_local"), ops.conv_workspace(s.ws), ops.tile_policy(shared):
+        with torch.cuda.graph(s.graph, capture_error_mode="thread_local"), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine):
             s.out = run()
         s.out_pin = torch.empty(s.out["det_packed"].shape, dtype=torch.int32).pin_memory()
         s.event = torch.cuda.Event()
@@ -256,7 +260,7 @@ class DetectionEntry:
         c = self.cache
         return {"graphs": len(c), "sizes": len(c.keys()), "bytes": c.nbytes, "byte_budget": c.byte_budget, "captures": c.captures,
                 "hits": c.hits, "evictions": c.evictions, "capture_seconds": round(self.capture_seconds, 3), "in_flight": self.in_flight,
-                "device_preprocess": self.device_preprocess}
+                "device_preprocess": self.device_preprocess, "f32_engine": self.f32_engine}
 
 
 def for_models(manager, detector, num_rois=64, stride=16, in_flight=1):

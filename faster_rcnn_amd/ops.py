@@ -286,8 +286,13 @@ class PackedConv:
 # different summation order: the two agree to f32 rounding, not bit for bit, so the library default stays "native" and a
 # caller opts in for a scope (``with f32_engine("bf16x6"):`` -- bench.py and entry.DetectionEntry do, around their captures).
 F32_ENGINE = "native"
-X6_MIN_ROWS = 8192              # GEMM rows (output pixels) from which the split engine's 128x128 tiles fill the chip
-X6_MIN_K = 256                  # kh * kw * cin
+# where the split engine measures faster than the native kernels (MI355X, configs[1] shapes, each launch alone on the chip):
+# the head's 14 700-row GEMMs 350 / 189 / 169 us against 571 / 265 / 250; stage 3 (9 375 rows, 128 columns) ties; 64-column
+# layers (stage 2) and short k lose (a 128-wide tile is half empty / the prologue dominates) and stay native; grids under
+# ~8 000 rows need a split-K form the engine does not have.
+X6_MIN_ROWS = 8192              # GEMM rows (output pixels)
+X6_MIN_K = 512                  # kh * kw * cin
+X6_MIN_COUT = 128
 
 
 class f32_engine:
@@ -309,7 +314,7 @@ def _use_x6(d, pc, tile):
         return pc.cin % 32 == 0                                  # explicit tile code of the split engine
     if F32_ENGINE != "bf16x6" or tile % 100 not in (0, 50):
         return False
-    return pc.cin % 32 == 0 and d.n * d.ho * d.wo >= X6_MIN_ROWS and pc.kh * pc.kw * pc.cin >= X6_MIN_K and pc.cout >= 64
+    return pc.cin % 32 == 0 and d.n * d.ho * d.wo >= X6_MIN_ROWS and pc.kh * pc.kw * pc.cin >= X6_MIN_K and pc.cout >= X6_MIN_COUT
 
 
 X6_KERNEL_NAMES = {71: "k_conv_igemm_x6<2,1,2,4>", 72: "k_conv_igemm_x6<2,2,4,2>", 73: "k_conv_igemm_x6<2,2,2,2>", 74: "k_conv_igemm_x6<1,1,2,2>",

@@ -51,15 +51,27 @@ def test_config0_vgg16_600x1000_rpn_forward():
         assert rel(cls, c_ref) < 1e-4 and rel(reg, r_ref) < 1e-4, (rel(cls, c_ref), rel(reg, r_ref))
 
 
-def test_config1_resnet50_600x1000_inference_fp32():
-    """configs[1], the headline: ResNet-50, 600x1000, 9 anchors, RPN + detector, fp32 -- bench.py's own parity object."""
+@pytest.mark.parametrize("engine", ["native", "bf16x6"])
+def test_config1_resnet50_600x1000_inference_fp32(engine):
+    """configs[1], the headline: ResNet-50, 600x1000, 9 anchors, RPN + detector, fp32 -- bench.py's own parity object, on
+    both fp32 matrix paths: the native f32 MFMA and the split-bf16 engine bench.py runs by default (the head's 14 700-row
+    GEMMs on v_mfma_f32_32x32x16_bf16 with exactly split operands): the SAME 1e-4 bars, the same exact discrete stages."""
     import bench
-    pipe, weights, anchors = bench.build_pipeline()
-    res = bench.full_size_parity(pipe, weights, anchors)
+    from faster_rcnn_amd import ops
+    with ops.f32_engine(engine):
+        pipe, weights, anchors = bench.build_pipeline()
+        ops.CONV_PROFILE = []
+        try:
+            res = bench.full_size_parity(pipe, weights, anchors)
+            kernels = [r["kernel"] for r in ops.CONV_PROFILE]
+        finally:
+            ops.CONV_PROFILE = None
     assert res["ok"], res
     assert res["proposals_equal"] and res["detections_equal"] and res["n_rois"] == 300
     for k in ("feat", "rpn_cls", "rpn_reg", "det_cls", "det_reg"):
         assert res[k] < 1e-4, res
+    n_x6 = sum("x6" in k for k in kernels)
+    assert n_x6 == (0 if engine == "native" else 8 + 7), (engine, n_x6, kernels)      # the head's 8 launches + stage 3's seven 128-column layers
 
 
 def test_config1_end_to_end_pair_and_map_delta():

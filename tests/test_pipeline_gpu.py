@@ -137,12 +137,23 @@ def test_end_to_end_resnet50_small_image():
     assert err(out_cls[0], k64) < 1e-4 and err(out_reg[0], g64) < 1e-4
 
     # (4) discrete stage: get_dets == oracle post-process of the SAME detector outputs
-    dets = voc_dets.get_dets(mgr, det, img, 1.6, det_threshold=0.0)
+    # (the EAGER path is the one that sequences the stages as above -- get_det_inputs, detector.predict -- so its output is
+    #  the post-process of exactly these detector outputs; the captured path replays other launch forms and is held to the
+    #  same boxes and classes with scores to 1e-5 here, and to the eager path on more sizes in test_entry_gpu.py)
+    voc_dets.FAST_ENTRY = False
+    try:
+        dets = voc_dets.get_dets(mgr, det, img, 1.6, det_threshold=0.0)
+    finally:
+        voc_dets.FAST_ENTRY = True
     want_dets = np_ref.detections(rois, out_cls[0], out_reg[0], 20, 1.6)
     assert len(dets) == len(want_dets) and len(dets) > 0
     rev = {v: k for k, v in VOC_CLASS_MAPPING.items()}
     for d, wd in zip(dets, want_dets):
         assert d["cls_name"] == rev[wd[0]] and d["prob"] == wd[1] and np.array_equal(d["bbox"], wd[2])
+    fast = voc_dets.get_dets(mgr, det, img, 1.6, det_threshold=0.0)
+    assert len(fast) == len(dets)
+    for d, f in zip(dets, fast):
+        assert d["cls_name"] == f["cls_name"] and np.array_equal(d["bbox"], f["bbox"]) and abs(float(d["prob"]) - float(f["prob"])) < 1e-5
 
     # (5) the fused device pipeline (eager and hipGraph replay) reproduces the staged results
     pipe = InferencePipeline(rpn, det, anchors, max_proposals=300)
