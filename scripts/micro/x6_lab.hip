@@ -228,6 +228,159 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_x6(const Args p) {
     }
 }
 
+// ---- the same loop on v_mfma_f32_16x16x32_bf16 (one MFMA = the whole 32-deep chunk of a 16x16 tile): under the clock the
+// chip holds in MFMA-dense loops this shape delivers 1.12-1.15x the FLOP/s of 32x32x16 (MI355X_MICROARCH.md, DVFS give-back 7).
+// Lane l supplies A[row l & 15][k = 8 (l >> 4) .. +7]: one ds_read_b128 at logical slot l >> 4 of row l & 15.
+// Swizzle for THIS read pattern: slot s of row r at s ^ F[(r >> 2) & 3], F = {0, 2, 3, 1} (each b128 lane group then meets 16 distinct slots).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int swz16(int row) { const int q = (row >> 2) & 3; return (0x1320 >> (4 * q)) & 3; }      // F = {0, 2, 3, 1}
+
+template <int TM, int TN, int WM, int WN>           // TM x TN tiles of 16x16 per wave
+__global__ void __launch_bounds__(64 * WM * WN) k_gemm_x6_16(const Args p) {
+    constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN, NT = 64 * WM * WN;
+    constexpr int PA = BM * 8 / NT, PB = BN * 4 / NT;
+    static_assert(PA >= 1 && PB >= 1, "tile too small for the thread count");
+    constexpr int RB = 64;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* As = lds;
+    char* Bs = lds + 3 * BM * RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, lr = lane & 15, ls = lane >> 4;
+    int bid = blockIdx.x;
+    {
+        const int nwg = p.tiles_m * p.tiles_n, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n, m0 = tm * BM, n0 = tn * BN;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((size_t)p.M * p.K * 4), 0x00020000);
+    const size_t plane = (size_t)p.N * p.K * 2;
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.Bp), 0, (int)(3 * plane), 0x00020000);
+    unsigned a_off[PA], b_off[PB];
+    int a_lds[PA], b_lds[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int pc = tid + NT * i, row = pc >> 3, g = pc & 7;
+        a_off[i] = m0 + row < p.M ? (unsigned)(((size_t)(m0 + row) * p.K + g * 4) * 4) : OOB;
+        a_lds[i] = row * RB + 16 * ((g >> 1) ^ swz16(row)) + 8 * (g & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int pc = tid + NT * i, row = pc >> 2, g = pc & 3;
+        b_off[i] = n0 + row < p.N ? (unsigned)(((size_t)(n0 + row) * p.K + g * 8) * 2) : OOB;
+        b_lds[i] = row * RB + 16 * (g ^ swz16(row));
+    }
+    f32x4 ra[2][PA];
+    f32x4 rb[2][3][PB];
+    auto load = [&](int kt, auto setc) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_off[i], kt * (BK * 4), 0));
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[S][pl][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, b_off[i] == OOB ? OOB : b_off[i] + (unsigned)(pl * plane), kt * (BK * 2), 0));
+    };
+    auto store = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            bf16x4 h, m, l;
+            split3(ra[S][i], h, m, l);
+            *reinterpret_cast<bf16x4*>(As + 0 * BM * RB + a_lds[i]) = h;
+            *reinterpret_cast<bf16x4*>(As + 1 * BM * RB + a_lds[i]) = m;
+            *reinterpret_cast<bf16x4*>(As + 2 * BM * RB + a_lds[i]) = l;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(Bs + pl * BN * RB + b_lds[i]) = rb[S][pl][i];
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    f32x4v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int nk = p.K / BK;
+    const char* abase = As + (wm * TM * 16 + lr) * RB + 16 * (ls ^ swz16(lr));      // tile bases are multiples of 16 rows: (row >> 2) & 3 is the lane's own
+    const char* bbase = Bs + (wn * TN * 16 + lr) * RB + 16 * (ls ^ swz16(lr));
+    auto compute = [&]() {
+        bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const bf16x8*>(abase + pl * BM * RB + i * 16 * RB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const bf16x8*>(bbase + pl * BN * RB + j * 16 * RB);
+        }
+        constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[IA[t]][i], fb[IB[t]][j], acc[i][j], 0, 0, 0);
+    };
+    load(0, I0{});
+    load(nk > 1 ? 1 : 0, I1{});
+    store(I0{});
+    load(nk > 2 ? 2 : 0, I0{});
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        compute();
+        __syncthreads();
+        store(I1{});
+        load(kt + 3 < nk ? kt + 3 : 0, I1{});
+        __syncthreads();
+        compute();
+        __syncthreads();
+        if (kt + 2 < nk) {
+            store(I0{});
+            load(kt + 4 < nk ? kt + 4 : 0, I0{});
+            __syncthreads();
+        }
+    }
+    if (kt < nk) compute();
+    // C/D of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 16 + j * 16 + lr;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm * TM * 16 + i * 16 + ls * 4 + e;
+                if (m < p.M) p.C[(size_t)m * p.N + n] = acc[i][j][e];
+            }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+static float run16(const Args& a0, int reps, const char* name) {
+    constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+    Args a = a0;
+    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
+    const size_t lds = (size_t)3 * (BM + BN) * 64;
+    CHECK(hipFuncSetAttribute((const void*)k_gemm_x6_16<TM, TN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    k_gemm_x6_16<TM, TN, WM, WN><<<a.tiles_m * a.tiles_n, 64 * WM * WN, lds>>>(a);
+    CHECK(hipGetLastError());
+    CHECK(hipDeviceSynchronize());
+    if (reps <= 0) return 0.0f;
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) k_gemm_x6_16<TM, TN, WM, WN><<<a.tiles_m * a.tiles_n, 64 * WM * WN, lds>>>(a);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / reps;
+    printf("  %-34s M=%-6d N=%-5d K=%-5d  %8.1f us  %7.1f TFLOP/s fp32-equivalent  (%d workgroups, %zu B LDS)\n", name, a.M, a.N, a.K, us, 2.0 * a.M * a.N * a.K / us / 1e6, a.tiles_m * a.tiles_n, lds);
+    return (float)us;
+}
+
 // reference: the native fp32 matrix instruction, same tile walk, no pipelining (for the error comparison only)
 __global__ void __launch_bounds__(256) k_gemm_f32_ref(const Args p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -319,6 +472,7 @@ int main(int argc, char** argv) {
             run<2, 2, 2, 2, 6, 2>(a, 0, ""); report("bf16x6, loads two chunks ahead");
             run<2, 1, 2, 4, 6, 2>(a, 0, ""); report("bf16x6, 8 waves, loads two chunks ahead");
             run<2, 1, 2, 4, 6, 3>(a, 0, ""); report("bf16x6, 8 waves, LDS double buffer");
+            run16<4, 2, 2, 4>(a, 0, ""); report("bf16x6 on v_mfma_f32_16x16x32_bf16, 128x128 8 waves");
             run<2, 2, 2, 2, 3>(a, 0, ""); report("bf16x3 (a1b1 + a1b2 + a2b1)");
             run<2, 2, 2, 2, 1>(a, 0, ""); report("plain bf16 (a1b1)");
             CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC)); CHECK(hipFree(dBp));
@@ -345,6 +499,9 @@ int main(int argc, char** argv) {
         run<2, 1, 2, 4, 6>(a, 10, "128x128, 8 waves (64x32 per wave)");
         run<2, 1, 2, 4, 6, 2>(a, 10, "128x128, 8 waves, loads 2 ahead");
         run<2, 2, 4, 2, 6, 2>(a, 10, "256x128, 8 waves, loads 2 ahead");
+        run16<4, 2, 2, 4>(a, 10, "128x128, 8 waves, 16x16x32 MFMA");
+        run16<4, 4, 2, 2>(a, 10, "128x128, 4 waves, 16x16x32 MFMA");
+        run16<4, 4, 4, 2>(a, 10, "256x128, 8 waves, 16x16x32 MFMA");
         run<2, 1, 2, 4, 6, 2, 1>(a, 10, "  ladder: no split arithmetic");
         run<2, 1, 2, 4, 6, 2, 2>(a, 10, "  ladder: no LDS stores");
         run<2, 1, 2, 4, 6, 2, 4>(a, 10, "  ladder: no global loads");
