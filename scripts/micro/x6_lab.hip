@@ -381,6 +381,146 @@ static float run16(const Args& a0, int reps, const char* name) {
     return (float)us;
 }
 
+// ---- ONE workgroup per CU, 16 waves (4 per SIMD), 256x128 tile, TWO LDS buffers (147 KB), ONE barrier per chunk: chunk kt multiplies
+// from buffer kt & 1 while chunk kt+1 (in registers since the previous iteration) is split and stored into the other buffer and
+// chunk kt+2 is requested.  MODE 1: the split / store / load of the next chunk sits between the two k-steps of the current one.
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_gemm_x6_db16(const Args p) {
+    constexpr int TM = 2, TN = 1, WM = 4, WN = 4, BM = 256, BN = 128, NT = 1024, RB = 64;
+    constexpr int PA = BM * 8 / NT;                       // 2
+    constexpr int NBP = 3 * BN * 4;                       // 16-byte pieces of the three B planes per chunk: 1536
+    constexpr int PBT = (NBP + NT - 1) / NT;              // 2 (the second one for tid < 512 only)
+    constexpr int BUFB = 3 * (BM + BN) * RB;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nwg = p.tiles_m * p.tiles_n, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n, m0 = tm * BM, n0 = tn * BN;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)((size_t)p.M * p.K * 4), 0x00020000);
+    const size_t plane = (size_t)p.N * p.K * 2;
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.Bp), 0, (int)(3 * plane), 0x00020000);
+    unsigned a_off[PA], b_off[PBT];
+    int a_lds[PA], b_lds[PBT];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int pc = tid + NT * i, row = pc >> 3, g = pc & 7;
+        a_off[i] = m0 + row < p.M ? (unsigned)(((size_t)(m0 + row) * p.K + g * 4) * 4) : OOB;
+        a_lds[i] = row * RB + 16 * ((g >> 1) ^ swz(row)) + 8 * (g & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < PBT; ++i) {
+        const int q = tid + NT * i, pl = q / (BN * 4), r = q % (BN * 4), row = r >> 2, g = r & 3;
+        const bool ok = q < NBP && n0 + row < p.N;
+        b_off[i] = ok ? (unsigned)(((size_t)(n0 + row) * p.K + g * 8) * 2 + pl * plane) : OOB;
+        b_lds[i] = q < NBP ? 3 * BM * RB + pl * BN * RB + row * RB + 16 * (g ^ swz(row)) : -1;
+    }
+    f32x4 ra[PA], rb[PBT];
+    auto load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, a_off[i], kt * (BK * 4), 0));
+#pragma unroll
+        for (int i = 0; i < PBT; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, b_off[i], kt * (BK * 2), 0));
+    };
+    auto store = [&](int buf) {
+        char* base = lds + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            bf16x4 h, m, l;
+            split3(ra[i], h, m, l);
+            *reinterpret_cast<bf16x4*>(base + 0 * BM * RB + a_lds[i]) = h;
+            *reinterpret_cast<bf16x4*>(base + 1 * BM * RB + a_lds[i]) = m;
+            *reinterpret_cast<bf16x4*>(base + 2 * BM * RB + a_lds[i]) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < PBT; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<f32x4*>(base + b_lds[i]) = rb[i];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int nk = p.K / BK;
+    const int aoff = (wm * TM * 32 + li) * RB, boff = 3 * BM * RB + (wn * TN * 32 + li) * RB;
+    const int koff[2] = {16 * (lh ^ swz(li)), 16 * ((2 + lh) ^ swz(li))};
+    auto kstep = [&](int buf, int s) {
+        const char* base = lds + buf * BUFB;
+        bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const bf16x8*>(base + aoff + pl * BM * RB + i * 32 * RB + koff[s]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const bf16x8*>(base + boff + pl * BN * RB + j * 32 * RB + koff[s]);
+        }
+        constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[IA[t]][i], fb[IB[t]][j], acc[i][j], 0, 0, 0);
+    };
+    load(0);
+    store(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if constexpr (MODE == 0) {
+            if (kt + 1 < nk) { store(buf ^ 1); load(kt + 2 < nk ? kt + 2 : 0); }
+            kstep(buf, 0);
+            kstep(buf, 1);
+        } else {
+            kstep(buf, 0);
+            if (kt + 1 < nk) { store(buf ^ 1); load(kt + 2 < nk ? kt + 2 : 0); }
+            kstep(buf, 1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + li;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < p.M) p.C[(size_t)m * p.N + n] = acc[i][j][e];
+            }
+        }
+    }
+}
+
+template <int MODE>
+static float run_db16(const Args& a0, int reps, const char* name) {
+    Args a = a0;
+    a.tiles_m = (a.M + 255) / 256; a.tiles_n = (a.N + 127) / 128;
+    const size_t lds = (size_t)2 * 3 * (256 + 128) * 64;
+    CHECK(hipFuncSetAttribute((const void*)k_gemm_x6_db16<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    k_gemm_x6_db16<MODE><<<a.tiles_m * a.tiles_n, 1024, lds>>>(a);
+    CHECK(hipGetLastError());
+    CHECK(hipDeviceSynchronize());
+    if (reps <= 0) return 0.0f;
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) k_gemm_x6_db16<MODE><<<a.tiles_m * a.tiles_n, 1024, lds>>>(a);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / reps;
+    printf("  %-34s M=%-6d N=%-5d K=%-5d  %8.1f us  %7.1f TFLOP/s fp32-equivalent  (%d workgroups, %zu B LDS)\n", name, a.M, a.N, a.K, us, 2.0 * a.M * a.N * a.K / us / 1e6, a.tiles_m * a.tiles_n, lds);
+    return (float)us;
+}
+
 // reference: the native fp32 matrix instruction, same tile walk, no pipelining (for the error comparison only)
 __global__ void __launch_bounds__(256) k_gemm_f32_ref(const Args p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -473,6 +613,7 @@ int main(int argc, char** argv) {
             run<2, 1, 2, 4, 6, 2>(a, 0, ""); report("bf16x6, 8 waves, loads two chunks ahead");
             run<2, 1, 2, 4, 6, 3>(a, 0, ""); report("bf16x6, 8 waves, LDS double buffer");
             run16<4, 2, 2, 4>(a, 0, ""); report("bf16x6 on v_mfma_f32_16x16x32_bf16, 128x128 8 waves");
+            run_db16<1>(a, 0, ""); report("bf16x6, 16 waves 256x128, LDS double buffer");
             run<2, 2, 2, 2, 3>(a, 0, ""); report("bf16x3 (a1b1 + a1b2 + a2b1)");
             run<2, 2, 2, 2, 1>(a, 0, ""); report("plain bf16 (a1b1)");
             CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC)); CHECK(hipFree(dBp));
@@ -499,6 +640,8 @@ int main(int argc, char** argv) {
         run<2, 1, 2, 4, 6>(a, 10, "128x128, 8 waves (64x32 per wave)");
         run<2, 1, 2, 4, 6, 2>(a, 10, "128x128, 8 waves, loads 2 ahead");
         run<2, 2, 4, 2, 6, 2>(a, 10, "256x128, 8 waves, loads 2 ahead");
+        run_db16<0>(a, 10, "256x128, 16 waves, LDS double buffer");
+        run_db16<1>(a, 10, "256x128, 16 waves, DB, store mid-chunk");
         run16<4, 2, 2, 4>(a, 10, "128x128, 8 waves, 16x16x32 MFMA");
         run16<4, 4, 2, 2>(a, 10, "128x128, 4 waves, 16x16x32 MFMA");
         run16<4, 4, 4, 2>(a, 10, "256x128, 8 waves, 16x16x32 MFMA");

@@ -15,6 +15,9 @@ def bench_kernel_name(k):
     m = re.search(r"k_conv_igemm_f32_sk<(\d+), (\d+)>", k)
     if m:
         return "k_conv_igemm_f32_sk<%s,%s>" % m.groups()
+    m = re.search(r"k_conv_igemm_x6<(\d+), (\d+), (\d+), (\d+)>", k)
+    if m:
+        return "k_conv_igemm_x6<%s,%s,%s,%s>" % m.groups()
     m = re.search(r"k_conv_igemm_bf16<", k)
     if m:
         return "k_conv_igemm_bf16"
