@@ -736,7 +736,40 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
     finally:
         voc_dets.FAST_ENTRY = True
     same = all(k in dets and all(len(v[i]) == len(dets[k][i]) for i in v) for k, v in dets_eager.items())
-    return {"value": round(n_images * passes / t, 3), "unit": "img/s", "images": n_images, "passes": passes,
+    # ---- the same call on FILES: the VOC frame as voc_dets.main feeds it (a 500x375 JPEG on disk, metadata resized to 800x600):
+    # JPEG decode on a few host threads, the decoded frame uploaded, INTER_CUBIC resize + preprocess + network on the device;
+    # the eager path beside it decodes and resizes on the host the way the reference does (cv2 there, integer numpy here)
+    from_files = None
+    try:
+        from faster_rcnn_amd import util
+        from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+        base = extract_img_data(os.path.join(ROOT, "tests", "golden", "VOC_test"), "000005")
+        frames = []
+        for i in range(n_images):
+            (r,), (ratio,) = util.resize_imgs([base], min_size=600, max_size=1000)
+            r.metadata.name = "file%03d" % i
+            frames.append(r)
+        fr = [ratio] * n_images
+
+        def run_files(imgs):
+            with contextlib.redirect_stdout(sink):
+                t0 = time.perf_counter()
+                d = voc_dets.get_dets_by_cls(mgr, pipe.det, fr[:len(imgs)], imgs)
+                return time.perf_counter() - t0, d
+        run_files(frames)
+        tf = sum(run_files(frames)[0] for _ in range(passes))
+        voc_dets.FAST_ENTRY = False
+        try:
+            te, _ = run_files(frames[:4])
+        finally:
+            voc_dets.FAST_ENTRY = True
+        from_files = {"value": round(n_images * passes / tf, 3), "unit": "img/s", "frame": "tests/golden/VOC_test 000005.jpg, 500x375 -> 800x600",
+                      "decode_threads": voc_dets.DECODE_THREADS, "eager": {"value": round(4 / te, 3), "unit": "img/s", "images": 4},
+                      "what": "JPEG decode (PIL, host threads) -> H2D of the decoded frame -> device INTER_CUBIC resize + preprocess + captured pass -> dicts; "
+                              "eager: decode + integer-numpy resize + float64 preprocess on the host, then the eager device path"}
+    except Exception as e:
+        from_files = {"error": "%s: %s" % (type(e).__name__, e)}
+    return {"value": round(n_images * passes / t, 3), "from_files": from_files, "unit": "img/s", "images": n_images, "passes": passes,
             "detections_per_image": round(n_dets / n_images, 1), "first_pass_s": round(t_first, 3), "graph_cache": eng.stats(),
             "eager": {"value": round(eager_images / t_eager, 3), "unit": "img/s", "images": eager_images,
                       "what": "the same call with voc_dets.FAST_ENTRY = False: get_det_inputs returns the conv map and the RoIs as numpy "

@@ -25,6 +25,8 @@ SIGNATURES = {
     "frcnn_version": (I, []),
     "frcnn_device_count": (I, []),
     "frcnn_preprocess_u8": (I, [P, c_size_t, P, P, P]),
+    "frcnn_resize_cubic_taps": (I, [I, I, P]),
+    "frcnn_resize_cubic_u8": (I, [P, I, I, P, P, I, I, I, P, P]),
     "frcnn_anchors_image": (I, [I, I, P, I, I, P, P]),
     "frcnn_anchors_conv": (I, [I, I, P, I, P, P]),
     "frcnn_cross_ious_f32": (I, [P, I, P, I, P, P]),

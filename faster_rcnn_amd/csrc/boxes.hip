@@ -4,6 +4,7 @@
 // per-GT arg-max.  This translation unit is compiled with -ffp-contract=off: every
 // float expression below must round exactly where the reference's numpy code rounds.
 #include "common.h"
+#include <math.h>
 
 namespace frcnn {
 
@@ -249,11 +250,78 @@ __global__ void k_preprocess_u8(const uint8_t* img, size_t n, double m0, double 
     }
 }
 
+// shapes.Image.data (shapes.py:19-29): cv2.resize(img, (w, h), interpolation=cv2.INTER_CUBIC) on the decoded uint8 frame --
+// OpenCV's 8-bit path: per axis four taps (BORDER_REPLICATE), cubic coefficients (A = -0.75) in 11-bit fixed point, horizontal
+// then vertical pass, (v + 2^21) >> 22, saturate.  No intermediate rounding between the passes, so one thread sums the 16
+// products of a destination pixel directly: the same integer the two-pass form produces.  tab_[xy]: [dst][8] = 4 source
+// indices (clamped), 4 coefficients (frcnn_resize_cubic_taps).  flip: Image.horizontal_flip (shapes.py:27: data[:, ::-1]).
+__global__ void k_resize_cubic_u8(const uint8_t* src, int sw, const int32_t* tab_x, const int32_t* tab_y, int dh, int dw, int flip, uint8_t* dst) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    const int32_t* tx = tab_x + 8 * x;
+    const int32_t* ty = tab_y + 8 * y;
+    long long acc0 = 0, acc1 = 0, acc2 = 0;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const uint8_t* row = src + (size_t)ty[ky] * sw * 3;
+        int h0 = 0, h1 = 0, h2 = 0;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const uint8_t* px = row + (size_t)tx[kx] * 3;
+            const int c = tx[4 + kx];
+            h0 += c * px[0]; h1 += c * px[1]; h2 += c * px[2];
+        }
+        const long long cy = ty[4 + ky];
+        acc0 += cy * h0; acc1 += cy * h1; acc2 += cy * h2;
+    }
+    auto fin = [](long long v) { v = (v + (1ll << 21)) >> 22; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+    uint8_t* o = dst + ((size_t)y * dw + (flip ? dw - 1 - x : x)) * 3;
+    o[0] = fin(acc0); o[1] = fin(acc1); o[2] = fin(acc2);
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
 
 extern "C" {
+
+// HOST function: the tap table of one axis, in f32 exactly as OpenCV's resize computes it (and shapes._cubic_taps restates it):
+// f = (float)((d + 0.5) * (src / dst) - 0.5) with the product in double, s = floor(f), x = f - s, the four cubic weights in f32
+// (this translation unit is compiled with -ffp-contract=off: every operation rounds once), x 2048, round half to even, int16.
+int frcnn_resize_cubic_taps(int dst, int src, int32_t* tab_h) {
+    if (dst <= 0 || src <= 0 || !tab_h) return fail(FRCNN_E_ARG, "resize_cubic_taps: bad argument");
+    const double scale = (double)src / (double)dst;
+    const float A = -0.75f, one = 1.0f;
+    for (int d = 0; d < dst; ++d) {
+        const float f = (float)(((double)d + 0.5) * scale - 0.5);
+        const float fl = floorf(f);
+        const int s = (int)fl;
+        const float x = f - fl;
+        const float xp = x + one, xm = one - x;
+        float c[4];
+        c[0] = ((A * xp - 5.0f * A) * xp + 8.0f * A) * xp - 4.0f * A;
+        c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + one;
+        c[2] = ((A + 2.0f) * xm - (A + 3.0f)) * xm * xm + one;
+        c[3] = one - c[0] - c[1] - c[2];
+        for (int k = 0; k < 4; ++k) {
+            int idx = s - 1 + k;
+            idx = idx < 0 ? 0 : (idx > src - 1 ? src - 1 : idx);
+            float v = nearbyintf(c[k] * 2048.0f);                 // default rounding mode: half to even (cvRound)
+            v = v < -32768.0f ? -32768.0f : (v > 32767.0f ? 32767.0f : v);
+            tab_h[8 * d + k] = idx;
+            tab_h[8 * d + 4 + k] = (int32_t)v;
+        }
+    }
+    return FRCNN_OK;
+}
+
+int frcnn_resize_cubic_u8(const uint8_t* src_hwc, int src_h, int src_w, const int32_t* tab_x, const int32_t* tab_y,
+                          int dst_h, int dst_w, int flip, uint8_t* dst_hwc, void* stream) {
+    if (!src_hwc || !tab_x || !tab_y || !dst_hwc) return fail(FRCNN_E_ARG, "resize_cubic_u8: null pointer");
+    if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || dst_h > 65535) return fail(FRCNN_E_ARG, "resize_cubic_u8: bad size");
+    k_resize_cubic_u8<<<dim3((dst_w + 127) / 128, dst_h), 128, 0, as_stream(stream)>>>(src_hwc, src_w, tab_x, tab_y, dst_h, dst_w, flip ? 1 : 0, dst_hwc);
+    return check_launch("resize_cubic_u8");
+}
 
 const char* frcnn_last_error(void) { return g_err; }
 int frcnn_version(void) { return 100; }

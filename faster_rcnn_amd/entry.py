@@ -17,6 +17,10 @@ models, the same call runs here as ONE captured pass per image:
 * ``get_dets_by_cls`` keeps several images in flight (one HIP stream each; a size seen several times in a row gets as
   many captured instances as are in flight) and hands results back in submission order, so the returned dict is the
   reference's, entry for entry.
+* The frame is uploaded as DECODED (``image.raw``: the file's own size, 0.56 MB for a 500x375 VOC frame) and resized on the
+  device inside the captured pass (frcnn_resize_cubic_u8: OpenCV's 8-bit INTER_CUBIC in integers, bit-identical to the host
+  restatement in shapes._resize, which takes ~90 ms per frame in numpy); such a pass is keyed by (height, width, source
+  height, source width, flip).  ``get_dets_by_cls`` decodes the JPEGs of the next images on a small thread pool meanwhile.
 * A foreign ``preprocess_func`` (anything but resnet.preprocess / vgg.preprocess) is called on the host, as the reference
   does (det_util.py:36), and its float image is uploaded instead of the bytes; a foreign ``detector`` (any other object
   with Keras' ``predict``) keeps voc_dets' eager path.
@@ -57,7 +61,7 @@ def default_in_flight(dtype="f32"):
 class _Slot:
     """One captured pass for one image size, with its staging on both sides of PCIe."""
     __slots__ = ("key", "pipe", "graph", "out", "io_dev", "io_pin", "pix_host", "dyn_host", "out_pin", "event", "busy", "nbytes",
-                 "x_f32", "ws", "seq")
+                 "x_f32", "ws", "seq", "tabs", "u8_resized")
 
 
 class GraphCache:
@@ -161,14 +165,17 @@ class DetectionEntry:
         return 0 < n_rows <= 512                        # frcnn_detections: one workgroup, <= 512 scored rows
 
     # ------------------------------------------------------------------ capture
-    def _capture(self, H, W):
+    def _capture(self, H, W, src=None, flip=False):
+        """``src`` = (source height, source width): the pass starts from the decoded frame at the file's size and resizes
+        (and flips) it on the device; None: the uploaded pixels are already (H, W)."""
         import time
         t0 = time.perf_counter()
         m = self.manager
         pipe = InferencePipeline(m.rpn_model, self.detector, m.anchor_dims, stride=self.stride, pre_nms_top_n=PRE_NMS_TOP_N,
                                  max_proposals=MAX_PROPOSALS, roi_batch=self.num_rois, pad_to_batch=True, bg_idx=m.class_mapping["bg"])
         reserved0 = torch.cuda.memory_reserved()
-        npix = H * W * 3
+        in_h, in_w = src if src is not None else (H, W)
+        npix = in_h * in_w * 3
         pix_bytes = npix if self.device_preprocess else 4 * npix
         off = (pix_bytes + 15) // 16 * 16
         s = _Slot()
@@ -176,19 +183,27 @@ class DetectionEntry:
         s.io_dev = torch.zeros(off + 16, dtype=torch.uint8, device="cuda")
         s.io_pin = torch.zeros(off + 16, dtype=torch.uint8).pin_memory()
         host = s.io_pin.numpy()
-        s.pix_host = host[:npix].reshape(H, W, 3) if self.device_preprocess else host[:pix_bytes].view(np.float32).reshape(H, W, 3)
+        s.pix_host = host[:npix].reshape(in_h, in_w, 3) if self.device_preprocess else host[:pix_bytes].view(np.float32).reshape(H, W, 3)
         s.dyn_host = host[off:off + 16].view(np.float64)
         s.dyn_host[:] = (1.0, 0.0)
         dyn_dev = s.io_dev[off:off + 16].view(torch.float64)
+        s.tabs = s.u8_resized = None
         if self.device_preprocess:
-            u8 = s.io_dev[:npix].view(H, W, 3)
+            u8 = s.io_dev[:npix].view(in_h, in_w, 3)
             s.x_f32 = torch.empty((1, H, W, 3), dtype=torch.float32, device="cuda")
+            if src is not None:
+                assert self.device_preprocess
+                s.tabs = (torch.from_numpy(ops.resize_cubic_taps(W, in_w)).cuda(), torch.from_numpy(ops.resize_cubic_taps(H, in_h)).cuda())
+                s.u8_resized = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
         else:
             s.x_f32 = s.io_dev[:pix_bytes].view(torch.float32).view(1, H, W, 3)
 
         def run():
             if self.device_preprocess:
-                ops.preprocess_u8(u8, MEAN_BGR, out=s.x_f32)        # resnet.preprocess + the f32 feed cast, bit for bit
+                frame = u8
+                if src is not None:                                 # shapes.Image.data: INTER_CUBIC resize (+ flip) of the decoded frame
+                    frame = ops.resize_cubic_u8(u8, H, W, flip=flip, tabs=s.tabs, out=s.u8_resized)
+                ops.preprocess_u8(frame, MEAN_BGR, out=s.x_f32)     # resnet.preprocess + the f32 feed cast, bit for bit
             return pipe.forward_dev(s.x_f32, dyn=dyn_dev)
 
         shared = self.in_flight > 1
@@ -220,8 +235,17 @@ class DetectionEntry:
             self.cache.clear()
             self._epoch = models.weights_epoch()
 
-    def submit(self, image, resize_ratio, det_threshold=0.0):
-        self._check_epoch()
+    def host_pixels(self, image):
+        """What ``submit`` uploads for this image -- safe to call from another thread ahead of time (JPEG decode).
+        Returns (array, H, W, src or None, flip)."""
+        if self.device_preprocess and hasattr(image, "raw") and hasattr(image, "height"):
+            raw = np.asarray(image.raw)
+            if raw.dtype != np.uint8 or raw.ndim != 3 or raw.shape[2] != 3:
+                raise TypeError("image pixels must be uint8 BGR (h, w, 3) (shapes.py:19-29), got %s %s" % (raw.dtype, raw.shape))
+            H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
+            if raw.shape[:2] == (H, W) and not flip:
+                return raw, H, W, None, False
+            return raw, H, W, (int(raw.shape[0]), int(raw.shape[1])), flip
         data = image.data
         if self.device_preprocess:
             data = np.asarray(data)
@@ -229,8 +253,14 @@ class DetectionEntry:
                 raise TypeError("image.data must be uint8 BGR (shapes.py:19-29), got %s" % data.dtype)
         else:
             data = self.manager.preprocess_func(data)               # det_util.py:36 (float64 on the host, cast on feed)
-        H, W = int(data.shape[0]), int(data.shape[1])
-        s = self.cache.acquire((H, W), lambda: self._capture(H, W))
+        return data, int(data.shape[0]), int(data.shape[1]), None, False
+
+    def submit(self, image, resize_ratio, det_threshold=0.0, pixels=None):
+        """``pixels``: the result of ``host_pixels(image)`` when the caller fetched it ahead of time."""
+        self._check_epoch()
+        data, H, W, src, flip = self.host_pixels(image) if pixels is None else pixels
+        key = (H, W) if src is None else (H, W) + src + (flip,)
+        s = self.cache.acquire(key, lambda: self._capture(H, W, src, flip))
         np.copyto(s.pix_host, data, casting="same_kind")            # into pinned memory (f64 -> f32 cast for a foreign preprocess)
         s.dyn_host[0], s.dyn_host[1] = float(resize_ratio), float(det_threshold)
         st = self._streams[self._seq % self.in_flight]

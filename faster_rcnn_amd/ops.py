@@ -81,6 +81,38 @@ def preprocess_u8(img_u8, mean_bgr, out=None):
     return out
 
 
+_TAPS = {}
+
+
+def resize_cubic_taps(dst, src):
+    """One axis' INTER_CUBIC tap table [dst][8] int32 = {4 clamped source indices, 4 fixed-point weights} (host array;
+    frcnn_resize_cubic_taps: OpenCV's f32 arithmetic).  Cached: a dataset has a handful of (dst, src) pairs."""
+    key = (int(dst), int(src))
+    tab = _TAPS.get(key)
+    if tab is None:
+        tab = np.empty((key[0], 8), dtype=np.int32)
+        _lib.call("frcnn_resize_cubic_taps", key[0], key[1], tab.ctypes.data_as(ctypes.c_void_p))
+        if len(_TAPS) > 512:
+            _TAPS.clear()
+        _TAPS[key] = tab
+    return tab
+
+
+def resize_cubic_u8(src, dst_h, dst_w, flip=False, tabs=None, out=None):
+    """cv2.resize(src, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC) [+ horizontal flip] of a (h,w,3) uint8 device image
+    (shapes.Image.data, shapes.py:19-29) -> (dst_h, dst_w, 3) uint8 device tensor.  ``tabs``: (tab_x, tab_y) DEVICE int32
+    tables to reuse (a captured pass keeps its own); ``out``: write into this tensor."""
+    _require_gpu()
+    assert src.is_cuda and src.dtype == torch.uint8 and src.dim() == 3 and src.shape[2] == 3 and src.is_contiguous()
+    sh, sw = int(src.shape[0]), int(src.shape[1])
+    if tabs is None:
+        tabs = (torch.from_numpy(resize_cubic_taps(dst_w, sw)).cuda(), torch.from_numpy(resize_cubic_taps(dst_h, sh)).cuda())
+    if out is None:
+        out = torch.empty((dst_h, dst_w, 3), dtype=torch.uint8, device="cuda")
+    _lib.call("frcnn_resize_cubic_u8", _p(src), sh, sw, _p(tabs[0]), _p(tabs[1]), int(dst_h), int(dst_w), 1 if flip else 0, _p(out), _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- anchors
 def anchors_image(rows, cols, anchor_hw, stride):
     _require_gpu()

@@ -91,15 +91,19 @@ class Image:
     _image_path = property(lambda s: s.metadata.image_path)
 
     @property
+    def raw(self):
+        """The decoded frame as cv2.imread delivers it: BGR uint8 at the FILE's size, before the resize and the flip that
+        ``data`` applies (shapes.py:24-27).  entry.DetectionEntry uploads this and resizes on the device."""
+        if self._pixels is not None:
+            return self._pixels
+        from PIL import Image as PilImage
+        return np.ascontiguousarray(np.asarray(PilImage.open(self._image_path).convert("RGB"))[:, :, ::-1])
+
+    @property
     def data(self):
         """BGR uint8 (height, width, 3) at the metadata's size, flipped if requested."""
-        if self._pixels is not None:
-            img = self._pixels
-            if img.shape[0] != self.height or img.shape[1] != self.width:
-                img = _resize(img, self.width, self.height)
-        else:
-            from PIL import Image as PilImage
-            img = np.asarray(PilImage.open(self._image_path).convert("RGB"))[:, :, ::-1]
+        img = self.raw
+        if img.shape[0] != self.height or img.shape[1] != self.width:
             img = _resize(img, self.width, self.height)
         return img[:, ::-1].copy() if self.flipped else img
 
@@ -119,6 +123,10 @@ class Image:
 class InMemoryImage:
     def __init__(self, data, width, height):
         self._data, self.width, self.height = data, width, height
+
+    @property
+    def raw(self):
+        return self._data
 
     @property
     def data(self):

@@ -24,6 +24,7 @@ from . import entry, nets, ops
 from .det_util import DetTrainingManager, nms  # noqa: F401  (re-exported like the reference module)
 
 DEFAULT_DET_THRESHOLD = 0.0
+DECODE_THREADS = int(os.environ.get("FRCNN_DECODE_THREADS", "4"))   # get_dets_by_cls: threads fetching the next images' pixels (0: inline)
 FAST_ENTRY = os.environ.get("FRCNN_ENTRY_EAGER", "0") == "0"      # False: always the eager path (tests and bench.py compare the two)
 
 
@@ -105,15 +106,30 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
         print("num rois: {}".format(num_boxes))
         fold(image, dets, start_time)
 
+    # the pixels of the NEXT images are fetched on a few threads while the GPU works (PIL's JPEG decode releases the GIL;
+    # the reference decodes and resizes inline, shapes.py:19-29); results are consumed strictly in list order
+    from concurrent.futures import ThreadPoolExecutor
+    images, resized_ratios = list(images), list(resized_ratios)
+    n = min(len(images), len(resized_ratios))
+    ahead = 2 * eng.in_flight
+    pool = ThreadPoolExecutor(max_workers=DECODE_THREADS) if n > 1 and DECODE_THREADS > 0 else None
+    pending = {}
     try:
-        for image, resized_ratio in zip(images, resized_ratios):
+        for i in range(n):
+            if pool is not None:
+                for j in range(i, min(n, i + ahead)):
+                    if j not in pending:
+                        pending[j] = pool.submit(eng.host_pixels, images[j])
             start_time = timeit.default_timer()
-            window.append((image, eng.submit(image, resized_ratio, det_threshold), start_time))
+            pixels = pending.pop(i).result() if pool is not None else None
+            window.append((images[i], eng.submit(images[i], resized_ratios[i], det_threshold, pixels=pixels), start_time))
             if len(window) >= eng.in_flight:
                 finish()
         while window:
             finish()
     finally:
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
         for _, ticket, _ in window:                    # an exception mid-list: no slot stays marked busy
             ticket.slot.event.synchronize()
             ticket.slot.busy = False

@@ -47,6 +47,15 @@ int frcnn_device_count(void);
  * for an interleaved 3-channel u8 image (BGR as cv2.imread delivers it); mean3_h is a HOST array of 3 doubles.
  * Bit-identical to the host path (float64 subtraction, one rounding to f32). */
 int frcnn_preprocess_u8(const uint8_t* img_hwc, size_t n_pixels, const double* mean3_h, float* out, void* stream);
+/* shapes.Image.data (shapes.py:19-29): cv2.resize(img, (width, height), interpolation=cv2.INTER_CUBIC) of the decoded uint8
+ * frame, then the optional horizontal flip (data[:, ::-1]).  OpenCV's 8-bit algorithm: four taps per axis (border replicated),
+ * cubic weights (A = -0.75) computed in f32 and rounded to 11-bit fixed point, both passes in integers, (v + 2^21) >> 22,
+ * saturate.  frcnn_resize_cubic_taps is a HOST function filling one axis' table [dst][8] = {4 source indices, 4 weights};
+ * frcnn_resize_cubic_u8 takes DEVICE copies of the x and y tables and writes dst [dst_h][dst_w][3].  Bit-identical to the
+ * integer restatement in shapes._resize (tests); like it, not pinned against cv2 itself (absent offline). */
+int frcnn_resize_cubic_taps(int dst, int src, int32_t* tab_h);
+int frcnn_resize_cubic_u8(const uint8_t* src_hwc, int src_h, int src_w, const int32_t* tab_x, const int32_t* tab_y,
+                          int dst_h, int dst_w, int flip, uint8_t* dst_hwc, void* stream);
 /* rpn_util._get_all_anchor_coords (rpn_util.py:276-298): all anchors in image pixels.
  * anchor_hw_h: host [A][2] = {height, width} (util.get_anchors, util.py:242-253).
  * out: [rows*cols*A][4] f32. */

@@ -45,3 +45,17 @@ def test_only_this_packages_models_take_the_captured_path():
     assert not entry.DetectionEntry.usable(mgr, object(), 64)                # foreign Keras-style models: eager path
     assert entry.for_models(mgr, object()) is None
     assert entry.default_in_flight("bf16") == 4
+
+
+def test_cubic_tap_tables_from_the_c_abi_equal_the_numpy_restatement():
+    """frcnn_resize_cubic_taps is a HOST function of the library (no GPU): OpenCV's f32 tap arithmetic written in C must give
+    the integers shapes._cubic_taps derives in numpy, for enlarging, shrinking, odd and degenerate sizes."""
+    import numpy as np
+    from faster_rcnn_amd import ops, shapes
+    rs = np.random.RandomState(0)
+    pairs = [(800, 500), (600, 375), (375, 600), (1000, 353), (901, 500), (7, 3), (3, 7), (1, 5), (5, 1), (640, 640)]
+    pairs += [(int(rs.randint(1, 1600)), int(rs.randint(1, 1600))) for _ in range(60)]
+    for dst, src in pairs:
+        tab = ops.resize_cubic_taps(dst, src)
+        idx, coef = shapes._cubic_taps(dst, src)
+        assert tab.shape == (dst, 8) and np.array_equal(tab[:, :4], idx) and np.array_equal(tab[:, 4:], coef), (dst, src)

@@ -223,3 +223,50 @@ def test_a_failed_image_leaves_no_slot_busy(models):
     assert not any(s.busy for v in eng.cache._slots.values() for s in v)
     res, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, [1.0, 1.0], [good, good])
     assert res
+
+
+def test_device_cubic_resize_is_the_host_resize_bit_for_bit():
+    """shapes.Image.data = cv2.resize(..., INTER_CUBIC) restated in integer numpy (shapes._resize, shapes.py:19-29 of the
+    reference); frcnn_resize_cubic_u8 must reproduce it exactly: enlarging, shrinking, odd sizes, saturation at both ends,
+    and the horizontal flip Image.horizontal_flip adds."""
+    from faster_rcnn_amd import ops, shapes
+    rs = np.random.RandomState(1)
+    cases = [((375, 500), (600, 800)), ((333, 500), (600, 901)), ((500, 375), (800, 600)), ((600, 800), (375, 500)), ((37, 53), (61, 40)), ((9, 7), (7, 23))]
+    for (sh, sw), (dh, dw) in cases:
+        for kind in ("noise", "extremes"):
+            src = rs.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
+            if kind == "extremes":                                   # blocks of 0 / 255: the cubic overshoots, the result saturates
+                src = (rs.randint(0, 2, (sh // 3 + 1, sw // 3 + 1, 3)) * 255).astype(np.uint8).repeat(3, axis=0).repeat(3, axis=1)[:sh, :sw]
+                src = np.ascontiguousarray(src)
+            want = shapes._resize(src, dw, dh)
+            got = ops.resize_cubic_u8(torch.from_numpy(src).cuda(), dh, dw)
+            assert got.shape == (dh, dw, 3) and np.array_equal(got.cpu().numpy(), want), ((sh, sw), (dh, dw), kind)
+            flipped = ops.resize_cubic_u8(torch.from_numpy(src).cuda(), dh, dw, flip=True, out=torch.full((dh, dw, 3), 7, dtype=torch.uint8, device="cuda"))
+            assert np.array_equal(flipped.cpu().numpy(), want[:, ::-1])
+
+
+def test_file_backed_images_are_resized_on_the_device_and_match_the_eager_path(models):
+    """The VOC frame as voc_dets.main feeds it: a JPEG on disk, metadata resized to 600x800.  The captured pass uploads the
+    decoded 375x500 frame and resizes it on the device; the eager path resizes on the host (shapes._resize).  Same pixels, so
+    the same detections; a flipped copy (train-time augmentation, shapes.py:27) likewise."""
+    from faster_rcnn_amd import entry, voc_dets
+    mgr, det, _, _ = models
+    image, ratio = voc_frame(True)
+    fast, eager, _, _ = both_paths(voc_dets.get_dets, mgr, det, image, ratio)
+    same_dets(fast, eager)
+    eng = entry.for_models(mgr, det, 64, 16, 1)
+    assert (600, 800, 375, 500, False) in eng.cache.keys()
+    flipped = image.horizontal_flip()
+    fast, eager, _, _ = both_paths(voc_dets.get_dets, mgr, det, flipped, ratio)
+    same_dets(fast, eager)
+    assert (600, 800, 375, 500, True) in eng.cache.keys()
+    # a list of files through get_dets_by_cls: pixels fetched ahead on threads, results in list order
+    frames = [voc_frame(True)[0] for _ in range(6)]
+    for i, f in enumerate(frames):
+        f.metadata.name = "f%d" % i
+    by_cls, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, [ratio] * 6, frames)
+    one, _ = quiet(voc_dets.get_dets, mgr, det, frames[0], ratio)
+    for cls_name, per_img in by_cls.items():
+        assert list(per_img) == ["f%d" % i for i in range(6) if "f%d" % i in per_img]
+        for name, dets in per_img.items():
+            same_dets(dets, [d for d in one if d["cls_name"] == cls_name], tol=1e-4)
