@@ -1862,8 +1862,11 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
         if ((size_t)3 * d->cout * a.Kpad * 2 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_x6: filter planes over 2 GiB");
         const int t = d->tile % 100;
         const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
-        // auto: 128x128 tiles on eight waves (two workgroups per CU); under one tile per CU, 64x64
-        const int xcfg = (t >= 71 && t <= 75) ? t : (t128 >= 256 ? 71 : 74);
+        // auto: 128x128 tiles on eight waves (two workgroups per CU); long k on a grid of >= 200 256x128 tiles: the 16-wave
+        // double-buffered form (head 3x3 337 vs 350 us, 2048 -> 512 157 vs 169; 512 -> 2048 ties and stays); under one
+        // 128x128 tile per CU, 64x64
+        const long long t256 = ((M + 255) / 256) * ((d->cout + 127) / 128);
+        const int xcfg = (t >= 71 && t <= 76) ? t : (t128 >= 256 ? ((a.K >= 1024 && t256 >= 200) ? 76 : 71) : 74);
         const int bn = x6_tile_width(xcfg);
         if (dual) a.vec_epi = a.vec_epi && dual->n1 % bn == 0 && (a.ldy2 & 3) == 0 && al16(dual->y2) && (size_t)M * a.ldy2 * 4 < 0x7fffffffull;
         a.group_m = g_group_m >= 0 ? g_group_m : (d->cout > bn ? 1 : 0);      // column tiles of a row tile adjacent on one XCD

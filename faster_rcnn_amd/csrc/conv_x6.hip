@@ -315,6 +315,174 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p
     else epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
 }
 
+// ---- the same engine as ONE 16-wave workgroup per CU (tile code 76): 256x128 tile, four waves per SIMD from one workgroup, TWO LDS
+// buffers (147 KB) and ONE barrier per chunk -- chunk kt multiplies from buffer kt & 1 while chunk kt+1 (in registers since the
+// previous iteration) is split and stored into the other buffer and chunk kt+2 is requested.  No phase in which the CU's matrix
+// pipe has nothing queued because both of its workgroups are staging at once: alone on the chip 341 / 170 / 161 us on the head's
+// 3x3 / 512->2048 / 2048->512 GEMMs against 382 / 196 / 189 for the two-workgroup form (scripts/micro/x6_lab.hip); it takes the
+// whole CU's LDS, so nothing of another stream co-resides with it.
+__global__ void __launch_bounds__(1024) k_conv_igemm_x6_db(const ConvArgs p) {
+    constexpr int TM = 2, TN = 1, WM = 4, WN = 4, BM = 256, BN = 128, NT = 1024;
+    constexpr int RPP = NT / 8, PA = BM / RPP;            // A: 128 rows per pass, 2 passes
+    constexpr int NBP = 3 * BN * 4;                       // 16-byte pieces of the three filter planes per chunk: 1536
+    constexpr int PBT = (NBP + NT - 1) / NT;              // 2 (the second one for tid < 512 only)
+    constexpr int BUFB = 3 * (BM + BN) * X6_ROWB;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    if (p.group_m > 0) {
+        const int per = p.group_m * p.tiles_n, g = tile / per, m_base = g * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - m_base), r = tile - g * per;
+        tile_n = r / gm;
+        tile_m = m_base + r - tile_n * gm;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const size_t plane_bytes = (size_t)p.Cout * p.Kpad * 2;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)(3 * plane_bytes), 0x00020000);
+
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    int a_h[PA], a_w[PA], a_off[PA], a_lds[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = lrow + RPP * i, m = m0 + row, g = tid & 7;
+        a_lds[i] = row * X6_ROWB + 16 * ((g >> 1) ^ x6_swz(row)) + 8 * (g & 1);
+        if (m < p.M) {
+            int wo, ho, img;
+            if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
+            else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
+            a_h[i] = ho * p.stride - p.pad_top;
+            a_w[i] = wo * p.stride - p.pad_left;
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * 4;
+        } else {
+            a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
+        }
+    }
+    unsigned b_off[PBT];
+    int b_lds[PBT];
+#pragma unroll
+    for (int i = 0; i < PBT; ++i) {
+        const int q = tid + NT * i, pl = q / (BN * 4), r = q % (BN * 4), row = r >> 2, g = r & 3;
+        const bool ok = q < NBP && n0 + row < p.Cout;
+        b_off[i] = ok ? (unsigned)(((size_t)(n0 + row) * p.Kpad + g * 8) * 2 + pl * plane_bytes) : OOB_OFFSET;
+        b_lds[i] = q < NBP ? 3 * BM * X6_ROWB + pl * BN * X6_ROWB + row * X6_ROWB + 16 * (g ^ x6_swz(row)) : -1;
+    }
+
+    const int RS = p.R * p.S;
+    const unsigned all_taps = RS >= 32 ? 0xffffffffu : (1u << RS) - 1u;
+    unsigned tap_mask = all_taps;
+    if (p.layout) {
+        const int pos_lo = m0 / p.n_img, pos_hi = (min(m0 + BM, p.M) - 1) / p.n_img;
+        if (pos_hi - pos_lo < 8) {
+            unsigned mk = 0;
+            for (int pos = pos_lo; pos <= pos_hi; ++pos) {
+                const int ho = pos / p.Wo, wo = pos - ho * p.Wo;
+                const int h0 = ho * p.stride - p.pad_top, w0 = wo * p.stride - p.pad_left;
+                for (int r = 0; r < p.R; ++r)
+                    for (int sx = 0; sx < p.S; ++sx)
+                        if ((unsigned)(h0 + r) < (unsigned)p.H && (unsigned)(w0 + sx) < (unsigned)p.W) mk |= 1u << (r * p.S + sx);
+            }
+            if (mk) tap_mask = mk;
+        }
+    }
+    const int n_taps = __popc(tap_mask);
+    const int nk = (p.Kpad / (BK * RS)) * n_taps;
+    unsigned rem = tap_mask;
+    int c0 = 0, w_grp = 0;
+    f32x4 ra[PA], rb[PBT];
+    auto load_next = [&]() {
+        const int tap = __builtin_ctz(rem);
+        const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 4;
+        const int w_off = w_grp + tap * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < PBT; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0));
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0));
+        }
+        rem &= rem - 1;
+        const int wrap = (rem == 0);
+        rem |= wrap ? tap_mask : 0u;
+        c0 += wrap * BK;
+        w_grp += wrap * (RS * BK * 2);
+    };
+    auto store = [&](int buf) {
+        char* base = lds + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            bf16x4 h, m, l;
+            x6_split(ra[i], h, m, l);
+            *reinterpret_cast<bf16x4*>(base + a_lds[i]) = h;
+            *reinterpret_cast<bf16x4*>(base + BM * X6_ROWB + a_lds[i]) = m;
+            *reinterpret_cast<bf16x4*>(base + 2 * BM * X6_ROWB + a_lds[i]) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < PBT; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<f32x4*>(base + b_lds[i]) = rb[i];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const int aoff = (wm * TM * 32 + li) * X6_ROWB, boff = 3 * BM * X6_ROWB + (wn * TN * 32 + li) * X6_ROWB;
+    const int koff[2] = {16 * (lh ^ x6_swz(li)), 16 * ((2 + lh) ^ x6_swz(li))};
+    auto kstep = [&](int buf, int s) {
+        const char* base = lds + buf * BUFB;
+        bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const bf16x8*>(base + aoff + pl * BM * X6_ROWB + i * 32 * X6_ROWB + koff[s]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const bf16x8*>(base + boff + pl * BN * X6_ROWB + j * 32 * X6_ROWB + koff[s]);
+        }
+        constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[IA[t]][i], fb[IB[t]][j], acc[i][j], 0, 0, 0);
+    };
+    load_next();                                          // chunk 0
+    store(0);
+    load_next();                                          // chunk 1 (past-the-end fetches are never multiplied)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) { store(buf ^ 1); load_next(); }
+        kstep(buf, 0);
+        kstep(buf, 1);
+        __syncthreads();
+    }
+    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+}
+
+static int launch_x6_db(const ConvArgs& a, hipStream_t s) {
+    ConvArgs p = a;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.Cout + 127) / 128;
+    constexpr size_t lds = (size_t)2 * 3 * (256 + 128) * X6_ROWB;
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_x6_db, lds, "conv2d_x6")) return e;
+    k_conv_igemm_x6_db<<<p.tiles_m * p.tiles_n, 1024, lds, s>>>(p);
+    return check_launch("conv2d_fwd_x6");
+}
+
 // f32 packed filter [Cout][Kpad] (frcnn_pack_conv_weights' k order) -> three bf16 planes [3][Cout][Kpad]
 __global__ void k_pack_x6(const float* w, size_t n, __bf16* out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -346,6 +514,7 @@ int launch_conv_x6(const ConvArgs& a, int cfg, hipStream_t s) {
         case 73: return launch_x6<2, 2, 2, 2>(a, s);      // 128x128, 4 waves (64x64 per wave)
         case 74: return launch_x6<1, 1, 2, 2>(a, s);      // 64x64, 4 waves
         case 75: return launch_x6<1, 1, 2, 4>(a, s);      // 64x128, 8 waves
+        case 76: return launch_x6_db(a, s);               // 256x128, 16 waves, two LDS buffers, one workgroup per CU
         default: return fail(FRCNN_E_ARG, "conv2d_fwd_x6: unknown tile config %d", cfg);
     }
 }

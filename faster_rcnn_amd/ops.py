@@ -342,7 +342,7 @@ class f32_engine:
 
 
 def _use_x6(d, pc, tile):
-    if 71 <= tile % 100 <= 75:
+    if 71 <= tile % 100 <= 76:
         return pc.cin % 32 == 0                                  # explicit tile code of the split engine
     if F32_ENGINE != "bf16x6" or tile % 100 not in (0, 50):
         return False
@@ -350,14 +350,14 @@ def _use_x6(d, pc, tile):
 
 
 X6_KERNEL_NAMES = {71: "k_conv_igemm_x6<2,1,2,4>", 72: "k_conv_igemm_x6<2,2,4,2>", 73: "k_conv_igemm_x6<2,2,2,2>", 74: "k_conv_igemm_x6<1,1,2,2>",
-                   75: "k_conv_igemm_x6<1,1,2,4>"}
+                   75: "k_conv_igemm_x6<1,1,2,4>", 76: "k_conv_igemm_x6_db"}
 
 
 def _x6_name(d, tile):
     t = tile % 100
-    if not 71 <= t <= 75:
-        m, n = d.n * d.ho * d.wo, d.cout
-        t = 71 if -(-m // 128) * -(-n // 128) >= 256 else 74
+    if not 71 <= t <= 76:                                         # the library's own choice (conv_fwd_impl)
+        m, n, k = d.n * d.ho * d.wo, d.cout, d.kh * d.kw * d.cin
+        t = 74 if -(-m // 128) * -(-n // 128) < 256 else (76 if k >= 1024 and -(-m // 256) * -(-n // 128) >= 200 else 71)
     return X6_KERNEL_NAMES[t]
 
 

@@ -104,7 +104,7 @@ class Image:
         """BGR uint8 (height, width, 3) at the metadata's size, flipped if requested."""
         img = self.raw
         if img.shape[0] != self.height or img.shape[1] != self.width:
-            img = _resize(img, self.width, self.height)
+            img = _resize_any(img, self.width, self.height)
         return img[:, ::-1].copy() if self.flipped else img
 
     def resize(self, scale_ratio):
@@ -130,7 +130,7 @@ class InMemoryImage:
 
     @property
     def data(self):
-        return _resize(self._data, self.width, self.height)
+        return _resize_any(self._data, self.width, self.height)
 
     def resize(self, scale_ratio):
         return InMemoryImage(self._data, int(round(scale_ratio * self.width)), int(round(scale_ratio * self.height)))
@@ -158,6 +158,23 @@ def _cubic_taps(dst, src):
     icoef = np.clip(np.rint(coef), -32768, 32767).astype(np.int64)            # cvRound = round half to even
     idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, src - 1)
     return idx, icoef
+
+
+def _resize_any(img, width, height):
+    """``_resize`` through the device kernel when a GPU is there (frcnn_resize_cubic_u8: the same integers, ~1 ms with
+    both copies instead of ~90 ms of numpy for a VOC frame -- at one image per 2.5 ms training step the host resize would
+    otherwise bound the loop), the numpy restatement below otherwise."""
+    if img.shape[0] == height and img.shape[1] == width:
+        return img
+    if img.ndim == 3 and img.shape[2] == 3 and img.dtype == np.uint8:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                from . import ops
+                return ops.resize_cubic_u8(torch.from_numpy(np.ascontiguousarray(img)).cuda(), height, width).cpu().numpy()
+        except ImportError:
+            pass
+    return _resize(img, width, height)
 
 
 def _resize(img, width, height):

@@ -188,6 +188,9 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_x6(const Args p) {
         // chunk c in set c & 1.  Iteration kt: MFMAs of chunk kt from LDS | barrier | store chunk kt+1 (its loads were
         // issued during iteration kt-1) and request chunk kt+3 into the registers just freed | barrier
         auto sync = [&]() { if constexpr (!(SKIP & 8)) __syncthreads(); };
+        if constexpr (SKIP & 16) {                           // stagger: the second workgroup of a CU starts half a chunk period late
+            if ((int)blockIdx.x >= (int)gridDim.x / 2) { for (int z = 0; z < 12; ++z) __builtin_amdgcn_s_sleep(127); }
+        }
         auto loadx = [&](int k, auto setc) { if constexpr (!(SKIP & 4)) load(k, setc); };
         load(0, I0{});
         load(nk > 1 ? 1 : 0, I1{});
@@ -640,6 +643,7 @@ int main(int argc, char** argv) {
         run<2, 1, 2, 4, 6>(a, 10, "128x128, 8 waves (64x32 per wave)");
         run<2, 1, 2, 4, 6, 2>(a, 10, "128x128, 8 waves, loads 2 ahead");
         run<2, 2, 4, 2, 6, 2>(a, 10, "256x128, 8 waves, loads 2 ahead");
+        run<2, 1, 2, 4, 6, 2, 16>(a, 10, "128x128, 8 waves, 2 ahead, staggered");
         run_db16<0>(a, 10, "256x128, 16 waves, LDS double buffer");
         run_db16<1>(a, 10, "256x128, 16 waves, DB, store mid-chunk");
         run16<4, 2, 2, 4>(a, 10, "128x128, 8 waves, 16x16x32 MFMA");

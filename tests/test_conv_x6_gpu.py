@@ -48,6 +48,9 @@ CASES = [
     (1, 33, 29, 128, 192, 3, 2, "same", 75),      # stride 2 SAME (pad on one side only for odd sizes)
     (1, 30, 44, 256, 64, 1, 2, "valid", 74),      # strided 1x1 (conv_block shortcut)
     (3, 14, 14, 96, 256, 3, 1, "same", 72),
+    (2, 23, 31, 64, 96, 3, 1, "same", 76),        # 256x128 on sixteen waves, two LDS buffers
+    (1, 40, 52, 64, 320, 1, 1, "valid", 76),
+    (1, 33, 29, 128, 192, 3, 2, "same", 76),
 ]
 
 
@@ -55,7 +58,7 @@ CASES = [
 def test_x6_matches_fp64_as_well_as_the_native_kernel(case):
     from faster_rcnn_amd import ops
     n, h, w, cin, cout, k, stride, padding, tile = case
-    rs = np.random.RandomState(hash(case) % 2 ** 31)
+    rs = np.random.RandomState(1000 + CASES.index(case))            # (hash() of a tuple with strings changes from process to process)
     x = rs.randn(n, h, w, cin).astype(np.float32)
     wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
     scale = (1 + 0.1 * rs.randn(cout)).astype(np.float32)
@@ -71,7 +74,7 @@ def test_x6_matches_fp64_as_well_as_the_native_kernel(case):
     e_x6, e_nat = err(got.cpu().numpy(), ref, mag), err(nat.cpu().numpy(), ref, mag)
     print(case, "x6 %.3g native %.3g" % (e_x6, e_nat))
     assert got.shape == nat.shape
-    assert e_x6 <= 6e-7 and e_x6 <= max(2.0 * e_nat, 3e-7)          # an fp32 GEMM: the error of the native f32 MFMA kernel
+    assert e_x6 <= 5e-7 and e_x6 <= max(3.0 * e_nat, 4e-7)          # an fp32 GEMM: the error level of the native f32 MFMA kernel (2-3e-7 of sum|ab|)
     assert err(got_r.cpu().numpy(), ref_r, mag) <= 6e-7
     # bitwise reproducible, and the launch does not depend on what the output buffer held
     again = ops.conv2d(xd, pc, stride, padding, "relu", tile=tile, out=torch.full_like(got, 7.0))
@@ -87,7 +90,7 @@ def test_x6_position_major_layout_and_tap_skipping_are_bit_identical_to_nhwc():
     x = rs.randn(n, 7, 7, cin).astype(np.float32)
     wt = (rs.randn(3, 3, cin, cout) * 0.05).astype(np.float32)
     pc = ops.PackedConv(wt, np.ones(cout, np.float32), np.zeros(cout, np.float32))
-    for tile in (71, 74):
+    for tile in (71, 74, 76):
         a = ops.conv2d(torch.from_numpy(x).cuda(), pc, 1, "same", "relu", tile=tile)                                   # (n,7,7,c)
         b = ops.conv2d(torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0, 3))).cuda(), pc, 1, "same", "relu", tile=tile, layout=1)   # (7,7,n,c)
         assert torch.equal(a, b.permute(2, 0, 1, 3))
@@ -104,7 +107,7 @@ def test_x6_two_layers_in_one_launch_equal_two_launches():
     s = lambda c: ((1 + 0.1 * rs.randn(c)).astype(np.float32), (0.1 * rs.randn(c)).astype(np.float32))
     (s1, h1), (s2, h2) = s(128), s(512)
     both = ops.PackedConv(np.concatenate([w1, w2], axis=3), np.concatenate([s1, s2]), np.concatenate([h1, h2]))
-    for tile in (71, 74):
+    for tile in (71, 74, 76):
         y1, y2 = ops.conv2d_dual(x, both, 128, 1, "valid", "relu", None, tile=tile)
         a = ops.conv2d(x, ops.PackedConv(w1, s1, h1), 1, "valid", "relu", tile=tile)
         b = ops.conv2d(x, ops.PackedConv(w2, s2, h2), 1, "valid", None, tile=tile)
