@@ -57,7 +57,8 @@ SIGNATURES = {
     "frcnn_conv2d_fwd_dual": (I, [P, P, P, P, P, P, I, I, P, I, P, c_size_t, P]),
     "frcnn_conv2d_dual_config": (I, [P, I]),
     "frcnn_pack_conv_weights_x6": (I, [P, I, I, P, P]),
-    "frcnn_conv2d_fwd_x6": (I, [P, P, P, P, P, P, P, P, P]),
+    "frcnn_conv2d_x6_workspace_bytes": (c_size_t, [P]),
+    "frcnn_conv2d_fwd_x6": (I, [P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_conv2d_fwd_dual_x6": (I, [P, P, P, P, P, P, I, I, P, I, P]),
     "frcnn_pack_conv_weights_dgrad": (I, [P, P, I, I, I, I, P, P]),
     "frcnn_conv2d_wgrad_workspace_bytes": (c_size_t, [P]),

@@ -1788,9 +1788,40 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
                          const float* scale, const float* shift, const float* residual, const float* mask, float* y,
                          const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream, bool x6 = false);
 
+// split-K factor of the split-bf16 engine's 64x64 form: grids under ~1.5 tiles per CU slot with a LONG k loop only
+// (k >= 2048: rpn_conv1, stage 4's 3x3, the 64-RoI training head); everything else runs unsplit or stays native
+static int choose_splits_x6(const frcnn_conv_desc* d) {
+    if (d->cin % BK) return 1;
+    const int t = d->tile % 100;
+    if (t != 0 && t != 50 && t != 74) return 1;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long tiles = ((M + 63) / 64) * ((d->cout + 63) / 64);
+    const int nk = (d->kh * d->kw * d->cin) / BK;
+    if (tiles * sizeof(unsigned) > SPLITK_TICKET_BYTES) return 1;
+    int s = d->tile / 100;
+    if (s <= 0) {
+        if (tiles >= 640 || nk < 64) return 1;
+        s = tiles >= 384 ? 3 : (tiles >= 100 ? (tiles >= 250 ? 4 : 6) : (int)((768 + tiles - 1) / tiles));
+        if (s > nk / 8) s = nk / 8;
+        if (s > 16) s = 16;
+    }
+    if (s > nk) s = nk;
+    return s < 1 ? 1 : s;
+}
+
+size_t frcnn_conv2d_x6_workspace_bytes(const frcnn_conv_desc* d) {
+    if (!d || d->cin <= 0) return 0;
+    const int splits = choose_splits_x6(d);
+    if (splits <= 1) return 0;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const size_t tiles = (size_t)((M + 63) / 64) * ((d->cout + 63) / 64);
+    return SPLITK_TICKET_BYTES + tiles * splits * 64 * 64 * sizeof(float);
+}
+
 int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16,
-                        const float* scale, const float* shift, const float* residual, const float* mask, float* y, void* stream) {
-    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_bf16), scale, shift, residual, mask, y, nullptr, nullptr, 0, stream, true);
+                        const float* scale, const float* shift, const float* residual, const float* mask, float* y,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_bf16), scale, shift, residual, mask, y, nullptr, workspace, workspace_bytes, stream, true);
 }
 
 int frcnn_conv2d_fwd_dual_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16, const float* scale, const float* shift,
@@ -1867,6 +1898,17 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
         // 128x128 tile per CU, 64x64
         const long long t256 = ((M + 255) / 256) * ((d->cout + 127) / 128);
         const int xcfg = (t >= 71 && t <= 76) ? t : (t128 >= 256 ? ((a.K >= 1024 && t256 >= 200) ? 76 : 71) : 74);
+        if (workspace && !dual) {
+            const size_t need = frcnn_conv2d_x6_workspace_bytes(d);
+            if (need) {
+                if (workspace_bytes < need) return fail(FRCNN_E_WORKSPACE, "conv2d_fwd_x6: workspace needs %zu bytes", need);
+                a.splits = choose_splits_x6(d);
+                a.tickets = (unsigned*)workspace;
+                a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
+                a.group_m = 0;
+                return launch_conv_x6(a, 174, s);
+            }
+        }
         const int bn = x6_tile_width(xcfg);
         if (dual) a.vec_epi = a.vec_epi && dual->n1 % bn == 0 && (a.ldy2 & 3) == 0 && al16(dual->y2) && (size_t)M * a.ldy2 * 4 < 0x7fffffffull;
         a.group_m = g_group_m >= 0 ? g_group_m : (d->cout > bn ? 1 : 0);      // column tiles of a row tile adjacent on one XCD

@@ -122,7 +122,10 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
     }
 }
 
-template <int TM, int TN, int WM, int WN>
+// SPLITK (64x64 tiles): small grids with a long k loop (rpn_conv1, stage 4's 3x3 at 2 394 rows) cut the chunk sequence into
+// `splits` slices, one workgroup each; the f32 kernel's protocol (conv_igemm.hip): write-through partial tiles, a ticket per
+// tile, the last arriver sums the slabs in slice order (bitwise reproducible) and runs the epilogue.
+template <int TM, int TN, int WM, int WN, bool SPLITK = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p) {
     using T = X6Tile<TM, TN, WM, WN>;
     constexpr int NT = T::NT, BM = T::BM, BN = T::BN;
@@ -139,8 +142,11 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int splits = SPLITK ? p.splits : 1;
+    const int nwg = p.tiles_m * p.tiles_n * splits;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tile = SPLITK ? logical / splits : logical;         // a tile's slices are neighbours on one XCD
+    const int slice = SPLITK ? logical - tile * splits : 0;
     int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
     if (p.group_m > 0) {                                  // grouped order (see k_conv_igemm_f32_v2): g row tiles x all column tiles
         const int per = p.group_m * p.tiles_n, g = tile / per, m_base = g * p.group_m;
@@ -199,10 +205,17 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p
         }
     }
     const int n_taps = __popc(tap_mask);
-    const int nk = (p.Kpad / (BK * RS)) * n_taps;         // chunks of this tile: (channel group, needed tap) pairs
+    const int nk_all = (p.Kpad / (BK * RS)) * n_taps;     // chunks of this tile: (channel group, needed tap) pairs
+    const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
+    const int nk = (SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all) - kb;      // this workgroup's chunks
 
     unsigned rem = tap_mask;                              // taps of the current channel group still to load
     int c0 = 0, w_grp = 0;                                // channel offset / bf16 byte offset of the group's filter chunks
+    if (SPLITK) {
+        const int grp = kb / n_taps;
+        c0 = grp * BK; w_grp = grp * RS * (BK * 2);
+        for (int t = kb - grp * n_taps; t > 0; --t) rem &= rem - 1;
+    }
     // the NEXT chunk of the sequence -> staging set S (calls walk the sequence in order; calls past its end fetch in-bounds
     // or zero data that is never multiplied)
     f32x4 ra[2][PA];
@@ -310,6 +323,56 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p
     if (kt < nk) {
         compute();
         __syncthreads();                                  // the epilogue reuses the buffer
+    }
+    if constexpr (SPLITK) {
+        // publish this slice's partial tile WRITE-THROUGH (sc1 stores need no release fence), thread-major 16-byte rows
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.slabs, 0, (int)((size_t)p.tiles_m * p.tiles_n * splits * (BM * BN) * 4), 0x00020000);
+        const unsigned slab_off = (unsigned)((tile * splits + slice) * (BM * BN) * 4 + tid * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), srsrc, slab_off + ((i * TN + j) * 4 + q) * (NT * 16), 0, 16 /* sc1 */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains ...
+        __syncthreads();                                       // ... before ONE lane draws the ticket
+        int* last = reinterpret_cast<int*>(lds);
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = (t == (unsigned)(splits - 1));
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // drop this CU's stale L1 lines
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            *last = is_last;
+        }
+        __syncthreads();
+        if (!*last) return;
+        const float4* base = reinterpret_cast<const float4*>(p.slabs + (size_t)tile * splits * (BM * BN));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+        for (int sl = 0; sl < splits; ++sl) {                  // slice order: two runs are bitwise equal
+            const float4* sp = base + (size_t)sl * (BM * BN / 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = sp[((i * TN + j) * 4 + q) * NT + tid];
+                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                    }
+        }
+        __syncthreads();                                       // the flag word is read; the epilogue reuses the buffer
     }
     if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
     else epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
@@ -515,6 +578,14 @@ int launch_conv_x6(const ConvArgs& a, int cfg, hipStream_t s) {
         case 74: return launch_x6<1, 1, 2, 2>(a, s);      // 64x64, 4 waves
         case 75: return launch_x6<1, 1, 2, 4>(a, s);      // 64x128, 8 waves
         case 76: return launch_x6_db(a, s);               // 256x128, 16 waves, two LDS buffers, one workgroup per CU
+        case 174: {                                       // 64x64 with split-K (a.splits / a.slabs / a.tickets set by the caller)
+            using T = X6Tile<1, 1, 2, 2>;
+            ConvArgs p = a;
+            p.tiles_m = (p.M + 63) / 64;
+            p.tiles_n = (p.Cout + 63) / 64;
+            k_conv_igemm_x6<1, 1, 2, 2, true><<<p.tiles_m * p.tiles_n * p.splits, T::NT, T::lds, s>>>(p);
+            return check_launch("conv2d_fwd_x6 (split-K)");
+        }
         default: return fail(FRCNN_E_ARG, "conv2d_fwd_x6: unknown tile config %d", cfg);
     }
 }

@@ -346,7 +346,12 @@ def _use_x6(d, pc, tile):
         return pc.cin % 32 == 0                                  # explicit tile code of the split engine
     if F32_ENGINE != "bf16x6" or tile % 100 not in (0, 50):
         return False
-    return pc.cin % 32 == 0 and d.n * d.ho * d.wo >= X6_MIN_ROWS and pc.kh * pc.kw * pc.cin >= X6_MIN_K and pc.cout >= X6_MIN_COUT
+    if pc.cin % 32 or pc.cout < X6_MIN_COUT or pc.kh * pc.kw * pc.cin < X6_MIN_K:
+        return False
+    if d.n * d.ho * d.wo >= X6_MIN_ROWS:
+        return True
+    # small grids with a long k loop (rpn_conv1, stage 4's 3x3): the engine's split-K form, where split-K launches are allowed
+    return _CONV_WS is not NO_SPLIT_K and _ws_need(d, "frcnn_conv2d_x6_workspace_bytes") > 0
 
 
 X6_KERNEL_NAMES = {71: "k_conv_igemm_x6<2,1,2,4>", 72: "k_conv_igemm_x6<2,2,4,2>", 73: "k_conv_igemm_x6<2,2,2,2>", 74: "k_conv_igemm_x6<1,1,2,2>",
@@ -465,11 +470,14 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
     if _use_x6(d, pc, tile or AUTO_TILE):
-        args = (ctypes.byref(d), _p(x), _p(pc.x6_planes()), _p(pc.scale), _p(pc.shift), _p(residual), None, _p(out))
+        ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_x6_workspace_bytes"))
+        args = (ctypes.byref(d), _p(x), _p(pc.x6_planes()), _p(pc.scale), _p(pc.shift), _p(residual), None, _p(out),
+                _p(ws), ws.numel() if ws is not None else 0)
         _lib.call("frcnn_conv2d_fwd_x6", *args, _stream())
         if CONV_PROFILE is not None:
-            keep = (d, x, pc, residual, out)
-            CONV_PROFILE.append({"kernel": _x6_name(d, tile), "flops": 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin,
+            keep = (d, x, pc, residual, out, ws)
+            CONV_PROFILE.append({"kernel": "k_conv_igemm_x6<1,1,2,2> split-K" if ws is not None else _x6_name(d, tile),
+                                 "flops": 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin,
                                  "shape": (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
                                  "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_x6", *args, _stream())})
         return out

@@ -260,13 +260,17 @@ int frcnn_conv2d_dual_config(const frcnn_conv_desc* d, int has_workspace);
  * f32 operand is the exact sum of three bf16 values; the six partial products that matter are multiplied on
  * v_mfma_f32_32x32x16_bf16 (each exact in f32) and accumulated in f32: the error against fp64 is that of the native f32 MFMA
  * kernel (measured 2.2e-7 vs 2.7e-7 of sum|ab|), at up to 2.67x its matrix rate.  A different summation order: results agree
- * with frcnn_conv2d_fwd to f32 rounding, not bit for bit.  cin % 32 == 0, no split-K form (large grids only).
+ * with frcnn_conv2d_fwd to f32 rounding, not bit for bit.  cin % 32 == 0.
  * frcnn_pack_conv_weights_x6: f32 packed filter [cout][packed_k] (frcnn_pack_conv_weights, scale folded or not) -> three
  * bf16 planes [3][cout][packed_k] (6 bytes per weight).  tile: 0 = auto, 71: 128x128 on 8 waves, 72: 256x128, 73: 128x128 on
  * 4 waves, 74: 64x64, 75: 64x128. */
 int frcnn_pack_conv_weights_x6(const float* w_packed, int cout, int packed_k, void* planes_bf16, void* stream);
+/* workspace (may be NULL): small grids with k >= 2048 cut K over several workgroups like frcnn_conv2d_fwd_ws does (tickets zero on
+ * entry, left zero; frcnn_conv2d_x6_workspace_bytes: 0 = this shape runs unsplit). */
+size_t frcnn_conv2d_x6_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16,
-                        const float* scale, const float* shift, const float* residual, const float* mask, float* y, void* stream);
+                        const float* scale, const float* shift, const float* residual, const float* mask, float* y,
+                        void* workspace, size_t workspace_bytes, void* stream);
 int frcnn_conv2d_fwd_dual_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16, const float* scale, const float* shift,
                              float* y1, int n1, int act1, float* y2, int act2, void* stream);
 /* Filter of the input-gradient convolution: transposed (cin <-> cout), flipped in both taps, input

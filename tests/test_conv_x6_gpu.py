@@ -145,4 +145,34 @@ def test_engine_policy_scope_and_refusals():
     with pytest.raises(_lib.FrcnnError):
         import ctypes
         d = ops._conv_desc((1, 8, 8, 48), 1, 1, 64, 1, "valid", 0, 0, 71)
-        _lib.call("frcnn_conv2d_fwd_x6", ctypes.byref(d), y.data_ptr(), y.data_ptr(), None, None, None, None, y.data_ptr(), None)
+        _lib.call("frcnn_conv2d_fwd_x6", ctypes.byref(d), y.data_ptr(), y.data_ptr(), None, None, None, None, y.data_ptr(), None, 0, None)
+
+
+def test_x6_split_k_small_grid_long_k():
+    """rpn_conv1 / stage-4 shapes (2 394 rows, k = 9 216 / 2 304): the engine's 64x64 split-K form -- partial tiles summed in slice
+    order by the last arriver -- against fp64, bitwise reproducible, tickets left zero (a second launch on the same workspace)."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(8)
+    for (h, w, cin, cout, k) in ((38, 63, 1024, 512, 3), (38, 63, 256, 256, 3), (19, 31, 2048, 192, 1)):
+        x = rs.randn(1, h, w, cin).astype(np.float32)
+        wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+        scale = (1 + 0.1 * rs.randn(cout)).astype(np.float32); shift = (0.1 * rs.randn(cout)).astype(np.float32)
+        pc = ops.PackedConv(wt, scale, shift)
+        xd = torch.from_numpy(x).cuda()
+        ws = ops.ConvWorkspace()
+        ops.CONV_PROFILE = []
+        try:
+            with ops.f32_engine("bf16x6"), ops.conv_workspace(ws):
+                got = ops.conv2d(xd, pc, 1, "same", "relu")
+                again = ops.conv2d(xd, pc, 1, "same", "relu", out=torch.full_like(got, 3.0))
+            with ops.f32_engine("bf16x6"), ops.conv_workspace(ops.NO_SPLIT_K):
+                plain = ops.conv2d(xd, pc, 1, "same", "relu")
+            names = [r["kernel"] for r in ops.CONV_PROFILE]
+        finally:
+            ops.CONV_PROFILE = None
+        assert names[0].endswith("split-K") and "x6" in names[0] and "x6" not in names[2], names      # without a workspace the small grid stays native
+        ref, mag = ref_conv(x, wt, 1, "same", scale, shift, None, "relu")
+        assert err(got.cpu().numpy(), ref, mag) <= 5e-7
+        assert torch.equal(got, again)
+        assert err(plain.cpu().numpy(), ref, mag) <= 5e-7
+        assert not ws.buf[:16384].any().item()                   # tickets back to zero
