@@ -1801,7 +1801,7 @@ static int choose_splits_x6(const frcnn_conv_desc* d) {
     int s = d->tile / 100;
     if (s <= 0) {
         if (tiles >= 640 || nk < 64) return 1;
-        s = tiles >= 384 ? 3 : (tiles >= 100 ? (tiles >= 250 ? 4 : 6) : (int)((768 + tiles - 1) / tiles));
+        s = tiles >= 100 ? 3 : (int)((768 + tiles - 1) / tiles);      // sweep (MI355X): rpn_conv1 (304 tiles) 209 / 192 / 204 / 189 us at 2 / 3 / 4 / 5 slices, stage 4 3x3 (152) 32.6 / 34.2 / 33.4 at 3 / 4 / 6
         if (s > nk / 8) s = nk / 8;
         if (s > 16) s = 16;
     }

@@ -235,6 +235,11 @@ class DetectionEntry:
             self.cache.clear()
             self._epoch = models.weights_epoch()
 
+    def prefetchable(self, image):
+        """True when ``host_pixels(image)`` is pure host work (a JPEG decode) that another thread may do ahead of time; images
+        without ``raw`` and foreign preprocess functions are fetched inline (their ``data`` may use the device)."""
+        return self.device_preprocess and hasattr(image, "raw") and hasattr(image, "height")
+
     def host_pixels(self, image):
         """What ``submit`` uploads for this image -- safe to call from another thread ahead of time (JPEG decode).
         Returns (array, H, W, src or None, flip)."""

@@ -553,6 +553,11 @@ class _StepDriver:
         if self._refresh_jobs is None:
             self._refresh_jobs = make_refresh_jobs(self._tconvs())
         refresh_packed(self._refresh_jobs)
+        # the packed f32 filters were rewritten IN PLACE: bf16 planes derived from them for the split-bf16 engine
+        # (ops.PackedConv.x6_planes, cached on tensor identity) are stale now
+        for c in self._tconvs():
+            if getattr(c.pc, "_x6", None) is not None:
+                c.pc._x6 = None
 
     def _stage(self, host_inputs):
         """Host arrays (any dtype: Keras hands float64 images and bool targets) -> pinned float32 staging memory in ONE

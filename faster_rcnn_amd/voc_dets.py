@@ -118,10 +118,10 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
         for i in range(n):
             if pool is not None:
                 for j in range(i, min(n, i + ahead)):
-                    if j not in pending:
+                    if j not in pending and eng.prefetchable(images[j]):
                         pending[j] = pool.submit(eng.host_pixels, images[j])
             start_time = timeit.default_timer()
-            pixels = pending.pop(i).result() if pool is not None else None
+            pixels = pending.pop(i).result() if i in pending else None
             window.append((images[i], eng.submit(images[i], resized_ratios[i], det_threshold, pixels=pixels), start_time))
             if len(window) >= eng.in_flight:
                 finish()
