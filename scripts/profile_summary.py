@@ -15,9 +15,11 @@ def bench_kernel_name(k):
     m = re.search(r"k_conv_igemm_f32_sk<(\d+), (\d+)>", k)
     if m:
         return "k_conv_igemm_f32_sk<%s,%s>" % m.groups()
-    m = re.search(r"k_conv_igemm_x6<(\d+), (\d+), (\d+), (\d+)>", k)
+    m = re.search(r"k_conv_igemm_x6<(\d+), (\d+), (\d+), (\d+)(, (true|false))?>", k)
     if m:
-        return "k_conv_igemm_x6<%s,%s,%s,%s>" % m.groups()
+        return "k_conv_igemm_x6<%s,%s,%s,%s>" % m.groups()[:4] + (" split-K" if m.group(6) == "true" else "")
+    if "k_conv_igemm_x6_db" in k:
+        return "k_conv_igemm_x6_db"
     m = re.search(r"k_conv_igemm_bf16<", k)
     if m:
         return "k_conv_igemm_bf16"
