@@ -3,7 +3,7 @@
 #   bash scripts/sanitize_host.sh [out.txt]
 set -e
 cd "$(dirname "$0")/.."
-OUT=${1:-profiles/round3_host_sanitizers.txt}
+OUT=${1:-profiles/round4_host_sanitizers.txt}
 B=/tmp/frcnn_sanitize; mkdir -p $B
 FLAGS="-O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=address,undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
 pids=""

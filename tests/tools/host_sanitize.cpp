@@ -84,6 +84,48 @@ int main() {
     if (frcnn_roi_crop_resize_fwd_bf16_batch(&dummy, 2, 38, 94, 12, &dummy, 300, 7, nullptr, 0, 1, &dummy, nullptr) == FRCNN_OK) { printf("roi batch accepted C %% 8 != 0\n"); ++failures; }
     if (frcnn_roi_crop_resize_fwd_bf16_batch(nullptr, 2, 38, 94, 16, nullptr, 300, 7, nullptr, 0, 1, nullptr, nullptr) == FRCNN_OK) { printf("roi batch accepted nulls\n"); ++failures; }
     checked += 14;
+    // ---- round 4: the split-bf16 engine's host logic (split-K policy / workspace sizing over random descriptors), the resize tap
+    // tables (a pure host function), argument validation of the new entry points
+    for (int it = 0; it < 20000; ++it) {
+        frcnn_conv_desc q;
+        memset(&q, 0, sizeof q);
+        q.n = 1 + rnd() % 4; q.h = 1 + rnd() % 200; q.w = 1 + rnd() % 200;
+        q.cin = pick({32, 64, 128, 256, 512, 1024, 2048, 48, 3}); q.cout = pick({18, 45, 64, 128, 256, 512, 1024, 2048});
+        q.kh = q.kw = pick({1, 3}); q.stride = pick({1, 2});
+        q.ho = (q.h + q.stride - 1) / q.stride; q.wo = (q.w + q.stride - 1) / q.stride;
+        q.tile = pick({0, 50, 71, 74, 76, 274, 374, 1674, 23});
+        q.layout = rnd() % 2;
+        const size_t need = frcnn_conv2d_x6_workspace_bytes(&q);
+        const long long tiles = (((long long)q.n * q.ho * q.wo + 63) / 64) * ((q.cout + 63) / 64);
+        if (need && (need < 16384 || (need - 16384) % (64 * 64 * 4) != 0 || (long long)((need - 16384) / (64 * 64 * 4)) % tiles != 0)) { printf("x6 workspace size inconsistent\n"); ++failures; }
+        if (need && (q.cin % 32)) { printf("x6 split-K offered for cin %% 32 != 0\n"); ++failures; }
+        ++checked;
+    }
+    for (int it = 0; it < 300; ++it) {
+        const int dst = 1 + rnd() % 1600, src = 1 + rnd() % 1600;
+        std::vector<int32_t> tab((size_t)dst * 8 + 8, 0x5a5a5a5a);
+        if (frcnn_resize_cubic_taps(dst, src, tab.data()) != FRCNN_OK) { printf("resize taps failed\n"); ++failures; }
+        for (int d2 = 0; d2 < dst; ++d2)
+            for (int k = 0; k < 4; ++k)
+                if (tab[8 * d2 + k] < 0 || tab[8 * d2 + k] >= src || tab[8 * d2 + 4 + k] < -32768 || tab[8 * d2 + 4 + k] > 32767) { printf("resize tap out of range\n"); ++failures; }
+        if (tab[(size_t)dst * 8] != 0x5a5a5a5a) { printf("resize taps wrote past the table\n"); ++failures; }
+        ++checked;
+    }
+    if (frcnn_resize_cubic_taps(0, 5, nullptr) == FRCNN_OK) { printf("resize taps accepted a bad argument\n"); ++failures; }
+    if (frcnn_resize_cubic_u8(nullptr, 1, 1, nullptr, nullptr, 1, 1, 0, nullptr, nullptr) == FRCNN_OK) { printf("resize accepted nulls\n"); ++failures; }
+    if (frcnn_pack_conv_weights_x6(&dummy, 64, 48, &dummy, nullptr) == FRCNN_OK) { printf("pack x6 accepted k %% 32 != 0\n"); ++failures; }
+    memset(&d, 0, sizeof d);
+    d.n = 1; d.h = d.w = d.ho = d.wo = 8; d.cin = 48; d.cout = 64; d.kh = d.kw = 1; d.stride = 1;
+    if (frcnn_conv2d_fwd_x6(&d, &dummy, &dummy, nullptr, nullptr, nullptr, nullptr, &dummy, nullptr, 0, nullptr) == FRCNN_OK) { printf("x6 accepted cin %% 32 != 0\n"); ++failures; }
+    d.cin = 64;
+    if (frcnn_conv2d_fwd_dual_x6(&d, &dummy, &dummy, nullptr, nullptr, &dummy, 64, 1, &dummy, 0, nullptr) == FRCNN_OK) { printf("dual x6 accepted n1 == cout\n"); ++failures; }
+    {
+        int32_t i32 = 0; double dyn_misaligned[2];
+        if (frcnn_detections_dyn(&dummy, &i32, 64, 600, &dummy, &dummy, 21, 20, 16.0, 0.5, dyn_misaligned, &i32, &dummy, &i32, &i32, &i32, nullptr) == FRCNN_OK) { printf("detections_dyn accepted 600 rows\n"); ++failures; }
+        if (frcnn_detections_dyn(&dummy, &i32, 64, 320, &dummy, &dummy, 21, 20, 16.0, 0.5, nullptr, &i32, &dummy, &i32, &i32, &i32, nullptr) == FRCNN_OK) { printf("detections_dyn accepted a null dyn\n"); ++failures; }
+        if (frcnn_conv2d_dual_config(nullptr, 0) >= 0) { printf("dual_config accepted null\n"); ++failures; }
+    }
+    checked += 8;
     printf("host sanitizer driver: %d checks, %d failures\n", checked, failures);
     return failures ? 1 : 0;
 }
