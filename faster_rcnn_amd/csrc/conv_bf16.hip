@@ -43,6 +43,14 @@ constexpr int LDS_STRIDE_B = 144;       // bytes per LDS row
 constexpr unsigned OOB_OFFSET_B = 0x80000000u;
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+// Lab builds (scripts/micro/bf16_stamps.hip) compile this file with FRCNN_LAB_STAMPS: a workgroup of the direct-to-LDS forms then
+// records the 100 MHz wall clock at its phase boundaries.  The product library never defines it.
+#ifdef FRCNN_LAB_STAMPS
+__device__ unsigned long long* g_lab_stamps_b = nullptr;
+#define LAB_STAMP_B(i) do { if (g_lab_stamps_b && threadIdx.x == 0) g_lab_stamps_b[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LAB_STAMP_B(i) do { } while (0)
+#endif
 constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
 
 __device__ __forceinline__ int xcd_remap_b(int bid, int nwg) {
@@ -78,6 +86,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
+    LAB_STAMP_B(0);
 
     const int splits = SPLITK ? p.splits : 1;
     const int nwg = p.tiles_m * p.tiles_n * splits;
@@ -329,6 +338,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         prep();                                                   // chunk kb + 1 (never issued if the range has one chunk)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        LAB_STAMP_B(1);
         for (int kc = kb; kc < ke; ++kc) {
             const int buf = (kc - kb) & 1;
             if (kc + 1 < ke) issue(buf ^ 1);
@@ -517,6 +527,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
     }
 
     // epilogue: C/D map col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    LAB_STAMP_B(2);
     if constexpr (EPI_ROWS) {
         if (p.epi_rows) {
             float* stg = reinterpret_cast<float*>(smem_b);               // [BM][BN] f32, unpadded (see the read order below)
@@ -533,6 +544,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                 }
             }
             __syncthreads();
+            LAB_STAMP_B(3);
             const int prow = tid / PPR, pcol = (tid % PPR) * 8;
             // a row is BN floats, unpadded: lanes c and c + 8 of a row would meet on the same banks, so the upper eight read
             // their second 16 bytes first
@@ -573,6 +585,16 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                     }
                 }
             }
+#ifdef FRCNN_LAB_STAMPS
+            LAB_STAMP_B(4);                                      // stores issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LAB_STAMP_B(5);                                      // stores done
+            if (g_lab_stamps_b && threadIdx.x == 0) {
+                unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                g_lab_stamps_b[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+            }
+#endif
             return;
         }
     }
@@ -631,6 +653,16 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                 }
             }
         }
+#ifdef FRCNN_LAB_STAMPS
+        LAB_STAMP_B(3); LAB_STAMP_B(4);                          // (per-wave patches: no workgroup-wide staging phase)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LAB_STAMP_B(5);
+        if (g_lab_stamps_b && threadIdx.x == 0) {
+            unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_lab_stamps_b[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+        }
+#endif
         return;
     }
 #pragma unroll
