@@ -727,6 +727,12 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
         dt, dets = run(images)
         t += dt
     n_dets = sum(len(v) for per_img in dets.values() for v in per_img.values())
+    # the same call on a list eight times as long (the 32 frames repeated): a 32-frame call spends ~1/8 of its time filling and
+    # draining the images in flight (the host waits on the device for 90 % of the call: scripts/dev/entry_profile.py)
+    long_imgs = [shapes.Image(shapes.Metadata("synth%03d_%d" % (i, k), WIDTH, HEIGHT, [], "none"), im.raw) for k in range(8) for i, im in enumerate(images)]
+    ratios = ratios * 8
+    t_long, _ = run(long_imgs)
+    ratios = ratios[:n_images]
     dtype = getattr(pipe.det.head, "dtype", "f32")
     eng = entry.for_models(mgr, pipe.det, 64, 16, entry.default_in_flight(dtype))
     voc_dets.FAST_ENTRY = False
@@ -771,12 +777,15 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
         from_files = {"error": "%s: %s" % (type(e).__name__, e)}
     return {"value": round(n_images * passes / t, 3), "from_files": from_files, "unit": "img/s", "images": n_images, "passes": passes,
             "detections_per_image": round(n_dets / n_images, 1), "first_pass_s": round(t_first, 3), "graph_cache": eng.stats(),
+            "long_list": {"value": round(len(long_imgs) / t_long, 3), "unit": "img/s", "images": len(long_imgs)},
             "eager": {"value": round(eager_images / t_eager, 3), "unit": "img/s", "images": eager_images,
                       "what": "the same call with voc_dets.FAST_ENTRY = False: get_det_inputs returns the conv map and the RoIs as numpy "
                               "(det_util.py:136-158), the detector takes them back (voc_dets.py:49), one image at a time"},
             "same_detection_counts_as_eager": bool(same),
             "what": "voc_dets.get_dets_by_cls(DetTrainingManager, detector, ratios, images) over %d distinct %dx%d uint8 frames in host memory, "
-                    "%d images in flight, list of detection dicts out; wall clock of the whole call" % (n_images, HEIGHT, WIDTH, eng.in_flight)}
+                    "%d images in flight, list of detection dicts out; wall clock of the whole call.  The detector head runs over %d RoI rows per "
+                    "image here (the reference pads the last batch of 64 with copies of its first RoI and scores the copies too, "
+                    "voc_dets.py:42-51), against %d in the headline" % (n_images, HEIGHT, WIDTH, eng.in_flight, -(-PROPOSALS // 64) * 64, PROPOSALS)}
 
 
 _JSON_OUT = None
