@@ -4,11 +4,12 @@
 //   v2  k_gemm_ring2_bf16<RES, NSLOT, AUX>    MFMA operands swapped: a lane owns one output row, 8-byte stores straight from registers
 //   v3  k_gemm_ring3_bf16<RES, NSLOT, NLOAD>  dedicated loader waves (the compute waves' vmcnt sees no operand request)
 //   v4  k_gemm_ring4_bf16<RES, NSTORE>        dedicated store waves (bf16 half tiles handed over through LDS)
+//   v5  k_gemm_ring5_bf16<RES>                sixteen waves, the epilogue of tile j spread over the chunk steps of tile j + 1
 // Lab switches: -DFRCNN_RING_NOMUL / -DFRCNN_RING_NOEPI (v1: the request stream alone), -DFRCNN_RING_FAKEEPI (v2: accumulators
 // consumed, nothing stored).  Dev tool, GPU box only.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude scripts/micro/bf16_ring_lab.hip -o scripts/micro/_bin/bf16_ring_lab
-//   bf16_ring_lab <rows> <cin> <cout> <residual 0/1> <variant>     variant: v1_32_4 v1_64_3 v1_64_4 v2_2 v2_3 v2_4 v2_2nt v3_2_1 v3_2_2 v3_4_2 v4_2 v4_4
+//   bf16_ring_lab <rows> <cin> <cout> <residual 0/1> <variant>     variant: v1_32_4 v1_64_3 v1_64_4 v2_2 v2_3 v2_4 v2_2nt v3_2_1 v3_2_2 v3_4_2 v4_2 v4_4 v5
 #include "../../faster_rcnn_amd/csrc/conv_bf16.hip"
 #include <string>
 #include <vector>
@@ -733,6 +734,177 @@ static int launch_ring_bf16(const ConvArgsBf16& a, hipStream_t s) {
 }
 
 
+// Ring form, fifth version: the epilogue DEFERRED into the next tile's chunk steps.  store_probe.hip: the 481 MB of a 512 -> 2048
+// output leave in 82-88 us by themselves (5.5-5.9 TB/s) and in 188-191 us with the residual read beside them (5.0 TB/s of
+// copy traffic) -- and the tiled kernel's 458 us are its 260 us operand / multiply phase PLUS that: all workgroups reach their
+// epilogue together, HBM saturates for 6.5 us, then sits idle for 10 (a convoy).  Here the memory traffic of tile j is
+// spread over the steps of tile j + 1: at the tile boundary the accumulators move to a second register set, and each of the
+// next four steps turns ONE 32-row strip through one of two LDS strips (written by the four waves that own it after the step's
+// barrier, read as whole-row pieces by everybody after the next one), adds the residual pieces requested a tile ago and stores.
+// Sixteen waves (4 x 4, 32x32 each: the second accumulator set costs 16 registers), one workgroup per CU, three operand slots.
+__device__ __forceinline__ void wait_vm_upto8(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <bool RES>
+__global__ void __launch_bounds__(1024) k_gemm_ring5_bf16(const ConvArgsBf16 p) {
+    constexpr int BM = 128, BN = 128, BK = 64, ROWB = BK * 2, SLOT = (BM + BN) * ROWB, NSLOT = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem_v[];
+    char* ring = smem_v;                                                   // [3][A 128 rows | B 128 rows][128 B]
+    float* stg = reinterpret_cast<float*>(smem_v + NSLOT * SLOT);          // [2][32][128] f32
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
+    const int nk = p.Kpad / BK, tiles_n = p.Cout / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    if (first >= ntiles) return;
+    const int T = ((ntiles - first + G - 1) / G) * nk;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x), 0, (int)((size_t)p.M * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, (int)((size_t)p.Cout * p.Kpad * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(RES ? p.residual : p.x), 0, RES ? (int)((size_t)p.M * p.Cout * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<__bf16*>(p.y), 0, (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+
+    // ---- request side: wave w lands rows 8w .. 8w + 7 of A and of B (one wave instruction each)
+    const int drow = wave * 8 + (lane >> 3);
+    const int dgran = ((lane & 7) ^ ((drow >> 1) & 7)) * 16;
+    int i_tile = first, i_c = 0;
+    unsigned ia_off, ib_off;
+    auto aim = [&](int L) {
+        const int tm = L / tiles_n, tn = L - tm * tiles_n;
+        const int m = tm * BM + drow, n = tn * BN + drow;
+        ia_off = (L < ntiles && m < p.M) ? (unsigned)((size_t)m * p.Cin * 2 + dgran) : OOB_OFFSET_B;
+        ib_off = L < ntiles ? (unsigned)((size_t)n * p.Kpad * 2 + dgran) : OOB_OFFSET_B;
+    };
+    int issued = 0, mark_a = 0, mark_b = 0;                                // vmcnt bookkeeping: instructions issued so far / right after the
+    auto request = [&](int t) {                                            // requests of the two chunks in flight
+        char* dst = ring + (t % NSLOT) * SLOT + wave * 1024;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)dst, 16, ia_off, i_c * ROWB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(dst + BM * ROWB), 16, ib_off, i_c * ROWB, 0, 0);
+#endif
+        issued += 2;
+        if (++i_c == nk) { i_c = 0; i_tile += G; aim(i_tile); }
+    };
+    aim(first);
+    request(0); mark_a = issued;
+    request(1); mark_b = issued;
+
+    // ---- compute side
+    const int arow = wm * 32 + li, brow = wn * 32 + li, sw = (li >> 1) & 7;
+    const int prow = tid >> 5, pcol = (tid & 31) * 4;                      // this thread's 8-byte piece of a 32-row strip
+    i32x2 rpre[4] = {}, rprev[4] = {}, r_res = {0, 0};
+    f32x16 acc, accp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; accp[e] = 0.0f; }
+    int tile = first, c = 0;
+    int e_step = 99, ptile = 0;                                            // steps since the previous tile ended (1..4: its strips are written)
+    bool read_pending = false; int r_strip = 0, r_tile = 0;
+    for (int t = 0; t < T + 5; ++t) {
+        if (t < T) wait_vm_upto8(issued - mark_a);                         // chunk t has landed (what was issued behind its request may fly on)
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t < T) {
+            mark_a = mark_b;
+            if (t + 2 < T) request(t + 2);
+            mark_b = issued;
+            const char* a = ring + (t % NSLOT) * SLOT + arow * ROWB;
+            const char* b = ring + (t % NSLOT) * SLOT + BM * ROWB + brow * ROWB;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int slot = ((2 * st + lh) ^ sw) * 16;
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(a + slot);
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(b + slot);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+            }
+            if (RES && c == 0) {
+                const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = tm * BM + q * 32 + prow;
+                    rpre[q] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        rrsrc, m < p.M ? (unsigned)(((size_t)m * p.Cout + tn * BN + pcol) * 2) : OOB_OFFSET_B, 0, 0));
+                }
+                issued += 4;
+            }
+        }
+        // ---- the previous tile's epilogue, one strip per step
+        if (read_pending) {
+            const int tm = r_tile / tiles_n, tn = r_tile - tm * tiles_n;
+            const int m = tm * BM + r_strip * 32 + prow;
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stg + (r_strip & 1) * (32 * BN) + prow * BN + pcol);
+            float v[4] = {v4[0], v4[1], v4[2], v4[3]};
+            if (RES) {
+                const bf16x4 r = __builtin_bit_cast(bf16x4, r_res);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += (float)r[k];
+            }
+            bf16x4 ob;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ob[k] = (__bf16)activate_b(v[k], p.act);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, ob), yrsrc,
+                                                  m < p.M ? (unsigned)(((size_t)m * p.Cout + tn * BN + pcol) * 2) : OOB_OFFSET_B, 0, 0);
+            issued += 1;
+            read_pending = false;
+        }
+        if (e_step >= 1 && e_step <= 4) {
+            const int s4 = e_step - 1;
+            if (wm == s4) {
+                const int tm = ptile / tiles_n, tn = ptile - tm * tiles_n;
+                const int ncl = wn * 32 + li;
+                const float sc = p.scale ? p.scale[tn * BN + ncl] : 1.0f;
+                const float sh = p.shift ? p.shift[tn * BN + ncl] : 0.0f;
+                float* dst = stg + (s4 & 1) * (32 * BN) + (4 * lh) * BN + ncl;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = accp[e] * sc + sh;
+            }
+            read_pending = true; r_strip = s4; r_tile = ptile; r_res = rprev[0];
+            rprev[0] = rprev[1]; rprev[1] = rprev[2]; rprev[2] = rprev[3];
+        }
+        ++e_step;
+        if (t < T) {
+            if (c == nk - 1) {
+                accp = acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rprev[q] = rpre[q];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                ptile = tile; e_step = 1;
+                tile += G; c = 0;
+            } else {
+                ++c;
+            }
+        }
+    }
+}
+
+static int launch_ring5_bf16(const ConvArgsBf16& a, hipStream_t s) {
+    const size_t lds = (size_t)3 * (128 + 128) * 128 + 2 * 32 * 128 * 4;
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_gemm_ring5_bf16<true>, lds, "conv2d_bf16")) return e;
+    static std::atomic<uint64_t> lds_seen2{0};
+    if (int e = raise_lds_once(lds_seen2, (const void*)k_gemm_ring5_bf16<false>, lds, "conv2d_bf16")) return e;
+    const int ntiles = ((a.M + 127) / 128) * (a.Cout / 128);
+    const int grid = ntiles >= 256 ? 256 : ((ntiles + 7) / 8) * 8;
+    if (a.residual) k_gemm_ring5_bf16<true><<<grid, 1024, lds, s>>>(a);
+    else k_gemm_ring5_bf16<false><<<grid, 1024, lds, s>>>(a);
+    return check_launch("conv2d_fwd_bf16 (ring)");
+}
+
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -780,6 +952,7 @@ int main(int argc, char** argv) {
         if (v == "v3_4_2") return launch_ring3_bf16<4, 2>(a, s);
         if (v == "v4_2") return launch_ring4_bf16<2>(a, s);
         if (v == "v4_4") return launch_ring4_bf16<4>(a, s);
+        if (v == "v5") return launch_ring5_bf16(a, s);
         fprintf(stderr, "unknown variant\n"); exit(2);
     };
     auto tiled = [&]() { if (int e = frcnn_conv2d_fwd_bf16(&d, x, w, nullptr, nullptr, r, y0, 0, s)) { fprintf(stderr, "tiled: %d %s\n", e, frcnn_last_error()); exit(1); } };
