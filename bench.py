@@ -1109,9 +1109,9 @@ def main():
                        "images_per_step_per_gpu": S * B, "graphs_in_flight": S, "images_per_graph": B, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "proposals": PROPOSALS, "classes": NUM_CLASSES,
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
-                       "f32_matrix_path": ("bf16x6: launches of >= %d rows, k >= %d, >= %d columns multiply on v_mfma_f32_32x32x16_bf16 with every f32 operand split EXACTLY "
+                       "f32_matrix_path": ("bf16x6: launches of >= %d 64x64 output tiles and >= %d columns (and the long-k small grids, split-K) multiply on v_mfma_f32_32x32x16_bf16 with every f32 operand split EXACTLY "
                                            "into three bf16 values, six exact partial products per product, f32 accumulate (csrc/conv_x6.hip; error against fp64 at the native "
-                                           "kernel's level); the rest on v_mfma_f32_32x32x2_f32" % (_ops.X6_MIN_ROWS, _ops.X6_MIN_K, _ops.X6_MIN_COUT))
+                                           "kernel's level); the rest on v_mfma_f32_32x32x2_f32" % (_ops.X6_MIN_TILES, _ops.X6_MIN_COUT))
                                           if args.f32_engine == "bf16x6" and DTYPE == "f32" else "native: v_mfma_f32_32x32x2_f32",
                        "head_order": "no detector head" if DEPTH == 16 else
                        "res5a 1x1 layers on the conv4 map, then RoI resampling (algebraically equal, see DESIGN 5)" if HOIST else "reference order",

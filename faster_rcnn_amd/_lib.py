@@ -56,6 +56,7 @@ SIGNATURES = {
     "frcnn_conv2d_dual_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_fwd_dual": (I, [P, P, P, P, P, P, I, I, P, I, P, c_size_t, P]),
     "frcnn_conv2d_dual_config": (I, [P, I]),
+    "frcnn_conv2d_x6_config": (I, [P, I]),
     "frcnn_pack_conv_weights_x6": (I, [P, I, I, P, P]),
     "frcnn_conv2d_x6_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_fwd_x6": (I, [P, P, P, P, P, P, P, P, P, c_size_t, P]),

@@ -1790,6 +1790,26 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
 
 // split-K factor of the split-bf16 engine's 64x64 form: grids under ~1.5 tiles per CU slot with a LONG k loop only
 // (k >= 2048: rpn_conv1, stage 4's 3x3, the 64-RoI training head); everything else runs unsplit or stays native
+// The split engine's tile for a descriptor (n1 > 0: a two-layer launch whose first layer has n1 columns).
+// auto: 128x128 tiles on eight waves (two workgroups per CU); long k on a grid of >= 200 256x128 tiles: the 16-wave double-buffered
+// form (head 3x3 337 vs 350 us, 2048 -> 512 157 vs 169; 512 -> 2048 ties and stays); under one 128x128 tile per CU, 64x64.
+// 64-column layers (a 128-wide tile would be half empty: stage 2's 3x3 48.8 us against 30.9 on 64x64 tiles, 36.3 native): 64x64,
+// or 128x64 on four waves once there are >= 1024 of them (VGG16 conv1_2, 600 000 rows: 361 us against 389 / 458 native).
+static int x6_config(const frcnn_conv_desc* d, int n1) {
+    const int t = d->tile % 100;
+    if (t >= 71 && t <= 77) return t;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const int K = d->kh * d->kw * d->cin;
+    int cfg;
+    if (d->cout <= 64) cfg = ((M + 127) / 128) >= 1024 ? 77 : 74;
+    else {
+        const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128), t256 = ((M + 255) / 256) * ((d->cout + 127) / 128);
+        cfg = t128 >= 256 ? ((K >= 1024 && t256 >= 200) ? 76 : 71) : 74;
+    }
+    if (n1 > 0 && (n1 % 128) != 0 && cfg != 77) cfg = 74;       // the layer boundary of a paired launch must be a tile boundary (16-byte epilogue)
+    return cfg;
+}
+
 static int choose_splits_x6(const frcnn_conv_desc* d) {
     if (d->cin % BK) return 1;
     const int t = d->tile % 100;
@@ -1891,13 +1911,7 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
         // the split-bf16 engine (conv_x6.hip): w_packed points at the three bf16 filter planes
         if (generic || d->kh * d->kw > 32) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_x6: cin %% 32 == 0 and at most 32 taps");
         if ((size_t)3 * d->cout * a.Kpad * 2 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_x6: filter planes over 2 GiB");
-        const int t = d->tile % 100;
-        const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
-        // auto: 128x128 tiles on eight waves (two workgroups per CU); long k on a grid of >= 200 256x128 tiles: the 16-wave
-        // double-buffered form (head 3x3 337 vs 350 us, 2048 -> 512 157 vs 169; 512 -> 2048 ties and stays); under one
-        // 128x128 tile per CU, 64x64
-        const long long t256 = ((M + 255) / 256) * ((d->cout + 127) / 128);
-        const int xcfg = (t >= 71 && t <= 76) ? t : (t128 >= 256 ? ((a.K >= 1024 && t256 >= 200) ? 76 : 71) : 74);
+        const int xcfg = x6_config(d, dual ? dual->n1 : 0);
         if (workspace && !dual) {
             const size_t need = frcnn_conv2d_x6_workspace_bytes(d);
             if (need) {
@@ -2226,6 +2240,11 @@ int frcnn_conv2d_config(const frcnn_conv_desc* d) {
     const int cfg = choose_config(d);
     if (choose_streamk(d, cfg)) return (cfg == 21 || cfg == 26 || cfg == 61) ? 61 : 62;     // what a launch WITH a workspace runs
     return (cfg == 61 || cfg == 62) ? cfg - 40 : cfg;                           // asked for, but the shape is not eligible
+}
+
+int frcnn_conv2d_x6_config(const frcnn_conv_desc* d, int n1) {
+    if (!d) return fail(FRCNN_E_ARG, "conv2d_x6_config: null descriptor");
+    return x6_config(d, n1);
 }
 
 int frcnn_conv2d_dual_config(const frcnn_conv_desc* d, int has_workspace) {

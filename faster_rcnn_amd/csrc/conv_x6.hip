@@ -578,6 +578,7 @@ int launch_conv_x6(const ConvArgs& a, int cfg, hipStream_t s) {
         case 74: return launch_x6<1, 1, 2, 2>(a, s);      // 64x64, 4 waves
         case 75: return launch_x6<1, 1, 2, 4>(a, s);      // 64x128, 8 waves
         case 76: return launch_x6_db(a, s);               // 256x128, 16 waves, two LDS buffers, one workgroup per CU
+        case 77: return launch_x6<2, 1, 2, 2>(a, s);      // 128x64, 4 waves (64x32 per wave): the 64-column layers
         case 174: {                                       // 64x64 with split-K (a.splits / a.slabs / a.tickets set by the caller)
             using T = X6Tile<1, 1, 2, 2>;
             ConvArgs p = a;
@@ -590,7 +591,7 @@ int launch_conv_x6(const ConvArgs& a, int cfg, hipStream_t s) {
     }
 }
 
-int x6_tile_width(int cfg) { return cfg == 74 ? 64 : 128; }
+int x6_tile_width(int cfg) { return (cfg == 74 || cfg == 77) ? 64 : 128; }
 
 }  // namespace frcnn
 

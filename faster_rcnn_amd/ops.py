@@ -318,13 +318,14 @@ class PackedConv:
 # different summation order: the two agree to f32 rounding, not bit for bit, so the library default stays "native" and a
 # caller opts in for a scope (``with f32_engine("bf16x6"):`` -- bench.py and entry.DetectionEntry do, around their captures).
 F32_ENGINE = "native"
-# where the split engine measures faster than the native kernels (MI355X, configs[1] shapes, each launch alone on the chip):
-# the head's 14 700-row GEMMs 350 / 189 / 169 us against 571 / 265 / 250; stage 3 (9 375 rows, 128 columns) ties; 64-column
-# layers (stage 2) and short k lose (a 128-wide tile is half empty / the prologue dominates) and stay native; grids under
-# ~8 000 rows need a split-K form the engine does not have.
-X6_MIN_ROWS = 8192              # GEMM rows (output pixels)
-X6_MIN_K = 512                  # kh * kw * cin
-X6_MIN_COUT = 128
+# where the split engine measures faster than the native kernels (MI355X, configs[1] shapes, each launch alone on the chip;
+# scripts/conv_shapes.py 0,74,77,71,76): the head's 14 700-row GEMMs 355 / 189 / 167 us against 530 / 275 / 269; with 64x64 tiles
+# almost every trunk layer too -- stage 2 (37 101 rows) 3x3 30.9 vs 36.3 us, 1x1 23.4 vs 27.2 / 19.0 vs 20.9, stage 3's wide 1x1
+# 19.6 vs 22.0 / 28.2 vs 32.6, stage 4's 1024-column 1x1 18.9 vs 20.9 / 28.7 vs 33.6 -- as long as the launch has >= 256 tiles of
+# 64x64; under that (stage 4's 256-column layers: 26.8 vs 21.1 us) the native split-K launches win, except where the engine's own
+# split-K form applies (rpn_conv1 176 vs 202, stage 4's 3x3 32.7 vs 34.9).  Layers with fewer than 64 columns stay native.
+X6_MIN_TILES = 256              # 64x64 tiles of the output
+X6_MIN_COUT = 64
 
 
 class f32_engine:
@@ -342,28 +343,24 @@ class f32_engine:
 
 
 def _use_x6(d, pc, tile):
-    if 71 <= tile % 100 <= 76:
+    if 71 <= tile % 100 <= 77:
         return pc.cin % 32 == 0                                  # explicit tile code of the split engine
     if F32_ENGINE != "bf16x6" or tile % 100 not in (0, 50):
         return False
-    if pc.cin % 32 or pc.cout < X6_MIN_COUT or pc.kh * pc.kw * pc.cin < X6_MIN_K:
+    if pc.cin % 32 or pc.cout < X6_MIN_COUT or pc.kh * pc.kw > 32:
         return False
-    if d.n * d.ho * d.wo >= X6_MIN_ROWS:
+    if -(-(d.n * d.ho * d.wo) // 64) * -(-pc.cout // 64) >= X6_MIN_TILES:
         return True
     # small grids with a long k loop (rpn_conv1, stage 4's 3x3): the engine's split-K form, where split-K launches are allowed
-    return _CONV_WS is not NO_SPLIT_K and _ws_need(d, "frcnn_conv2d_x6_workspace_bytes") > 0
+    return pc.cout >= 128 and _CONV_WS is not NO_SPLIT_K and _ws_need(d, "frcnn_conv2d_x6_workspace_bytes") > 0
 
 
 X6_KERNEL_NAMES = {71: "k_conv_igemm_x6<2,1,2,4>", 72: "k_conv_igemm_x6<2,2,4,2>", 73: "k_conv_igemm_x6<2,2,2,2>", 74: "k_conv_igemm_x6<1,1,2,2>",
-                   75: "k_conv_igemm_x6<1,1,2,4>", 76: "k_conv_igemm_x6_db"}
+                   75: "k_conv_igemm_x6<1,1,2,4>", 76: "k_conv_igemm_x6_db", 77: "k_conv_igemm_x6<2,1,2,2>"}
 
 
-def _x6_name(d, tile):
-    t = tile % 100
-    if not 71 <= t <= 76:                                         # the library's own choice (conv_fwd_impl)
-        m, n, k = d.n * d.ho * d.wo, d.cout, d.kh * d.kw * d.cin
-        t = 74 if -(-m // 128) * -(-n // 128) < 256 else (76 if k >= 1024 and -(-m // 256) * -(-n // 128) >= 200 else 71)
-    return X6_KERNEL_NAMES[t]
+def _x6_name(d, n1=0):
+    return X6_KERNEL_NAMES[_lib.load().frcnn_conv2d_x6_config(ctypes.byref(d), n1)]
 
 
 # When set to a list, every conv2d launch appends {kernel, flops, shape, relaunch()} so bench.py can
@@ -476,7 +473,7 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
         _lib.call("frcnn_conv2d_fwd_x6", *args, _stream())
         if CONV_PROFILE is not None:
             keep = (d, x, pc, residual, out, ws)
-            CONV_PROFILE.append({"kernel": "k_conv_igemm_x6<1,1,2,2> split-K" if ws is not None else _x6_name(d, tile),
+            CONV_PROFILE.append({"kernel": "k_conv_igemm_x6<1,1,2,2> split-K" if ws is not None else _x6_name(d),
                                  "flops": 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin,
                                  "shape": (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
                                  "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_x6", *args, _stream())})
@@ -508,7 +505,7 @@ def conv2d_dual(x, pc, n1, stride=1, padding="valid", act1=None, act2=None, layo
         _lib.call("frcnn_conv2d_fwd_dual_x6", *args, _stream())
         if CONV_PROFILE is not None:
             keep = (d, x, pc, y1, y2)
-            CONV_PROFILE.append({"kernel": _x6_name(d, tile), "flops": 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin,
+            CONV_PROFILE.append({"kernel": _x6_name(d, n1), "flops": 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin,
                                  "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
                                  "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_dual_x6", *args, _stream())})
         return y1, y2

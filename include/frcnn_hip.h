@@ -267,6 +267,9 @@ int frcnn_conv2d_dual_config(const frcnn_conv_desc* d, int has_workspace);
 int frcnn_pack_conv_weights_x6(const float* w_packed, int cout, int packed_k, void* planes_bf16, void* stream);
 /* workspace (may be NULL): small grids with k >= 2048 cut K over several workgroups like frcnn_conv2d_fwd_ws does (tickets zero on
  * entry, left zero; frcnn_conv2d_x6_workspace_bytes: 0 = this shape runs unsplit). */
+/* The tile code (71..77) frcnn_conv2d_fwd_x6 / frcnn_conv2d_fwd_dual_x6 (n1 > 0) run for this descriptor when no split-K workspace
+ * applies: profiling tools name the kernel with it. */
+int frcnn_conv2d_x6_config(const frcnn_conv_desc* d, int n1);
 size_t frcnn_conv2d_x6_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16,
                         const float* scale, const float* shift, const float* residual, const float* mask, float* y,

@@ -72,10 +72,14 @@ def test_config1_resnet50_600x1000_inference_fp32(engine):
         assert res[k] < 1e-4, res
     n_x6 = sum("x6" in k and "split-K" not in k for k in kernels)
     n_sk = sum("x6" in k and "split-K" in k for k in kernels)
-    # whole-tile launches: the head's 8 + stage 3's seven 128-column layers; in-launch split-K (eager run, workspace at hand):
-    # the six 3x3 layers of the 38x63 stage (2 394 rows, k 2 304) + rpn_conv1 (k 9 216)
-    assert n_x6 == (0 if engine == "native" else 8 + 7), (engine, n_x6, n_sk, kernels)
-    assert n_sk == (0 if engine == "native" else 7), (engine, n_x6, n_sk, kernels)
+    n_native = sum("x6" not in k for k in kernels)
+    # split engine: the head's 8 launches and every trunk launch with >= 256 tiles of 64x64 and >= 64 columns (stages 2 and 3, stage 4's
+    # 1024-column layers); in-launch split-K (eager run, workspace at hand): the six 3x3 layers of the 38x63 stage (2 394 rows, k 2 304) +
+    # rpn_conv1 (k 9 216).  Native (8): the stem, stage 4's 256-column 1x1 layers, the RPN output pair, the dense pair.
+    if engine == "native":
+        assert n_x6 == 0 and n_sk == 0, (n_x6, n_sk, kernels)
+    else:
+        assert n_sk == 7 and n_x6 == 37 and n_native == 8, (engine, n_x6, n_sk, n_native, kernels)
 
 
 def test_config1_end_to_end_pair_and_map_delta():

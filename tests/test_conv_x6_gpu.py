@@ -132,7 +132,7 @@ def test_engine_policy_scope_and_refusals():
         ops.conv2d(big, pc, 1, "same")
         with ops.f32_engine("bf16x6"):
             ops.conv2d(big, pc, 1, "same")
-            ops.conv2d(small, pc, 1, "same")                     # under X6_MIN_ROWS: stays native
+            ops.conv2d(small, pc, 1, "same")                     # 14 tiles of 64x64, under X6_MIN_TILES: stays native
         ops.conv2d(big, pc, 1, "same")
         names = [r["kernel"] for r in ops.CONV_PROFILE]
     finally:
@@ -170,7 +170,9 @@ def test_x6_split_k_small_grid_long_k():
             names = [r["kernel"] for r in ops.CONV_PROFILE]
         finally:
             ops.CONV_PROFILE = None
-        assert names[0].endswith("split-K") and "x6" in names[0] and "x6" not in names[2], names      # without a workspace the small grid stays native
+        assert names[0].endswith("split-K") and "x6" in names[0], names
+        tiles64 = -(-(h * w) // 64) * -(-cout // 64)
+        assert ("x6" in names[2]) == (tiles64 >= ops.X6_MIN_TILES), names      # without a workspace a grid under X6_MIN_TILES stays native
         ref, mag = ref_conv(x, wt, 1, "same", scale, shift, None, "relu")
         assert err(got.cpu().numpy(), ref, mag) <= 5e-7
         assert torch.equal(got, again)
