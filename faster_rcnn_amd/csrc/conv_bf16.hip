@@ -1153,12 +1153,17 @@ static int choose_config_bf16(const frcnn_conv_desc* d) {
         // 36.8 -> 46.4: those are bound by their output / residual bytes, and the 128x128 tile requests its residual
         // pieces before the main loop), so: long k, two or more rounds of whole tiles
         if ((d->cout % 256) == 0 && t256 >= 512 && d->kh * d->kw * d->cin >= 1024) return 45;
+        // round 4 (scripts/conv_shapes_c4.py): a very long k loop pays for ONE round of 256x256 tiles too -- rpn_conv1 over eight maps
+        // (28 576 rows, k 9 216, 224 tiles) 225 us against 282 on 128x128 tiles
+        if ((d->cout % 256) == 0 && t256 >= 192 && d->kh * d->kw * d->cin >= 8192) return 45;
         static const bool dma64 = getenv("FRCNN_BF16_DMA64") && atoi(getenv("FRCNN_BF16_DMA64")) != 0;   // dev knob
         static const int big = getenv("FRCNN_BF16_BIG") ? atoi(getenv("FRCNN_BF16_BIG")) : 47;            // dev knob: 42 = register-staged
         // 47 (direct-to-LDS 128x128) on long row ranges -- the detector head over 300 RoIs: 1024->2048 103 -> 81 us, 3x3
         // 83 -> 77 (901 TFLOP/s), 512->2048 69 -> 51 -- and the register-staged 42 on the training steps' 2-3 k rows
         // (measured equal to 1-2 % slower there, beside the weight-gradient stream)
-        cfg = t128 >= (cfg == 50 ? 16 : 256) ? (d->cout >= 128 ? (M >= 8192 ? big : 42) : 43) : (dma64 ? 48 : 2);
+        // 64-column layers on long row ranges (stage 2 of a batched pass, 445 808 rows): the direct-to-LDS 64x64 tile, five workgroups
+        // per CU -- 29.6 / 66.4 / 57.3 us against 32.3 / 69.5 / 62.5 on the register-staged 128x64 one
+        cfg = t128 >= (cfg == 50 ? 16 : 256) ? (d->cout >= 128 ? (M >= 8192 ? big : 42) : (M >= 65536 ? 48 : 43)) : (dma64 ? 48 : 2);
     }
     return cfg;
 }

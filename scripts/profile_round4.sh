@@ -49,7 +49,7 @@ done
 python3 $R/scripts/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 head -40 $OUT/summary.txt | cut -c1-400
 for t in trace_default trace_streams1 trace_c4; do
-  f=$(find $OUT/$t -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${t}_kernel_stats.csv
+  f=$(ls -S $(find $OUT/$t -name "*kernel_stats.csv") 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/${t}_kernel_stats.csv
 done
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete

@@ -32,9 +32,9 @@ for f in ("bench_default.json", "bench_streams1.json"):
     if os.path.exists(p):
         print(f, open(p).read().strip())
 for tag in ("trace_streams1", "trace_default"):
-    fs = glob.glob(os.path.join(root, tag, "**", "*kernel_stats.csv"), recursive=True)
+    fs = sorted(glob.glob(os.path.join(root, tag, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getsize, reverse=True)
     if not fs:
-        continue
+        continue                                    # (several processes leave one file each: the largest is bench.py's own)
     print("\n== rocprofv3 --kernel-trace --stats:", tag)
     print("%-78s %7s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
     for r in csv.DictReader(open(fs[0])):
@@ -46,7 +46,7 @@ for tag in ("trace_streams1", "trace_default"):
 # comparable with bench.py's roofline (each distinct launch re-issued back to back on one stream) is the average
 # over the isolated dispatches -- which are mostly those very re-issues.
 for tag in ("trace_streams1", "trace_default"):
-    fs = glob.glob(os.path.join(root, tag, "**", "*kernel_trace.csv"), recursive=True)
+    fs = sorted(glob.glob(os.path.join(root, tag, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getsize, reverse=True)
     if not fs:
         continue
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(fs[0]))]
