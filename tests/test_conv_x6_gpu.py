@@ -51,6 +51,8 @@ CASES = [
     (2, 23, 31, 64, 96, 3, 1, "same", 76),        # 256x128 on sixteen waves, two LDS buffers
     (1, 40, 52, 64, 320, 1, 1, "valid", 76),
     (1, 33, 29, 128, 192, 3, 2, "same", 76),
+    (2, 23, 31, 64, 64, 3, 1, "same", 77),        # 128x64 on four waves: the 64-column layers
+    (1, 40, 52, 96, 160, 1, 1, "valid", 77),      # ragged column tiles (160 = 2.5 x 64)
 ]
 
 
@@ -146,6 +148,28 @@ def test_engine_policy_scope_and_refusals():
         import ctypes
         d = ops._conv_desc((1, 8, 8, 48), 1, 1, 64, 1, "valid", 0, 0, 71)
         _lib.call("frcnn_conv2d_fwd_x6", ctypes.byref(d), y.data_ptr(), y.data_ptr(), None, None, None, None, y.data_ptr(), None, 0, None)
+
+
+def test_engine_tile_choice_is_what_the_library_reports():
+    """frcnn_conv2d_x6_config: 64x64 tiles for 64-column and small-grid layers, the four-wave 128x64 tile for >= 1024 row tiles of 64
+    columns, 128x128 / the sixteen-wave form otherwise; a two-layer launch whose boundary is not a multiple of 128 takes 64-wide tiles."""
+    import ctypes
+    from faster_rcnn_amd import _lib, ops
+    lib = _lib.load()
+
+    def cfg(shape, k, cout, n1=0, stride=1, padding="same"):
+        d = ops._conv_desc(shape, k, k, cout, stride, padding, 0, 0, 0)
+        return lib.frcnn_conv2d_x6_config(ctypes.byref(d), n1)
+    assert cfg((1, 149, 249, 64), 3, 64) == 74                       # stage 2's 3x3: 290 row tiles of 128
+    assert cfg((1, 600, 1000, 64), 3, 64) == 77                      # VGG16 conv1_2
+    assert cfg((1, 75, 125, 128), 3, 128) == 74                      # under 256 tiles of 128x128
+    assert cfg((300, 7, 7, 512), 1, 2048) == 71
+    assert cfg((300, 7, 7, 512), 3, 512) == 76                       # long k, >= 200 tiles of 256x128
+    assert cfg((1, 149, 249, 64), 1, 320, n1=64, padding="valid") == 74
+    assert cfg((1, 38, 63, 1024), 1, 2560, n1=512, padding="valid") == 76
+    d = ops._conv_desc((300, 7, 7, 512), 3, 3, 512, 1, "same", 0, 0, 73)
+    assert lib.frcnn_conv2d_x6_config(ctypes.byref(d), 0) == 73      # an explicit code is returned as asked
+    assert lib.frcnn_conv2d_x6_config(None, 0) < 0
 
 
 def test_x6_split_k_small_grid_long_k():

@@ -93,12 +93,17 @@ int main() {
         q.cin = pick({32, 64, 128, 256, 512, 1024, 2048, 48, 3}); q.cout = pick({18, 45, 64, 128, 256, 512, 1024, 2048});
         q.kh = q.kw = pick({1, 3}); q.stride = pick({1, 2});
         q.ho = (q.h + q.stride - 1) / q.stride; q.wo = (q.w + q.stride - 1) / q.stride;
-        q.tile = pick({0, 50, 71, 74, 76, 274, 374, 1674, 23});
+        q.tile = pick({0, 50, 71, 74, 76, 77, 274, 374, 1674, 23});
         q.layout = rnd() % 2;
         const size_t need = frcnn_conv2d_x6_workspace_bytes(&q);
         const long long tiles = (((long long)q.n * q.ho * q.wo + 63) / 64) * ((q.cout + 63) / 64);
         if (need && (need < 16384 || (need - 16384) % (64 * 64 * 4) != 0 || (long long)((need - 16384) / (64 * 64 * 4)) % tiles != 0)) { printf("x6 workspace size inconsistent\n"); ++failures; }
         if (need && (q.cin % 32)) { printf("x6 split-K offered for cin %% 32 != 0\n"); ++failures; }
+        const int n1 = (rnd() % 3) ? 0 : pick({9, 64, 128, 512});
+        const int xc = frcnn_conv2d_x6_config(&q, n1);
+        const int asked = q.tile % 100;
+        if (xc < 71 || xc > 77 || (asked >= 71 && asked <= 77 && xc != asked)) { printf("x6 tile code %d out of range / not the one asked for\n", xc); ++failures; }
+        if (!(asked >= 71 && asked <= 77) && n1 > 0 && (n1 % 128) && xc != 74 && xc != 77) { printf("x6 paired launch: boundary %d on a 128-wide tile\n", n1); ++failures; }
         ++checked;
     }
     for (int it = 0; it < 300; ++it) {
@@ -124,6 +129,7 @@ int main() {
         if (frcnn_detections_dyn(&dummy, &i32, 64, 600, &dummy, &dummy, 21, 20, 16.0, 0.5, dyn_misaligned, &i32, &dummy, &i32, &i32, &i32, nullptr) == FRCNN_OK) { printf("detections_dyn accepted 600 rows\n"); ++failures; }
         if (frcnn_detections_dyn(&dummy, &i32, 64, 320, &dummy, &dummy, 21, 20, 16.0, 0.5, nullptr, &i32, &dummy, &i32, &i32, &i32, nullptr) == FRCNN_OK) { printf("detections_dyn accepted a null dyn\n"); ++failures; }
         if (frcnn_conv2d_dual_config(nullptr, 0) >= 0) { printf("dual_config accepted null\n"); ++failures; }
+        if (frcnn_conv2d_x6_config(nullptr, 0) >= 0) { printf("x6_config accepted null\n"); ++failures; }
     }
     checked += 8;
     printf("host sanitizer driver: %d checks, %d failures\n", checked, failures);
