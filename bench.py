@@ -770,8 +770,8 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
         finally:
             voc_dets.FAST_ENTRY = True
         from_files = {"value": round(n_images * passes / tf, 3), "unit": "img/s", "frame": "tests/golden/VOC_test 000005.jpg, 500x375 -> 800x600",
-                      "decode_threads": voc_dets.DECODE_THREADS, "eager": {"value": round(4 / te, 3), "unit": "img/s", "images": 4},
-                      "what": "JPEG decode (PIL, host threads) -> H2D of the decoded frame -> device INTER_CUBIC resize + preprocess + captured pass -> dicts; "
+                      "decode": "inline (threads start when a fetch takes over %.1f ms)" % voc_dets.DECODE_INLINE_MS, "eager": {"value": round(4 / te, 3), "unit": "img/s", "images": 4},
+                      "what": "JPEG decode (PIL) -> H2D of the decoded frame -> device INTER_CUBIC resize + preprocess + captured pass -> dicts; "
                               "eager: decode + integer-numpy resize + float64 preprocess on the host, then the eager device path"}
     except Exception as e:
         from_files = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -24,7 +24,11 @@ from . import entry, nets, ops
 from .det_util import DetTrainingManager, nms  # noqa: F401  (re-exported like the reference module)
 
 DEFAULT_DET_THRESHOLD = 0.0
-DECODE_THREADS = int(os.environ.get("FRCNN_DECODE_THREADS", "4"))   # get_dets_by_cls: threads fetching the next images' pixels (0: inline)
+# get_dets_by_cls: threads fetching the next images' pixels (0: always inline).  They are only started when a frame's decode is slow
+# enough to matter (DECODE_INLINE_MS): on 500x375 VOC JPEGs (1.2 ms each) inline decoding measures 315 img/s and four threads 257 --
+# the interpreter lock changes hands at every numpy conversion -- while a multi-megapixel photograph needs them.
+DECODE_THREADS = int(os.environ.get("FRCNN_DECODE_THREADS", "4"))
+DECODE_INLINE_MS = float(os.environ.get("FRCNN_DECODE_INLINE_MS", "2.5"))
 FAST_ENTRY = os.environ.get("FRCNN_ENTRY_EAGER", "0") == "0"      # False: always the eager path (tests and bench.py compare the two)
 
 
@@ -106,14 +110,16 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
         print("num rois: {}".format(num_boxes))
         fold(image, dets, start_time)
 
-    # the pixels of the NEXT images are fetched on a few threads while the GPU works (PIL's JPEG decode releases the GIL;
-    # the reference decodes and resizes inline, shapes.py:19-29); results are consumed strictly in list order
+    # the pixels are fetched inline, as the reference does (shapes.py:19-29), until that proves slow (DECODE_INLINE_MS); from then on
+    # the NEXT images are fetched on a few threads while the GPU works (PIL's JPEG decode releases the GIL); results are consumed
+    # strictly in list order
     from concurrent.futures import ThreadPoolExecutor
     images, resized_ratios = list(images), list(resized_ratios)
     n = min(len(images), len(resized_ratios))
     ahead = 2 * eng.in_flight
-    pool = ThreadPoolExecutor(max_workers=DECODE_THREADS) if n > 1 and DECODE_THREADS > 0 else None
+    pool = None
     pending = {}
+    slow_fetches = 0
     try:
         for i in range(n):
             if pool is not None:
@@ -121,7 +127,13 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
                     if j not in pending and eng.prefetchable(images[j]):
                         pending[j] = pool.submit(eng.host_pixels, images[j])
             start_time = timeit.default_timer()
-            pixels = pending.pop(i).result() if i in pending else None
+            if i in pending:
+                pixels = pending.pop(i).result()
+            else:
+                pixels = eng.host_pixels(images[i])
+                slow_fetches = slow_fetches + 1 if (timeit.default_timer() - start_time) * 1e3 > DECODE_INLINE_MS else 0
+                if slow_fetches >= 2 and pool is None and DECODE_THREADS > 0 and i + 1 < n and eng.prefetchable(images[i]):
+                    pool = ThreadPoolExecutor(max_workers=DECODE_THREADS)       # (two slow fetches in a row: not a cold file cache)
             window.append((images[i], eng.submit(images[i], resized_ratios[i], det_threshold, pixels=pixels), start_time))
             if len(window) >= eng.in_flight:
                 finish()

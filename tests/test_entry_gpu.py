@@ -140,6 +140,41 @@ def test_get_dets_by_cls_pipelined_equals_one_by_one(models):
             same_dets(again[cls_name][img_name], fast[cls_name][img_name], tol=0.0)
 
 
+def test_slow_image_sources_are_fetched_on_threads_with_the_same_result(models):
+    """get_dets_by_cls decodes inline until two fetches in a row take longer than DECODE_INLINE_MS; from then on the next images'
+    pixels come from a few threads.  Same dict, same order, same bits either way."""
+    import threading
+    import time
+    from faster_rcnn_amd import shapes, voc_dets
+    mgr, det, _, _ = models
+    seen = set()
+
+    class SlowImage(shapes.Image):
+        @property
+        def raw(self):
+            seen.add(threading.current_thread().name)
+            time.sleep(0.006)
+            return self._pixels
+    images = [SlowImage(shapes.Metadata("slow%02d" % i, 480, 352, [], "none"), synth_pixels(352, 480, 60 + i)) for i in range(9)]
+    ratios = [1.0] * len(images)
+    threaded, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.1)
+    assert len(seen) >= 2, seen                                   # the calling thread first, pool threads later
+    prev, seen_inline = voc_dets.DECODE_THREADS, None
+    voc_dets.DECODE_THREADS = 0
+    try:
+        seen.clear()
+        inline, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.1)
+        seen_inline = set(seen)
+    finally:
+        voc_dets.DECODE_THREADS = prev
+    assert seen_inline == {threading.current_thread().name}
+    assert list(threaded) == list(inline)
+    for cls_name in inline:
+        assert list(threaded[cls_name]) == list(inline[cls_name])
+        for img_name in inline[cls_name]:
+            same_dets(threaded[cls_name][img_name], inline[cls_name][img_name], tol=0.0)
+
+
 def test_graph_cache_budget_evicts_least_recently_used(models):
     from faster_rcnn_amd import entry
     mgr, det, _, _ = models
