@@ -123,6 +123,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_x6(const Args p) {
     using I1 = std::integral_constant<int, DEPTH == 2 ? 1 : 0>;
 
     f32x16 acc[TM][TN];
+    f32x16 acc_lo[TM][TN];                                // SKIP & 32: the five small partial products accumulate apart from a1*b1
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_lo[i][j][e] = 0.0f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -153,7 +160,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_x6(const Args p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[IA[t]][i], fb[IB[t]][j], acc[i][j], 0, 0, 0);
+                        if ((SKIP & 32) && t < 5) acc_lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[IA[t]][i], fb[IB[t]][j], acc_lo[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[IA[t]][i], fb[IB[t]][j], acc[i][j], 0, 0, 0);
         }
     };
     if constexpr (DEPTH == 1) {
@@ -225,7 +233,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_x6(const Args p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < p.M) p.C[(size_t)m * p.N + n] = acc[i][j][e];
+                if (m < p.M) p.C[(size_t)m * p.N + n] = (SKIP & 32) ? acc[i][j][e] + acc_lo[i][j][e] : acc[i][j][e];
             }
         }
     }
@@ -576,11 +584,14 @@ int main(int argc, char** argv) {
     // ---- 1. numerics: error against fp64 of (a) the native f32 MFMA, (b) x6, (c) x3 (a1b1 + a1b2 + a2b1: "bf16x3")
     {
         const int M = 256, N = 256;
-        for (int K : {512, 4608}) {
+        for (int K : {512, 4608, -4608}) {                     // (negative: the same K with ALL-POSITIVE operands -- nothing cancels)
+            const bool positive = K < 0;
+            K = K < 0 ? -K : K;
             std::vector<float> A((size_t)M * K), B((size_t)N * K);
             srand(7);
-            for (auto& v : A) v = (float)rand() / RAND_MAX * 2.0f - 1.0f;                 // activations: O(1), mixed sign
-            for (auto& v : B) v = ((float)rand() / RAND_MAX * 2.0f - 1.0f) * 0.05f;        // filters
+            for (auto& v : A) v = positive ? 0.5f + 0.5f * (float)rand() / RAND_MAX : (float)rand() / RAND_MAX * 2.0f - 1.0f;                 // activations: O(1), mixed sign
+            for (auto& v : B) v = positive ? 0.025f + 0.025f * (float)rand() / RAND_MAX : ((float)rand() / RAND_MAX * 2.0f - 1.0f) * 0.05f;        // filters
+            if (positive) printf("  -- all-positive operands\n");
             std::vector<unsigned short> Bp((size_t)3 * N * K);
             for (size_t i = 0; i < B.size(); ++i) {
                 const unsigned short h = f2bf(B[i]); const float r1 = B[i] - bf2f(h);
@@ -613,6 +624,7 @@ int main(int argc, char** argv) {
             a.Bp = dBp;
             run<2, 2, 2, 2, 6>(a, 0, ""); report("bf16x6 (six exact partial products)");
             run<2, 2, 2, 2, 6, 2>(a, 0, ""); report("bf16x6, loads two chunks ahead");
+            run<2, 2, 2, 2, 6, 2, 32>(a, 0, ""); report("bf16x6, a1*b1 and the five small terms in separate accumulators");
             run<2, 1, 2, 4, 6, 2>(a, 0, ""); report("bf16x6, 8 waves, loads two chunks ahead");
             run<2, 1, 2, 4, 6, 3>(a, 0, ""); report("bf16x6, 8 waves, LDS double buffer");
             run16<4, 2, 2, 4>(a, 0, ""); report("bf16x6 on v_mfma_f32_16x16x32_bf16, 128x128 8 waves");

@@ -83,6 +83,44 @@ def test_x6_matches_fp64_as_well_as_the_native_kernel(case):
     assert torch.equal(again, got)
 
 
+@pytest.mark.parametrize("kind", ["all_positive", "wide_exponents", "integers", "subnormal_neighbours"])
+def test_x6_error_on_operands_that_do_not_cancel(kind):
+    """The three-way split is exact for every finite f32 whose bf16 pieces stay normal; what the engine drops are the three partial
+    products below 2^-24 of a product.  Random normal operands hide a systematic error behind cancellation: here nothing cancels
+    (all-positive operands: sum|ab| = |sum ab|), magnitudes span 2^-12..2^12 inside one dot product, operands are integers whose
+    products and sums are exact in f32 (the result must be EXACT), and values sit next to the bf16-subnormal range."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState({"all_positive": 1, "wide_exponents": 2, "integers": 3, "subnormal_neighbours": 4}[kind])
+    n, h, w, cin, cout, k = 1, 30, 44, 128, 128, 3
+    if kind == "all_positive":
+        x = rs.uniform(0.5, 1.0, (n, h, w, cin)).astype(np.float32); wt = rs.uniform(0.5, 1.0, (k, k, cin, cout)).astype(np.float32)
+    elif kind == "wide_exponents":
+        x = (rs.randn(n, h, w, cin) * 2.0 ** rs.randint(-12, 13, (n, h, w, cin))).astype(np.float32)
+        wt = (rs.randn(k, k, cin, cout) * 2.0 ** rs.randint(-12, 13, (k, k, cin, cout))).astype(np.float32)
+    elif kind == "integers":
+        x = rs.randint(-60, 61, (n, h, w, cin)).astype(np.float32); wt = rs.randint(-60, 61, (k, k, cin, cout)).astype(np.float32)
+    else:
+        x = (rs.randn(n, h, w, cin) * 1e-30).astype(np.float32); wt = (rs.randn(k, k, cin, cout) * 1e-6).astype(np.float32)
+    pc = ops.PackedConv(wt)
+    xd = torch.from_numpy(x).cuda()
+    ref, mag = ref_conv(x, wt, 1, "same")
+    for tile in (71, 74, 76):
+        with ops.conv_workspace(ops.NO_SPLIT_K):                 # like for like: both sum k = 0 .. K - 1 in ONE accumulator (a split-K launch
+            got = ops.conv2d(xd, pc, 1, "same", None, tile=tile).cpu().numpy()     # sums slices pairwise and would flatter either side)
+            nat = ops.conv2d(xd, pc, 1, "same", None, tile=0).cpu().numpy()
+        if kind == "integers":                                   # |sum| < 9 * 128 * 3600 < 2^24: every partial sum is an integer f32 holds
+            assert np.array_equal(got.astype(np.float64), ref) and np.array_equal(nat.astype(np.float64), ref)
+            continue
+        if kind == "subnormal_neighbours":                       # products ~1e-36: f32 subnormal range starts at 1.2e-38, results are normal
+            scale = 1e36
+            e_x6 = float((np.abs(got.astype(np.float64) - ref) * scale).max() / (mag * scale).max())
+            e_nat = float((np.abs(nat.astype(np.float64) - ref) * scale).max() / (mag * scale).max())
+        else:
+            e_x6, e_nat = err(got, ref, mag), err(nat, ref, mag)
+        print(kind, tile, "x6 %.3g native %.3g" % (e_x6, e_nat))
+        assert e_x6 <= max(1.5 * e_nat, 4e-7), (kind, tile, e_x6, e_nat)
+
+
 def test_x6_position_major_layout_and_tap_skipping_are_bit_identical_to_nhwc():
     """The detector head's [7][7][roi][c] tensors: a 128-row tile covers one or two output positions and skips the taps that
     only meet zero padding -- exact zeros, so the NHWC launch of the same engine must give the same bits."""
