@@ -1397,6 +1397,157 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_bf16(const WgradArgs p) {
     wgrad_body_bf16(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Weight gradient of an f32 layer on the bf16 matrix cores by exact three-way operand splitting (the forward engine of
+// conv_x6.hip, for dW = X^T . G): BOTH operands arrive in f32 ([pixel][channel] as they lie in NHWC) and are split as they move
+// into LDS -- x = x1 + x2 + x3 with bf16 pieces, each subtraction exact -- into three planes of 32 pixels x 128 channels
+// (320-byte rows: the four pixel rows of a transposing read land on disjoint 16-bank groups).  The reduction index is the pixel,
+// so fragments come back through ds_read_b64_tr_b16 as in the bf16 body above; the six partial products with i + j <= 4 go
+// through v_mfma_f32_32x32x16_bf16, smallest first, into the same f32 accumulators.  Tile, grid, slabs, slice boundaries and
+// the fixed-order reduction are those of the 128x128 f32 body (kind 3); ONE LDS buffer of 60 KB (two workgroups per CU), the
+// next chunk's operands wait in registers.  Error against fp64: the native f32 kernel's level (tests/test_conv_bwd_gpu.py).
+constexpr int WX_ROW = 320;               // LDS row stride in bytes: 128 channels x 2 B + 64
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wg_split3(const f32x4 v, i32x2& h, i32x2& m, i32x2& l) {
+    typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+    bf16x4s hh, mm, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hh[e] = (__bf16)v[e];
+        const float r1 = v[e] - (float)hh[e];
+        mm[e] = (__bf16)r1;
+        ll[e] = (__bf16)(r1 - (float)mm[e]);
+    }
+    h = __builtin_bit_cast(i32x2, hh); m = __builtin_bit_cast(i32x2, mm); l = __builtin_bit_cast(i32x2, ll);
+}
+
+__device__ __forceinline__ void wgrad_body_x6_big(const WgradArgs& p, int bx, int by, int bz) {
+    __shared__ __attribute__((aligned(16))) char Xp[3][WG_MC][WX_ROW];
+    __shared__ __attribute__((aligned(16))) char Gp[3][WG_MC][WX_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int ci_tiles = (p.Cin + 127) / 128;
+    const int tap = bx / ci_tiles, ci0 = (bx % ci_tiles) * 128;
+    const int r_tap = tap / p.S, s_tap = tap % p.S;
+    const int co0 = by * 128;
+    const int m_begin = bz * p.m_per_slice, m_end = min(p.M, m_begin + p.m_per_slice);
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.g), 0, (int)((size_t)p.M * p.Cout * 4), 0x00020000);
+
+    // staging: 256 threads move 32 pixels x 128 channels per operand per chunk: 8 rows per pass, 4 passes (the f32 body's walk)
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    const bool ci_ok = ci0 + scol < p.Cin, co_ok = co0 + scol < p.Cout;
+    const float inv_wo = 1.0f / (float)p.Wo, inv_ho = 1.0f / (float)p.Ho;
+    auto divmod = [](int n, int d, float inv, int& q, int& r) {
+        q = (int)((float)n * inv); r = n - q * d;
+        if (r < 0) { r += d; --q; }
+        if (r >= d) { r -= d; ++q; }
+    };
+    int mc = m_begin;
+    i32x4 rx[4], rg[4];
+    auto load = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = mc + srow + 8 * q;
+            int wo, t, ho, img;
+            divmod(m, p.Wo, inv_wo, t, wo);
+            divmod(t, p.Ho, inv_ho, img, ho);
+            const int hi = ho * p.stride - p.pad_top + r_tap, wi = wo * p.stride - p.pad_left + s_tap;
+            const bool in = m < m_end && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned xoff = (unsigned)(((img * p.H + hi) * p.W + wi) * p.Cin + ci0 + scol) * 4u;
+            rx[q] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in && ci_ok ? xoff : OOB_OFFSET, 0, 0);
+            const unsigned goff = (unsigned)(m * p.Cout + co0 + scol) * 4u;
+            rg[q] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, m < m_end && co_ok ? goff : OOB_OFFSET, 0, 0);
+        }
+        mc += WG_MC;
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            i32x2 h, m, l;
+            wg_split3(__builtin_bit_cast(f32x4, rx[q]), h, m, l);
+            *reinterpret_cast<i32x2*>(&Xp[0][srow + 8 * q][scol * 2]) = h;
+            *reinterpret_cast<i32x2*>(&Xp[1][srow + 8 * q][scol * 2]) = m;
+            *reinterpret_cast<i32x2*>(&Xp[2][srow + 8 * q][scol * 2]) = l;
+            wg_split3(__builtin_bit_cast(f32x4, rg[q]), h, m, l);
+            *reinterpret_cast<i32x2*>(&Gp[0][srow + 8 * q][scol * 2]) = h;
+            *reinterpret_cast<i32x2*>(&Gp[1][srow + 8 * q][scol * 2]) = m;
+            *reinterpret_cast<i32x2*>(&Gp[2][srow + 8 * q][scol * 2]) = l;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // transposed-read addressing (wgrad_body_bf16): lane 4q+p of a 16-lane group supplies (pixel row q, channels 4p..4p+3) of its
+    // block; lanes 0-15 / 16-31 take channels 0-15 / 16-31 of a 32-channel tile, lanes 32-63 the next 8 pixels (lh)
+    const int g16 = lane & 15, tq = g16 >> 2, tp = g16 & 3, cblk = ((lane >> 4) & 1) * 16;
+    const int a_byte = (8 * lh + tq) * WX_ROW + (wk * 64 + cblk + 4 * tp) * 2;
+    const int b_byte = (8 * lh + tq) * WX_ROW + (wn * 64 + cblk + 4 * tp) * 2;
+    typedef i16x4 __attribute__((address_space(3))) * lds_i16x4;
+    auto frag = [&](const char* base) {
+        const i16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4)base);
+        const i16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4)(base + 4 * WX_ROW));
+        return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    const int n_chunks = (m_end - m_begin + WG_MC - 1) / WG_MC;
+    if (n_chunks > 0) {
+        load();
+        store();
+        load();                                              // chunk 1 (zeros past the slice)
+        __syncthreads();
+        for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+            for (int st = 0; st < WG_MC / 16; ++st) {        // 16 pixels per MFMA
+                bf16x8w fa[3][2], fb[3][2];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        fa[pl][i] = frag(&Xp[pl][0][0] + a_byte + (16 * st) * WX_ROW + i * 64);
+                        fb[pl][i] = frag(&Gp[pl][0][0] + b_byte + (16 * st) * WX_ROW + i * 64);
+                    }
+                constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[IA[t]][i], fb[IB[t]][j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();                                 // everybody is done reading chunk c
+            if (c + 1 < n_chunks) {
+                store();                                     // chunk c + 1 (in registers since the previous iteration)
+                load();                                      // chunk c + 2
+            }
+            __syncthreads();
+        }
+    }
+    // partial slab layout = HWIO: [slice][tap][ci][co]; tile (i, j) of this wave = channels 32 i + row, 32 j + column
+    float* dst = p.partial + ((size_t)bz * p.R * p.S + tap) * p.Cin * p.Cout;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wn * 64 + 32 * j + li;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = ci0 + wk * 64 + 32 * i + 4 * lh + (e & 3) + 8 * (e >> 2);
+                if (ci < p.Cin) dst[(size_t)ci * p.Cout + co] = acc[i][j][e];
+            }
+    }
+}
+
 // dW = s[co] * sum over slices (fixed order); dbias[co] handled by k_colsum
 __global__ void k_wgrad_reduce(const float* partial, int slices, size_t elems, int Cout, const float* scale, float* dw) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
@@ -1420,7 +1571,7 @@ struct WgradBatch { WgradArgs job[WGRAD_BATCH]; int first_block[WGRAD_BATCH + 1]
 struct WgradReduceJob { const float* partial; const float* scale; float* dw; unsigned long long elems; int slices, cout; };
 struct WgradReduceBatch { WgradReduceJob job[2 * WGRAD_BATCH]; int first_block[2 * WGRAD_BATCH + 1]; int n; };   // workgroups in proportion to job size
 
-template <int KIND>          // 0: f32 operands; 1: bf16 operands on the bf16 MFMA; 2: bf16 operands widened onto the f32 MFMA; 3: f32, 128x128 tiles
+template <int KIND>          // 0: f32 operands; 1: bf16 operands on the bf16 MFMA; 2: bf16 operands widened onto the f32 MFMA; 3: f32, 128x128 tiles; 4: f32 operands split onto the bf16 MFMA, 128x128 tiles
 __global__ void __launch_bounds__(256) k_conv_wgrad_batch(const WgradBatch t) {
     int j = 0;
     while (j + 1 < t.n && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
@@ -1428,11 +1579,16 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_batch(const WgradBatch t) {
     const int bx = local % t.gx[j], r = local / t.gx[j], by = r % t.gy[j], bz = r / t.gy[j];
     if constexpr (KIND == 1) wgrad_body_bf16(t.job[j], bx, by, bz);
     else if constexpr (KIND == 3) wgrad_body_f32_big(t.job[j], bx, by, bz);
+    else if constexpr (KIND == 4) wgrad_body_x6_big(t.job[j], bx, by, bz);
     else wgrad_body_f32<KIND == 2>(t.job[j], bx, by, bz);
 }
 
 __global__ void __launch_bounds__(256) k_conv_wgrad_f32_big(const WgradArgs p) {
     wgrad_body_f32_big(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+__global__ void __launch_bounds__(256) k_conv_wgrad_x6_big(const WgradArgs p) {
+    wgrad_body_x6_big(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 __global__ void __launch_bounds__(256) k_wgrad_reduce_batch(const WgradReduceBatch t) {
@@ -2010,6 +2166,9 @@ int frcnn_pack_conv_weights_dgrad(const float* w_hwio, const float* scale, int k
 }
 
 // f32 operands, cin and cout >= 128: the 128x128-tile kernel (dev knob FRCNN_WGRAD_BIG=0: the 64x64 kernel everywhere)
+// frcnn_conv_desc.tile 71..77 on an f32 job asks for the split-bf16 engine (kind 4) where the 128x128 form applies
+static bool wgrad_wants_x6(const frcnn_conv_desc* d) { const int t = d->tile % 100; return t >= 71 && t <= 77; }
+
 static bool wgrad_big(const frcnn_conv_desc* d, bool in_bf16) {
     static const bool on = !(getenv("FRCNN_WGRAD_BIG") && atoi(getenv("FRCNN_WGRAD_BIG")) == 0);
     if (!on || in_bf16 || d->cin < 128 || d->cout < 128 || (d->cin & 3) || (d->cout & 3)) return false;
@@ -2077,7 +2236,8 @@ static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bo
     hipStream_t s = as_stream(stream);
     const int tw = big ? 128 : 64;
     dim3 grid(d->kh * d->kw * ((d->cin + tw - 1) / tw), (d->cout + tw - 1) / tw, slices);
-    if (big) k_conv_wgrad_f32_big<<<grid, 256, 0, s>>>(a);
+    if (big && wgrad_wants_x6(d)) k_conv_wgrad_x6_big<<<grid, 256, 0, s>>>(a);
+    else if (big) k_conv_wgrad_f32_big<<<grid, 256, 0, s>>>(a);
     else if (in_bf16 && (d->cin & 7) == 0 && (d->cout & 7) == 0) k_conv_wgrad_bf16<<<grid, 256, 0, s>>>(a);      // bf16 MFMA
     else if (in_bf16) k_conv_wgrad_f32<true><<<grid, 256, 0, s>>>(a);                                          // widened, f32 MFMA
     else k_conv_wgrad_f32<false><<<grid, 256, 0, s>>>(a);
@@ -2106,7 +2266,7 @@ static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bo
 }
 
 static int wgrad_kind(const frcnn_wgrad_job& j) {
-    if (!j.in_bf16) return wgrad_big(&j.d, false) ? 3 : 0;
+    if (!j.in_bf16) return wgrad_big(&j.d, false) ? (wgrad_wants_x6(&j.d) ? 4 : 3) : 0;
     return ((j.d.cin & 7) == 0 && (j.d.cout & 7) == 0) ? 1 : 2;
 }
 
@@ -2138,7 +2298,7 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
         slab[i] = (float*)((char*)workspace + off);
         off += wgrad_slab_bytes(&j.d);
     }
-    for (int kind = 0; kind < 4; ++kind) {
+    for (int kind = 0; kind < 5; ++kind) {
         WgradBatch t;
         t.n = 0;
         int blocks = 0;
@@ -2149,7 +2309,8 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             if (kind == 0) k_conv_wgrad_batch<0><<<blocks, 256, 0, s>>>(t);
             else if (kind == 1) k_conv_wgrad_batch<1><<<blocks, 256, 0, s>>>(t);
             else if (kind == 2) k_conv_wgrad_batch<2><<<blocks, 256, 0, s>>>(t);
-            else k_conv_wgrad_batch<3><<<blocks, 256, 0, s>>>(t);
+            else if (kind == 3) k_conv_wgrad_batch<3><<<blocks, 256, 0, s>>>(t);
+            else k_conv_wgrad_batch<4><<<blocks, 256, 0, s>>>(t);
             t.n = 0; blocks = 0;
             return check_launch("conv2d_wgrad_batch");
         };
@@ -2162,9 +2323,9 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
             a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
             a.M = d->n * d->ho * d->wo;
-            const int slices = wgrad_slices(d, kind == 3);
+            const int slices = wgrad_slices(d, kind >= 3);
             a.m_per_slice = ((a.M + slices - 1) / slices + WG_MC - 1) / WG_MC * WG_MC;
-            const int tw = kind == 3 ? 128 : 64;
+            const int tw = kind >= 3 ? 128 : 64;
             t.gx[t.n] = d->kh * d->kw * ((d->cin + tw - 1) / tw);
             t.gy[t.n] = (d->cout + tw - 1) / tw;
             t.first_block[t.n] = blocks;
@@ -2182,7 +2343,7 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             const frcnn_conv_desc* d = &jobs[q].d;
             r.job[i].partial = slab[q]; r.job[i].scale = jobs[q].scale; r.job[i].dw = jobs[q].dw;
             r.job[i].elems = (unsigned long long)d->kh * d->kw * d->cin * d->cout;
-            r.job[i].slices = wgrad_slices(d, wgrad_kind(jobs[q]) == 3); r.job[i].cout = d->cout;
+            r.job[i].slices = wgrad_slices(d, wgrad_kind(jobs[q]) >= 3); r.job[i].cout = d->cout;
         }
         int rblocks = 0;
         for (int i = 0; i <= 2 * WGRAD_BATCH; ++i) {

@@ -5,6 +5,7 @@ arithmetic happens inside libfrcnn_hip.so.  Every function takes/returns CUDA(=H
 and is asynchronous on ``torch.cuda.current_stream()``.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -667,11 +668,22 @@ def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
     return out
 
 
+# Weight gradients of f32 layers: "native" = v_mfma_f32_32x32x2_f32; "bf16x6" = both operands split exactly into three bf16 pieces
+# inside the kernel, six partial products on the bf16 matrix cores (conv_igemm.hip wgrad_body_x6_big; layers with cin, cout >= 128,
+# the others stay native).  Same slabs and fixed-order reduction: runs are bitwise reproducible either way, the two engines agree
+# to f32 rounding.  The library default stays "native"; train.py opts in.
+WGRAD_ENGINE = os.environ.get("FRCNN_WGRAD_ENGINE", "native")
+
+
+def _wgrad_tile(dtype):
+    return 71 if WGRAD_ENGINE == "bf16x6" and dtype == torch.float32 else 0
+
+
 def conv2d_wgrad(x, g, kh, kw, stride=1, padding="valid", scale=None, dw=None, dbias=None, want_bias=True):
     """-> (dw (kh,kw,cin,cout), dbias (cout,) or None); g: (n,ho,wo,cout)."""
     _require_gpu()
     cout = g.shape[-1]
-    d = _conv_desc(tuple(x.shape), kh, kw, cout, stride, padding)
+    d = _conv_desc(tuple(x.shape), kh, kw, cout, stride, padding, tile=_wgrad_tile(x.dtype))
     assert (d.ho, d.wo) == (g.shape[1], g.shape[2])
     if dw is None:
         dw = torch.empty((kh, kw, x.shape[-1], cout), dtype=torch.float32, device="cuda")
@@ -696,7 +708,7 @@ def conv2d_wgrad_batch(jobs):
         assert x.dtype == g.dtype and x.dtype in (torch.float32, torch.bfloat16) and dw.dtype == torch.float32 and dw.is_contiguous()
         x, g = x.contiguous(), g.contiguous()
         keep.append((x, g))
-        d = _conv_desc(tuple(x.shape), kh, kw, g.shape[-1], stride, padding)
+        d = _conv_desc(tuple(x.shape), kh, kw, g.shape[-1], stride, padding, tile=_wgrad_tile(x.dtype))
         assert (d.ho, d.wo) == (g.shape[1], g.shape[2]) and tuple(dw.shape[-4:]) == (kh, kw, x.shape[-1], g.shape[-1])
         j.d = d
         j.x, j.g, j.dw = x.data_ptr(), g.data_ptr(), dw.data_ptr()

@@ -312,7 +312,12 @@ int frcnn_colsum_batch(const frcnn_colsum_job* jobs, int n_jobs, void* stream);
 /* Weight / bias gradient of the convolution described by d (forward geometry):
  *   dw[kh][kw][cin][cout] = scale[co] * sum_m im2col(x)[m][(tap,ci)] * g[m][co],  dbias[co] = scale[co] * sum_m g[m][co]
  * g [M][cout] = gradient w.r.t. the layer's post-BatchNorm, pre-activation output.  Deterministic
- * (slice partials reduced in a fixed order).  dbias may be NULL. */
+ * (slice partials reduced in a fixed order).  dbias may be NULL.
+ * d->tile % 100 in 71..77 asks for the split-bf16 engine (round 4): on layers with cin, cout >= 128 both f32 operands are split
+ * exactly into three bf16 pieces inside the kernel and the six partial products that matter run on v_mfma_f32_32x32x16_bf16
+ * (same tiles, slabs and fixed-order reduction; error against fp64 at the native kernel's level, results agree with the
+ * native engine to f32 rounding, not bit for bit); other layers ignore the request.  Also honoured per job by
+ * frcnn_conv2d_wgrad_batch. */
 size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_wgrad(const frcnn_conv_desc* d, const float* x, const float* g, const float* scale,
                        float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes, void* stream);

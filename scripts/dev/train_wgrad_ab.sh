@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+for e in native bf16x6 native bf16x6; do
+  FRCNN_TRAIN_WGRAD=$e python3 scripts/bench_train.py --steps 60 --warmup 40 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('wgrad $e: rpn %.3f ms  det %.3f ms' % (d['rpn_step1']['ms_per_step'], d['det_step2']['ms_per_step']))"
+done

@@ -35,8 +35,18 @@ CASES = [  # n,h,w,cin,cout,k,stride,padding
 ]
 
 
+@pytest.fixture(params=["native", "bf16x6"])
+def wgrad_engine(request):
+    """Both engines of the f32 weight gradient (ops.WGRAD_ENGINE): the split-bf16 one takes the layers with cin, cout >= 128,
+    the others run natively under either setting -- every case is held to the same bars under both."""
+    from faster_rcnn_amd import ops
+    prev, ops.WGRAD_ENGINE = ops.WGRAD_ENGINE, request.param
+    yield request.param
+    ops.WGRAD_ENGINE = prev
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_conv_backward(case):
+def test_conv_backward(case, wgrad_engine):
     from faster_rcnn_amd import ops
     n, h, w, cin, cout, k, stride, padding = case
     rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
@@ -114,7 +124,37 @@ def test_colsum_batch():
         assert torch.equal(out, f)                              # fixed summation order
 
 
-def test_wgrad_batch_is_bitwise_the_single_layer_calls():
+def test_wgrad_split_engine_error_is_the_native_kernels():
+    """The split-bf16 weight gradient (both f32 operands split exactly into three bf16 pieces inside the kernel) against fp64, in
+    units of sum |x g| per element: at or under the native f32 MFMA kernel's error, on mixed-sign and on all-positive operands."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(11)
+    for positive in (False, True):
+        for (n, h, w, cin, cout, k, stride, padding) in ((1, 38, 63, 256, 256, 3, 1, "same"), (2, 15, 18, 160, 132, 3, 2, "same"), (1, 37, 50, 256, 128, 1, 2, "valid")):
+            x = rs.uniform(0.5, 1.0, (n, h, w, cin)) if positive else rs.randn(n, h, w, cin)
+            ho = -(-h // stride) if padding == "same" else (h - k) // stride + 1
+            wo = -(-w // stride) if padding == "same" else (w - k) // stride + 1
+            g = rs.uniform(0.05, 0.1, (n, ho, wo, cout)) if positive else rs.randn(n, ho, wo, cout) * 0.1
+            x, g = x.astype(np.float32), g.astype(np.float32)
+            wt = torch.zeros(k, k, cin, cout, dtype=torch.float64, requires_grad=True)
+            (ref_conv(torch.from_numpy(x).double(), wt, stride, padding) * torch.from_numpy(g).double()).sum().backward()
+            want = wt.grad.clone()
+            wa = torch.zeros(k, k, cin, cout, dtype=torch.float64, requires_grad=True)
+            (ref_conv(torch.from_numpy(np.abs(x)).double(), wa, stride, padding) * torch.from_numpy(np.abs(g)).double()).sum().backward()
+            mag = wa.grad.clamp(min=1e-30)
+            errs = {}
+            for eng in ("native", "bf16x6"):
+                prev, ops.WGRAD_ENGINE = ops.WGRAD_ENGINE, eng
+                try:
+                    dw, _ = ops.conv2d_wgrad(torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda(), k, k, stride, padding, want_bias=False)
+                finally:
+                    ops.WGRAD_ENGINE = prev
+                errs[eng] = ((dw.cpu().double() - want).abs() / mag).max().item()
+            print(positive, (n, h, w, cin, cout, k, stride), errs)
+            assert errs["bf16x6"] <= max(1.5 * errs["native"], 3e-7), errs
+
+
+def test_wgrad_batch_is_bitwise_the_single_layer_calls(wgrad_engine):
     """frcnn_conv2d_wgrad_batch: every trainable layer's weight gradient in one launch per operand kind (+ one reduction
     launch) -- per layer the same slices, slabs and summation order as frcnn_conv2d_wgrad / _bf16, so bit-identical."""
     from faster_rcnn_amd import ops
