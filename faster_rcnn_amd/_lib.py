@@ -58,6 +58,7 @@ SIGNATURES = {
     "frcnn_conv2d_dual_config": (I, [P, I]),
     "frcnn_conv2d_x6_config": (I, [P, I]),
     "frcnn_pack_conv_weights_x6": (I, [P, I, I, P, P]),
+    "frcnn_refresh_x6_planes": (I, [P, I, P]),
     "frcnn_conv2d_x6_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_fwd_x6": (I, [P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_conv2d_fwd_dual_x6": (I, [P, P, P, P, P, P, I, I, P, I, P]),
@@ -130,6 +131,11 @@ class PackJob(ctypes.Structure):
 class WgradJob(ctypes.Structure):
     """frcnn_wgrad_job (include/frcnn_hip.h)."""
     _fields_ = [("d", ConvDesc)] + [(k, c_void_p) for k in ("x", "g", "scale", "dw")] + [(k, ctypes.c_int32) for k in ("in_bf16", "reserved")]
+
+
+class X6Job(ctypes.Structure):
+    """frcnn_x6_job (include/frcnn_hip.h)."""
+    _fields_ = [("w_packed", c_void_p), ("planes_bf16", c_void_p), ("rows", ctypes.c_int32), ("kpad", ctypes.c_int32)]
 
 
 class ColsumJob(ctypes.Structure):

@@ -557,6 +557,32 @@ __global__ void k_pack_x6(const float* w, size_t n, __bf16* out) {
     }
 }
 
+// the same for MANY filters in one launch (a training step re-derives the planes of every trainable layer's forward and
+// input-gradient filter after the optimiser has rewritten the f32 forms): a workgroup finds its job by the block prefix
+constexpr int X6_REFRESH_JOBS = 48;
+struct X6RefreshTable { const float* w[X6_REFRESH_JOBS]; __bf16* out[X6_REFRESH_JOBS]; unsigned long long n[X6_REFRESH_JOBS]; int first_block[X6_REFRESH_JOBS + 1]; int jobs; };
+__global__ void __launch_bounds__(256) k_pack_x6_batch(const X6RefreshTable t) {
+    int j = 0;
+    while (j + 1 < t.jobs && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
+    const size_t n = t.n[j];
+    const int nb = t.first_block[j + 1] - t.first_block[j], b = (int)blockIdx.x - t.first_block[j];
+    const float* w = t.w[j];
+    __bf16* out = t.out[j];
+    for (size_t i = ((size_t)b * 256 + threadIdx.x) * 4; i < n; i += (size_t)nb * 256 * 4) {       // n % 4 == 0 (packed k is a multiple of 32)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + i);
+        typedef __bf16 bf16x4p __attribute__((ext_vector_type(4)));
+        bf16x4p a1, a2, a3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a1[e] = (__bf16)v[e];
+            const float r1 = v[e] - (float)a1[e];
+            a2[e] = (__bf16)r1;
+            a3[e] = (__bf16)(r1 - (float)a2[e]);
+        }
+        *reinterpret_cast<bf16x4p*>(out + i) = a1; *reinterpret_cast<bf16x4p*>(out + n + i) = a2; *reinterpret_cast<bf16x4p*>(out + 2 * n + i) = a3;
+    }
+}
+
 template <int TM, int TN, int WM, int WN>
 static int launch_x6(const ConvArgs& a, hipStream_t s) {
     using T = X6Tile<TM, TN, WM, WN>;
@@ -605,4 +631,28 @@ extern "C" int frcnn_pack_conv_weights_x6(const float* w_packed, int cout, int k
     if (grid > 4096) grid = 4096;
     k_pack_x6<<<grid, 256, 0, as_stream(stream)>>>(w_packed, n, (__bf16*)planes_bf16);
     return check_launch("pack_conv_weights_x6");
+}
+
+extern "C" int frcnn_refresh_x6_planes(const frcnn_x6_job* jobs, int n_jobs, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(FRCNN_E_ARG, "refresh_x6_planes: bad argument");
+    for (int i = 0; i < n_jobs; ++i)
+        if (!jobs[i].w_packed || !jobs[i].planes_bf16 || jobs[i].rows <= 0 || jobs[i].kpad <= 0 || (jobs[i].kpad % 32)
+            || (reinterpret_cast<uintptr_t>(jobs[i].w_packed) & 15) || (reinterpret_cast<uintptr_t>(jobs[i].planes_bf16) & 7))
+            return fail(FRCNN_E_ARG, "refresh_x6_planes: job %d is malformed (packed k must be a multiple of 32, pointers 16 / 8-byte aligned)", i);
+    for (int b = 0; b < n_jobs; b += X6_REFRESH_JOBS) {
+        X6RefreshTable t;
+        const int n = n_jobs - b < X6_REFRESH_JOBS ? n_jobs - b : X6_REFRESH_JOBS;
+        int blocks = 0;
+        for (int i = 0; i < X6_REFRESH_JOBS; ++i) {
+            const frcnn_x6_job& j = jobs[b + (i < n ? i : 0)];
+            t.w[i] = j.w_packed; t.out[i] = (__bf16*)j.planes_bf16; t.n[i] = (unsigned long long)j.rows * j.kpad;
+            t.first_block[i] = blocks;
+            if (i < n) { const unsigned long long g = (t.n[i] + 4095) / 4096; blocks += (int)(g < 1 ? 1 : (g > 512 ? 512 : g)); }      // 16 elements per thread
+        }
+        t.first_block[X6_REFRESH_JOBS] = blocks;
+        t.jobs = n;
+        k_pack_x6_batch<<<blocks, 256, 0, as_stream(stream)>>>(t);
+        if (int e = check_launch("refresh_x6_planes")) return e;
+    }
+    return FRCNN_OK;
 }

@@ -649,6 +649,8 @@ class PackedDgrad:
         _lib.call("frcnn_pack_conv_weights_dgrad", _p(w), _p(sc), self.kh, self.kw, cin, cout, _p(self.w), _stream())
         self.scale = self.shift = None
 
+    x6_planes = PackedConv.x6_planes                         # the same [rows][packed k] f32 layout: the same three-plane form
+
 
 def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
     """Gradient w.r.t. the input of a stride-1 conv.  gy: (n,ho,wo,cout_fwd) gradient w.r.t. the layer's
@@ -664,7 +666,13 @@ def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
         out = torch.empty((n, ho, wo, pd.cout), dtype=torch.float32, device="cuda")
     d = _conv_desc((n, ho, wo, pd.cin), pd.kh, pd.kw, pd.cout, 1, padding, 0, 0, 0)      # (see conv2d_dgrad_bf16)
     assert (d.pad_top, d.pad_left, d.ho, d.wo) == (pt, pl, ho, wo)
-    _conv_launch(d, gy.contiguous(), pd.w, None, None, residual, mask, out)
+    gy = gy.contiguous()
+    if _use_x6(d, pd, 0):                                       # the split engine's policy, as for a forward launch of this geometry
+        ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_x6_workspace_bytes"))
+        _lib.call("frcnn_conv2d_fwd_x6", ctypes.byref(d), _p(gy), _p(pd.x6_planes()), None, None, _p(residual), _p(mask), _p(out),
+                  _p(ws), ws.numel() if ws is not None else 0, _stream())
+        return out
+    _conv_launch(d, gy, pd.w, None, None, residual, mask, out)
     return out
 
 

@@ -567,9 +567,21 @@ class _StepDriver:
         refresh_packed(self._refresh_jobs)
         # the packed f32 filters were rewritten IN PLACE: bf16 planes derived from them for the split-bf16 engine
         # (ops.PackedConv.x6_planes, cached on tensor identity) are stale now
-        for c in self._tconvs():
-            if getattr(c.pc, "_x6", None) is not None:
-                c.pc._x6 = None
+        self._refresh_x6()
+
+    def _refresh_x6(self):
+        """The packed f32 filters were rewritten IN PLACE: the three bf16 planes the split-bf16 engine multiplies with
+        (ops.PackedConv.x6_planes, cached on tensor identity) are stale.  Every plane set that exists -- a layer gets one the first
+        time the engine's policy picks it, forward or input gradient -- is re-derived in ONE launch (frcnn_refresh_x6_planes)."""
+        live = [pk for c in self._tconvs() for pk in (c.pc, getattr(c, "pd", None)) if getattr(pk, "_x6", None) is not None and pk._x6_src is pk.w]
+        key = tuple(id(pk._x6) for pk in live)
+        if getattr(self, "_x6_key", None) != key:
+            jobs = (_lib.X6Job * max(1, len(live)))()
+            for j, pk in zip(jobs, live):
+                j.w_packed, j.planes_bf16, j.rows, j.kpad = pk.w.data_ptr(), pk._x6.data_ptr(), pk.w.shape[0], pk.w.shape[1]
+            self._x6_key, self._x6_jobs = key, jobs
+        if live:
+            _lib.call("frcnn_refresh_x6_planes", self._x6_jobs, len(live), _stream())
 
     def _stage(self, host_inputs):
         """Host arrays (any dtype: Keras hands float64 images and bool targets) -> pinned float32 staging memory in ONE

@@ -267,6 +267,14 @@ int frcnn_conv2d_dual_config(const frcnn_conv_desc* d, int has_workspace);
 int frcnn_pack_conv_weights_x6(const float* w_packed, int cout, int packed_k, void* planes_bf16, void* stream);
 /* workspace (may be NULL): small grids with k >= 2048 cut K over several workgroups like frcnn_conv2d_fwd_ws does (tickets zero on
  * entry, left zero; frcnn_conv2d_x6_workspace_bytes: 0 = this shape runs unsplit). */
+/* The three bf16 planes of MANY packed f32 filters in one launch (frcnn_pack_conv_weights_x6 per job): a training step calls it
+ * after frcnn_refresh_packed has rewritten the trainable layers' forward and input-gradient filters.  `jobs` is a HOST array. */
+typedef struct frcnn_x6_job {
+    const float* w_packed;         /* [rows][kpad] f32 (frcnn_pack_conv_weights / _dgrad layout), 16-byte aligned */
+    void* planes_bf16;             /* [3][rows][kpad] bf16 */
+    int32_t rows, kpad;            /* kpad % 32 == 0 */
+} frcnn_x6_job;
+int frcnn_refresh_x6_planes(const frcnn_x6_job* jobs, int n_jobs, void* stream);
 /* The tile code (71..77) frcnn_conv2d_fwd_x6 / frcnn_conv2d_fwd_dual_x6 (n1 > 0) run for this descriptor when no split-K workspace
  * applies: profiling tools name the kernel with it. */
 int frcnn_conv2d_x6_config(const frcnn_conv_desc* d, int n1);

@@ -188,6 +188,30 @@ def test_engine_policy_scope_and_refusals():
         _lib.call("frcnn_conv2d_fwd_x6", ctypes.byref(d), y.data_ptr(), y.data_ptr(), None, None, None, None, y.data_ptr(), None, 0, None)
 
 
+def test_refresh_x6_planes_equals_the_single_filter_pack():
+    """frcnn_refresh_x6_planes: the three bf16 planes of many packed filters in one launch == frcnn_pack_conv_weights_x6 per
+    filter, bit for bit; the pieces sum back to the f32 value exactly; malformed jobs are refused."""
+    import ctypes
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(21)
+    shapes = [(3, 3, 64, 96), (1, 1, 256, 1024), (1, 1, 32, 8), (3, 3, 512, 512)] * 15          # 60 jobs: more than one table
+    packs = [ops.PackedConv((rs.randn(*sh) * 0.05).astype(np.float32)) for sh in shapes]
+    want = [pc.x6_planes().clone() for pc in packs]
+    outs = [torch.full_like(w, 7.0) for w in want]
+    jobs = (_lib.X6Job * len(packs))()
+    for j, pc, o in zip(jobs, packs, outs):
+        j.w_packed, j.planes_bf16, j.rows, j.kpad = pc.w.data_ptr(), o.data_ptr(), pc.w.shape[0], pc.w.shape[1]
+    _lib.call("frcnn_refresh_x6_planes", jobs, len(packs), None)
+    torch.cuda.synchronize()
+    for o, w_, pc in zip(outs, want, packs):
+        assert torch.equal(o.view(torch.int16), w_.view(torch.int16))
+        assert torch.equal(o[0].float() + o[1].float() + o[2].float(), pc.w)
+    jobs[1].kpad = 48
+    with pytest.raises(_lib.FrcnnError):
+        _lib.call("frcnn_refresh_x6_planes", jobs, 2, None)
+    _lib.call("frcnn_refresh_x6_planes", None, 0, None)          # nothing to do is fine
+
+
 def test_engine_tile_choice_is_what_the_library_reports():
     """frcnn_conv2d_x6_config: 64x64 tiles for 64-column and small-grid layers, the four-wave 128x64 tile for >= 1024 row tiles of 64
     columns, 128x128 / the sixteen-wave form otherwise; a two-layer launch whose boundary is not a multiple of 128 takes 64-wide tiles."""

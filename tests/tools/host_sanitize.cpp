@@ -130,6 +130,10 @@ int main() {
         if (frcnn_detections_dyn(&dummy, &i32, 64, 320, &dummy, &dummy, 21, 20, 16.0, 0.5, nullptr, &i32, &dummy, &i32, &i32, &i32, nullptr) == FRCNN_OK) { printf("detections_dyn accepted a null dyn\n"); ++failures; }
         if (frcnn_conv2d_dual_config(nullptr, 0) >= 0) { printf("dual_config accepted null\n"); ++failures; }
         if (frcnn_conv2d_x6_config(nullptr, 0) >= 0) { printf("x6_config accepted null\n"); ++failures; }
+        frcnn_x6_job xj; xj.w_packed = &dummy; xj.planes_bf16 = &dummy; xj.rows = 4; xj.kpad = 40;
+        if (frcnn_refresh_x6_planes(&xj, 1, nullptr) == FRCNN_OK) { printf("refresh_x6_planes accepted kpad %% 32 != 0\n"); ++failures; }
+        if (frcnn_refresh_x6_planes(nullptr, 3, nullptr) == FRCNN_OK) { printf("refresh_x6_planes accepted a null table\n"); ++failures; }
+        if (frcnn_refresh_x6_planes(nullptr, 0, nullptr) != FRCNN_OK) { printf("refresh_x6_planes refused an empty table\n"); ++failures; }
     }
     checked += 8;
     printf("host sanitizer driver: %d checks, %d failures\n", checked, failures);
