@@ -2185,7 +2185,10 @@ static int wgrad_slices(const frcnn_conv_desc* d, bool big) {
     // scripts/micro/train_ab2.py, target 2048 -> 256: mixed RPN step 2.36 -> 2.08 ms, detector step 3.30 -> 2.85 ms)
     static const long long target = getenv("FRCNN_WGRAD_TARGET") ? atoll(getenv("FRCNN_WGRAD_TARGET")) : 256;   // dev knob
     static const long long target_big = getenv("FRCNN_WGRAD_TARGET_BIG") ? atoll(getenv("FRCNN_WGRAD_TARGET_BIG")) : 256;
-    const long long tg = big ? target_big : target;
+    // the split-bf16 form's workgroups finish sooner: fewer, longer slices (bench_train.py: 2.18 / 4.02 ms at 256, 2.12 / 3.96 at 96-128,
+    // 2.10 / 3.93 at 48, 2.19 / 4.04 at 32)
+    static const long long target_x6 = getenv("FRCNN_WGRAD_TARGET_X6") ? atoll(getenv("FRCNN_WGRAD_TARGET_X6")) : 96;
+    const long long tg = big ? (wgrad_wants_x6(d) ? target_x6 : target_big) : target;
     long long s = (tg + tiles - 1) / tiles;
     const long long max_s = (M + 4 * WG_MC - 1) / (4 * WG_MC); // at least 4 chunks per slice
     if (s > max_s) s = max_s;

@@ -126,7 +126,10 @@ def test_colsum_batch():
 
 def test_wgrad_split_engine_error_is_the_native_kernels():
     """The split-bf16 weight gradient (both f32 operands split exactly into three bf16 pieces inside the kernel) against fp64, in
-    units of sum |x g| per element: at or under the native f32 MFMA kernel's error, on mixed-sign and on all-positive operands."""
+    units of sum |x g| per element, on mixed-sign and on all-positive operands (nothing cancels).  Per accumulated product the
+    engine is as exact as the native f32 MFMA (tests/test_conv_x6_gpu.py, like for like); here its slices are 2-3x LONGER than
+    the native form's (fewer, longer slices suit its faster workgroups), so one accumulator sums 2-3x more terms: the bar is
+    2.5x the native kernel's error, and 2e-6 absolute -- two orders under the 1e-4 the gradients are held to."""
     from faster_rcnn_amd import ops
     rs = np.random.RandomState(11)
     for positive in (False, True):
@@ -151,7 +154,7 @@ def test_wgrad_split_engine_error_is_the_native_kernels():
                     ops.WGRAD_ENGINE = prev
                 errs[eng] = ((dw.cpu().double() - want).abs() / mag).max().item()
             print(positive, (n, h, w, cin, cout, k, stride), errs)
-            assert errs["bf16x6"] <= max(1.5 * errs["native"], 3e-7), errs
+            assert errs["bf16x6"] <= max(2.5 * errs["native"], 3e-7) and errs["bf16x6"] <= 2e-6, errs
 
 
 def test_wgrad_batch_is_bitwise_the_single_layer_calls(wgrad_engine):
