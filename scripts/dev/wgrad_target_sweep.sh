@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for t in 128 96 64 48 32 128; do
-  FRCNN_WGRAD_TARGET_BIG=$t python3 scripts/bench_train.py --steps 60 --warmup 40 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('wgrad target_big $t: rpn %.3f ms  det %.3f ms' % (d['rpn_step1']['ms_per_step'], d['det_step2']['ms_per_step']))"
+for t in 256 128 96 64 256 128; do
+  FRCNN_WGRAD_TARGET=$t python3 scripts/bench_train.py --bf16 --steps 60 --warmup 40 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('mixed: wgrad target $t: rpn %.3f ms  det %.3f ms' % (d['rpn_step1']['ms_per_step'], d['det_step2']['ms_per_step']))"
 done
