@@ -1548,6 +1548,127 @@ __device__ __forceinline__ void wgrad_body_x6_big(const WgradArgs& p, int bx, in
     }
 }
 
+// The 128 (ci) x 128 (co) form of the bf16 weight gradient (mixed-precision steps; layers with cin, cout >= 128): the tile and
+// wave layout of the split-engine body above with ONE plane per operand -- each wave owns 64 x 64, eight transposing reads feed four
+// MFMAs per 16 pixels (the 64x64 body: four reads per MFMA) -- 64 pixels per chunk in ONE 40 KB LDS buffer, the next chunk's
+// operands waiting in registers.  Slabs, slice boundaries and the fixed-order reduction as everywhere.
+constexpr int WB2_MC = 64;
+__device__ __forceinline__ void wgrad_body_bf16_big(const WgradArgs& p, int bx, int by, int bz) {
+    __shared__ __attribute__((aligned(16))) char Xb[WB2_MC][WX_ROW];
+    __shared__ __attribute__((aligned(16))) char Gb[WB2_MC][WX_ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int ci_tiles = (p.Cin + 127) / 128;
+    const int tap = bx / ci_tiles, ci0 = (bx % ci_tiles) * 128;
+    const int r_tap = tap / p.S, s_tap = tap % p.S;
+    const int co0 = by * 128;
+    const int m_begin = bz * p.m_per_slice, m_end = min(p.M, m_begin + p.m_per_slice);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.g), 0, (int)((size_t)p.M * p.Cout * 2), 0x00020000);
+
+    // staging: 256 threads move 64 pixels x 128 channels (16 x 16 B per pixel) per operand per chunk: 16 rows per pass, 4 passes
+    const int srow = tid >> 4, scol = (tid & 15) * 8;
+    const bool ci_ok = ci0 + scol < p.Cin, co_ok = co0 + scol < p.Cout;
+    const float inv_wo = 1.0f / (float)p.Wo, inv_ho = 1.0f / (float)p.Ho;
+    auto divmod = [](int n, int d, float inv, int& q, int& r) {
+        q = (int)((float)n * inv); r = n - q * d;
+        if (r < 0) { r += d; --q; }
+        if (r >= d) { r -= d; ++q; }
+    };
+    int mc = m_begin;
+    i32x4 rx[4], rg[4];
+    auto load = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = mc + srow + 16 * q;
+            int wo, t, ho, img;
+            divmod(m, p.Wo, inv_wo, t, wo);
+            divmod(t, p.Ho, inv_ho, img, ho);
+            const int hi = ho * p.stride - p.pad_top + r_tap, wi = wo * p.stride - p.pad_left + s_tap;
+            const bool in = m < m_end && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned xoff = (unsigned)(((img * p.H + hi) * p.W + wi) * p.Cin + ci0 + scol) * 2u;
+            rx[q] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, in && ci_ok ? xoff : OOB_OFFSET, 0, 0);
+            const unsigned goff = (unsigned)(m * p.Cout + co0 + scol) * 2u;
+            rg[q] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, m < m_end && co_ok ? goff : OOB_OFFSET, 0, 0);
+        }
+        mc += WB2_MC;
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<i32x4*>(&Xb[srow + 16 * q][scol * 2]) = rx[q];
+            *reinterpret_cast<i32x4*>(&Gb[srow + 16 * q][scol * 2]) = rg[q];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int g16 = lane & 15, tq = g16 >> 2, tp = g16 & 3, cblk = ((lane >> 4) & 1) * 16;
+    const int a_byte = (8 * lh + tq) * WX_ROW + (wk * 64 + cblk + 4 * tp) * 2;
+    const int b_byte = (8 * lh + tq) * WX_ROW + (wn * 64 + cblk + 4 * tp) * 2;
+    typedef i16x4 __attribute__((address_space(3))) * lds_i16x4;
+    auto frag = [&](const char* base) {
+        const i16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4)base);
+        const i16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4)(base + 4 * WX_ROW));
+        return __builtin_bit_cast(bf16x8w, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    const int n_chunks = (m_end - m_begin + WB2_MC - 1) / WB2_MC;
+    if (n_chunks > 0) {
+        load();
+        store();
+        load();
+        __syncthreads();
+        for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+            for (int st = 0; st < WB2_MC / 16; ++st) {
+                bf16x8w fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = frag(&Xb[0][0] + a_byte + (16 * st) * WX_ROW + i * 64);
+                    fb[i] = frag(&Gb[0][0] + b_byte + (16 * st) * WX_ROW + i * 64);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (c + 1 < n_chunks) {
+                store();
+                load();
+            }
+            __syncthreads();
+        }
+    }
+    float* dst = p.partial + ((size_t)bz * p.R * p.S + tap) * p.Cin * p.Cout;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = co0 + wn * 64 + 32 * j + li;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = ci0 + wk * 64 + 32 * i + 4 * lh + (e & 3) + 8 * (e >> 2);
+                if (ci < p.Cin) dst[(size_t)ci * p.Cout + co] = acc[i][j][e];
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_conv_wgrad_bf16_big(const WgradArgs p) {
+    wgrad_body_bf16_big(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // dW = s[co] * sum over slices (fixed order); dbias[co] handled by k_colsum
 __global__ void k_wgrad_reduce(const float* partial, int slices, size_t elems, int Cout, const float* scale, float* dw) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
@@ -1571,7 +1692,7 @@ struct WgradBatch { WgradArgs job[WGRAD_BATCH]; int first_block[WGRAD_BATCH + 1]
 struct WgradReduceJob { const float* partial; const float* scale; float* dw; unsigned long long elems; int slices, cout; };
 struct WgradReduceBatch { WgradReduceJob job[2 * WGRAD_BATCH]; int first_block[2 * WGRAD_BATCH + 1]; int n; };   // workgroups in proportion to job size
 
-template <int KIND>          // 0: f32 operands; 1: bf16 operands on the bf16 MFMA; 2: bf16 operands widened onto the f32 MFMA; 3: f32, 128x128 tiles; 4: f32 operands split onto the bf16 MFMA, 128x128 tiles
+template <int KIND>          // 0: f32 operands; 1: bf16 operands on the bf16 MFMA; 2: bf16 operands widened onto the f32 MFMA; 3: f32, 128x128 tiles; 4: f32 operands split onto the bf16 MFMA, 128x128 tiles; 5: bf16 operands, 128x128 tiles
 __global__ void __launch_bounds__(256) k_conv_wgrad_batch(const WgradBatch t) {
     int j = 0;
     while (j + 1 < t.n && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
@@ -1580,6 +1701,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad_batch(const WgradBatch t) {
     if constexpr (KIND == 1) wgrad_body_bf16(t.job[j], bx, by, bz);
     else if constexpr (KIND == 3) wgrad_body_f32_big(t.job[j], bx, by, bz);
     else if constexpr (KIND == 4) wgrad_body_x6_big(t.job[j], bx, by, bz);
+    else if constexpr (KIND == 5) wgrad_body_bf16_big(t.job[j], bx, by, bz);
     else wgrad_body_f32<KIND == 2>(t.job[j], bx, by, bz);
 }
 
@@ -2176,7 +2298,15 @@ static bool wgrad_big(const frcnn_conv_desc* d, bool in_bf16) {
     return xb < 0x80000000ull && gb < 0x80000000ull && (long long)d->n * d->ho * d->wo < (1 << 23);         // 32-bit buffer offsets, float-exact pixel index
 }
 
-static int wgrad_slices(const frcnn_conv_desc* d, bool big) {
+// the 128x128 bf16 form (kind 5): both channel counts >= 128 and multiples of 8, 32-bit byte offsets, float-exact pixel index
+static bool wgrad_big_bf16(const frcnn_conv_desc* d) {
+    static const bool on = !(getenv("FRCNN_WGRAD_BIG_BF16") && atoi(getenv("FRCNN_WGRAD_BIG_BF16")) == 0);
+    if (!on || d->cin < 128 || d->cout < 128 || (d->cin & 7) || (d->cout & 7)) return false;
+    const size_t xb = (size_t)d->n * d->h * d->w * d->cin * 2, gb = (size_t)d->n * d->ho * d->wo * d->cout * 2;
+    return xb < 0x80000000ull && gb < 0x80000000ull && (long long)d->n * d->ho * d->wo < (1 << 23);
+}
+
+static int wgrad_slices(const frcnn_conv_desc* d, bool big, bool fast = false) {
     const long long M = (long long)d->n * d->ho * d->wo;
     const int tw = big ? 128 : 64;
     const long long tiles = (long long)d->kh * d->kw * ((d->cin + tw - 1) / tw) * ((d->cout + tw - 1) / tw);
@@ -2188,7 +2318,7 @@ static int wgrad_slices(const frcnn_conv_desc* d, bool big) {
     // the split-bf16 form's workgroups finish sooner: fewer, longer slices (bench_train.py: 2.18 / 4.02 ms at 256, 2.12 / 3.96 at 96-128,
     // 2.10 / 3.93 at 48, 2.19 / 4.04 at 32)
     static const long long target_x6 = getenv("FRCNN_WGRAD_TARGET_X6") ? atoll(getenv("FRCNN_WGRAD_TARGET_X6")) : 96;
-    const long long tg = big ? (wgrad_wants_x6(d) ? target_x6 : target_big) : target;
+    const long long tg = big ? ((fast || wgrad_wants_x6(d)) ? target_x6 : target_big) : target;
     long long s = (tg + tiles - 1) / tiles;
     const long long max_s = (M + 4 * WG_MC - 1) / (4 * WG_MC); // at least 4 chunks per slice
     if (s > max_s) s = max_s;
@@ -2198,7 +2328,8 @@ static int wgrad_slices(const frcnn_conv_desc* d, bool big) {
 }
 static int wgrad_slices_max(const frcnn_conv_desc* d) {
     const int a = wgrad_slices(d, false), b = wgrad_big(d, false) ? wgrad_slices(d, true) : 0;
-    return a > b ? a : b;
+    const int c = (wgrad_big(d, false) || wgrad_big_bf16(d)) ? wgrad_slices(d, true, true) : 0;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 size_t frcnn_conv2d_wgrad_workspace_bytes(const frcnn_conv_desc* d) {
@@ -2233,13 +2364,15 @@ static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bo
     a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
     a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
     a.M = d->n * d->ho * d->wo;
-    const bool big = wgrad_big(d, in_bf16);
-    const int slices = wgrad_slices(d, big);
+    const bool big16 = in_bf16 && wgrad_big_bf16(d);
+    const bool big = wgrad_big(d, in_bf16) || big16;
+    const int slices = wgrad_slices(d, big, big16);
     a.m_per_slice = ((a.M + slices - 1) / slices + WG_MC - 1) / WG_MC * WG_MC;
     hipStream_t s = as_stream(stream);
     const int tw = big ? 128 : 64;
     dim3 grid(d->kh * d->kw * ((d->cin + tw - 1) / tw), (d->cout + tw - 1) / tw, slices);
-    if (big && wgrad_wants_x6(d)) k_conv_wgrad_x6_big<<<grid, 256, 0, s>>>(a);
+    if (big16) k_conv_wgrad_bf16_big<<<grid, 256, 0, s>>>(a);
+    else if (big && wgrad_wants_x6(d)) k_conv_wgrad_x6_big<<<grid, 256, 0, s>>>(a);
     else if (big) k_conv_wgrad_f32_big<<<grid, 256, 0, s>>>(a);
     else if (in_bf16 && (d->cin & 7) == 0 && (d->cout & 7) == 0) k_conv_wgrad_bf16<<<grid, 256, 0, s>>>(a);      // bf16 MFMA
     else if (in_bf16) k_conv_wgrad_f32<true><<<grid, 256, 0, s>>>(a);                                          // widened, f32 MFMA
@@ -2270,6 +2403,7 @@ static int wgrad_impl(const frcnn_conv_desc* d, const void* x, const void* g, bo
 
 static int wgrad_kind(const frcnn_wgrad_job& j) {
     if (!j.in_bf16) return wgrad_big(&j.d, false) ? (wgrad_wants_x6(&j.d) ? 4 : 3) : 0;
+    if (wgrad_big_bf16(&j.d)) return 5;
     return ((j.d.cin & 7) == 0 && (j.d.cout & 7) == 0) ? 1 : 2;
 }
 
@@ -2301,7 +2435,7 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
         slab[i] = (float*)((char*)workspace + off);
         off += wgrad_slab_bytes(&j.d);
     }
-    for (int kind = 0; kind < 5; ++kind) {
+    for (int kind = 0; kind < 6; ++kind) {
         WgradBatch t;
         t.n = 0;
         int blocks = 0;
@@ -2313,7 +2447,8 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             else if (kind == 1) k_conv_wgrad_batch<1><<<blocks, 256, 0, s>>>(t);
             else if (kind == 2) k_conv_wgrad_batch<2><<<blocks, 256, 0, s>>>(t);
             else if (kind == 3) k_conv_wgrad_batch<3><<<blocks, 256, 0, s>>>(t);
-            else k_conv_wgrad_batch<4><<<blocks, 256, 0, s>>>(t);
+            else if (kind == 4) k_conv_wgrad_batch<4><<<blocks, 256, 0, s>>>(t);
+            else k_conv_wgrad_batch<5><<<blocks, 256, 0, s>>>(t);
             t.n = 0; blocks = 0;
             return check_launch("conv2d_wgrad_batch");
         };
@@ -2326,7 +2461,7 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             a.n_img = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout; a.R = d->kh; a.S = d->kw;
             a.stride = d->stride; a.pad_top = d->pad_top; a.pad_left = d->pad_left; a.Ho = d->ho; a.Wo = d->wo;
             a.M = d->n * d->ho * d->wo;
-            const int slices = wgrad_slices(d, kind >= 3);
+            const int slices = wgrad_slices(d, kind >= 3, kind == 5);
             a.m_per_slice = ((a.M + slices - 1) / slices + WG_MC - 1) / WG_MC * WG_MC;
             const int tw = kind >= 3 ? 128 : 64;
             t.gx[t.n] = d->kh * d->kw * ((d->cin + tw - 1) / tw);
@@ -2346,7 +2481,7 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
             const frcnn_conv_desc* d = &jobs[q].d;
             r.job[i].partial = slab[q]; r.job[i].scale = jobs[q].scale; r.job[i].dw = jobs[q].dw;
             r.job[i].elems = (unsigned long long)d->kh * d->kw * d->cin * d->cout;
-            r.job[i].slices = wgrad_slices(d, wgrad_kind(jobs[q]) >= 3); r.job[i].cout = d->cout;
+            r.job[i].slices = wgrad_slices(d, wgrad_kind(jobs[q]) >= 3, wgrad_kind(jobs[q]) == 5); r.job[i].cout = d->cout;
         }
         int rblocks = 0;
         for (int i = 0; i <= 2 * WGRAD_BATCH; ++i) {
