@@ -1055,7 +1055,7 @@ def main():
         torch.cuda.synchronize()
 
     via_entry = None
-    if world == 1 and not force_dist and not args.no_graph and not args.no_io and DEPTH != 16 and B == 1 and "FRCNN_BENCH_NO_ENTRY" not in os.environ:
+    if world == 1 and not force_dist and not args.no_graph and not args.no_io and DEPTH != 16 and "FRCNN_BENCH_NO_ENTRY" not in os.environ:
         try:
             via_entry = reference_entry_leg(pipe, anchors, rank)
         except Exception as e:

@@ -93,7 +93,8 @@ class DetTrainingManager:
         """det_util.py:136-158: (conv feature map (1,R,C,Cf) or None, nms_rois (n,4) int16)."""
         with self._own_stream():
             rois, feat = self._proposals_dev(image, 8000, 300)
-            return (feat.cpu().numpy() if feat is not None else None), rois.cpu().numpy()
+            # (a bf16 base hands its map over as float32 -- numpy has no bf16, the widening is exact and the detector narrows it back)
+            return (feat.float().cpu().numpy() if feat is not None else None), rois.cpu().numpy()
 
 
 def _get_anchor_coords(conv_rows, conv_cols, anchor_dims, multiplier=1):

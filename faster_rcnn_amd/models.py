@@ -176,6 +176,9 @@ class DetModel(_Model):
 
     def forward_dev(self, first, rois):
         feat = self.base.net(first) if self.base is not None else first
+        if getattr(self.head, "dtype", "f32") == "bf16" and feat.dtype == torch.float32:
+            from . import ops
+            feat = ops.cast_bf16(feat)                      # a conv map that travelled as float32 numpy (det_util.get_det_inputs): exact narrowing
         return self.head(feat, rois)
 
     # ---- training (train_util.py:95-118): compile / train_on_batch / flushing live in _Model

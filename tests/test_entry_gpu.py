@@ -175,6 +175,42 @@ def test_slow_image_sources_are_fetched_on_threads_with_the_same_result(models):
             same_dets(threaded[cls_name][img_name], inline[cls_name][img_name], tol=0.0)
 
 
+def test_bf16_models_through_both_entry_paths():
+    """configs[3]'s models (ResNet-101, bf16 conv, KITTI classes) through voc_dets.get_dets_by_cls: the captured path, and the eager
+    path whose conv map travels to the host and back as float32 numpy (numpy has no bf16: the widening is exact and
+    DetModel.forward_dev narrows it back) -- same detections."""
+    from faster_rcnn_amd import resnet, util, voc_dets
+    from faster_rcnn_amd.data.voc_data_helpers import KITTI_CLASS_MAPPING
+    from faster_rcnn_amd.det_util import DetTrainingManager
+    from faster_rcnn_amd.weights import synthetic_resnet
+    anchors = util.get_anchors([16, 32, 64, 128, 256, 512])
+    w = synthetic_resnet(101, anchors_per_loc=len(anchors), num_classes=len(KITTI_CLASS_MAPPING), seed=1)
+    rpn = resnet.resnet101_rpn(resnet.resnet101_base(weights=w, dtype="bf16"), include_conv=True, anchors_per_loc=len(anchors))
+    det = resnet.resnet101_classifier(64, len(KITTI_CLASS_MAPPING), weights=w, dtype="bf16")
+    mgr = DetTrainingManager(rpn_model=rpn, class_mapping=KITTI_CLASS_MAPPING, preprocess_func=resnet.preprocess, anchor_dims=anchors)
+    images = [named_image("k%02d" % i, synth_pixels(320, 480 if i % 2 else 544, 70 + i)) for i in range(5)]
+    ratios = [1.0] * len(images)
+    from oracle.e2e import match_detections
+    fast, eager, out_fast, out_eager = both_paths(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.0)
+    assert list(fast) == list(eager) and sum(len(v) for c in eager.values() for v in c.values()) > 0
+    # bf16 activations: the captured passes' launch forms (split-K partitions, a 320-row head pass) round a few pre-activations to the
+    # neighbouring bf16 value, a box edge moves by a pixel, NMS keeps a neighbour -- the sets are compared the way a scorer pairs boxes
+    n_eager = n_fast = n_matched = 0
+    worst = 0.0
+    for cls_name in eager:
+        assert list(fast[cls_name]) == list(eager[cls_name])
+        for img_name in eager[cls_name]:
+            a = [(cls_name, d["prob"], d["bbox"]) for d in eager[cls_name][img_name]]
+            b = [(cls_name, d["prob"], d["bbox"]) for d in fast[cls_name][img_name]]
+            pairs = match_detections(a, b, 0.5)
+            n_eager += len(a); n_fast += len(b); n_matched += len(pairs)
+            worst = max([worst] + [abs(x - y) for x, y, _ in pairs])
+    print("bf16 entry: eager %d, captured %d, matched %d, worst score difference %.3g" % (n_eager, n_fast, n_matched, worst))
+    assert n_matched >= 0.95 * max(n_eager, n_fast) and worst <= 5e-3      # measured: 1041 of 1079 matched, worst 2.1e-4
+    conv_out, rois = mgr.get_det_inputs(images[0])
+    assert conv_out.dtype == np.float32 and rois.dtype == np.int16 and conv_out.shape[-1] == 1024
+
+
 def test_graph_cache_budget_evicts_least_recently_used(models):
     from faster_rcnn_amd import entry
     mgr, det, _, _ = models
