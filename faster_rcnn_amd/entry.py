@@ -61,7 +61,7 @@ def default_in_flight(dtype="f32"):
 class _Slot:
     """One captured pass for one image size, with its staging on both sides of PCIe."""
     __slots__ = ("key", "pipe", "graph", "out", "io_dev", "io_pin", "pix_host", "dyn_host", "out_pin", "event", "busy", "nbytes",
-                 "x_f32", "ws", "seq", "tabs", "u8_resized")
+                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed")
 
 
 class GraphCache:
@@ -144,6 +144,13 @@ class DetectionEntry:
         # images per second; FRCNN_F32_ENGINE=native keeps v_mfma_f32_32x32x2_f32 everywhere
         self.f32_engine = f32_engine or os.environ.get("FRCNN_F32_ENGINE", "bf16x6")
         self.num_rois, self.stride, self.in_flight = int(num_rois), stride, max(1, int(in_flight))
+        # images per captured pass.  The bf16 detector makes ONE head pass over the RoIs of eight images and runs its trunk at batch
+        # eight (pipeline.BatchedInferencePipeline: what configs[3]'s headline times); get_dets_by_cls groups neighbouring images of
+        # one size into such passes.  The f32 models keep one image per pass (a batched fp32 head gains nothing).
+        head = getattr(detector, "head", None)
+        self.batch = 1
+        if getattr(head, "dtype", "f32") == "bf16" and hasattr(head, "forward_batched"):
+            self.batch = max(1, int(os.environ.get("FRCNN_ENTRY_BATCH", "8")))
         from . import resnet, vgg
         self.device_preprocess = manager.preprocess_func in (resnet.preprocess, vgg.preprocess)
         self.rev_class_mapping = dict((v, k) for k, v in manager.class_mapping.items())
@@ -165,46 +172,59 @@ class DetectionEntry:
         return 0 < n_rows <= 512                        # frcnn_detections: one workgroup, <= 512 scored rows
 
     # ------------------------------------------------------------------ capture
-    def _capture(self, H, W, src=None, flip=False):
+    def _capture(self, H, W, src=None, flip=False, B=1):
         """``src`` = (source height, source width): the pass starts from the decoded frame at the file's size and resizes
-        (and flips) it on the device; None: the uploaded pixels are already (H, W)."""
+        (and flips) it on the device; None: the uploaded pixels are already (H, W).  ``B`` > 1: one pass over B frames of that
+        geometry (pipeline.BatchedInferencePipeline), each with its own [resize_ratio, det_threshold] pair."""
         import time
         t0 = time.perf_counter()
         m = self.manager
-        pipe = InferencePipeline(m.rpn_model, self.detector, m.anchor_dims, stride=self.stride, pre_nms_top_n=PRE_NMS_TOP_N,
-                                 max_proposals=MAX_PROPOSALS, roi_batch=self.num_rois, pad_to_batch=True, bg_idx=m.class_mapping["bg"])
+        kw = dict(stride=self.stride, pre_nms_top_n=PRE_NMS_TOP_N, max_proposals=MAX_PROPOSALS, roi_batch=self.num_rois, pad_to_batch=True,
+                  bg_idx=m.class_mapping["bg"])
+        if B > 1:
+            from .pipeline import BatchedInferencePipeline
+            pipe = BatchedInferencePipeline(m.rpn_model, self.detector, m.anchor_dims, B, **kw)
+        else:
+            pipe = InferencePipeline(m.rpn_model, self.detector, m.anchor_dims, **kw)
         reserved0 = torch.cuda.memory_reserved()
         in_h, in_w = src if src is not None else (H, W)
         npix = in_h * in_w * 3
         pix_bytes = npix if self.device_preprocess else 4 * npix
-        off = (pix_bytes + 15) // 16 * 16
+        seg = (pix_bytes + 15) // 16 * 16                           # one frame's segment of the staging buffer
+        off = B * seg                                               # ... then B x [resize_ratio, det_threshold]
         s = _Slot()
-        s.key, s.pipe, s.busy, s.seq = (H, W), pipe, False, 0
-        s.io_dev = torch.zeros(off + 16, dtype=torch.uint8, device="cuda")
-        s.io_pin = torch.zeros(off + 16, dtype=torch.uint8).pin_memory()
+        s.key, s.pipe, s.busy, s.seq, s.batch = (H, W), pipe, False, 0, B
+        s.io_dev = torch.zeros(off + 16 * B, dtype=torch.uint8, device="cuda")
+        s.io_pin = torch.zeros(off + 16 * B, dtype=torch.uint8).pin_memory()
         host = s.io_pin.numpy()
-        s.pix_host = host[:npix].reshape(in_h, in_w, 3) if self.device_preprocess else host[:pix_bytes].view(np.float32).reshape(H, W, 3)
-        s.dyn_host = host[off:off + 16].view(np.float64)
+        if self.device_preprocess:
+            s.pix_hosts = [host[i * seg:i * seg + npix].reshape(in_h, in_w, 3) for i in range(B)]
+        else:
+            s.pix_hosts = [host[i * seg:i * seg + pix_bytes].view(np.float32).reshape(H, W, 3) for i in range(B)]
+        s.pix_host = s.pix_hosts[0]
+        s.dyn_host = host[off:off + 16 * B].view(np.float64).reshape(B, 2)
         s.dyn_host[:] = (1.0, 0.0)
-        dyn_dev = s.io_dev[off:off + 16].view(torch.float64)
+        dyn_dev = s.io_dev[off:off + 16 * B].view(torch.float64).view(B, 2)
         s.tabs = s.u8_resized = None
         if self.device_preprocess:
-            u8 = s.io_dev[:npix].view(in_h, in_w, 3)
-            s.x_f32 = torch.empty((1, H, W, 3), dtype=torch.float32, device="cuda")
+            u8 = [s.io_dev[i * seg:i * seg + npix].view(in_h, in_w, 3) for i in range(B)]
+            s.x_f32 = torch.empty((B, H, W, 3), dtype=torch.float32, device="cuda")
             if src is not None:
                 assert self.device_preprocess
                 s.tabs = (torch.from_numpy(ops.resize_cubic_taps(W, in_w)).cuda(), torch.from_numpy(ops.resize_cubic_taps(H, in_h)).cuda())
                 s.u8_resized = torch.empty((H, W, 3), dtype=torch.uint8, device="cuda")
         else:
+            assert B == 1
             s.x_f32 = s.io_dev[:pix_bytes].view(torch.float32).view(1, H, W, 3)
 
         def run():
             if self.device_preprocess:
-                frame = u8
-                if src is not None:                                 # shapes.Image.data: INTER_CUBIC resize (+ flip) of the decoded frame
-                    frame = ops.resize_cubic_u8(u8, H, W, flip=flip, tabs=s.tabs, out=s.u8_resized)
-                ops.preprocess_u8(frame, MEAN_BGR, out=s.x_f32)     # resnet.preprocess + the f32 feed cast, bit for bit
-            return pipe.forward_dev(s.x_f32, dyn=dyn_dev)
+                for i in range(B):
+                    frame = u8[i]
+                    if src is not None:                             # shapes.Image.data: INTER_CUBIC resize (+ flip) of the decoded frame
+                        frame = ops.resize_cubic_u8(u8[i], H, W, flip=flip, tabs=s.tabs, out=s.u8_resized)
+                    ops.preprocess_u8(frame, MEAN_BGR, out=s.x_f32[i:i + 1])     # resnet.preprocess + the f32 feed cast, bit for bit
+            return pipe.forward_dev(s.x_f32, dyn=dyn_dev if B > 1 else dyn_dev[0])
 
         shared = self.in_flight > 1
         # one image in flight: split-K on the small grids (a latency tool); several: plain launches, tiles for a shared chip
@@ -220,7 +240,9 @@ class DetectionEntry:
         s.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(s.graph, capture_error_mode="thread_local"), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine):
             s.out = run()
-        s.out_pin = torch.empty(s.out["det_packed"].shape, dtype=torch.int32).pin_memory()
+        packed = s.out["det_packed"]
+        s.out_packed = packed if isinstance(packed, (list, tuple)) else [packed]
+        s.out_pin = torch.empty((B,) + tuple(s.out_packed[0].shape), dtype=torch.int32).pin_memory()
         s.event = torch.cuda.Event()
         torch.cuda.synchronize()
         s.nbytes = max(int(torch.cuda.memory_reserved() - reserved0), int(s.io_dev.numel() + s.x_f32.numel() * 4))
@@ -260,42 +282,66 @@ class DetectionEntry:
             data = self.manager.preprocess_func(data)               # det_util.py:36 (float64 on the host, cast on feed)
         return data, int(data.shape[0]), int(data.shape[1]), None, False
 
+    @staticmethod
+    def geometry(pixels):
+        """The captured-pass key of a ``host_pixels`` result: images with equal keys can share a batched pass."""
+        _, H, W, src, flip = pixels
+        return (H, W) if src is None else (H, W) + src + (flip,)
+
     def submit(self, image, resize_ratio, det_threshold=0.0, pixels=None):
         """``pixels``: the result of ``host_pixels(image)`` when the caller fetched it ahead of time."""
+        return self.submit_batch([image], [resize_ratio], det_threshold, [self.host_pixels(image) if pixels is None else pixels], batch=1)
+
+    def submit_batch(self, images, resize_ratios, det_threshold, pixels, batch=None):
+        """Up to ``batch`` images of ONE geometry (``geometry(pixels[i])`` equal) in one captured pass; a short group is padded with
+        copies of its first frame, whose results nobody reads.  ``collect_batch`` returns the images' results in order."""
         self._check_epoch()
-        data, H, W, src, flip = self.host_pixels(image) if pixels is None else pixels
-        key = (H, W) if src is None else (H, W) + src + (flip,)
-        s = self.cache.acquire(key, lambda: self._capture(H, W, src, flip))
-        np.copyto(s.pix_host, data, casting="same_kind")            # into pinned memory (f64 -> f32 cast for a foreign preprocess)
-        s.dyn_host[0], s.dyn_host[1] = float(resize_ratio), float(det_threshold)
+        B = self.batch if batch is None else batch
+        assert 1 <= len(images) <= B and len(images) == len(pixels) == len(resize_ratios)
+        _, H, W, src, flip = pixels[0]
+        key = self.geometry(pixels[0])
+        assert all(self.geometry(p) == key for p in pixels), "one pass, one geometry"
+        s = self.cache.acquire(key + ((B,) if B > 1 else ()), lambda: self._capture(H, W, src, flip, B))
+        for i in range(B):
+            j = i if i < len(images) else 0
+            np.copyto(s.pix_hosts[i], pixels[j][0], casting="same_kind")      # into pinned memory (f64 -> f32 cast for a foreign preprocess)
+            s.dyn_host[i, 0], s.dyn_host[i, 1] = float(resize_ratios[j]), float(det_threshold)
         st = self._streams[self._seq % self.in_flight]
         self._seq += 1
         with torch.cuda.stream(st):
             s.io_dev.copy_(s.io_pin, non_blocking=True)
             s.graph.replay()
-            s.out_pin.copy_(s.out["det_packed"], non_blocking=True)
+            for i in range(len(images)):
+                s.out_pin[i].copy_(s.out_packed[i], non_blocking=True)
             s.event.record(st)
         s.busy = True
-        return Ticket(s, image)
+        return Ticket(s, list(images))
 
-    def collect(self, ticket):
+    def collect_batch(self, ticket):
+        """-> [(num_rois, dets)] for the images of a ``submit_batch`` ticket."""
         s = ticket.slot
         s.event.synchronize()
-        packed = s.out_pin.numpy()
-        nd, n_rois = int(packed[0]), int(packed[1])
-        rows = (packed.size - 4) // 7
-        bbox = packed[4:4 + 4 * nd].reshape(nd, 4).astype(np.int64)
-        cls = packed[4 + 4 * rows:4 + 4 * rows + nd].copy()
-        prob = packed[4 + 5 * rows:4 + 5 * rows + nd].view(np.float32).copy()
-        s.busy = False
         rev = self.rev_class_mapping
-        return n_rois, [{"bbox": bbox[i], "cls_name": rev[int(cls[i])], "prob": prob[i]} for i in range(nd)]
+        res = []
+        for i in range(len(ticket.image)):
+            packed = s.out_pin[i].numpy()
+            nd, n_rois = int(packed[0]), int(packed[1])
+            rows = (packed.size - 4) // 7
+            bbox = packed[4:4 + 4 * nd].reshape(nd, 4).astype(np.int64)
+            cls = packed[4 + 4 * rows:4 + 4 * rows + nd].copy()
+            prob = packed[4 + 5 * rows:4 + 5 * rows + nd].view(np.float32).copy()
+            res.append((n_rois, [{"bbox": bbox[k], "cls_name": rev[int(cls[k])], "prob": prob[k]} for k in range(nd)]))
+        s.busy = False
+        return res
+
+    def collect(self, ticket):
+        return self.collect_batch(ticket)[0]
 
     def stats(self):
         c = self.cache
         return {"graphs": len(c), "sizes": len(c.keys()), "bytes": c.nbytes, "byte_budget": c.byte_budget, "captures": c.captures,
                 "hits": c.hits, "evictions": c.evictions, "capture_seconds": round(self.capture_seconds, 3), "in_flight": self.in_flight,
-                "device_preprocess": self.device_preprocess, "f32_engine": self.f32_engine}
+                "device_preprocess": self.device_preprocess, "f32_engine": self.f32_engine, "images_per_pass": self.batch}
 
 
 def for_models(manager, detector, num_rois=64, stride=16, in_flight=1):

@@ -150,10 +150,11 @@ class BatchedInferencePipeline(InferencePipeline):
             main.wait_stream(st)
         return outs
 
-    def forward_dev(self, x, resize_ratio=1.0):
+    def forward_dev(self, x, resize_ratio=1.0, dyn=None):
         """x: (B,H,W,3) f32 device tensor.  Returns a dict: batch tensors with a leading image axis (rpn_cls, rpn_reg, feat,
         rois (B,n_rois,4), cls (B,n_rois,C), reg) and per-image LISTS of the small outputs (n_rois, n_dets, det_packed, det_bbox,
-        det_cls, det_prob, det_roi: entry i is image i's tensor, exactly what InferencePipeline returns for one image)."""
+        det_cls, det_prob, det_roi: entry i is image i's tensor, exactly what InferencePipeline returns for one image).
+        ``dyn``: (B,2) f64 device tensor, row i = image i's [resize_ratio, det_threshold] (InferencePipeline.forward_dev)."""
         B = self.batch
         assert x.shape[0] == B
         cls, reg, feat = self.rpn.forward_dev(x)
@@ -162,8 +163,12 @@ class BatchedInferencePipeline(InferencePipeline):
         out_cls, out_reg = self.det.head.forward_batched(feat, rois, self.n_rois)
         res = {"rpn_cls": cls, "rpn_reg": reg, "feat": feat, "rois": rois.view(B, self.n_rois, 4), "n_rois": n_keep,
                "cls": out_cls.view(B, self.n_rois, -1), "reg": out_reg.view(B, self.n_rois, -1)}
-        dets = self._fan_out(lambda i: ops.detections(rois[i * self.n_rois:(i + 1) * self.n_rois], n_keep[i], res["cls"][i], res["reg"][i], self.roi_batch,
-                                                      self.bg_idx, self.det_threshold, float(self.stride), float(resize_ratio)))
+        if dyn is not None:
+            dets = self._fan_out(lambda i: ops.detections_dyn(rois[i * self.n_rois:(i + 1) * self.n_rois], n_keep[i], res["cls"][i], res["reg"][i],
+                                                              self.roi_batch if self.pad_to_batch else 0, self.bg_idx, float(self.stride), dyn[i]))
+        else:
+            dets = self._fan_out(lambda i: ops.detections(rois[i * self.n_rois:(i + 1) * self.n_rois], n_keep[i], res["cls"][i], res["reg"][i], self.roi_batch,
+                                                          self.bg_idx, self.det_threshold, float(self.stride), float(resize_ratio)))
         for k in dets[0]:
             res[k] = [d[k] for d in dets]
         return res

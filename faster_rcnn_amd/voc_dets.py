@@ -105,10 +105,22 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
     window = collections.deque()
 
     def finish():
-        image, ticket, start_time = window.popleft()
-        num_boxes, dets = eng.collect(ticket)
-        print("num rois: {}".format(num_boxes))
-        fold(image, dets, start_time)
+        group, ticket = window.popleft()
+        for (image, start_time), (num_boxes, dets) in zip(group, eng.collect_batch(ticket)):
+            print("num rois: {}".format(num_boxes))
+            fold(image, dets, start_time)
+
+    def flush(group):
+        """A run of neighbouring images of one geometry: whole batched passes where the engine has them (bf16 detector: eight images
+        per pass), single-image passes for what is left unless it fills at least half a batch."""
+        B = eng.batch
+        while group:
+            take = B if (B > 1 and len(group) >= max(2, B // 2)) else 1
+            part, group = group[:take], group[take:]
+            ticket = eng.submit_batch([g[0] for g in part], [g[1] for g in part], det_threshold, [g[2] for g in part], batch=B if take > 1 else 1)
+            window.append(([(g[0], g[3]) for g in part], ticket))
+            if len(window) >= eng.in_flight:
+                finish()
 
     # the pixels are fetched inline, as the reference does (shapes.py:19-29), until that proves slow (DECODE_INLINE_MS); from then on
     # the NEXT images are fetched on a few threads while the GPU works (PIL's JPEG decode releases the GIL); results are consumed
@@ -116,10 +128,11 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
     from concurrent.futures import ThreadPoolExecutor
     images, resized_ratios = list(images), list(resized_ratios)
     n = min(len(images), len(resized_ratios))
-    ahead = 2 * eng.in_flight
+    ahead = 2 * eng.in_flight * eng.batch
     pool = None
     pending = {}
     slow_fetches = 0
+    group = []
     try:
         for i in range(n):
             if pool is not None:
@@ -134,15 +147,21 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
                 slow_fetches = slow_fetches + 1 if (timeit.default_timer() - start_time) * 1e3 > DECODE_INLINE_MS else 0
                 if slow_fetches >= 2 and pool is None and DECODE_THREADS > 0 and i + 1 < n and eng.prefetchable(images[i]):
                     pool = ThreadPoolExecutor(max_workers=DECODE_THREADS)       # (two slow fetches in a row: not a cold file cache)
-            window.append((images[i], eng.submit(images[i], resized_ratios[i], det_threshold, pixels=pixels), start_time))
-            if len(window) >= eng.in_flight:
-                finish()
+            if group and (eng.geometry(group[0][2]) != eng.geometry(pixels) or len(group) >= eng.batch):
+                flush(group)
+                group = []
+            group.append((images[i], resized_ratios[i], pixels, start_time))
+            if eng.batch == 1:
+                flush(group)
+                group = []
+        flush(group)
+        group = []
         while window:
             finish()
     finally:
         if pool is not None:
             pool.shutdown(wait=True, cancel_futures=True)
-        for _, ticket, _ in window:                    # an exception mid-list: no slot stays marked busy
+        for _, ticket in window:                       # an exception mid-list: no slot stays marked busy
             ticket.slot.event.synchronize()
             ticket.slot.busy = False
     return dets_by_cls

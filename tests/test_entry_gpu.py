@@ -188,8 +188,9 @@ def test_bf16_models_through_both_entry_paths():
     rpn = resnet.resnet101_rpn(resnet.resnet101_base(weights=w, dtype="bf16"), include_conv=True, anchors_per_loc=len(anchors))
     det = resnet.resnet101_classifier(64, len(KITTI_CLASS_MAPPING), weights=w, dtype="bf16")
     mgr = DetTrainingManager(rpn_model=rpn, class_mapping=KITTI_CLASS_MAPPING, preprocess_func=resnet.preprocess, anchor_dims=anchors)
-    images = [named_image("k%02d" % i, synth_pixels(320, 480 if i % 2 else 544, 70 + i)) for i in range(5)]
-    ratios = [1.0] * len(images)
+    # thirteen frames of one size then two of another: one whole eight-image pass, one padded pass of five (>= half a batch), two single passes
+    images = [named_image("k%02d" % i, synth_pixels(320, 480 if i < 13 else 544, 70 + i)) for i in range(15)]
+    ratios = [1.0 + 0.01 * i for i in range(len(images))]
     from oracle.e2e import match_detections
     fast, eager, out_fast, out_eager = both_paths(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.0)
     assert list(fast) == list(eager) and sum(len(v) for c in eager.values() for v in c.values()) > 0
@@ -209,6 +210,12 @@ def test_bf16_models_through_both_entry_paths():
     assert n_matched >= 0.95 * max(n_eager, n_fast) and worst <= 5e-3      # measured: 1041 of 1079 matched, worst 2.1e-4
     conv_out, rois = mgr.get_det_inputs(images[0])
     assert conv_out.dtype == np.float32 and rois.dtype == np.int16 and conv_out.shape[-1] == 1024
+    from faster_rcnn_amd import entry
+    st = entry.for_models(mgr, det, 64, 16, entry.default_in_flight("bf16")).stats()
+    assert st["images_per_pass"] == 8 and st["sizes"] == 2 and st["captures"] == 4, st       # two eight-image passes of (320, 480), two single passes of (320, 544)
+    # strip the timing from the reference's progress lines: same lines, same order
+    strip = lambda s_: [ln.split(" ran in ")[0] for ln in s_.splitlines() if not ln.startswith("num rois")]
+    assert strip(out_fast) == strip(out_eager)
 
 
 def test_graph_cache_budget_evicts_least_recently_used(models):
