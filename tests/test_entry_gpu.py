@@ -216,6 +216,16 @@ def test_bf16_models_through_both_entry_paths():
     # strip the timing from the reference's progress lines: same lines, same order
     strip = lambda s_: [ln.split(" ran in ")[0] for ln in s_.splitlines() if not ln.startswith("num rois")]
     assert strip(out_fast) == strip(out_eager)
+    # an image that cannot be submitted, in the middle of a batched run: the error surfaces, no pass stays marked busy, the next call works
+    bad = named_image("bad", synth_pixels(320, 480, 3).astype(np.float32))
+    with pytest.raises(TypeError):
+        quiet(voc_dets.get_dets_by_cls, mgr, det, [1.0] * 12, images[:10] + [bad, images[11]])
+    eng = entry.for_models(mgr, det, 64, 16, entry.default_in_flight("bf16"))
+    assert not any(sl.busy for v in eng.cache._slots.values() for sl in v)
+    again, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios[:9], images[:9])
+    for cls_name in again:
+        for img_name in again[cls_name]:
+            same_dets(again[cls_name][img_name], fast[cls_name][img_name], tol=0.0)       # a whole pass of eight + one single pass: the same bits as before
 
 
 def test_graph_cache_budget_evicts_least_recently_used(models):
