@@ -58,6 +58,14 @@ def default_in_flight(dtype="f32"):
     return 8 if (queues >= 8 and dtype == "f32") else 4
 
 
+# The reference pads the last batch of 64 RoIs with copies of its first RoI and scores the copies too (voc_dets.py:42-51).  A copy
+# has the box, class and score of its original, so the per-class NMS that follows (threshold 0.5) keeps exactly one of them where it
+# would have kept the original: the returned list is the same with or without the copies.  The captured passes therefore score the
+# kept proposals only (300 rows instead of 320: 6 % less detector-head work); FRCNN_ENTRY_PAD=1 scores the padded list as the eager
+# path does.  tests/test_entry_gpu.py compares the two paths detection by detection.
+PAD_TO_BATCH = os.environ.get("FRCNN_ENTRY_PAD", "0") != "0"
+
+
 class _Slot:
     """One captured pass for one image size, with its staging on both sides of PCIe."""
     __slots__ = ("key", "pipe", "graph", "out", "io_dev", "io_pin", "pix_host", "dyn_host", "out_pin", "event", "busy", "nbytes",
@@ -179,7 +187,7 @@ class DetectionEntry:
         import time
         t0 = time.perf_counter()
         m = self.manager
-        kw = dict(stride=self.stride, pre_nms_top_n=PRE_NMS_TOP_N, max_proposals=MAX_PROPOSALS, roi_batch=self.num_rois, pad_to_batch=True,
+        kw = dict(stride=self.stride, pre_nms_top_n=PRE_NMS_TOP_N, max_proposals=MAX_PROPOSALS, roi_batch=self.num_rois, pad_to_batch=PAD_TO_BATCH,
                   bg_idx=m.class_mapping["bg"])
         if B > 1:
             from .pipeline import BatchedInferencePipeline
@@ -228,7 +236,10 @@ class DetectionEntry:
 
         shared = self.in_flight > 1
         # one image in flight: split-K on the small grids (a latency tool); several: plain launches, tiles for a shared chip
-        s.ws = ops.NO_SPLIT_K if shared else ops.ConvWorkspace()
+        # (fp32 models keep split-K also beside other passes, as bench.py's headline does: the small grids of rpn_conv1 / stage 4 then run
+        # the split engine's split-K form; the bf16 engine loses with it when several passes share the chip)
+        dtype = getattr(getattr(self.detector, "head", None), "dtype", "f32")
+        s.ws = ops.NO_SPLIT_K if (shared and (dtype == "bf16" or os.environ.get("FRCNN_ENTRY_NO_SPLITK"))) else ops.ConvWorkspace()
         s.io_dev.copy_(s.io_pin)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
