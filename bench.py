@@ -783,9 +783,9 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
                               "(det_util.py:136-158), the detector takes them back (voc_dets.py:49), one image at a time"},
             "same_detection_counts_as_eager": bool(same),
             "what": "voc_dets.get_dets_by_cls(DetTrainingManager, detector, ratios, images) over %d distinct %dx%d uint8 frames in host memory, "
-                    "%d captured passes in flight x %d image(s) per pass, list of detection dicts out; wall clock of the whole call.  The detector head runs over %d RoI rows per "
-                    "image here (the reference pads the last batch of 64 with copies of its first RoI and scores the copies too, "
-                    "voc_dets.py:42-51), against %d in the headline" % (n_images, HEIGHT, WIDTH, eng.in_flight, eng.batch, -(-PROPOSALS // 64) * 64, PROPOSALS)}
+                    "%d captured passes in flight x %d image(s) per pass, list of detection dicts out; wall clock of the whole call.  The captured passes score the %d kept proposals (the "
+                    "reference's padded copies of a batch's first RoI, voc_dets.py:42-51, have their original's box, class and score: the per-class NMS "
+                    "returns the same list without them; the eager path beside it scores the %d-row padded list)" % (n_images, HEIGHT, WIDTH, eng.in_flight, eng.batch, PROPOSALS, -(-PROPOSALS // 64) * 64)}
 
 
 _JSON_OUT = None
