@@ -184,8 +184,23 @@ class DetectionEntry:
         """``src`` = (source height, source width): the pass starts from the decoded frame at the file's size and resizes
         (and flips) it on the device; None: the uploaded pixels are already (H, W).  ``B`` > 1: one pass over B frames of that
         geometry (pipeline.BatchedInferencePipeline), each with its own [resize_ratio, det_threshold] pair."""
+        import gc
         import time
         t0 = time.perf_counter()
+        # No cyclic-garbage collection inside the capture: a collection that starts while the stream is capturing may run the
+        # finalizers of unrelated dead objects -- another engine's captured passes, their private memory pools -- whose HIP calls
+        # are not legal in a capturing thread (seen as a crash inside a launch when a test's models died just before).
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            return self._capture_locked(H, W, src, flip, B, t0)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _capture_locked(self, H, W, src, flip, B, t0):
+        import time
         m = self.manager
         kw = dict(stride=self.stride, pre_nms_top_n=PRE_NMS_TOP_N, max_proposals=MAX_PROPOSALS, roi_batch=self.num_rois, pad_to_batch=PAD_TO_BATCH,
                   bg_idx=m.class_mapping["bg"])

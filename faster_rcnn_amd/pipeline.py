@@ -89,7 +89,7 @@ class InferencePipeline:
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         # thread_local: another thread of this process (e.g. an RCCL watchdog) may call into HIP during the capture
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), \
+        with no_gc(), torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), \
                 ops.f32_engine(f32_engine):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
@@ -106,6 +106,24 @@ class InferencePipeline:
             self._static_in.copy_(x)
         self._graph.replay()
         return self._static_out
+
+
+import contextlib as _contextlib
+import gc as _gc
+
+
+@_contextlib.contextmanager
+def no_gc():
+    """No cyclic-garbage collection while a stream is capturing: a collection may run the finalizers of unrelated dead objects
+    (other captured graphs, their memory pools) whose HIP calls are not legal in a capturing thread (entry.DetectionEntry._capture)."""
+    was_on = _gc.isenabled()
+    _gc.collect()
+    _gc.disable()
+    try:
+        yield
+    finally:
+        if was_on:
+            _gc.enable()
 
 
 import os as _os
@@ -184,6 +202,6 @@ class BatchedInferencePipeline(InferencePipeline):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+        with no_gc(), torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
