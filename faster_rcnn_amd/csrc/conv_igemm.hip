@@ -2088,18 +2088,35 @@ static int x6_config(const frcnn_conv_desc* d, int n1) {
     return cfg;
 }
 
+// Split-K on the split engine: tile edge (64 or 128) and slices for a descriptor.  64x64 tiles (four waves) fill the chip from the
+// smallest grids; from ~64 tiles of 128x128 on, the eight-wave 128x128 tile (nine fragment reads per twelve MFMAs instead of six per
+// six) is the better workgroup -- the detector head's 3x3 over 64 RoIs (3 136 rows, k 4 608), rpn_conv1.  tile % 100: 74 / 78 force
+// the 64 / 128 form, tile / 100 the slice count (dev).
+static int x6_sk_tile(const frcnn_conv_desc* d) {
+    const int t = d->tile % 100;
+    if (t == 78) return 128;
+    if (t == 74) return 64;
+    static const long long min128 = getenv("FRCNN_X6_SK128_MIN") ? atoll(getenv("FRCNN_X6_SK128_MIN")) : 64;      // dev knob
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
+    return t128 >= min128 ? 128 : 64;
+}
+
 static int choose_splits_x6(const frcnn_conv_desc* d) {
     if (d->cin % BK) return 1;
     const int t = d->tile % 100;
-    if (t != 0 && t != 50 && t != 74) return 1;
+    if (t != 0 && t != 50 && t != 74 && t != 78) return 1;
+    const int edge = x6_sk_tile(d);
     const long long M = (long long)d->n * d->ho * d->wo;
-    const long long tiles = ((M + 63) / 64) * ((d->cout + 63) / 64);
+    const long long tiles = ((M + edge - 1) / edge) * ((d->cout + edge - 1) / edge);
+    const long long tiles64 = ((M + 63) / 64) * ((d->cout + 63) / 64);
     const int nk = (d->kh * d->kw * d->cin) / BK;
     if (tiles * sizeof(unsigned) > SPLITK_TICKET_BYTES) return 1;
     int s = d->tile / 100;
     if (s <= 0) {
-        if (tiles >= 640 || nk < 64) return 1;
-        s = tiles >= 100 ? 3 : (int)((768 + tiles - 1) / tiles);      // sweep (MI355X): rpn_conv1 (304 tiles) 209 / 192 / 204 / 189 us at 2 / 3 / 4 / 5 slices, stage 4 3x3 (152) 32.6 / 34.2 / 33.4 at 3 / 4 / 6
+        if (tiles64 >= 640 || nk < 64) return 1;
+        if (edge == 128) s = (int)(512 / tiles);                     // ONE round of two workgroups per CU: 3 136 x 512 (100 tiles) 94 us at 5 slices, 110 at 4 or 6; rpn_conv1 (76 tiles) 161 at 6, 169 / 175 at 5 / 3
+        else s = tiles >= 100 ? 3 : (int)((768 + tiles - 1) / tiles);      // sweep (MI355X): rpn_conv1 (304 tiles) 209 / 192 / 204 / 189 us at 2 / 3 / 4 / 5 slices, stage 4 3x3 (152) 32.6 / 34.2 / 33.4 at 3 / 4 / 6
         if (s > nk / 8) s = nk / 8;
         if (s > 16) s = 16;
     }
@@ -2111,9 +2128,10 @@ size_t frcnn_conv2d_x6_workspace_bytes(const frcnn_conv_desc* d) {
     if (!d || d->cin <= 0) return 0;
     const int splits = choose_splits_x6(d);
     if (splits <= 1) return 0;
+    const int edge = x6_sk_tile(d);
     const long long M = (long long)d->n * d->ho * d->wo;
-    const size_t tiles = (size_t)((M + 63) / 64) * ((d->cout + 63) / 64);
-    return SPLITK_TICKET_BYTES + tiles * splits * 64 * 64 * sizeof(float);
+    const size_t tiles = (size_t)((M + edge - 1) / edge) * ((d->cout + edge - 1) / edge);
+    return SPLITK_TICKET_BYTES + tiles * splits * edge * edge * sizeof(float);
 }
 
 int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16,
@@ -2198,7 +2216,7 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
                 a.tickets = (unsigned*)workspace;
                 a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
                 a.group_m = 0;
-                return launch_conv_x6(a, 174, s);
+                return launch_conv_x6(a, x6_sk_tile(d) == 128 ? 171 : 174, s);
             }
         }
         const int bn = x6_tile_width(xcfg);

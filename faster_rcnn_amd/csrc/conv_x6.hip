@@ -613,6 +613,16 @@ int launch_conv_x6(const ConvArgs& a, int cfg, hipStream_t s) {
             k_conv_igemm_x6<1, 1, 2, 2, true><<<p.tiles_m * p.tiles_n * p.splits, T::NT, T::lds, s>>>(p);
             return check_launch("conv2d_fwd_x6 (split-K)");
         }
+        case 171: {                                       // 128x128 on eight waves with split-K: the taller small grids (>= 64 such tiles)
+            using T = X6Tile<2, 1, 2, 4>;
+            ConvArgs p = a;
+            p.tiles_m = (p.M + 127) / 128;
+            p.tiles_n = (p.Cout + 127) / 128;
+            static std::atomic<uint64_t> lds_seen{0};
+            if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_x6<2, 1, 2, 4, true>, T::lds, "conv2d_x6")) return e;
+            k_conv_igemm_x6<2, 1, 2, 4, true><<<p.tiles_m * p.tiles_n * p.splits, T::NT, T::lds, s>>>(p);
+            return check_launch("conv2d_fwd_x6 (split-K)");
+        }
         default: return fail(FRCNN_E_ARG, "conv2d_fwd_x6: unknown tile config %d", cfg);
     }
 }

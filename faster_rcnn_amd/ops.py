@@ -344,7 +344,7 @@ class f32_engine:
 
 
 def _use_x6(d, pc, tile):
-    if 71 <= tile % 100 <= 77:
+    if 71 <= tile % 100 <= 78:
         return pc.cin % 32 == 0                                  # explicit tile code of the split engine
     if F32_ENGINE != "bf16x6" or tile % 100 not in (0, 50):
         return False

@@ -239,7 +239,7 @@ def test_x6_split_k_small_grid_long_k():
     order by the last arriver -- against fp64, bitwise reproducible, tickets left zero (a second launch on the same workspace)."""
     from faster_rcnn_amd import ops
     rs = np.random.RandomState(8)
-    for (h, w, cin, cout, k) in ((38, 63, 1024, 512, 3), (38, 63, 256, 256, 3), (19, 31, 2048, 192, 1)):
+    for (h, w, cin, cout, k) in ((38, 63, 1024, 512, 3), (38, 63, 256, 256, 3), (19, 31, 2048, 192, 1), (56, 56, 512, 512, 3)):      # (the last: 3 136 rows, 100 tiles of 128x128 -> the eight-wave split-K form)
         x = rs.randn(1, h, w, cin).astype(np.float32)
         wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
         scale = (1 + 0.1 * rs.randn(cout)).astype(np.float32); shift = (0.1 * rs.randn(cout)).astype(np.float32)

@@ -93,11 +93,15 @@ int main() {
         q.cin = pick({32, 64, 128, 256, 512, 1024, 2048, 48, 3}); q.cout = pick({18, 45, 64, 128, 256, 512, 1024, 2048});
         q.kh = q.kw = pick({1, 3}); q.stride = pick({1, 2});
         q.ho = (q.h + q.stride - 1) / q.stride; q.wo = (q.w + q.stride - 1) / q.stride;
-        q.tile = pick({0, 50, 71, 74, 76, 77, 274, 374, 1674, 23});
+        q.tile = pick({0, 50, 71, 74, 76, 77, 78, 274, 374, 578, 1674, 23});
         q.layout = rnd() % 2;
         const size_t need = frcnn_conv2d_x6_workspace_bytes(&q);
-        const long long tiles = (((long long)q.n * q.ho * q.wo + 63) / 64) * ((q.cout + 63) / 64);
-        if (need && (need < 16384 || (need - 16384) % (64 * 64 * 4) != 0 || (long long)((need - 16384) / (64 * 64 * 4)) % tiles != 0)) { printf("x6 workspace size inconsistent\n"); ++failures; }
+        const long long rows = (long long)q.n * q.ho * q.wo;
+        const long long tiles64 = ((rows + 63) / 64) * ((q.cout + 63) / 64), tiles128 = ((rows + 127) / 128) * ((q.cout + 127) / 128);
+        // tickets + slices x tiles x one f32 tile, on 64x64 or (taller small grids) 128x128 tiles
+        const bool ok64 = need >= 16384 && (need - 16384) % (64 * 64 * 4) == 0 && (long long)((need - 16384) / (64 * 64 * 4)) % tiles64 == 0;
+        const bool ok128 = need >= 16384 && (need - 16384) % (128 * 128 * 4) == 0 && (long long)((need - 16384) / (128 * 128 * 4)) % tiles128 == 0;
+        if (need && !ok64 && !ok128) { printf("x6 workspace size inconsistent\n"); ++failures; }
         if (need && (q.cin % 32)) { printf("x6 split-K offered for cin %% 32 != 0\n"); ++failures; }
         const int n1 = (rnd() % 3) ? 0 : pick({9, 64, 128, 512});
         const int xc = frcnn_conv2d_x6_config(&q, n1);
