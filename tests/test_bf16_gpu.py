@@ -225,6 +225,26 @@ def test_mixed_precision_training_step_tracks_f32(which):
     assert worst > 0.9, worst
 
 
+@pytest.mark.parametrize("case", [(2, 15, 18, 160, 136, 3, 2, "same"), (1, 37, 50, 256, 128, 1, 2, "valid"), (3, 7, 7, 192, 136, 3, 1, "same")])
+def test_wgrad_bf16_big_tile_strided_and_ragged(case):
+    """The 128x128 bf16 weight-gradient tile (cin, cout >= 128, multiples of 8): stride 2 with the asymmetric SAME halo, a strided
+    1x1, ragged channel tiles and rows wrapping over images -- against autograd in f64 on the same bf16-rounded tensors; twice the
+    same bits."""
+    from faster_rcnn_amd import ops
+    from oracle import keras_ref
+    n, h, w, cin, cout, k, stride, padding = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = _bf(rs.randn(n, h, w, cin))
+    wtt = torch.zeros(k, k, cin, cout, dtype=torch.float64, requires_grad=True)
+    y = keras_ref.conv2d(x.double(), wtt, None, stride, padding, dtype=torch.float64)
+    g = _bf(rs.randn(*y.shape))
+    y.backward(g.double())
+    dw, _ = ops.conv2d_wgrad_bf16(x.cuda(), g.cuda(), k, k, stride, padding, want_bias=False)
+    dw2, _ = ops.conv2d_wgrad_bf16(x.cuda(), g.cuda(), k, k, stride, padding, want_bias=False)
+    assert torch.equal(dw, dw2)
+    assert ((dw.cpu().double() - wtt.grad).abs().max() / wtt.grad.abs().max()).item() < 1e-4
+
+
 def test_wgrad_bf16_widening_fallback():
     """Channel counts that are not multiples of 8 cannot use the 16-byte bf16 staging: the kernel that widens to f32
     while staging takes over (same contract)."""
