@@ -37,3 +37,7 @@ torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
 print("\n".join(l[:150] for l in s.getvalue().splitlines()[:45]))
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(r"train\.py|models\.py|nets\.py", 24)
+print("-- by cumulative time, train.py / models.py / nets.py")
+print("\n".join(l[:150] for l in s.getvalue().splitlines()[:45]))
