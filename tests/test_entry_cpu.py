@@ -59,3 +59,104 @@ def test_cubic_tap_tables_from_the_c_abi_equal_the_numpy_restatement():
         tab = ops.resize_cubic_taps(dst, src)
         idx, coef = shapes._cubic_taps(dst, src)
         assert tab.shape == (dst, 8) and np.array_equal(tab[:, :4], idx) and np.array_equal(tab[:, 4:], coef), (dst, src)
+
+
+class _FakeEngine:
+    """Stands in for entry.DetectionEntry in voc_dets.get_dets_by_cls: records what is submitted, returns one detection per image."""
+
+    def __init__(self, batch, in_flight, fetch_ms=0.0):
+        self.batch, self.in_flight, self.fetch_ms = batch, in_flight, fetch_ms
+        self.submitted, self.fetch_threads, self.open_tickets = [], set(), 0
+        self.max_open = 0
+
+    def prefetchable(self, image):
+        return True
+
+    def host_pixels(self, image):
+        import threading
+        import time
+        self.fetch_threads.add(threading.current_thread().name)
+        if self.fetch_ms:
+            time.sleep(self.fetch_ms / 1e3)
+        h, w = image.size
+        return (image.name, h, w, None, False)
+
+    @staticmethod
+    def geometry(pixels):
+        return entry.DetectionEntry.geometry(pixels)
+
+    def submit_batch(self, images, ratios, thr, pixels, batch=None):
+        assert 1 <= len(images) <= (batch or self.batch) and len({self.geometry(p) for p in pixels}) == 1
+        assert [p[0] for p in pixels] == [im.name for im in images]          # each image travels with ITS pixels
+        self.submitted.append((batch, [im.name for im in images], list(ratios)))
+        self.open_tickets += 1
+        self.max_open = max(self.max_open, self.open_tickets)
+        return types.SimpleNamespace(slot=types.SimpleNamespace(event=types.SimpleNamespace(synchronize=lambda: None), busy=True), image=list(images))
+
+    def collect_batch(self, ticket):
+        self.open_tickets -= 1
+        return [(300, [{"bbox": [0, 0, 1, 1], "cls_name": "car" if i % 2 else "person", "prob": 0.5}]) for i, _ in enumerate(ticket.image)]
+
+
+def _run_by_cls(monkeypatch, eng, sizes, **kw):
+    import contextlib
+    import io
+    from faster_rcnn_amd import voc_dets
+    monkeypatch.setattr(voc_dets.entry, "for_models", lambda *a, **k: eng)
+    monkeypatch.setattr(voc_dets.entry, "default_in_flight", lambda dtype: eng.in_flight)
+    images = [types.SimpleNamespace(name="im%02d" % i, size=s) for i, s in enumerate(sizes)]
+    ratios = [1.0 + 0.1 * i for i in range(len(images))]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        dets = voc_dets.get_dets_by_cls(object(), types.SimpleNamespace(head=None), ratios, images, **kw)
+    return images, ratios, dets, buf.getvalue()
+
+
+def test_get_dets_by_cls_groups_runs_of_one_geometry_into_batched_passes(monkeypatch):
+    """Batched passes for runs of equal geometry (whole batches, a padded pass when the rest fills at least half a batch, single
+    passes otherwise), never more tickets open than the engine's depth, results folded in list order, the reference's lines."""
+    A, B = (600, 1500), (600, 1400)
+    sizes = [A] * 13 + [B] * 2 + [A] * 3 + [B] * 9
+    eng = _FakeEngine(batch=8, in_flight=2)
+    images, ratios, dets, out = _run_by_cls(monkeypatch, eng, sizes)
+    shape = [(b, len(names)) for b, names, _ in eng.submitted]
+    assert shape == [(8, 8), (8, 5), (1, 1), (1, 1), (1, 1), (1, 1), (1, 1), (8, 8), (1, 1)], shape
+    assert [n for _, names, _ in eng.submitted for n in names] == [im.name for im in images]
+    assert [r for _, _, rs_ in eng.submitted for r in rs_] == ratios
+    assert eng.max_open <= 2 and eng.open_tickets == 0
+    lines = [ln.split(" ran in ")[0] for ln in out.splitlines()]
+    assert lines == [x for im in images for x in ("num rois: 300", "image %s" % im.name)]
+    assert set(dets) == {"person", "car"} and sum(len(v) for c in dets.values() for v in c.values()) == len(images)
+    assert eng.fetch_threads == {__import__("threading").current_thread().name}      # fast fetches stay inline
+
+
+def test_get_dets_by_cls_single_image_engine_and_slow_fetches(monkeypatch):
+    from faster_rcnn_amd import voc_dets
+    eng = _FakeEngine(batch=1, in_flight=3, fetch_ms=voc_dets.DECODE_INLINE_MS + 3.0)
+    images, ratios, dets, out = _run_by_cls(monkeypatch, eng, [(375, 500)] * 7)
+    assert [(b, len(n)) for b, n, _ in eng.submitted] == [(1, 1)] * 7 and eng.max_open <= 3
+    assert len(eng.fetch_threads) >= 2                                     # two slow fetches in a row: the next ones come from pool threads
+    assert sum(len(v) for c in dets.values() for v in c.values()) == 7
+
+
+def test_get_dets_by_cls_failure_leaves_no_ticket_open(monkeypatch):
+    import pytest
+    eng = _FakeEngine(batch=8, in_flight=2)
+    real = eng.host_pixels
+
+    def failing(image):
+        if image.name == "im10":
+            raise TypeError("bad pixels")
+        return real(image)
+    eng.host_pixels = failing
+    synced = []
+    orig_submit = eng.submit_batch
+
+    def submit(*a, **k):
+        t = orig_submit(*a, **k)
+        t.slot.event.synchronize = lambda: synced.append(1)
+        return t
+    eng.submit_batch = submit
+    with pytest.raises(TypeError):
+        _run_by_cls(monkeypatch, eng, [(600, 1500)] * 12)
+    assert len(eng.submitted) == 1 and synced == [1]                       # the whole batch of eight was in flight: waited for, slot released
