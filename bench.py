@@ -66,22 +66,27 @@ class RpnOnlyPipeline:
         self.rpn, self._graph = rpn, None
 
     def forward_dev(self, x, resize_ratio=1.0):
+        from faster_rcnn_amd import ops
+        ops.amax_begin()
         cls, reg, feat = self.rpn.forward_dev(x)
         return {"rpn_cls": cls, "rpn_reg": reg, "feat": feat}
 
     def capture(self, height, width, split_k=True, throughput=False, f32_engine="native"):
         from faster_rcnn_amd import ops
         self._static_in = torch.zeros((1, height, width, 3), dtype=torch.float32, device="cuda")
+        from faster_rcnn_amd.pipeline import no_gc
         self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
+        self._amax = ops.AmaxArena() if f32_engine == "f16x3" else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.f32_engine(f32_engine):
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.f32_engine(f32_engine), ops.amax_arena(self._amax):
             for _ in range(2):
                 self.forward_dev(self._static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.f32_engine(f32_engine):
+        with no_gc(), torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), \
+                ops.f32_engine(f32_engine), ops.amax_arena(self._amax):
             self._static_out = self.forward_dev(self._static_in)
         return self
 
@@ -138,6 +143,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1, en
     event pair brackets a replay; its average is the launch duration.  Returns the roofline object for the
     DOMINANT kernel instantiation (largest summed duration per image) plus the aggregate over all conv launches."""
     from faster_rcnn_amd import ops
+    from faster_rcnn_amd.pipeline import no_gc
     with ops.conv_workspace(None if split_k else ops.NO_SPLIT_K), ops.tile_policy(throughput), ops.f32_engine(engine):     # the launch forms the timed graphs hold
         pipe.forward_dev(x)
         torch.cuda.synchronize()
@@ -162,7 +168,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1, en
         rec = g["rec"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         graph = torch.cuda.CUDAGraph()          # the product path replays hipGraphs: time the launch the same way
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with no_gc(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             for _ in range(reps):
                 rec["relaunch"]()
         graph.replay()                          # the shader clock settles over the first launches of a shape
@@ -186,9 +192,22 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1, en
     tpath = os.path.join(ROOT, "profiles", "traffic.json")       # PMC passes (rocprofv3 --pmc), committed
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
-    # the split-bf16 engine's ceiling is the bf16 matrix pipe: six v_mfma_f32_32x32x16_bf16 products per fp32 product
-    x6_dom = "x6" in dom_name
-    peak = PEAK_BF16_TFLOPS / 6.0 if x6_dom else PEAK_F32_MATRIX_TFLOPS
+    # a split engine's ceiling is the 16-bit matrix pipe: six v_mfma_f32_32x32x16_bf16 (bf16x6) or three v_mfma_f32_32x32x16_f16
+    # (f16x3) matrix instructions per block of fp32 products
+    x6_dom, h3_dom = "x6" in dom_name, "h3" in dom_name
+    per_product = 6.0 if x6_dom else 3.0 if h3_dom else None
+    peak = PEAK_BF16_TFLOPS / per_product if per_product else PEAK_F32_MATRIX_TFLOPS
+    engine_peak = PEAK_BF16_TFLOPS / {"bf16x6": 6.0, "f16x3": 3.0}[engine] if engine in ("bf16x6", "f16x3") else None
+
+    def both(tf):
+        """A rate against BOTH denominators: the native fp32 matrix peak the north star was written against, and the
+        ceiling of the engine the launches actually ran on (most of them: the stem and a few small grids stay native)."""
+        d = {"frac": round(tf / PEAK_F32_MATRIX_TFLOPS, 4), "peak": PEAK_F32_MATRIX_TFLOPS, "peak_basis": "native fp32 matrix peak (v_mfma_f32_32x32x2_f32)"}
+        if engine_peak:
+            d["frac_of_engine_ceiling"] = round(tf / engine_peak, 4)
+            d["engine_ceiling"] = round(engine_peak, 1)
+            d["engine_ceiling_basis"] = "2.5 PFLOP/s dense 16-bit MFMA / %d matrix instructions per block of fp32 products (%s)" % (6 if engine == "bf16x6" else 3, engine)
+        return d
     roof = {
         "bound": "mfma", "kernel": dom_name,
         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -204,44 +223,56 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1, en
                               "gflop_per_image": round(tot_flops / 1e9, 2),
                               "ms_per_image": round(tot_ms, 3),
                               "achieved": round(tot_flops / (tot_ms * 1e-3) / 1e12, 2),
-                              "frac": round(tot_flops / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4)},
+                              **both(tot_flops / (tot_ms * 1e-3) / 1e12)},
         "backbone_conv": {"launches_per_image": n_base, "layers_per_image": len(list(pipe.rpn.base.net.units())), "gflop_per_image": round(base_flops / 1e9, 2), "ms_per_image": round(base_ms, 3),
                           "achieved": round(base_flops / (base_ms * 1e-3) / 1e12, 2),
-                          "frac": round(base_flops / (base_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 4),
+                          **both(base_flops / (base_ms * 1e-3) / 1e12),
                           "note": "conv1..res4f, each launch alone on the chip (single image, no other stream): the latency view; "
                                   "with several images in flight the same launches overlap"},
         "method": "HIP events on the launch stream around a hipGraph that holds each distinct launch %d x back to back" % reps,
     }
-    if x6_dom:
-        roof["peak_basis"] = ("fp32-equivalent FLOP/s: 2.5 PFLOP/s dense bf16 MFMA / 6 bf16 MFMAs per fp32 product; `achieved` counts each fp32 multiply-add once "
-                              "(the matrix pipe executes 6x that in bf16: %.0f TFLOP/s bf16); against the native fp32 matrix peak (157.3) the same launches read %.3f; "
-                              "all_conv_launches / backbone_conv stay relative to the native fp32 peak" % (6 * achieved, achieved / PEAK_F32_MATRIX_TFLOPS))
+    if per_product:
+        roof["peak_basis"] = ("fp32-equivalent FLOP/s: 2.5 PFLOP/s dense 16-bit MFMA / %d matrix instructions per block of fp32 products (%s); `achieved` counts each "
+                              "fp32 multiply-add once (the matrix pipe executes %dx that: %.0f TFLOP/s of 16-bit MFMA work = %.3f of 2.5 PFLOP/s)"
+                              % (per_product, "bf16x6: exact three-way split" if x6_dom else "f16x3: two-way split with a scaled low part",
+                                 per_product, per_product * achieved, per_product * achieved / PEAK_BF16_TFLOPS))
+        roof["frac_of_native_fp32_peak"] = round(achieved / PEAK_F32_MATRIX_TFLOPS, 4)
+        roof["mfma_pipe_frac"] = round(per_product * achieved / PEAK_BF16_TFLOPS, 4)
+    else:
+        roof["peak_basis"] = "native fp32 matrix peak (v_mfma_f32_32x32x2_f32)"
     return roof, groups
 
 
-def backbone_in_flight(pipe, n_images, base_gflop, steps=20, batch=1):
+def backbone_in_flight(pipe, n_images, base_gflop, steps=20, batch=1, engine="native"):
     """The backbone (conv1 .. last base stage, with its pools) of `n_images` images at once, one hipGraph per image on its
     own stream -- how the timed pipeline keeps the chip busy -- timed as a whole: ms per image and the conv TFLOP/s that
     is.  The per-launch sum in `backbone_conv` is the latency view of the same launches."""
     from faster_rcnn_amd import ops
+    from faster_rcnn_amd.pipeline import no_gc
     net = pipe.rpn.base.net
     streams = [torch.cuda.Stream() for _ in range(n_images)]
     graphs = []
+
+    def run(x):
+        ops.amax_begin()
+        return net(x)
     for i, st in enumerate(streams):
         x = torch.from_numpy(np.concatenate([synth_image(200 + i * batch + j) for j in range(batch)])).cuda()
         ws = ops.ConvWorkspace() if batch == 1 else ops.NO_SPLIT_K
+        arena = ops.AmaxArena() if engine == "f16x3" else None
         shared = n_images > 1 or batch > 1
         st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st), ops.conv_workspace(ws), ops.tile_policy(shared):
-            net(x); net(x)
+        with torch.cuda.stream(st), ops.conv_workspace(ws), ops.tile_policy(shared), ops.f32_engine(engine), ops.amax_arena(arena):
+            run(x); run(x)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"), ops.conv_workspace(ws), ops.tile_policy(shared):
-            y = net(x)
-        graphs.append((g, x, y, ws))
+        with no_gc(), torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"), ops.conv_workspace(ws), ops.tile_policy(shared), \
+                ops.f32_engine(engine), ops.amax_arena(arena):
+            y = run(x)
+        graphs.append((g, x, y, ws, arena))
 
     def step():
-        for (g, _, _, _), st in zip(graphs, streams):
+        for (g, _, _, _, _), st in zip(graphs, streams):
             with torch.cuda.stream(st):
                 g.replay()
     for _ in range(3):
@@ -253,8 +284,14 @@ def backbone_in_flight(pipe, n_images, base_gflop, steps=20, batch=1):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / (steps * n_images * batch)
     tf = base_gflop / ms
-    return {"images_in_flight": n_images * batch, "graphs_in_flight": n_images, "images_per_graph": batch, "ms_per_image": round(ms, 3), "achieved": round(tf, 2),
-            "frac": round(tf / (PEAK_BF16_TFLOPS if DTYPE == "bf16" else PEAK_F32_MATRIX_TFLOPS), 4),
+    out = {"images_in_flight": n_images * batch, "graphs_in_flight": n_images, "images_per_graph": batch, "ms_per_image": round(ms, 3), "achieved": round(tf, 2),
+           "frac": round(tf / (PEAK_BF16_TFLOPS if DTYPE == "bf16" else PEAK_F32_MATRIX_TFLOPS), 4),
+           "peak": PEAK_BF16_TFLOPS if DTYPE == "bf16" else PEAK_F32_MATRIX_TFLOPS,
+           "peak_basis": "dense bf16 MFMA peak" if DTYPE == "bf16" else "native fp32 matrix peak (v_mfma_f32_32x32x2_f32)"}
+    if DTYPE != "bf16" and engine in ("bf16x6", "f16x3"):
+        ceil = PEAK_BF16_TFLOPS / (6.0 if engine == "bf16x6" else 3.0)
+        out.update({"frac_of_engine_ceiling": round(tf / ceil, 4), "engine_ceiling": round(ceil, 1)})
+    return {**out,
             "what": "one hipGraph of the base network per image, %d replaying concurrently on their own streams, wall clock over %d rounds" % (n_images, steps)}
 
 
@@ -363,11 +400,14 @@ def full_size_parity(pipe, weights, anchors):
     stages within 1e-4 (|a-b| / max(|b|, 1)), discrete stages (proposal selection, detection emission) exact."""
     from oracle import np_ref
     from oracle.keras_ref import KerasGraphs
+    from faster_rcnn_amd import ops
     g = KerasGraphs(weights, torch.float32)
     x = synth_image(100)
     with torch.no_grad():
+        measured0 = ops.AMAX_MEASURED
         out = pipe.forward_dev(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
+        measured = ops.AMAX_MEASURED - measured0             # f16x3 engine: tensors without a producer's magnitude record (each costs a pass)
         host = {k: v.cpu() for k, v in out.items()}
         err = lambda a, b: float(((a.double() - b.double()).abs() / b.double().abs().clamp(min=1)).max())
         feat = g.resnet_base(x, 50)
@@ -394,6 +434,7 @@ def full_size_parity(pipe, weights, anchors):
     res = {k: (v if isinstance(v, bool) else float("%.3g" % v)) for k, v in res.items()}
     res["ok"] = bool(res["proposals_equal"] and res["detections_equal"] and all(v < 1e-4 for v in res.values() if not isinstance(v, bool)))
     res["n_rois"], res["n_detections"] = n, nd
+    res["amax_measured"] = measured
     return res
 
 
@@ -828,9 +869,10 @@ def main():
                          "default: 8 for configs[3] (bf16), 1 otherwise")
     ap.add_argument("--unit-tiles", default="", help="dev: tile codes for named conv layers, e.g. res5a_branch2c=26,res5b_branch2c=26")
     ap.add_argument("--conv-table", action="store_true", help="print every distinct conv launch's duration alone on the chip to stderr")
-    ap.add_argument("--f32-engine", choices=("native", "bf16x6"), default="bf16x6",
-                    help="matrix path of the fp32 convolutions: native f32 MFMA, or the large launches on the bf16 matrix cores by exact "
-                         "three-way operand splitting (fp32-grade results, csrc/conv_x6.hip)")
+    ap.add_argument("--f32-engine", choices=("native", "bf16x6", "f16x3"), default="f16x3",
+                    help="matrix path of the fp32 convolutions: native f32 MFMA; bf16x6 = the large launches on the bf16 matrix cores by exact "
+                         "three-way operand splitting (csrc/conv_x6.hip, six matrix instructions per block of products); f16x3 = the same launches on "
+                         "the fp16 matrix cores by a two-way split with a scaled low part (csrc/conv_h3.hip, three).  fp32-grade results either way")
     ap.add_argument("--no-train-dp", action="store_true", help="N > 1: leave the data-parallel training steps (`train_dp`) out of the line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -963,13 +1005,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- the same K steps on the NATIVE fp32 matrix instruction, when the timed graphs above run their large launches on the
-    # split-bf16 engine: both numbers in one line, same process, same inputs (one rank only)
-    native = None
-    if not args.no_graph and args.f32_engine == "bf16x6" and DTYPE == "f32" and B == 1 and world == 1 and not force_dist and "FRCNN_BENCH_NO_NATIVE" not in os.environ:
+    # ---- the same K steps on the OTHER fp32 matrix paths, when the timed graphs above run their large launches on a split engine:
+    # all numbers in one line, same process, same inputs (one rank only).  `native_f32_mfma`: every convolution on
+    # v_mfma_f32_32x32x2_f32; `bf16x6_exact_split` (f16x3 runs): the exact three-way bf16 split of round 4.
+    native = x6_alt = None
+
+    def time_engine(engine, what):
         npipes = [more() for _ in range(S)]
         for i, pl in enumerate(npipes):
-            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1, f32_engine="native")
+            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1, f32_engine=engine)
             pl._static_in.copy_(synth_batch((rank * S + i) * B))
         torch.cuda.synchronize()
 
@@ -985,16 +1029,22 @@ def main():
             nstep()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        native = {"value": round(S * args.steps / el, 3), "unit": "img/s", "ms_per_step": round(1e3 * el / args.steps, 4),
-                  "what": "the same %d steps with every fp32 convolution on v_mfma_f32_32x32x2_f32 (--f32-engine native)" % args.steps}
+        res = {"value": round(S * args.steps / el, 3), "unit": "img/s", "ms_per_step": round(1e3 * el / args.steps, 4), "what": what % args.steps}
         if "det_bbox" in pipes[0]._static_out:
             same = all(torch.equal(a._static_out["det_bbox"], b._static_out["det_bbox"]) and torch.equal(a._static_out["det_cls"], b._static_out["det_cls"])
                        for a, b in zip(pipes, npipes))
-            native["same_boxes_and_classes_as_value_run"] = bool(same)
+            res["same_boxes_and_classes_as_value_run"] = bool(same)
+            res["max_score_difference_from_value_run"] = float(max((a._static_out["det_prob"] - b._static_out["det_prob"]).abs().max() for a, b in zip(pipes, npipes)))
         else:                                               # configs[0]: RPN outputs only
-            native["max_rpn_cls_difference_from_value_run"] = float(max((a._static_out["rpn_cls"] - b._static_out["rpn_cls"]).abs().max() for a, b in zip(pipes, npipes)))
+            res["max_rpn_cls_difference_from_value_run"] = float(max((a._static_out["rpn_cls"] - b._static_out["rpn_cls"]).abs().max() for a, b in zip(pipes, npipes)))
         del npipes
         torch.cuda.empty_cache()
+        return res
+    if not args.no_graph and args.f32_engine != "native" and DTYPE == "f32" and B == 1 and world == 1 and not force_dist and "FRCNN_BENCH_NO_NATIVE" not in os.environ:
+        native = time_engine("native", "the same %d steps with every fp32 convolution on v_mfma_f32_32x32x2_f32 (--f32-engine native)")
+        if args.f32_engine == "f16x3":
+            x6_alt = time_engine("bf16x6", "the same %d steps with the split launches on the bf16 matrix cores by EXACT three-way operand splitting, six matrix "
+                                           "instructions per block of products (--f32-engine bf16x6: round 4's headline path)")
 
     # ---- the same K steps again with the host on both ends (voc_dets.get_dets' contract: image in, detections out,
     # voc_dets.py:20-88): per image a FRESH uint8 BGR frame leaves pinned host memory (1.8 MB over PCIe), resnet.preprocess
@@ -1109,10 +1159,15 @@ def main():
                        "images_per_step_per_gpu": S * B, "graphs_in_flight": S, "images_per_graph": B, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "proposals": PROPOSALS, "classes": NUM_CLASSES,
                        "pre_nms_top_n": 8000, "launch": "eager" if args.no_graph else "hipGraph replay", "split_k": bool(split_k),
-                       "f32_matrix_path": ("bf16x6: launches of >= %d 64x64 output tiles and >= %d columns (and the long-k small grids, split-K) multiply on v_mfma_f32_32x32x16_bf16 with every f32 operand split EXACTLY "
-                                           "into three bf16 values, six exact partial products per product, f32 accumulate (csrc/conv_x6.hip; error against fp64 at the native "
-                                           "kernel's level); the rest on v_mfma_f32_32x32x2_f32" % (_ops.X6_MIN_TILES, _ops.X6_MIN_COUT))
-                                          if args.f32_engine == "bf16x6" and DTYPE == "f32" else "native: v_mfma_f32_32x32x2_f32",
+                       "f32_matrix_path": ("native: v_mfma_f32_32x32x2_f32" if (args.f32_engine == "native" or DTYPE != "f32") else
+                                           ("bf16x6: launches of >= %d 64x64 output tiles and >= %d columns (and the long-k small grids, split-K) multiply on v_mfma_f32_32x32x16_bf16 with every f32 operand split EXACTLY "
+                                            "into three bf16 values, six exact partial products per product, f32 accumulate (csrc/conv_x6.hip; error against fp64 at the native "
+                                            "kernel's level); the rest on v_mfma_f32_32x32x2_f32" % (_ops.X6_MIN_TILES, _ops.X6_MIN_COUT)) if args.f32_engine == "bf16x6" else
+                                           ("f16x3: launches of >= %d 64x64 output tiles and >= %d columns (and the long-k small grids, split-K) multiply on v_mfma_f32_32x32x16_f16: each operand tensor scaled by one "
+                                            "power of two into fp16's range (from a device-resident bound of max|x| the producing launch leaves behind), every value split into f16(a) and f16((a - f16(a)) * 2^11) "
+                                            "(23-24 of its 24 bits), ah*bh and ah*bl + al*bh accumulated in f32 in two accumulators: THREE matrix instructions per block of products instead of six "
+                                            "(csrc/conv_h3.hip; error against fp64 UNDER the native kernel's on every operand class measured, tests/test_conv_h3_gpu.py; NOT an exact split: the al*bl term, "
+                                            "<= 2^-22 of a product, is dropped); the rest on v_mfma_f32_32x32x2_f32" % (_ops.X6_MIN_TILES, _ops.X6_MIN_COUT))),
                        "head_order": "no detector head" if DEPTH == 16 else
                        "res5a 1x1 layers on the conv4 map, then RoI resampling (algebraically equal, see DESIGN 5)" if HOIST else "reference order",
                        "n_rois_kept": n_rois, "n_detections": n_dets, "parallelism": "replicas x%d (no collective)" % world,
@@ -1121,6 +1176,8 @@ def main():
         }
         if native is not None:
             line["native_f32_mfma"] = native
+        if x6_alt is not None:
+            line["bf16x6_exact_split"] = x6_alt
         if io is not None:
             line["with_host_io"] = io
         if via_entry is not None:
@@ -1138,7 +1195,7 @@ def main():
             line["roofline"]["end_to_end_conv_tflops"] = round(roof["all_conv_launches"]["gflop_per_image"] * line["value"] / 1e3, 2)
         if roof is not None and (S > 1 or B > 1) and world == 1:
             try:
-                roof["backbone_conv"]["in_flight"] = backbone_in_flight(pipe, S, roof["backbone_conv"]["gflop_per_image"], batch=B)
+                roof["backbone_conv"]["in_flight"] = backbone_in_flight(pipe, S, roof["backbone_conv"]["gflop_per_image"], batch=B, engine=args.f32_engine if DTYPE == "f32" else "native")
             except Exception as e:
                 roof["backbone_conv"]["in_flight"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if roof is not None and DTYPE == "bf16":

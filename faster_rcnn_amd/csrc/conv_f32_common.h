@@ -31,7 +31,37 @@ struct ConvArgs {
     // Two layers in one launch (frcnn_conv2d_fwd_dual): columns [0, n_split) are layer 1 -> y (ldy, act), columns
     // [n_split, Cout) are layer 2 -> y2 (ldy2, act2).  n_split == 0: one layer.  No residual / mask in this form.
     int n_split; float* y2; int ldy2, act2;
+    // Magnitude records (frcnn_amax_*; AMAX_SLOTS x AMAX_STRIDE floats each, NULL = not tracked): every epilogue folds max|y| of what
+    // it stores into y_amax (y2_amax: the second layer of a paired launch); the f16x3 engine (conv_h3.hip) reads x_amax -- an UPPER
+    // BOUND of |x| -- to bring the activations into fp16's range by one power of two.
+    const float* x_amax; float* y_amax; float* y2_amax;
 };
+
+// ---- magnitude records.  A record is AMAX_SLOTS floats, one per 128-byte line: a launch has hundreds to thousands of waves and a
+// single word takes ~90 atomics per microsecond (MI355X_MICROARCH.md, dequeue), so each wave folds its maximum into slot
+// (global wave id) % AMAX_SLOTS with ONE no-return atomic max on the value's bits (non-negative floats order like unsigned
+// integers); a reader takes the maximum over the slots.  Records are cleared by frcnn_amax_clear (a kernel: a memset node inside
+// a captured graph is not ordered against its neighbours on this runtime).
+constexpr int AMAX_SLOTS = 32, AMAX_STRIDE = 32;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ void amax_publish(float* rec, float v) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0 && v > 0.0f) {
+        const unsigned w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        atomicMax(reinterpret_cast<unsigned*>(rec + (w & (AMAX_SLOTS - 1)) * AMAX_STRIDE), __float_as_uint(v));
+    }
+}
+
+__device__ __forceinline__ float amax_read(const float* rec) {
+    const int lane = threadIdx.x & 63;
+    return wave_max(lane < AMAX_SLOTS ? rec[lane * AMAX_STRIDE] : 0.0f);
+}
 
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;     // floats per LDS row (144 B)
@@ -51,6 +81,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // fused epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int wm, int wn, int li, int lh) {
+    float vmax1 = 0.0f, vmax2 = 0.0f;                               // max |y| this lane stored, per layer of a paired launch
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 32 + j * 32 + li;
@@ -70,11 +101,15 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& 
                     float v = acc[i][j][e] * sc + sh;
                     if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
                     if (p.mask && !(p.mask[(size_t)m * p.Cout + n] > 0.0f)) v = 0.0f;
-                    yb[(size_t)m * ld + nn] = activate(v, act);
+                    v = activate(v, act);
+                    yb[(size_t)m * ld + nn] = v;
+                    if (second) vmax2 = fmaxf(vmax2, fabsf(v)); else vmax1 = fmaxf(vmax1, fabsf(v));
                 }
             }
         }
     }
+    if (p.y_amax) amax_publish(p.y_amax, vmax1);
+    if (p.y2_amax) amax_publish(p.y2_amax, vmax2);
 }
 
 
@@ -177,6 +212,7 @@ __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], const ConvAr
         }
     __syncthreads();
     const float* src = smem + (tid / E::C4) * E::LD + (tid % E::C4) * 4;
+    float vmax = 0.0f;
 #pragma unroll 1
     for (int g = 0; g < E::PASSES / GP; ++g) {
         if (g) fetch(g);
@@ -193,15 +229,108 @@ __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], const ConvAr
                 v[c] = activate(t, y_act);
             }
             const int ym = m0 + pass * E::RPP + tid / E::C4, yn = n0 - y_n0 + (tid % E::C4) * 4;
-            const unsigned yoff = (ym < p.M && yn < y_cols) ? (unsigned)(((size_t)ym * y_ld + yn) * 4) : OOB_OFFSET;
+            const bool in = ym < p.M && yn < y_cols;
+            const unsigned yoff = in ? (unsigned)(((size_t)ym * y_ld + yn) * 4) : OOB_OFFSET;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, yoff, 0, 0);
+            if (in) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
     }
+    if (float* rec = second ? p.y2_amax : p.y_amax) amax_publish(rec, vmax);
+}
+
+
+// ------------------------------------------------------------------------------------
+// Shared by the two split engines (conv_x6.hip: three bf16 planes per operand; conv_h3.hip: two fp16 planes): the LDS image of
+// an operand plane -- unpadded 64-byte rows (32 k of 2 bytes), the 16-byte slot s of row r stored at slot s ^ ((r >> 2) & 3) -- the
+// tile's LDS budget, and the 16-byte epilogue that turns the tile through that LDS one wave-row at a time.
+constexpr int X6_ROWB = 64;           // LDS bytes per row per plane
+__device__ __forceinline__ int x6_swz(int row) { return (row >> 2) & 3; }
+
+
+template <int TM, int TN, int WM, int WN, int PLANES = 3>
+struct X6Tile {
+    static constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static constexpr size_t planes = (size_t)PLANES * (BM + BN) * X6_ROWB;
+    static constexpr size_t epi = (size_t)(32 * TM) * (BN + 4) * 4;     // the 16-byte epilogue: one wave-row of the tile at a time
+    static constexpr size_t lds = planes > epi ? planes : epi;
+};
+
+// The 16-byte epilogue of conv_f32_common.h (epilogue_vec: same arithmetic per element, same order) with the tile turned through
+// LDS one WAVE-ROW at a time: pass h stages the 32 TM rows owned by the waves with wm == h, every thread then owns 16-byte pieces
+// of whole rows (scale / shift / residual / mask / y as b128, out-of-range pieces on the buffer descriptors).
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh, float* smem) {
+    constexpr int NT = 64 * WM * WN, BN = 32 * TN * WN, HB = 32 * TM, LD = BN + 4, C4 = BN / 4, RPP = NT / C4, PASSES = HB / RPP;
+    static_assert(HB % RPP == 0 && NT % C4 == 0 && PASSES >= 1 && PASSES <= 8, "epilogue passes");
+    const bool second = p.n_split && n0 >= p.n_split;       // two layers in one launch: the tile belongs to ONE of them (host guarantees it)
+    float* const yb = second ? p.y2 : p.y;
+    const int y_ld = second ? p.ldy2 : p.ldy, y_act = second ? p.act2 : p.act, y_n0 = second ? p.n_split : 0;
+    const int y_cols = p.n_split ? (second ? p.Cout - p.n_split : p.n_split) : p.Cout;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((size_t)p.M * y_ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.mask ? p.mask : p.x), 0, p.mask ? (int)((size_t)p.M * p.Cout * 4) : 0, 0x00020000);
+    const int prow = tid / C4, pcol = (tid % C4) * 4, n = n0 + pcol;
+    f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (n < p.Cout) {
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+    }
+    f32x4 rres[PASSES], rmask[PASSES];
+    float vmax = 0.0f;
+    auto fetch = [&](int h) {                                // the global reads of wave-row h: in flight while it goes through LDS
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            const int m = m0 + h * HB + q * RPP + prow;
+            const bool in = m < p.M && n < p.Cout;
+            if (p.residual) rres[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, in ? (unsigned)(((size_t)m * p.ldres + n) * 4) : OOB_OFFSET, 0, 0));
+            if (p.mask) rmask[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, in ? (unsigned)(((size_t)m * p.Cout + n) * 4) : OOB_OFFSET, 0, 0));
+        }
+    };
+#pragma unroll 1
+    for (int h = 0; h < WM; ++h) {
+        fetch(h);
+        if (h) __syncthreads();                              // the previous wave-row has been read out (the caller synchronised before pass 0)
+        if (wm == h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float* dst = smem + (i * 32 + 4 * lh) * LD + wn * TN * 32 + j * 32 + li;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * LD] = acc[i][j][e];
+                }
+        }
+        __syncthreads();
+        const float* src = smem + prow * LD + pcol;
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + q * RPP * LD);
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float t = a[c] * sc[c] + sh[c];
+                if (p.residual) t += rres[q][c];
+                if (p.mask && !(rmask[q][c] > 0.0f)) t = 0.0f;
+                v[c] = activate(t, y_act);
+            }
+            const int ym = m0 + h * HB + q * RPP + prow, yn = n0 - y_n0 + pcol;
+            const bool in = ym < p.M && yn < y_cols;
+            const unsigned yoff = in ? (unsigned)(((size_t)ym * y_ld + yn) * 4) : OOB_OFFSET;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, yoff, 0, 0);
+            if (in) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+    }
+    if (float* rec = second ? p.y2_amax : p.y_amax) amax_publish(rec, vmax);
 }
 
 
 // conv_x6.hip: the same GEMM on the bf16 matrix cores (exact three-way operand split); `a.w` = the three filter planes
 int launch_conv_x6(const ConvArgs& a, int cfg, hipStream_t s);
 int x6_tile_width(int cfg);
+// conv_h3.hip: the same GEMM on the fp16 matrix cores (two-way split with a scaled low part); `a.w` = header + two filter planes
+int launch_conv_h3(const ConvArgs& a, int cfg, hipStream_t s);
+int h3_tile_width(int cfg);
 
 }  // namespace frcnn

@@ -1,0 +1,629 @@
+// fp32 implicit-GEMM convolution on the fp16 matrix cores by a TWO-way operand split with a scaled low part ("f16x3"), gfx950.
+//
+// Same contract, operands and layouts as k_conv_igemm_f32_v2 / k_conv_igemm_x6 (f32 NHWC / position-major activations in, f32 out,
+// fused scale / shift / residual / mask / activation epilogue, filter taps walked per 32-channel chunk, halo and ragged edges on the
+// buffer descriptors) -- only the multiply differs:
+//
+//   each operand TENSOR is first brought into fp16's range by one power of two (exact):  a' = a * 2^eA,  max|a'| in [2^14, 2^15)
+//   (eA from an upper bound of max|a| that the producing launch left in a magnitude record, ConvArgs.x_amax; the filter's from the
+//   maximum stored in front of its planes), then
+//       ah = f16(a')                  11 significant bits, round to nearest even
+//       al = f16((a' - ah) * 2^11)    the EXACT residual (13 bits), scaled up into ah's exponent range, rounded to 11 bits
+//   so a' = ah + al * 2^-11 + eps,  |eps| <= 2^-24 |a'|  (the residual's last bit is rounded away in half of the cases); same for b.
+//       acc0 += ah * bh               v_mfma_f32_32x32x16_f16: every product exact in f32, f32 accumulate
+//       acc1 += ah * bl + al * bh     an accumulator of its own: it carries the weight 2^-11
+//       c = (acc0 + acc1 * 2^-11) * 2^-eA * 2^-eB
+//   The al * bl term (<= 2^-22 |ab|, typically 2^-25 |ab| with a random sign) is dropped.
+//
+// THREE MFMAs per block of products where the three-way bf16 split (conv_x6.hip) needs six: the fp32-equivalent ceiling of the matrix
+// pipe doubles (2.5 PFLOP/s / 3), and a chunk moves four LDS planes instead of six.  What is given up against conv_x6.hip: the split
+// is not exact -- an operand carries 23-24 bits instead of all 24.  Measured against fp64 (scripts/micro/h3_lab.hip, K = 512 / 4608):
+// max |err| / sum|ab| 7.2e-8 / 8.4e-8 on mixed-sign operands (native v_mfma_f32_32x32x2_f32: 2.8e-7 / 2.3e-7; the six-product bf16
+// split: 2.2e-7 / 1.8e-7), 5.0e-7 / 1.7e-6 when nothing cancels (native 1.4e-6 / 4.0e-6), exact on integers up to 2048, and 2.9e-7
+// on the adversarial input whose every residual has the same sign and the largest size (native 1.6e-6): at or under the native f32
+// matrix instruction everywhere, because one 16-deep MFMA block rounds once where the 2-deep f32 instruction rounds eight times.
+// Range: fp16 keeps full precision over 2^-12 .. 2^15 after scaling, so values down to 2^-27 of the tensor's bound keep all their
+// bits and smaller ones lose them gradually (absolute error <= 2^-50 of the bound); a bound up to 2^8 too large costs nothing.
+//
+// Loop structure, LDS image (unpadded 64-byte rows, XOR-swizzled 16-byte slots) and epilogue are those of conv_x6.hip; operands are
+// split in the loader (global f32 -> registers -> two fp16 planes in LDS: one multiply, two conversions and one fused multiply-add
+// per element pair, half of the three-way split's arithmetic); the filter is split once at pack time (frcnn_pack_conv_weights_h3).
+#include "conv_f32_common.h"
+
+namespace frcnn {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H3_HEADER_BYTES = 16;       // in front of a filter's two planes: word 0 = max|w| of the packed filter (f32)
+
+// e with amax * 2^e in [2^14, 2^15); clamped so that 2^e, 2^(e + 11) and 2^-e are normal f32 numbers whatever amax is
+__host__ __device__ __forceinline__ int h3_exponent(float amax) {
+    unsigned b;
+    __builtin_memcpy(&b, &amax, 4);
+    const int e = 141 - (int)((b >> 23) & 0xffu);         // amax = 1.m * 2^(be - 127)  ->  14 - (be - 127)
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+__host__ __device__ __forceinline__ float h3_pow2(int e) {
+    const unsigned b = (unsigned)(e + 127) << 23;
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+
+__device__ __forceinline__ void h3_split(const f32x4 v, float s, f16x4& h, f16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e] * s;                             // exact: s is a power of two
+        const _Float16 a1 = (_Float16)x;                      // round to nearest even (v_cvt_pk_f16_f32)
+        const float r = x - (float)a1;                        // exact
+        h[e] = a1; l[e] = (_Float16)(r * 2048.0f);
+    }
+}
+
+// the two scaled accumulators -> the f32 sum of products the epilogues expect
+template <int TM, int TN>
+__device__ __forceinline__ void h3_combine(f32x16 (&acc0)[TM][TN], const f32x16 (&acc1)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc0[i][j][e] = acc0[i][j][e] + acc1[i][j][e] * (1.0f / 2048.0f);
+}
+template <int TM, int TN>
+__device__ __forceinline__ void h3_unscale(f32x16 (&acc)[TM][TN], float inv_a, float inv_b) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] * inv_a) * inv_b;     // two exact steps: 2^-(eA + eB) itself may leave f32's range
+}
+
+// tile walk shared by the two kernels: which (row tile, column tile) a workgroup owns
+__device__ __forceinline__ void h3_tile_of(const ConvArgs& p, int tile, int& tile_m, int& tile_n) {
+    tile_n = tile / p.tiles_m; tile_m = tile - tile_n * p.tiles_m;
+    if (p.group_m > 0) {                                  // grouped order (see k_conv_igemm_f32_v2): g row tiles x all column tiles
+        const int per = p.group_m * p.tiles_n, g = tile / per, m_base = g * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - m_base), r = tile - g * per;
+        tile_n = r / gm;
+        tile_m = m_base + r - tile_n * gm;
+    }
+}
+
+// filter taps a tile needs (position-major rows: taps that meet only zero padding for ALL rows of the tile are skipped)
+__device__ __forceinline__ unsigned h3_tap_mask(const ConvArgs& p, int m0, int BM) {
+    const int RS = p.R * p.S;
+    const unsigned all_taps = RS >= 32 ? 0xffffffffu : (1u << RS) - 1u;
+    if (!p.layout) return all_taps;
+    const int pos_lo = m0 / p.n_img, pos_hi = (min(m0 + BM, p.M) - 1) / p.n_img;
+    if (pos_hi - pos_lo >= 8) return all_taps;
+    unsigned mk = 0;
+    for (int pos = pos_lo; pos <= pos_hi; ++pos) {
+        const int ho = pos / p.Wo, wo = pos - ho * p.Wo;
+        const int h0 = ho * p.stride - p.pad_top, w0 = wo * p.stride - p.pad_left;
+        for (int r = 0; r < p.R; ++r)
+            for (int sx = 0; sx < p.S; ++sx)
+                if ((unsigned)(h0 + r) < (unsigned)p.H && (unsigned)(w0 + sx) < (unsigned)p.W) mk |= 1u << (r * p.S + sx);
+    }
+    return mk ? mk : all_taps;
+}
+
+// ONE LDS buffer (four planes), the next two chunks waiting in registers, two barriers per chunk: k_conv_igemm_x6's loop.
+// SPLITK: the f32 kernel's protocol (write-through partial tiles, a ticket per tile, the last arriver sums the slabs in slice order).
+template <int TM, int TN, int WM, int WN, bool SPLITK = false>
+__global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3(const ConvArgs p) {
+    using T = X6Tile<TM, TN, WM, WN, 2>;
+    constexpr int NT = T::NT, BM = T::BM, BN = T::BN;
+    constexpr int RPP = NT / 8;                           // tile rows staged per pass of A (8 lanes x 16 B of f32 per row)
+    constexpr int PA = BM / RPP;
+    constexpr int RPB = NT / 4;                           // rows per pass of one B plane (4 lanes x 16 B of fp16 per row)
+    constexpr int PB = BN / RPB;
+    static_assert(BM % RPP == 0 && BN % RPB == 0 && PA >= 1 && PB >= 1, "tile rows must be a multiple of the staging pass");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* As = lds;                                       // [2][BM][X6_ROWB]
+    char* Bs = lds + 2 * BM * X6_ROWB;                    // [2][BN][X6_ROWB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int splits = SPLITK ? p.splits : 1;
+    const int nwg = p.tiles_m * p.tiles_n * splits;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tile = SPLITK ? logical / splits : logical;         // a tile's slices are neighbours on one XCD
+    const int slice = SPLITK ? logical - tile * splits : 0;
+    int tile_m, tile_n;
+    h3_tile_of(p, tile, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const size_t plane_bytes = (size_t)p.Cout * p.Kpad * 2;
+    const char* wbase = reinterpret_cast<const char*>(p.w);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(wbase + H3_HEADER_BYTES), 0, (int)(2 * plane_bytes), 0x00020000);
+
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;      // A: row within a pass, first of this lane's four channels
+    int a_h[PA], a_w[PA], a_off[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lrow + RPP * i;
+        if (m < p.M) {
+            int wo, ho, img;
+            if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
+            else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
+            a_h[i] = ho * p.stride - p.pad_top;
+            a_w[i] = wo * p.stride - p.pad_left;
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * 4;     // may be "negative" in the halo
+        } else {
+            a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
+        }
+    }
+    const int brow = tid >> 2, bcol = (tid & 3) * 8;      // B: row within a pass, first of this lane's eight k
+    unsigned b_off[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + brow + RPB * i;
+        b_off[i] = n < p.Cout ? (unsigned)((n * p.Kpad + bcol) * 2) : OOB_OFFSET;
+    }
+
+    const int RS = p.R * p.S;
+    const unsigned tap_mask = h3_tap_mask(p, m0, BM);
+    const int n_taps = __popc(tap_mask);
+    const int nk_all = (p.Kpad / (BK * RS)) * n_taps;     // chunks of this tile: (channel group, needed tap) pairs
+    const int kb = SPLITK ? (int)((long long)slice * nk_all / splits) : 0;
+    const int nk = (SPLITK ? (int)((long long)(slice + 1) * nk_all / splits) : nk_all) - kb;      // this workgroup's chunks
+
+    unsigned rem = tap_mask;                              // taps of the current channel group still to load
+    int c0 = 0, w_grp = 0;                                // channel offset / fp16 byte offset of the group's filter chunks
+    if (SPLITK) {
+        const int grp = kb / n_taps;
+        c0 = grp * BK; w_grp = grp * RS * (BK * 2);
+        for (int t = kb - grp * n_taps; t > 0; --t) rem &= rem - 1;
+    }
+    f32x4 ra[2][PA];
+    f32x4 rb[2][2][PB];
+    auto load_next = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+        const int tap = __builtin_ctz(rem);               // wave-uniform
+        const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 4;
+        const int w_off = w_grp + tap * (BK * 2);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[S][pl][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wrsrc, b_off[i] == OOB_OFFSET ? OOB_OFFSET : b_off[i] + (unsigned)(pl * plane_bytes), w_off, 0));
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0));
+        }
+        rem &= rem - 1;                                   // branch-free walk to the next needed tap
+        const int wrap = (rem == 0);
+        rem |= wrap ? tap_mask : 0u;
+        c0 += wrap * BK;
+        w_grp += wrap * (RS * BK * 2);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    load_next(I0{});                                      // chunk 0
+    load_next(I1{});                                      // chunk 1: both in flight while the two scales are fetched
+
+    // the two power-of-two scales (every wave derives the same numbers from the same words)
+    const int eA = h3_exponent(amax_read(p.x_amax));
+    const int eB = h3_exponent(*reinterpret_cast<const float*>(wbase));
+    const float sA = h3_pow2(eA);
+
+    auto store = [&](auto setc) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            f16x4 h, l;
+            h3_split(ra[S][i], sA, h, l);
+            const int row = lrow + RPP * i, g = tid & 7;
+            char* dst = As + row * X6_ROWB + 16 * ((g >> 1) ^ x6_swz(row)) + 8 * (g & 1);
+            *reinterpret_cast<f16x4*>(dst) = h;
+            *reinterpret_cast<f16x4*>(dst + BM * X6_ROWB) = l;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                *reinterpret_cast<f32x4*>(Bs + pl * BN * X6_ROWB + (brow + RPB * i) * X6_ROWB + 16 * ((tid & 3) ^ x6_swz(brow + RPB * i))) = rb[S][pl][i];
+    };
+
+    f32x16 acc0[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.0f; acc1[i][j][e] = 0.0f; }
+
+    const char* abase = As + (wm * TM * 32 + li) * X6_ROWB;
+    const char* bbase = Bs + (wn * TN * 32 + li) * X6_ROWB;
+    const int koff[2] = {16 * (lh ^ x6_swz(li)), 16 * ((2 + lh) ^ x6_swz(li))};       // k-step s reads logical slot 2 s + lh (tile bases are multiples of 32 rows)
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                     // two k-steps of 16 per 32-channel chunk
+            f16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const f16x8*>(abase + pl * BM * X6_ROWB + i * 32 * X6_ROWB + koff[s]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const f16x8*>(bbase + pl * BN * X6_ROWB + j * 32 * X6_ROWB + koff[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][j], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][j], acc1[i][j], 0, 0, 0);
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc0[i][j], 0, 0, 0);
+                }
+        }
+    };
+    // chunk c waits in set c & 1.  Iteration: MFMAs of chunk kt from LDS | barrier | split + store chunk kt+1 (requested one
+    // iteration earlier) and request chunk kt+3 into the registers just freed | barrier
+    store(I0{});
+    load_next(I0{});                                      // chunk 2
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        compute();
+        __syncthreads();
+        store(I1{});                                      // chunk kt+1
+        load_next(I1{});                                  // chunk kt+3
+        __syncthreads();
+        compute();
+        __syncthreads();
+        if (kt + 2 < nk) {
+            store(I0{});                                  // chunk kt+2
+            load_next(I0{});                              // chunk kt+4
+            __syncthreads();
+        }
+    }
+    if (kt < nk) {
+        compute();
+        __syncthreads();                                  // the epilogue reuses the buffer
+    }
+    h3_combine<TM, TN>(acc0, acc1);
+    if constexpr (SPLITK) {
+        // publish this slice's partial tile WRITE-THROUGH (sc1 stores need no release fence), thread-major 16-byte rows
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.slabs, 0, (int)((size_t)p.tiles_m * p.tiles_n * splits * (BM * BN) * 4), 0x00020000);
+        const unsigned slab_off = (unsigned)((tile * splits + slice) * (BM * BN) * 4 + tid * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc0[i][j][4 * q], acc0[i][j][4 * q + 1], acc0[i][j][4 * q + 2], acc0[i][j][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), srsrc, slab_off + ((i * TN + j) * 4 + q) * (NT * 16), 0, 16 /* sc1 */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains ...
+        __syncthreads();                                       // ... before ONE lane draws the ticket
+        int* last = reinterpret_cast<int*>(lds);
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = (t == (unsigned)(splits - 1));
+            if (is_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // drop this CU's stale L1 lines
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            *last = is_last;
+        }
+        __syncthreads();
+        if (!*last) return;
+        const float4* base = reinterpret_cast<const float4*>(p.slabs + (size_t)tile * splits * (BM * BN));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc0[i][j][e] = 0.0f;
+        for (int sl = 0; sl < splits; ++sl) {                  // slice order: two runs are bitwise equal
+            const float4* sp = base + (size_t)sl * (BM * BN / 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = sp[((i * TN + j) * 4 + q) * NT + tid];
+                        acc0[i][j][4 * q] += v.x; acc0[i][j][4 * q + 1] += v.y; acc0[i][j][4 * q + 2] += v.z; acc0[i][j][4 * q + 3] += v.w;
+                    }
+        }
+        __syncthreads();                                       // the flag word is read; the epilogue reuses the buffer
+    }
+    h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
+    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN>(acc0, p, m0, n0, wm, wn, li, lh);
+}
+
+// ---- ONE workgroup per CU, TWO LDS buffers (96 KB for a 256x128 tile) and ONE barrier per chunk: chunk kt multiplies from buffer
+// kt & 1 while chunk kt+1 (in registers since the previous iteration) is split and stored into the other buffer and chunk kt+2 is
+// requested (k_conv_igemm_x6_db's loop).  <2,1,4,4>: sixteen waves of 64x32; <2,2,4,2>: eight waves of 64x64 (eight fragment reads
+// per twelve MFMAs instead of six per six).  Lab (scripts/micro/h3_lab.hip, the head's 3x3 / 512->2048 / 2048->512 GEMMs alone on
+// the chip): 246 / 127 / 104 us and 242 / 118 / 107 us against 345 / 172 / 160 for k_conv_igemm_x6_db on the same box.
+template <int TM, int TN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArgs p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
+    constexpr int RPP = NT / 8, PA = BM / RPP;            // A: NT / 8 rows per pass
+    constexpr int NBP = 2 * BN * 4;                       // 16-byte pieces of the two filter planes per chunk
+    constexpr int PBT = (NBP + NT - 1) / NT;
+    constexpr int BUFB = 2 * (BM + BN) * X6_ROWB;
+    static_assert(BM % RPP == 0 && PA >= 1, "tile rows must be a multiple of the staging pass");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int tile_m, tile_n;
+    h3_tile_of(p, xcd_remap(blockIdx.x, nwg), tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const size_t plane_bytes = (size_t)p.Cout * p.Kpad * 2;
+    const char* wbase = reinterpret_cast<const char*>(p.w);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase + H3_HEADER_BYTES), 0, (int)(2 * plane_bytes), 0x00020000);
+
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    int a_h[PA], a_w[PA], a_off[PA], a_lds[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = lrow + RPP * i, m = m0 + row, g = tid & 7;
+        a_lds[i] = row * X6_ROWB + 16 * ((g >> 1) ^ x6_swz(row)) + 8 * (g & 1);
+        if (m < p.M) {
+            int wo, ho, img;
+            if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
+            else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
+            a_h[i] = ho * p.stride - p.pad_top;
+            a_w[i] = wo * p.stride - p.pad_left;
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * 4;
+        } else {
+            a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
+        }
+    }
+    unsigned b_off[PBT];
+    int b_lds[PBT];
+#pragma unroll
+    for (int i = 0; i < PBT; ++i) {
+        const int q = tid + NT * i, pl = q / (BN * 4), r = q % (BN * 4), row = r >> 2, g = r & 3;
+        const bool ok = q < NBP && n0 + row < p.Cout;
+        b_off[i] = ok ? (unsigned)(((size_t)(n0 + row) * p.Kpad + g * 8) * 2 + pl * plane_bytes) : OOB_OFFSET;
+        b_lds[i] = q < NBP ? 2 * BM * X6_ROWB + pl * BN * X6_ROWB + row * X6_ROWB + 16 * (g ^ x6_swz(row)) : -1;
+    }
+
+    const int RS = p.R * p.S;
+    const unsigned tap_mask = h3_tap_mask(p, m0, BM);
+    const int n_taps = __popc(tap_mask);
+    const int nk = (p.Kpad / (BK * RS)) * n_taps;
+    unsigned rem = tap_mask;
+    int c0 = 0, w_grp = 0;
+    f32x4 ra[PA], rb[PBT];
+    auto load_next = [&]() {
+        const int tap = __builtin_ctz(rem);
+        const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 4;
+        const int w_off = w_grp + tap * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < PBT; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0));
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET, 0, 0));
+        }
+        rem &= rem - 1;
+        const int wrap = (rem == 0);
+        rem |= wrap ? tap_mask : 0u;
+        c0 += wrap * BK;
+        w_grp += wrap * (RS * BK * 2);
+    };
+    load_next();                                          // chunk 0: in flight while the two scales are fetched
+    const int eA = h3_exponent(amax_read(p.x_amax));
+    const int eB = h3_exponent(*reinterpret_cast<const float*>(wbase));
+    const float sA = h3_pow2(eA);
+    auto store = [&](int buf) {
+        char* base = lds + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            f16x4 h, l;
+            h3_split(ra[i], sA, h, l);
+            *reinterpret_cast<f16x4*>(base + a_lds[i]) = h;
+            *reinterpret_cast<f16x4*>(base + BM * X6_ROWB + a_lds[i]) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < PBT; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<f32x4*>(base + b_lds[i]) = rb[i];
+    };
+    f32x16 acc0[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.0f; acc1[i][j][e] = 0.0f; }
+    const int aoff = (wm * TM * 32 + li) * X6_ROWB, boff = 2 * BM * X6_ROWB + (wn * TN * 32 + li) * X6_ROWB;
+    const int koff[2] = {16 * (lh ^ x6_swz(li)), 16 * ((2 + lh) ^ x6_swz(li))};
+    auto kstep = [&](int buf, int s) {
+        const char* base = lds + buf * BUFB;
+        f16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const f16x8*>(base + aoff + pl * BM * X6_ROWB + i * 32 * X6_ROWB + koff[s]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const f16x8*>(base + boff + pl * BN * X6_ROWB + j * 32 * X6_ROWB + koff[s]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][j], acc1[i][j], 0, 0, 0);
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][j], acc1[i][j], 0, 0, 0);
+                acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc0[i][j], 0, 0, 0);
+            }
+    };
+    store(0);
+    load_next();                                          // chunk 1 (past-the-end fetches are never multiplied)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) { store(buf ^ 1); load_next(); }
+        kstep(buf, 0);
+        kstep(buf, 1);
+        __syncthreads();
+    }
+    h3_combine<TM, TN>(acc0, acc1);
+    h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
+    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN>(acc0, p, m0, n0, wm, wn, li, lh);
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_h3_db(const ConvArgs& a, hipStream_t s) {
+    ConvArgs p = a;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    constexpr size_t lds = (size_t)2 * 2 * (BM + BN) * X6_ROWB;
+    static_assert(lds >= X6Tile<TM, TN, WM, WN, 2>::epi, "the epilogue's wave-row must fit in the operand buffers");
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_h3_db<TM, TN, WM, WN>, lds, "conv2d_h3")) return e;
+    k_conv_igemm_h3_db<TM, TN, WM, WN><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
+    return check_launch("conv2d_fwd_h3");
+}
+
+template <int TM, int TN, int WM, int WN, bool SPLITK = false>
+static int launch_h3(const ConvArgs& a, hipStream_t s) {
+    using T = X6Tile<TM, TN, WM, WN, 2>;
+    ConvArgs p = a;
+    p.tiles_m = (p.M + T::BM - 1) / T::BM;
+    p.tiles_n = (p.Cout + T::BN - 1) / T::BN;
+    static std::atomic<uint64_t> lds_seen{0};
+    if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_h3<TM, TN, WM, WN, SPLITK>, T::lds, "conv2d_h3")) return e;
+    k_conv_igemm_h3<TM, TN, WM, WN, SPLITK><<<p.tiles_m * p.tiles_n * (SPLITK ? p.splits : 1), T::NT, T::lds, s>>>(p);
+    return check_launch(SPLITK ? "conv2d_fwd_h3 (split-K)" : "conv2d_fwd_h3");
+}
+
+// tile codes of the f16x3 engine (frcnn_conv_desc.tile; 0 / 50 = auto)
+int launch_conv_h3(const ConvArgs& a, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case 81: return launch_h3<2, 1, 2, 4>(a, s);          // 128x128, 8 waves (64x32 per wave)
+        case 82: return launch_h3_db<2, 2, 4, 2>(a, s);       // 256x128, 8 waves (64x64 per wave), two LDS buffers, one workgroup per CU
+        case 83: return launch_h3<2, 2, 2, 2>(a, s);          // 128x128, 4 waves (64x64 per wave)
+        case 84: return launch_h3<1, 1, 2, 2>(a, s);          // 64x64, 4 waves
+        case 86: return launch_h3_db<2, 1, 4, 4>(a, s);       // 256x128, 16 waves, two LDS buffers, one workgroup per CU
+        case 87: return launch_h3<2, 1, 2, 2>(a, s);          // 128x64, 4 waves (64x32 per wave): the 64-column layers
+        case 184: return launch_h3<1, 1, 2, 2, true>(a, s);   // 64x64 with split-K (a.splits / a.slabs / a.tickets set by the caller)
+        case 181: return launch_h3<2, 1, 2, 4, true>(a, s);   // 128x128 on eight waves with split-K: the taller small grids
+        default: return fail(FRCNN_E_ARG, "conv2d_fwd_h3: unknown tile config %d", cfg);
+    }
+}
+
+int h3_tile_width(int cfg) { return (cfg == 84 || cfg == 87) ? 64 : 128; }
+
+// ---- packing: max|w| of the packed filter into the header word, then the two planes under that scale
+__global__ void __launch_bounds__(256) k_h3_wmax(const float* w, size_t n, unsigned* header) {
+    float v = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v = fmaxf(v, fabsf(w[i]));
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(header, __float_as_uint(v));
+}
+
+__global__ void __launch_bounds__(256) k_pack_h3(const float* w, size_t n, const float* header, _Float16* out) {
+    const float s = h3_pow2(h3_exponent(*header));
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {       // n % 4 == 0
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + i);
+        f16x4 h, l;
+        h3_split(v, s, h, l);
+        *reinterpret_cast<f16x4*>(out + i) = h;
+        *reinterpret_cast<f16x4*>(out + n + i) = l;
+    }
+}
+
+// ---- magnitude records
+__global__ void __launch_bounds__(256) k_amax_clear(float* rec, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) rec[i] = 0.0f;
+}
+
+__global__ void __launch_bounds__(256) k_amax_f32(const float* x, size_t n, float* rec) {
+    float v = 0.0f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        v = fmaxf(fmaxf(v, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) v = fmaxf(v, fabsf(x[4 * n4 + threadIdx.x]));
+    amax_publish(rec, v);
+}
+
+// dst := max(dst, max over src's slots, floor): the bound of a tensor made from `src`'s tensor by a map that cannot exceed
+// max(|input|, floor) -- max-pooling, the bilinear RoI resampling with a fill vector, ReLU
+__global__ void __launch_bounds__(64) k_amax_merge(float* dst, const float* src, float floor_value) {
+    const float v = fmaxf(src ? amax_read(src) : 0.0f, floor_value);
+    if (threadIdx.x == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" size_t frcnn_conv_h3_planes_bytes(int cout, int packed_k) {
+    if (cout <= 0 || packed_k <= 0) return 0;
+    return (size_t)H3_HEADER_BYTES + (size_t)4 * cout * packed_k;
+}
+
+extern "C" int frcnn_pack_conv_weights_h3(const float* w_packed, int cout, int kpad, void* planes_f16, void* stream) {
+    if (!w_packed || !planes_f16 || cout <= 0 || kpad <= 0 || (kpad % 32)) return fail(FRCNN_E_ARG, "pack_conv_weights_h3: bad argument");
+    if ((reinterpret_cast<uintptr_t>(w_packed) & 15) || (reinterpret_cast<uintptr_t>(planes_f16) & 15))
+        return fail(FRCNN_E_ARG, "pack_conv_weights_h3: 16-byte aligned buffers required");
+    const size_t n = (size_t)cout * kpad;
+    if (2 * n * 2 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "pack_conv_weights_h3: filter planes over 2 GiB");
+    hipStream_t s = as_stream(stream);
+    int grid = (int)((n + 1023) / 1024);
+    if (grid > 2048) grid = 2048;
+    k_amax_clear<<<1, 64, 0, s>>>(reinterpret_cast<float*>(planes_f16), H3_HEADER_BYTES / 4);
+    k_h3_wmax<<<grid, 256, 0, s>>>(w_packed, n, reinterpret_cast<unsigned*>(planes_f16));
+    k_pack_h3<<<grid, 256, 0, s>>>(w_packed, n, reinterpret_cast<const float*>(planes_f16),
+                                   reinterpret_cast<_Float16*>(reinterpret_cast<char*>(planes_f16) + H3_HEADER_BYTES));
+    return check_launch("pack_conv_weights_h3");
+}
+
+extern "C" int frcnn_amax_record_floats(void) { return AMAX_SLOTS * AMAX_STRIDE; }
+
+extern "C" int frcnn_amax_clear(float* records, int n_records, void* stream) {
+    if (!records || n_records <= 0) return fail(FRCNN_E_ARG, "amax_clear: bad argument");
+    const size_t n = (size_t)n_records * AMAX_SLOTS * AMAX_STRIDE;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    k_amax_clear<<<grid, 256, 0, as_stream(stream)>>>(records, n);
+    return check_launch("amax_clear");
+}
+
+extern "C" int frcnn_amax_f32(const float* x, size_t n, float* record, void* stream) {
+    if (!x || !record || n == 0) return fail(FRCNN_E_ARG, "amax_f32: bad argument");
+    if (reinterpret_cast<uintptr_t>(x) & 15) return fail(FRCNN_E_ARG, "amax_f32: 16-byte aligned tensor required");
+    int grid = (int)((n / 4 + 255) / 256);
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
+    k_amax_f32<<<grid, 256, 0, as_stream(stream)>>>(x, n, record);
+    return check_launch("amax_f32");
+}
+
+extern "C" int frcnn_amax_merge(float* dst_record, const float* src_record, float floor_value, void* stream) {
+    if (!dst_record || !(floor_value >= 0.0f)) return fail(FRCNN_E_ARG, "amax_merge: bad argument");
+    k_amax_merge<<<1, 64, 0, as_stream(stream)>>>(dst_record, src_record, floor_value);
+    return check_launch("amax_merge");
+}

@@ -2062,9 +2062,14 @@ size_t frcnn_conv2d_workspace_bytes(const frcnn_conv_desc* d) {
 
 struct DualOut { int n1; int act1; float* y2; int act2; };      // frcnn_conv2d_fwd_dual: the launch's second layer
 
+// which matrix path a forward launch takes, and the magnitude records that ride along (all NULL: nothing is tracked)
+enum { ENGINE_NATIVE = 0, ENGINE_X6 = 1, ENGINE_H3 = 2 };
+struct ConvRange { const float* x_amax; float* y_amax; float* y2_amax; };
+
 static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                          const float* scale, const float* shift, const float* residual, const float* mask, float* y,
-                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream, bool x6 = false);
+                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream, int engine = ENGINE_NATIVE,
+                         const ConvRange* range = nullptr);
 
 // split-K factor of the split-bf16 engine's 64x64 form: grids under ~1.5 tiles per CU slot with a LONG k loop only
 // (k >= 2048: rpn_conv1, stage 4's 3x3, the 64-RoI training head); everything else runs unsplit or stays native
@@ -2137,7 +2142,7 @@ size_t frcnn_conv2d_x6_workspace_bytes(const frcnn_conv_desc* d) {
 int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16,
                         const float* scale, const float* shift, const float* residual, const float* mask, float* y,
                         void* workspace, size_t workspace_bytes, void* stream) {
-    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_bf16), scale, shift, residual, mask, y, nullptr, workspace, workspace_bytes, stream, true);
+    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_bf16), scale, shift, residual, mask, y, nullptr, workspace, workspace_bytes, stream, ENGINE_X6);
 }
 
 int frcnn_conv2d_fwd_dual_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16, const float* scale, const float* shift,
@@ -2145,7 +2150,99 @@ int frcnn_conv2d_fwd_dual_x6(const frcnn_conv_desc* d, const float* x, const voi
     if (!d || !y2 || n1 <= 0 || n1 >= d->cout) return fail(FRCNN_E_ARG, "conv2d_fwd_dual_x6: need 0 < n1 < cout and two outputs");
     if (d->ldy > 0 || d->ldres > 0) return fail(FRCNN_E_ARG, "conv2d_fwd_dual_x6: dense outputs only (ldy = ldres = 0)");
     const DualOut dual = {n1, act1, y2, act2};
-    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_bf16), scale, shift, nullptr, nullptr, y1, &dual, nullptr, 0, stream, true);
+    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_bf16), scale, shift, nullptr, nullptr, y1, &dual, nullptr, 0, stream, ENGINE_X6);
+}
+
+// ---- the f16x3 engine (conv_h3.hip).  Tile for a descriptor: the double-buffered 256x128 forms wherever a launch has >= 256 tiles of
+// 128x128 (lab: the head's 3x3 / 512 -> 2048 / 2048 -> 512 GEMMs 246 / 127 / 104 us on sixteen waves against 359 / 154 / 138 on the
+// two-workgroup 128x128 tile and 331 / 147 / 148 on 64x64 tiles); everything smaller, and every 64-column layer, on 64x64 tiles (128x64 on
+// four waves once there are >= 1024 row tiles of 64 columns).
+static int h3_config(const frcnn_conv_desc* d, int n1) {
+    const int t = d->tile % 100;
+    if (t >= 81 && t <= 87) return t;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    int cfg;
+    if (d->cout <= 64) cfg = ((M + 127) / 128) >= 1024 ? 87 : 84;
+    else {
+        const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
+        cfg = t128 >= 256 ? 86 : 84;
+    }
+    if (n1 > 0 && (n1 % 128) != 0 && cfg != 87) cfg = 84;       // the layer boundary of a paired launch must be a tile boundary (16-byte epilogue)
+    return cfg;
+}
+
+// split-K of the f16x3 engine: the split-bf16 engine's rules (tile edge, slices) -- the chunk count per tile is the same
+static int h3_sk_tile(const frcnn_conv_desc* d) {
+    const int t = d->tile % 100;
+    if (t == 88) return 128;
+    if (t == 84) return 64;
+    // (the eight-wave 128x128 tile needs 154 registers with its two accumulator sets: one workgroup per CU, so the rule that sends
+    // the split-bf16 engine's taller small grids there -- ONE round of two workgroups per CU -- does not carry over)
+    return 64;
+}
+
+static int choose_splits_h3(const frcnn_conv_desc* d) {
+    if (d->cin % BK) return 1;
+    const int t = d->tile % 100;
+    if (t != 0 && t != 50 && t != 84 && t != 88) return 1;
+    const int edge = h3_sk_tile(d);
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const long long tiles = ((M + edge - 1) / edge) * ((d->cout + edge - 1) / edge);
+    const long long tiles64 = ((M + 63) / 64) * ((d->cout + 63) / 64);
+    const int nk = (d->kh * d->kw * d->cin) / BK;
+    if (tiles * sizeof(unsigned) > SPLITK_TICKET_BYTES) return 1;
+    int s = d->tile / 100;
+    if (s <= 0) {
+        if (tiles64 >= 640 || nk < 64) return 1;
+        if (edge == 128) s = (int)(512 / tiles);
+        else s = tiles >= 100 ? 3 : (int)((768 + tiles - 1) / tiles);
+        if (s > nk / 8) s = nk / 8;
+        if (s > 16) s = 16;
+    }
+    if (s > nk) s = nk;
+    return s < 1 ? 1 : s;
+}
+
+size_t frcnn_conv2d_h3_workspace_bytes(const frcnn_conv_desc* d) {
+    if (!d || d->cin <= 0) return 0;
+    const int splits = choose_splits_h3(d);
+    if (splits <= 1) return 0;
+    const int edge = h3_sk_tile(d);
+    const long long M = (long long)d->n * d->ho * d->wo;
+    const size_t tiles = (size_t)((M + edge - 1) / edge) * ((d->cout + edge - 1) / edge);
+    return SPLITK_TICKET_BYTES + tiles * splits * edge * edge * sizeof(float);
+}
+
+int frcnn_conv2d_h3_config(const frcnn_conv_desc* d, int n1) {
+    if (!d) return fail(FRCNN_E_ARG, "conv2d_h3_config: null descriptor");
+    return h3_config(d, n1);
+}
+
+int frcnn_conv2d_fwd_h3(const frcnn_conv_desc* d, const float* x, const float* x_amax, const void* w_planes_f16,
+                        const float* scale, const float* shift, const float* residual, const float* mask, float* y, float* y_amax,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x_amax) return fail(FRCNN_E_ARG, "conv2d_fwd_h3: the input's magnitude record is required (frcnn_amax_f32 makes one)");
+    const ConvRange rg = {x_amax, y_amax, nullptr};
+    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_f16), scale, shift, residual, mask, y, nullptr, workspace, workspace_bytes, stream, ENGINE_H3, &rg);
+}
+
+int frcnn_conv2d_fwd_dual_h3(const frcnn_conv_desc* d, const float* x, const float* x_amax, const void* w_planes_f16, const float* scale, const float* shift,
+                             float* y1, int n1, int act1, float* y1_amax, float* y2, int act2, float* y2_amax, void* stream) {
+    if (!d || !y2 || n1 <= 0 || n1 >= d->cout) return fail(FRCNN_E_ARG, "conv2d_fwd_dual_h3: need 0 < n1 < cout and two outputs");
+    if (d->ldy > 0 || d->ldres > 0) return fail(FRCNN_E_ARG, "conv2d_fwd_dual_h3: dense outputs only (ldy = ldres = 0)");
+    if (!x_amax) return fail(FRCNN_E_ARG, "conv2d_fwd_dual_h3: the input's magnitude record is required");
+    const DualOut dual = {n1, act1, y2, act2};
+    const ConvRange rg = {x_amax, y1_amax, y2_amax};
+    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_f16), scale, shift, nullptr, nullptr, y1, &dual, nullptr, 0, stream, ENGINE_H3, &rg);
+}
+
+// the native launches of frcnn_conv2d_fwd_ws / frcnn_conv2d_fwd_dual that also leave max|y| in a magnitude record: what feeds an
+// f16x3 launch from a layer that stays on the native kernels (the 3-channel stem, stage 4's 256-column 1x1 layers)
+int frcnn_conv2d_fwd_ws_amax(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                             const float* scale, const float* shift, const float* residual, const float* mask, float* y, float* y_amax,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    const ConvRange rg = {nullptr, y_amax, nullptr};
+    return conv_fwd_impl(d, x, w_packed, scale, shift, residual, mask, y, nullptr, workspace, workspace_bytes, stream, ENGINE_NATIVE, &rg);
 }
 
 int frcnn_conv2d_fwd_ws(const frcnn_conv_desc* d, const float* x, const float* w_packed,
@@ -2176,7 +2273,7 @@ int frcnn_conv2d_fwd_dual(const frcnn_conv_desc* d, const float* x, const float*
 
 static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                          const float* scale, const float* shift, const float* residual, const float* mask, float* y,
-                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream, bool x6) {
+                         const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream, int engine, const ConvRange* range) {
     if (!d || !x || !w_packed || !y) return fail(FRCNN_E_ARG, "conv2d_fwd: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->ho <= 0 || d->wo <= 0)
         return fail(FRCNN_E_ARG, "conv2d_fwd: bad shape");
@@ -2189,6 +2286,7 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
     a.M = (int)M; a.K = d->kh * d->kw * d->cin; a.Kpad = frcnn_conv_packed_k(d->kh, d->kw, d->cin);
     a.act = d->act; a.ldy = d->ldy > 0 ? d->ldy : d->cout; a.ldres = d->ldres > 0 ? d->ldres : d->cout;
     a.n_split = 0; a.y2 = nullptr; a.ldy2 = 0; a.act2 = 0;
+    a.x_amax = range ? range->x_amax : nullptr; a.y_amax = range ? range->y_amax : nullptr; a.y2_amax = range ? range->y2_amax : nullptr;
     if (dual) { a.n_split = dual->n1; a.act = dual->act1; a.ldy = dual->n1; a.y2 = dual->y2; a.ldy2 = d->cout - dual->n1; a.act2 = dual->act2; }
     a.tiles_m = a.tiles_n = 0;
     a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
@@ -2203,7 +2301,29 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
              && (!mask || (al16(mask) && (size_t)M * d->cout * 4 < 0x7fffffffull)) && (!scale || al16(scale)) && (!shift || al16(shift));
     hipStream_t s = as_stream(stream);
     const bool generic = (d->cin % BK) != 0;
-    if (x6) {
+    if (engine == ENGINE_H3) {
+        // the f16x3 engine (conv_h3.hip): w_packed points at the header + two fp16 filter planes
+        if (generic || d->kh * d->kw > 32) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3: cin %% 32 == 0 and at most 32 taps");
+        if ((size_t)2 * d->cout * a.Kpad * 2 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3: filter planes over 2 GiB");
+        if (reinterpret_cast<uintptr_t>(w_packed) & 15) return fail(FRCNN_E_ARG, "conv2d_fwd_h3: 16-byte aligned filter planes required");
+        const int hcfg = h3_config(d, dual ? dual->n1 : 0);
+        if (workspace && !dual) {
+            const size_t need = frcnn_conv2d_h3_workspace_bytes(d);
+            if (need) {
+                if (workspace_bytes < need) return fail(FRCNN_E_WORKSPACE, "conv2d_fwd_h3: workspace needs %zu bytes", need);
+                a.splits = choose_splits_h3(d);
+                a.tickets = (unsigned*)workspace;
+                a.slabs = (float*)((char*)workspace + SPLITK_TICKET_BYTES);
+                a.group_m = 0;
+                return launch_conv_h3(a, h3_sk_tile(d) == 128 ? 181 : 184, s);
+            }
+        }
+        const int bn = h3_tile_width(hcfg);
+        if (dual) a.vec_epi = a.vec_epi && dual->n1 % bn == 0 && (a.ldy2 & 3) == 0 && al16(dual->y2) && (size_t)M * a.ldy2 * 4 < 0x7fffffffull;
+        a.group_m = g_group_m >= 0 ? g_group_m : (d->cout > bn ? 1 : 0);      // column tiles of a row tile adjacent on one XCD
+        return launch_conv_h3(a, hcfg, s);
+    }
+    if (engine == ENGINE_X6) {
         // the split-bf16 engine (conv_x6.hip): w_packed points at the three bf16 filter planes
         if (generic || d->kh * d->kw > 32) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_x6: cin %% 32 == 0 and at most 32 taps");
         if ((size_t)3 * d->cout * a.Kpad * 2 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_x6: filter planes over 2 GiB");

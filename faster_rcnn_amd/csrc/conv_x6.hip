@@ -34,9 +34,6 @@ namespace frcnn {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int X6_ROWB = 64;           // LDS bytes per row per plane
-__device__ __forceinline__ int x6_swz(int row) { return (row >> 2) & 3; }
-
 __device__ __forceinline__ void x6_split(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -45,80 +42,6 @@ __device__ __forceinline__ void x6_split(const f32x4 v, bf16x4& h, bf16x4& m, bf
         const __bf16 a2 = (__bf16)r1;
         const float r2 = r1 - (float)a2;                      // exact; at most 8 significant bits are left
         h[e] = a1; m[e] = a2; l[e] = (__bf16)r2;
-    }
-}
-
-template <int TM, int TN, int WM, int WN>
-struct X6Tile {
-    static constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN;
-    static constexpr size_t planes = (size_t)3 * (BM + BN) * X6_ROWB;
-    static constexpr size_t epi = (size_t)(32 * TM) * (BN + 4) * 4;     // the 16-byte epilogue: one wave-row of the tile at a time
-    static constexpr size_t lds = planes > epi ? planes : epi;
-};
-
-// The 16-byte epilogue of conv_f32_common.h (epilogue_vec: same arithmetic per element, same order) with the tile turned through
-// LDS one WAVE-ROW at a time: pass h stages the 32 TM rows owned by the waves with wm == h, every thread then owns 16-byte pieces
-// of whole rows (scale / shift / residual / mask / y as b128, out-of-range pieces on the buffer descriptors).
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh, float* smem) {
-    constexpr int NT = 64 * WM * WN, BN = 32 * TN * WN, HB = 32 * TM, LD = BN + 4, C4 = BN / 4, RPP = NT / C4, PASSES = HB / RPP;
-    static_assert(HB % RPP == 0 && NT % C4 == 0 && PASSES >= 1 && PASSES <= 8, "epilogue passes");
-    const bool second = p.n_split && n0 >= p.n_split;       // two layers in one launch: the tile belongs to ONE of them (host guarantees it)
-    float* const yb = second ? p.y2 : p.y;
-    const int y_ld = second ? p.ldy2 : p.ldy, y_act = second ? p.act2 : p.act, y_n0 = second ? p.n_split : 0;
-    const int y_cols = p.n_split ? (second ? p.Cout - p.n_split : p.n_split) : p.Cout;
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((size_t)p.M * y_ld * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.mask ? p.mask : p.x), 0, p.mask ? (int)((size_t)p.M * p.Cout * 4) : 0, 0x00020000);
-    const int prow = tid / C4, pcol = (tid % C4) * 4, n = n0 + pcol;
-    f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (n < p.Cout) {
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-    }
-    f32x4 rres[PASSES], rmask[PASSES];
-    auto fetch = [&](int h) {                                // the global reads of wave-row h: in flight while it goes through LDS
-#pragma unroll
-        for (int q = 0; q < PASSES; ++q) {
-            const int m = m0 + h * HB + q * RPP + prow;
-            const bool in = m < p.M && n < p.Cout;
-            if (p.residual) rres[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, in ? (unsigned)(((size_t)m * p.ldres + n) * 4) : OOB_OFFSET, 0, 0));
-            if (p.mask) rmask[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, in ? (unsigned)(((size_t)m * p.Cout + n) * 4) : OOB_OFFSET, 0, 0));
-        }
-    };
-#pragma unroll 1
-    for (int h = 0; h < WM; ++h) {
-        fetch(h);
-        if (h) __syncthreads();                              // the previous wave-row has been read out (the caller synchronised before pass 0)
-        if (wm == h) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float* dst = smem + (i * 32 + 4 * lh) * LD + wn * TN * 32 + j * 32 + li;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * LD] = acc[i][j][e];
-                }
-        }
-        __syncthreads();
-        const float* src = smem + prow * LD + pcol;
-#pragma unroll
-        for (int q = 0; q < PASSES; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src + q * RPP * LD);
-            f32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float t = a[c] * sc[c] + sh[c];
-                if (p.residual) t += rres[q][c];
-                if (p.mask && !(rmask[q][c] > 0.0f)) t = 0.0f;
-                v[c] = activate(t, y_act);
-            }
-            const int ym = m0 + h * HB + q * RPP + prow, yn = n0 - y_n0 + pcol;
-            const unsigned yoff = (ym < p.M && yn < y_cols) ? (unsigned)(((size_t)ym * y_ld + yn) * 4) : OOB_OFFSET;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, yoff, 0, 0);
-        }
     }
 }
 

@@ -69,7 +69,7 @@ PAD_TO_BATCH = os.environ.get("FRCNN_ENTRY_PAD", "0") != "0"
 class _Slot:
     """One captured pass for one image size, with its staging on both sides of PCIe."""
     __slots__ = ("key", "pipe", "graph", "out", "io_dev", "io_pin", "pix_host", "dyn_host", "out_pin", "event", "busy", "nbytes",
-                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed")
+                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed", "amax")
 
 
 class GraphCache:
@@ -147,10 +147,11 @@ class DetectionEntry:
 
     def __init__(self, manager, detector, num_rois=64, stride=16, in_flight=1, byte_budget=None, f32_engine=None):
         self.manager, self.detector = manager, detector
-        # the matrix path of the fp32 convolutions inside the captured passes (ops.f32_engine): by default the large launches
-        # run on the bf16 matrix cores by exact three-way operand splitting -- fp32-grade results (csrc/conv_x6.hip), 1.2x the
-        # images per second; FRCNN_F32_ENGINE=native keeps v_mfma_f32_32x32x2_f32 everywhere
-        self.f32_engine = f32_engine or os.environ.get("FRCNN_F32_ENGINE", "bf16x6")
+        # the matrix path of the fp32 convolutions inside the captured passes (ops.f32_engine): by default the large launches run
+        # on the fp16 matrix cores by a two-way operand split with a scaled low part -- fp32-grade results (csrc/conv_h3.hip:
+        # error against fp64 under the native kernel's), three matrix instructions per block of products; FRCNN_F32_ENGINE=bf16x6
+        # selects the exact three-way bf16 split (six), FRCNN_F32_ENGINE=native keeps v_mfma_f32_32x32x2_f32 everywhere
+        self.f32_engine = f32_engine or os.environ.get("FRCNN_F32_ENGINE", "f16x3")
         self.num_rois, self.stride, self.in_flight = int(num_rois), stride, max(1, int(in_flight))
         # images per captured pass.  The bf16 detector makes ONE head pass over the RoIs of eight images and runs its trunk at batch
         # eight (pipeline.BatchedInferencePipeline: what configs[3]'s headline times); get_dets_by_cls groups neighbouring images of
@@ -256,15 +257,17 @@ class DetectionEntry:
         dtype = getattr(getattr(self.detector, "head", None), "dtype", "f32")
         s.ws = ops.NO_SPLIT_K if (shared and (dtype == "bf16" or os.environ.get("FRCNN_ENTRY_NO_SPLITK"))) else ops.ConvWorkspace()
         s.io_dev.copy_(s.io_pin)
+        s.amax = ops.AmaxArena() if self.f32_engine == "f16x3" else None      # the pass's magnitude records (fixed addresses across replays)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine):
+        with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine), ops.amax_arena(s.amax):
             for _ in range(2):
                 run()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         s.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(s.graph, capture_error_mode="thread_local"), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine):
+        with torch.cuda.graph(s.graph, capture_error_mode="thread_local"), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine), \
+                ops.amax_arena(s.amax):
             s.out = run()
         packed = s.out["det_packed"]
         s.out_packed = packed if isinstance(packed, (list, tuple)) else [packed]

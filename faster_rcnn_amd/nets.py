@@ -291,7 +291,7 @@ class ResNetHead:
 
     def _first_block_hoisted(self, feat, rois, resize):
         a = self.blocks[0]
-        fmap = feat.reshape(1, feat.shape[-3], feat.shape[-2], feat.shape[-1])
+        fmap = ops.amax_carry(feat.reshape(1, feat.shape[-3], feat.shape[-2], feat.shape[-1]), feat)    # (a view keeps its magnitude record)
         pair = _pair(a["2a"], a["1"])
         if pair is not None:
             u, v = pair(fmap, act1=None)                    # one launch: conv + BN of both on the map

@@ -50,6 +50,7 @@ class InferencePipeline:
         ``dyn``: device tensor [resize_ratio, det_threshold] (f64) read by the post-process INSTEAD of the two host scalars
         (entry.DetectionEntry: one captured pass serves every image of its size); the reference's padded RoI rows are then
         scored too when the pipeline was built with ``pad_to_batch`` (voc_dets.py:42-51)."""
+        ops.amax_begin()                                    # f16x3 engine: this pass's magnitude records start from zero
         cls, reg, feat = self.rpn.forward_dev(x)
         rois, n_keep, cand, keep = self.proposals_dev(cls, reg)
         out_cls, out_reg = self.det.forward_dev(feat, rois)
@@ -67,8 +68,10 @@ class InferencePipeline:
     def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=True, throughput=False, f32_engine="native"):
         """Capture one full pass for a fixed image size into a hipGraph.
 
-        ``f32_engine``: "native" (v_mfma_f32_32x32x2_f32) or "bf16x6" (ops.f32_engine: the large fp32 launches on the bf16
-        matrix cores by exact operand splitting, fp32-grade results in a different summation order).
+        ``f32_engine``: "native" (v_mfma_f32_32x32x2_f32), "bf16x6" (ops.f32_engine: the large fp32 launches on the bf16
+        matrix cores by exact operand splitting, fp32-grade results in a different summation order) or "f16x3" (the same
+        launches on the fp16 matrix cores by a two-way split with a scaled low part: half the matrix instructions; the pass
+        then owns an ``ops.AmaxArena`` with the magnitude records its tensors carry).
 
         ``split_k``: let small-grid convs cut K over several workgroups.  It shortens ONE image's pass (the
         stage-4 / RPN layers fill 60 % of the CUs otherwise); with several graphs replaying concurrently the
@@ -80,9 +83,11 @@ class InferencePipeline:
         # the graph owns its split-K workspace: graphs of several pipelines replay concurrently.  The warm-up
         # passes size it, so the capture itself allocates (and re-zeroes) nothing.
         self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
+        self._amax = ops.AmaxArena() if f32_engine == "f16x3" else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.f32_engine(f32_engine):
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.f32_engine(f32_engine), \
+                ops.amax_arena(self._amax):
             for _ in range(warmup):
                 self.forward_dev(self._static_in, resize_ratio)
         torch.cuda.current_stream().wait_stream(side)
@@ -90,7 +95,7 @@ class InferencePipeline:
         self._graph = torch.cuda.CUDAGraph()
         # thread_local: another thread of this process (e.g. an RCCL watchdog) may call into HIP during the capture
         with no_gc(), torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), \
-                ops.f32_engine(f32_engine):
+                ops.f32_engine(f32_engine), ops.amax_arena(self._amax):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
 
@@ -175,6 +180,7 @@ class BatchedInferencePipeline(InferencePipeline):
         ``dyn``: (B,2) f64 device tensor, row i = image i's [resize_ratio, det_threshold] (InferencePipeline.forward_dev)."""
         B = self.batch
         assert x.shape[0] == B
+        ops.amax_begin()
         cls, reg, feat = self.rpn.forward_dev(x)
         rois = torch.empty((B * self.n_rois, 4), dtype=torch.float32, device="cuda")
         n_keep = self._fan_out(lambda i: self.proposals_dev(cls[i], reg[i], rois_out=rois[i * self.n_rois:(i + 1) * self.n_rois])[1])

@@ -160,19 +160,44 @@ def _cubic_taps(dst, src):
     return idx, icoef
 
 
+# Whether ``Image.data`` may resize on the device.  None (default): only when this process has ALREADY initialised the HIP
+# runtime (a trainer or a detection entry is running) -- a host-only tool that reads pixels (eval, statistics, a launcher
+# that still has to fork its ranks) never starts the runtime as a side effect.  True / False force it either way.
+DEVICE_RESIZE = None
+_RESIZE_STREAM = None
+
+
+def _device_resize_ok():
+    if DEVICE_RESIZE is False:
+        return False
+    import torch
+    if DEVICE_RESIZE is True:
+        return torch.cuda.is_available()
+    return torch.cuda.is_initialized()
+
+
 def _resize_any(img, width, height):
-    """``_resize`` through the device kernel when a GPU is there (frcnn_resize_cubic_u8: the same integers, ~1 ms with
+    """``_resize`` through the device kernel when the HIP runtime is up (frcnn_resize_cubic_u8: the same integers, ~1 ms with
     both copies instead of ~90 ms of numpy for a VOC frame -- at one image per 2.5 ms training step the host resize would
-    otherwise bound the loop), the numpy restatement below otherwise."""
+    otherwise bound the loop), the numpy restatement below otherwise.  The device pass runs on a stream of its own, so the
+    copy back waits for THIS resize only, not for the training step queued on the current stream; anything that goes wrong
+    on the way (library not built, no memory, a forked worker without a context) falls back to the bit-identical host form."""
     if img.shape[0] == height and img.shape[1] == width:
         return img
     if img.ndim == 3 and img.shape[2] == 3 and img.dtype == np.uint8:
         try:
-            import torch
-            if torch.cuda.is_available():
+            if _device_resize_ok():
+                import torch
                 from . import ops
-                return ops.resize_cubic_u8(torch.from_numpy(np.ascontiguousarray(img)).cuda(), height, width).cpu().numpy()
-        except ImportError:
+                global _RESIZE_STREAM
+                if _RESIZE_STREAM is None:
+                    _RESIZE_STREAM = torch.cuda.Stream()
+                with torch.cuda.stream(_RESIZE_STREAM):
+                    dev = torch.from_numpy(np.ascontiguousarray(img)).cuda(non_blocking=False)
+                    out = ops.resize_cubic_u8(dev, height, width)
+                    host = out.cpu()                              # synchronises _RESIZE_STREAM only
+                return host.numpy()
+        except Exception:                                         # noqa: BLE001 -- a pure-host property must not raise because of the device
             pass
     return _resize(img, width, height)
 

@@ -284,6 +284,46 @@ int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_
                         void* workspace, size_t workspace_bytes, void* stream);
 int frcnn_conv2d_fwd_dual_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16, const float* scale, const float* shift,
                              float* y1, int n1, int act1, float* y2, int act2, void* stream);
+/* ---- fp32 convolution on the fp16 matrix cores by a TWO-way operand split with a scaled low part ("f16x3", csrc/conv_h3.hip).
+ * Same operation, operands, layouts and epilogue as frcnn_conv2d_fwd_x6 (resnet.py:150-176, 218-247, 508-533: Conv2D +
+ * BatchNormalization(training=False) [+ Scale] [+ add] + Activation), f32 activations in and out.  Each operand tensor is scaled by
+ * one power of two into fp16's range and every value split into ah = f16(a') and al = f16((a' - ah) * 2^11) (23-24 of its 24 bits);
+ * ah*bh and ah*bl + al*bh are accumulated in f32 on v_mfma_f32_32x32x16_f16 in two accumulators and recombined: THREE matrix
+ * instructions per block of products where frcnn_conv2d_fwd_x6 needs six.  Error against fp64 at or under the native f32 MFMA's on
+ * every operand class measured (7e-8 of sum|ab| on mixed-sign operands against 2.8e-7; exact on integers below 2048); not bit-equal
+ * to either other engine (another summation order).  cin % 32 == 0, at most 32 taps.
+ *
+ * Magnitude records: the activation scale comes from an UPPER BOUND of max|x| kept on the device in a record of
+ * frcnn_amax_record_floats() floats (several atomic slots; a reader takes their maximum; 16-byte aligned).  frcnn_amax_clear zeroes
+ * records (a kernel, safe inside a captured graph); every frcnn_conv2d_fwd_h3 / _dual_h3 / frcnn_conv2d_fwd_ws_amax launch folds
+ * max|y| of what it stores into y_amax (NULL: not tracked), so a chain of layers carries its bounds along without extra passes;
+ * frcnn_amax_f32 measures a tensor that has no producer record; frcnn_amax_merge(dst, src, floor) sets dst = max(dst, src, floor)
+ * for tensors derived by maps that cannot exceed max(|input|, floor): max-pooling (resnet.py:412), the bilinear RoI resampling
+ * with a fill vector (custom_layers.py:35-56), ReLU.  A bound that is too LARGE by up to 2^8 costs no precision; one that is too
+ * small overflows fp16 (inf / NaN in the output, as an f32 overflow would give).
+ * frcnn_pack_conv_weights_h3: f32 packed filter [cout][packed_k] -> 16-byte header (max|w|) + two fp16 planes [2][cout][packed_k]
+ * (frcnn_conv_h3_planes_bytes bytes, 16-byte aligned).  tile: 0 = auto, 81: 128x128 on 8 waves, 82 / 86: 256x128 on 8 / 16 waves
+ * with two LDS buffers, 83: 128x128 on 4 waves, 84: 64x64, 87: 128x64.  Workspace (may be NULL): the split-K contract of
+ * frcnn_conv2d_fwd_x6 (frcnn_conv2d_h3_workspace_bytes: 0 = this shape runs unsplit). */
+size_t frcnn_conv_h3_planes_bytes(int cout, int packed_k);
+int frcnn_pack_conv_weights_h3(const float* w_packed, int cout, int packed_k, void* planes_f16, void* stream);
+int frcnn_amax_record_floats(void);
+int frcnn_amax_clear(float* records, int n_records, void* stream);
+int frcnn_amax_f32(const float* x, size_t n, float* record, void* stream);
+int frcnn_amax_merge(float* dst_record, const float* src_record, float floor_value, void* stream);
+int frcnn_conv2d_h3_config(const frcnn_conv_desc* d, int n1);
+size_t frcnn_conv2d_h3_workspace_bytes(const frcnn_conv_desc* d);
+int frcnn_conv2d_fwd_h3(const frcnn_conv_desc* d, const float* x, const float* x_amax, const void* w_planes_f16,
+                        const float* scale, const float* shift, const float* residual, const float* mask, float* y, float* y_amax,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int frcnn_conv2d_fwd_dual_h3(const frcnn_conv_desc* d, const float* x, const float* x_amax, const void* w_planes_f16,
+                             const float* scale, const float* shift, float* y1, int n1, int act1, float* y1_amax,
+                             float* y2, int act2, float* y2_amax, void* stream);
+/* frcnn_conv2d_fwd_ws (the native f32 MFMA kernels) that also folds max|y| into y_amax: a layer that stays on the native path
+ * (the 3-channel stem, small grids) in front of an f16x3 layer. */
+int frcnn_conv2d_fwd_ws_amax(const frcnn_conv_desc* d, const float* x, const float* w_packed,
+                             const float* scale, const float* shift, const float* residual, const float* mask, float* y, float* y_amax,
+                             void* workspace, size_t workspace_bytes, void* stream);
 /* Filter of the input-gradient convolution: transposed (cin <-> cout), flipped in both taps, input
  * channel co scaled by scale[co] (the forward epilogue scale = folded BatchNorm; NULL = 1).
  * packed: [cin][frcnn_conv_packed_k(kh, kw, cout)]. */

@@ -51,11 +51,12 @@ def test_config0_vgg16_600x1000_rpn_forward():
         assert rel(cls, c_ref) < 1e-4 and rel(reg, r_ref) < 1e-4, (rel(cls, c_ref), rel(reg, r_ref))
 
 
-@pytest.mark.parametrize("engine", ["native", "bf16x6"])
+@pytest.mark.parametrize("engine", ["native", "bf16x6", "f16x3"])
 def test_config1_resnet50_600x1000_inference_fp32(engine):
     """configs[1], the headline: ResNet-50, 600x1000, 9 anchors, RPN + detector, fp32 -- bench.py's own parity object, on
-    both fp32 matrix paths: the native f32 MFMA and the split-bf16 engine bench.py runs by default (the head's 14 700-row
-    GEMMs on v_mfma_f32_32x32x16_bf16 with exactly split operands): the SAME 1e-4 bars, the same exact discrete stages."""
+    all three fp32 matrix paths: the native f32 MFMA, the split-bf16 engine (the head's 14 700-row GEMMs on
+    v_mfma_f32_32x32x16_bf16 with exactly split operands) and the f16x3 engine bench.py runs by default (the same launches on
+    v_mfma_f32_32x32x16_f16, two-way split with a scaled low part): the SAME 1e-4 bars, the same exact discrete stages."""
     import bench
     from faster_rcnn_amd import ops
     with ops.f32_engine(engine):
@@ -70,9 +71,10 @@ def test_config1_resnet50_600x1000_inference_fp32(engine):
     assert res["proposals_equal"] and res["detections_equal"] and res["n_rois"] == 300
     for k in ("feat", "rpn_cls", "rpn_reg", "det_cls", "det_reg"):
         assert res[k] < 1e-4, res
-    n_x6 = sum("x6" in k and "split-K" not in k for k in kernels)
-    n_sk = sum("x6" in k and "split-K" in k for k in kernels)
-    n_native = sum("x6" not in k for k in kernels)
+    tag = "h3" if engine == "f16x3" else "x6"
+    n_x6 = sum(tag in k and "split-K" not in k for k in kernels)
+    n_sk = sum(tag in k and "split-K" in k for k in kernels)
+    n_native = sum(tag not in k for k in kernels)
     # split engine: the head's 8 launches and every trunk launch with >= 256 tiles of 64x64 and >= 64 columns (stages 2 and 3, stage 4's
     # 1024-column layers); in-launch split-K (eager run, workspace at hand): the six 3x3 layers of the 38x63 stage (2 394 rows, k 2 304) +
     # rpn_conv1 (k 9 216).  Native (8): the stem, stage 4's 256-column 1x1 layers, the RPN output pair, the dense pair.
@@ -80,6 +82,8 @@ def test_config1_resnet50_600x1000_inference_fp32(engine):
         assert n_x6 == 0 and n_sk == 0, (n_x6, n_sk, kernels)
     else:
         assert n_sk == 7 and n_x6 == 37 and n_native == 8, (engine, n_x6, n_sk, n_native, kernels)
+    if engine == "f16x3":                                    # every tensor a split launch read carried its producer's magnitude record:
+        assert res["amax_measured"] <= 1, res                # nothing but (at most) the network input was measured by a pass of its own
 
 
 def test_config1_end_to_end_pair_and_map_delta():

@@ -1,0 +1,280 @@
+"""The f16x3 fp32 conv engine (csrc/conv_h3.hip, frcnn_conv2d_fwd_h3): fp32 convolution on the fp16 matrix cores by a two-way operand
+split with a scaled low part -- three matrix instructions per block of products where the split-bf16 engine needs six.  Held to the
+SAME bars as tests/test_conv_x6_gpu.py holds that engine to: error against an fp64 reference at or below the native f32 MFMA
+kernel's (same thresholds, unchanged), exact results on integer operands, layouts agree, skipped padding taps change nothing, runs
+are bitwise reproducible -- plus what is new here: the magnitude records the engine scales its operands with."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from tests.test_conv_x6_gpu import err, ref_conv      # noqa: E402  (the fp64 reference and the error measure of the split-bf16 tests)
+
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, padding, tile
+    (1, 40, 52, 64, 128, 1, 1, "valid", 81),
+    (1, 40, 52, 64, 128, 1, 1, "valid", 84),
+    (2, 23, 31, 64, 96, 3, 1, "same", 81),        # ragged rows / columns, batch, halo
+    (2, 23, 31, 64, 96, 3, 1, "same", 83),
+    (1, 33, 29, 128, 192, 3, 2, "same", 82),      # stride 2 SAME (pad on one side only for odd sizes); 256x128 on eight waves
+    (1, 30, 44, 256, 64, 1, 2, "valid", 84),      # strided 1x1 (conv_block shortcut)
+    (3, 14, 14, 96, 256, 3, 1, "same", 82),
+    (2, 23, 31, 64, 96, 3, 1, "same", 86),        # 256x128 on sixteen waves, two LDS buffers
+    (1, 40, 52, 64, 320, 1, 1, "valid", 86),
+    (1, 33, 29, 128, 192, 3, 2, "same", 86),
+    (2, 23, 31, 64, 64, 3, 1, "same", 87),        # 128x64 on four waves: the 64-column layers
+    (1, 40, 52, 96, 160, 1, 1, "valid", 87),      # ragged column tiles (160 = 2.5 x 64)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_h3_matches_fp64_as_well_as_the_native_kernel(case):
+    from faster_rcnn_amd import ops
+    n, h, w, cin, cout, k, stride, padding, tile = case
+    rs = np.random.RandomState(2000 + CASES.index(case))
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(cout)).astype(np.float32)
+    shift = (0.1 * rs.randn(cout)).astype(np.float32)
+    pc = ops.PackedConv(wt, scale, shift)
+    xd = torch.from_numpy(x).cuda()
+    got = ops.conv2d(xd, pc, stride, padding, "relu", tile=tile)
+    nat = ops.conv2d(xd, pc, stride, padding, "relu", tile=0)
+    res = rs.randn(*got.shape).astype(np.float32)
+    got_r = ops.conv2d(xd, pc, stride, padding, None, residual=torch.from_numpy(res).cuda(), tile=tile)
+    ref, mag = ref_conv(x, wt, stride, padding, scale, shift, None, "relu")
+    ref_r, _ = ref_conv(x, wt, stride, padding, scale, shift, res, None)
+    e_h3, e_nat = err(got.cpu().numpy(), ref, mag), err(nat.cpu().numpy(), ref, mag)
+    print(case, "f16x3 %.3g native %.3g" % (e_h3, e_nat))
+    assert got.shape == nat.shape
+    assert e_h3 <= 5e-7 and e_h3 <= max(3.0 * e_nat, 4e-7)          # the split-bf16 engine's bar, unchanged
+    assert err(got_r.cpu().numpy(), ref_r, mag) <= 6e-7
+    # the launch left max|y| in the output's magnitude record: an upper bound that is attained
+    assert float(got._amax.max()) == float(got.abs().max())
+    assert float(got_r._amax.max()) == float(got_r.abs().max())
+    # bitwise reproducible, and the launch does not depend on what the output buffer held
+    again = ops.conv2d(xd, pc, stride, padding, "relu", tile=tile, out=torch.full_like(got, 7.0))
+    assert torch.equal(again, got)
+
+
+@pytest.mark.parametrize("kind", ["all_positive", "wide_exponents", "integers", "subnormal_neighbours", "same_sign_residuals", "outlier"])
+def test_h3_error_on_operands_that_do_not_cancel(kind):
+    """The operand classes of test_x6_error_on_operands_that_do_not_cancel, same bars, and two that aim at THIS split: operands whose
+    residuals a' - ah all have the same sign and nearly the largest size (the dropped al * bl term then adds up instead of
+    averaging out: 2^-22 of every product), and a post-ReLU tensor with one value 4000 times the rest (the scale follows the
+    outlier; everything else sits 12 binades lower)."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState({"all_positive": 1, "wide_exponents": 2, "integers": 3, "subnormal_neighbours": 4, "same_sign_residuals": 5, "outlier": 6}[kind])
+    n, h, w, cin, cout, k = 1, 30, 44, 128, 128, 3
+    if kind == "all_positive":
+        x = rs.uniform(0.5, 1.0, (n, h, w, cin)).astype(np.float32); wt = rs.uniform(0.5, 1.0, (k, k, cin, cout)).astype(np.float32)
+    elif kind == "wide_exponents":
+        x = (rs.randn(n, h, w, cin) * 2.0 ** rs.randint(-12, 13, (n, h, w, cin))).astype(np.float32)
+        wt = (rs.randn(k, k, cin, cout) * 2.0 ** rs.randint(-12, 13, (k, k, cin, cout))).astype(np.float32)
+    elif kind == "integers":
+        x = rs.randint(-60, 61, (n, h, w, cin)).astype(np.float32); wt = rs.randint(-60, 61, (k, k, cin, cout)).astype(np.float32)
+    elif kind == "subnormal_neighbours":
+        x = (rs.randn(n, h, w, cin) * 1e-30).astype(np.float32); wt = (rs.randn(k, k, cin, cout) * 1e-6).astype(np.float32)
+    elif kind == "same_sign_residuals":
+        x = (1.0 + 2.0 ** -11 * rs.uniform(0.9, 0.99, (n, h, w, cin))).astype(np.float32)
+        wt = (1.0 + 2.0 ** -11 * rs.uniform(0.9, 0.99, (k, k, cin, cout))).astype(np.float32)
+    else:
+        x = np.maximum(rs.randn(n, h, w, cin), 0).astype(np.float32); x[0, 7, 9, 5] = 4000.0
+        wt = (rs.randn(k, k, cin, cout) * 0.03).astype(np.float32)
+    pc = ops.PackedConv(wt)
+    xd = torch.from_numpy(x).cuda()
+    ref, mag = ref_conv(x, wt, 1, "same")
+    for tile in (81, 84, 86):
+        with ops.conv_workspace(ops.NO_SPLIT_K):                 # like for like: both sum k = 0 .. K - 1 in one pass
+            got = ops.conv2d(xd, pc, 1, "same", None, tile=tile).cpu().numpy()
+            nat = ops.conv2d(xd, pc, 1, "same", None, tile=0).cpu().numpy()
+        if kind == "integers":                                   # |operand| < 2048: both fp16 pieces hold it exactly, every partial sum is an integer f32 holds
+            assert np.array_equal(got.astype(np.float64), ref) and np.array_equal(nat.astype(np.float64), ref)
+            continue
+        if kind == "subnormal_neighbours":
+            scale = 1e36
+            e_h3 = float((np.abs(got.astype(np.float64) - ref) * scale).max() / (mag * scale).max())
+            e_nat = float((np.abs(nat.astype(np.float64) - ref) * scale).max() / (mag * scale).max())
+        else:
+            e_h3, e_nat = err(got, ref, mag), err(nat, ref, mag)
+        print(kind, tile, "f16x3 %.3g native %.3g" % (e_h3, e_nat))
+        assert e_h3 <= max(1.5 * e_nat, 4e-7), (kind, tile, e_h3, e_nat)
+
+
+def test_h3_magnitude_bound_may_be_loose_but_not_wrong():
+    """The activation scale comes from an UPPER BOUND: a record 2^8 too large changes nothing measurable; records merge by maximum;
+    frcnn_amax_f32 measures exactly; frcnn_amax_clear zeroes; a launch without a record is refused."""
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(11)
+    x = rs.randn(1, 40, 52, 64).astype(np.float32)
+    wt = (rs.randn(3, 3, 64, 128) * 0.05).astype(np.float32)
+    pc = ops.PackedConv(wt)
+    xd = torch.from_numpy(x).cuda()
+    ref, mag = ref_conv(x, wt, 1, "same")
+    tight = ops.conv2d(xd, pc, 1, "same", tile=84)
+    assert float(xd._amax.max()) == float(np.abs(x).max())       # measured (no producer): exact
+    e_tight = err(tight.cpu().numpy(), ref, mag)
+    loose_in = torch.from_numpy(x).cuda()
+    rec = torch.zeros_like(xd._amax)
+    _lib.call("frcnn_amax_merge", rec.data_ptr(), xd._amax.data_ptr(), 256.0 * float(np.abs(x).max()), None)
+    loose_in._amax = rec
+    loose = ops.conv2d(loose_in, pc, 1, "same", tile=84)
+    e_loose = err(loose.cpu().numpy(), ref, mag)
+    print("tight %.3g loose (x256) %.3g" % (e_tight, e_loose))
+    assert e_tight <= 4e-7 and e_loose <= 4e-7
+    _lib.call("frcnn_amax_clear", rec.data_ptr(), 1, None)
+    assert not rec.any().item()
+    d = ops._conv_desc((1, 40, 52, 64), 3, 3, 128, 1, "same", 0, 0, 84)
+    with pytest.raises(_lib.FrcnnError):
+        _lib.call("frcnn_conv2d_fwd_h3", ctypes.byref(d), xd.data_ptr(), None, pc.h3_planes().data_ptr(), None, None, None, None,
+                  tight.data_ptr(), None, None, 0, None)
+    # a chain: pool and views inherit the bound, a native layer in an f16x3 scope leaves a record for the layer behind it
+    before = ops.AMAX_MEASURED
+    with ops.f32_engine("f16x3"):
+        y = ops.conv2d(torch.from_numpy(rs.randn(1, 96, 128, 64).astype(np.float32)).cuda(), pc, 1, "same", "relu")      # 12 288 rows: the engine
+        p = ops.pool2d(y, 3, 2, True)
+        z = ops.conv2d(p, ops.PackedConv((rs.randn(1, 1, 128, 128) * 0.05).astype(np.float32)), 1, "valid")
+        small = ops.conv2d(torch.from_numpy(rs.randn(1, 20, 20, 64).astype(np.float32)).cuda(), pc, 1, "same")        # 14 tiles: native, tracked
+    assert ops.AMAX_MEASURED == before + 1                       # only the first input was measured by a pass of its own
+    assert p._amax is y._amax and float(z._amax.max()) == float(z.abs().max())
+    assert float(small._amax.max()) == float(small.abs().max())
+
+
+def test_h3_position_major_layout_and_tap_skipping_are_bit_identical_to_nhwc():
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(3)
+    n, cin, cout = 300, 64, 128
+    x = rs.randn(n, 7, 7, cin).astype(np.float32)
+    wt = (rs.randn(3, 3, cin, cout) * 0.05).astype(np.float32)
+    pc = ops.PackedConv(wt, np.ones(cout, np.float32), np.zeros(cout, np.float32))
+    for tile in (81, 84, 86, 82):
+        a = ops.conv2d(torch.from_numpy(x).cuda(), pc, 1, "same", "relu", tile=tile)                                   # (n,7,7,c)
+        b = ops.conv2d(torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0, 3))).cuda(), pc, 1, "same", "relu", tile=tile, layout=1)   # (7,7,n,c)
+        assert torch.equal(a, b.permute(2, 0, 1, 3))
+    ref, mag = ref_conv(x, wt, 1, "same", None, None, None, "relu")
+    assert err(a.cpu().numpy(), ref, mag) <= 6e-7
+
+
+def test_h3_two_layers_in_one_launch_equal_two_launches():
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(4)
+    x = torch.from_numpy(rs.randn(1, 38, 63, 256).astype(np.float32)).cuda()
+    w1 = (rs.randn(1, 1, 256, 128) * 0.06).astype(np.float32)
+    w2 = (rs.randn(1, 1, 256, 512) * 0.06).astype(np.float32)
+    s = lambda c: ((1 + 0.1 * rs.randn(c)).astype(np.float32), (0.1 * rs.randn(c)).astype(np.float32))
+    (s1, h1), (s2, h2) = s(128), s(512)
+    cat = np.concatenate([w1, w2], axis=3)
+    both = ops.PackedConv(cat, np.concatenate([s1, s2]), np.concatenate([h1, h2]))
+    for tile in (81, 84, 86):
+        y1, y2 = ops.conv2d_dual(x, both, 128, 1, "valid", "relu", None, tile=tile)
+        # the filter's scale is taken over the WHOLE concatenated filter: single-layer launches agree bit for bit when their filters
+        # share that maximum, which two halves of one random draw need not -- so compare against slices of a one-layer launch
+        whole = ops.conv2d(x, ops.PackedConv(cat, np.concatenate([s1, s2]), np.concatenate([h1, h2])), 1, "valid", None, tile=tile)
+        assert torch.equal(y1, whole[..., :128].clamp(min=0)) and torch.equal(y2, whole[..., 128:])
+        assert float(y1._amax.max()) == float(y1.abs().max()) and float(y2._amax.max()) == float(y2.abs().max())
+    # a boundary that is not a tile boundary takes the per-column epilogue: 9 + 36 channels (the RPN output pair) padded to 64 k
+    w3 = (rs.randn(1, 1, 256, 9) * 0.06).astype(np.float32); w4 = (rs.randn(1, 1, 256, 36) * 0.06).astype(np.float32)
+    cat = np.concatenate([w3, w4], axis=3)
+    pair = ops.PackedConv(cat, np.ones(45, np.float32), np.zeros(45, np.float32))
+    y1, y2 = ops.conv2d_dual(x, pair, 9, 1, "valid", "sigmoid", None, tile=84)
+    whole = ops.conv2d(x, ops.PackedConv(cat, np.ones(45, np.float32), np.zeros(45, np.float32)), 1, "valid", None, tile=84)
+    assert torch.equal(y2, whole[..., 9:]) and torch.allclose(y1, torch.sigmoid(whole[..., :9]), atol=3e-6)
+    assert float(y2._amax.max()) == float(y2.abs().max())
+
+
+def test_h3_engine_policy_scope_and_tile_choice():
+    from faster_rcnn_amd import _lib, ops
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    big = torch.from_numpy(rs.randn(1, 96, 128, 64).astype(np.float32)).cuda()          # 12 288 rows
+    small = torch.from_numpy(rs.randn(1, 20, 20, 64).astype(np.float32)).cuda()
+    pc = ops.PackedConv((rs.randn(3, 3, 64, 128) * 0.05).astype(np.float32))
+    ops.CONV_PROFILE = []
+    try:
+        ops.conv2d(big, pc, 1, "same")
+        with ops.f32_engine("f16x3"):
+            ops.conv2d(big, pc, 1, "same")
+            ops.conv2d(small, pc, 1, "same")                     # 14 tiles of 64x64, under X6_MIN_TILES: stays native
+        ops.conv2d(big, pc, 1, "same")
+        names = [r["kernel"] for r in ops.CONV_PROFILE]
+        for r in ops.CONV_PROFILE:
+            r["relaunch"]()                                      # the profile's re-launch closures run (bench.py times launches through them)
+    finally:
+        ops.CONV_PROFILE = None
+    assert [("h3" in n) for n in names] == [False, True, False, False], names
+
+    def cfg(shape, k, cout, n1=0, stride=1, padding="same"):
+        d = ops._conv_desc(shape, k, k, cout, stride, padding, 0, 0, 0)
+        return lib.frcnn_conv2d_h3_config(ctypes.byref(d), n1)
+    assert cfg((1, 149, 249, 64), 3, 64) == 84                       # stage 2's 3x3
+    assert cfg((1, 600, 1000, 64), 3, 64) == 87                      # VGG16 conv1_2
+    assert cfg((1, 75, 125, 128), 3, 128) == 84                      # under 256 tiles of 128x128
+    assert cfg((300, 7, 7, 512), 1, 2048) == 86 and cfg((300, 7, 7, 512), 3, 512) == 86
+    assert cfg((1, 149, 249, 64), 1, 320, n1=64, padding="valid") == 84
+    assert lib.frcnn_conv2d_h3_config(None, 0) < 0
+    # cin % 32 != 0 has no split form: an explicit tile code is not honoured silently
+    odd = ops.PackedConv((rs.randn(1, 1, 48, 64) * 0.1).astype(np.float32))
+    y = ops.conv2d(torch.from_numpy(rs.randn(1, 8, 8, 48).astype(np.float32)).cuda(), odd, 1, "valid", tile=81)
+    assert y.shape == (1, 8, 8, 64)                                  # (took the native generic kernel)
+
+
+def test_h3_planes_reassemble_the_filter():
+    """frcnn_pack_conv_weights_h3: header = max|w|; hi + lo * 2^-11 under the header's scale gives every weight back to half an
+    f32 unit in its last place (2^-24 of ITS OWN magnitude; weights 2^27 under the largest one keep an absolute 2^-50 of it)."""
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(21)
+    for sh, mag in (((3, 3, 64, 96), 0.05), ((1, 1, 256, 1024), 3e-9), ((1, 1, 32, 8), 700.0)):
+        pc = ops.PackedConv((rs.randn(*sh) * mag).astype(np.float32))
+        raw = pc.h3_planes()
+        assert raw.numel() == _lib.load().frcnn_conv_h3_planes_bytes(pc.w.shape[0], pc.w.shape[1])
+        amax = float(raw[:4].view(torch.float32).item())
+        assert amax == float(pc.w.abs().max())
+        e = 14 - int(np.floor(np.log2(amax)))
+        planes = raw[16:].view(torch.float16).view(2, *pc.w.shape).double()
+        back = (planes[0] + planes[1] / 2048.0) * 2.0 ** -e
+        w64 = pc.w.double()
+        tol = torch.maximum(2.0 ** -24 * w64.abs(), torch.full_like(w64, 2.0 ** -49 * amax))
+        assert bool(((back - w64).abs() <= tol).all()), float(((back - w64).abs() / tol).max())
+        assert float(((back - w64).abs() > 0).double().mean()) < 0.75          # a good share of the weights come back exactly
+        assert float(planes[0].abs().max()) < 32768.0 and float(planes[0].abs().max()) >= 16384.0
+
+
+def test_h3_split_k_small_grid_long_k():
+    """rpn_conv1 / stage-4 shapes (2 394 rows, k = 9 216 / 2 304): the engine's 64x64 split-K form against fp64, bitwise
+    reproducible, tickets left zero (a second launch on the same workspace)."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(8)
+    for (h, w, cin, cout, k) in ((38, 63, 1024, 512, 3), (38, 63, 256, 256, 3), (19, 31, 2048, 192, 1)):
+        x = rs.randn(1, h, w, cin).astype(np.float32)
+        wt = (rs.randn(k, k, cin, cout) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+        scale = (1 + 0.1 * rs.randn(cout)).astype(np.float32); shift = (0.1 * rs.randn(cout)).astype(np.float32)
+        pc = ops.PackedConv(wt, scale, shift)
+        xd = torch.from_numpy(x).cuda()
+        ws = ops.ConvWorkspace()
+        ops.CONV_PROFILE = []
+        try:
+            with ops.f32_engine("f16x3"), ops.conv_workspace(ws):
+                got = ops.conv2d(xd, pc, 1, "same", "relu")
+                again = ops.conv2d(xd, pc, 1, "same", "relu", out=torch.full_like(got, 3.0))
+            names = [r["kernel"] for r in ops.CONV_PROFILE]
+        finally:
+            ops.CONV_PROFILE = None
+        assert names[0].endswith("split-K") and "h3" in names[0], names
+        ref, mag = ref_conv(x, wt, 1, "same", scale, shift, None, "relu")
+        assert err(got.cpu().numpy(), ref, mag) <= 5e-7
+        assert torch.equal(got, again)
+        assert float(got._amax.max()) == float(got.abs().max())
+        assert not ws.buf[:16384].any().item()                   # tickets back to zero
+    # the eight-wave 128x128 split-K form (explicit: tile code 88)
+    x = rs.randn(1, 56, 56, 512).astype(np.float32)
+    wt = (rs.randn(3, 3, 512, 512) * np.sqrt(2.0 / 4608)).astype(np.float32)
+    pc = ops.PackedConv(wt)
+    ws = ops.ConvWorkspace()
+    with ops.conv_workspace(ws):
+        got = ops.conv2d(torch.from_numpy(x).cuda(), pc, 1, "same", None, tile=88)
+    ref, mag = ref_conv(x, wt, 1, "same")
+    assert err(got.cpu().numpy(), ref, mag) <= 5e-7 and not ws.buf[:16384].any().item()

@@ -2,6 +2,8 @@
 recency order, byte budget and busy-slot rule, and which (manager, detector) pairs take the captured path."""
 import types
 
+import numpy as np
+
 from faster_rcnn_amd import entry
 
 
@@ -160,3 +162,19 @@ def test_get_dets_by_cls_failure_leaves_no_ticket_open(monkeypatch):
     with pytest.raises(TypeError):
         _run_by_cls(monkeypatch, eng, [(600, 1500)] * 12)
     assert len(eng.submitted) == 1 and synced == [1]                       # the whole batch of eight was in flight: waited for, slot released
+
+
+def test_image_data_falls_back_to_the_host_resize_when_the_device_path_fails(monkeypatch):
+    """``Image.data`` is a pure-host property; a device resize that cannot run (no library, no memory, a forked
+    worker) must fall back to the bit-identical numpy restatement instead of raising, and a process that has not started the
+    HIP runtime must not start it just to read pixels."""
+    from faster_rcnn_amd import shapes
+    rs = np.random.RandomState(5)
+    img = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    want = shapes._resize(img, 80, 60)
+    assert shapes._device_resize_ok() is False                      # CPU box / runtime not initialised: host path
+    assert np.array_equal(shapes._resize_any(img, 80, 60), want)
+    monkeypatch.setattr(shapes, "_device_resize_ok", lambda: True)  # pretend the runtime is up: the device path raises here
+    assert np.array_equal(shapes._resize_any(img, 80, 60), want)
+    monkeypatch.setattr(shapes, "DEVICE_RESIZE", False)
+    assert np.array_equal(shapes.InMemoryImage(img, 80, 60).data, want)
