@@ -406,6 +406,89 @@ int frcnn_rpn_assign(int rows, int cols, const int32_t* anchor_hw_h, int A, int 
     return FRCNN_OK;
 }
 
+// ---- RPN batch sampling on the device side of the host RNG (rpn_util.py:324-350).  The reference's _apply_sampling needs, from the
+// 21 546 - 64 296 anchors of an image, only HOW MANY usable positives / negatives there are: `random.sample(range(num_pos), ...)`
+// draws POSITIONS in the ascending lists np.where returns.  frcnn_rpn_sample_lists builds those lists on the device and hands the
+// two counts over (8 bytes instead of 1.2 MB of masks and targets); the host draws the positions to switch off (the global
+// `random` stream, frcnn_host_mt_sample_range) and frcnn_rpn_pack_targets applies them and writes y_class / y_bbreg as
+// rpn_y_true lays them out (rpn_util.py:126-140), as float32, straight into the training step's input tensors.
+__global__ void __launch_bounds__(1024) k_rpn_sample_lists(const uint8_t* can_use, const uint8_t* is_pos, int n,
+                                                           int32_t* pos_locs, int32_t* neg_locs, int32_t* counts) {
+    __shared__ int s_pos[1024], s_neg[1024];
+    const int tid = threadIdx.x, per = (n + 1023) / 1024, lo = min(tid * per, n), hi = min(lo + per, n);
+    int np_ = 0, nn = 0;
+    for (int i = lo; i < hi; ++i) {
+        const bool u = can_use[i] == 1, p = is_pos[i] == 1;
+        np_ += u && p;
+        nn += u && is_pos[i] == 0;
+    }
+    s_pos[tid] = np_; s_neg[tid] = nn;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {             // inclusive scan (Hillis-Steele; one workgroup, once per image)
+        const int a = tid >= off ? s_pos[tid - off] : 0, b = tid >= off ? s_neg[tid - off] : 0;
+        __syncthreads();
+        s_pos[tid] += a; s_neg[tid] += b;
+        __syncthreads();
+    }
+    int wp = s_pos[tid] - np_, wn = s_neg[tid] - nn;       // exclusive prefix: where this thread's run starts in each list
+    for (int i = lo; i < hi; ++i) {
+        const bool u = can_use[i] == 1;
+        if (u && is_pos[i] == 1) pos_locs[wp++] = i;
+        else if (u && is_pos[i] == 0) neg_locs[wn++] = i;
+    }
+    if (tid == 1023) { counts[0] = s_pos[1023]; counts[1] = s_neg[1023]; }
+}
+
+__global__ void k_rpn_clear_sampled(uint8_t* can_use, const int32_t* locs, int n_locs, const int32_t* off, int n_off) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_off) {
+        const int q = off[j];
+        if (q >= 0 && q < n_locs) can_use[locs[q]] = 0;
+    }
+}
+
+// one thread per (cell, anchor): y_class[cell] = [can_use x A | is_pos x A], y_bbreg[cell] = [(is_pos & can_use) repeated 4 x A | targets 4A]
+__global__ void k_rpn_pack_targets(const uint8_t* can_use, const uint8_t* is_pos, const float4* bbreg, int cells, int A,
+                                   float* y_class, float* y_bbreg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells * A) return;
+    const int cell = i / A, a = i - cell * A;
+    const bool u = can_use[i] != 0, p = is_pos[i] != 0;     // (np.concatenate of bool arrays: any non-zero byte is True)
+    y_class[(size_t)cell * 2 * A + a] = u ? 1.0f : 0.0f;
+    y_class[(size_t)cell * 2 * A + A + a] = p ? 1.0f : 0.0f;
+    const float both = (u && p) ? 1.0f : 0.0f;
+    float* yb = y_bbreg + (size_t)cell * 8 * A;
+    const float4 t = bbreg[i];
+    yb[4 * a] = both; yb[4 * a + 1] = both; yb[4 * a + 2] = both; yb[4 * a + 3] = both;
+    yb[4 * A + 4 * a] = t.x; yb[4 * A + 4 * a + 1] = t.y; yb[4 * A + 4 * a + 2] = t.z; yb[4 * A + 4 * a + 3] = t.w;
+}
+
+int frcnn_rpn_sample_lists(const uint8_t* can_use, const uint8_t* is_pos, int n, int32_t* pos_locs, int32_t* neg_locs, int32_t* counts, void* stream) {
+    if (!can_use || !is_pos || !pos_locs || !neg_locs || !counts || n <= 0) return fail(FRCNN_E_ARG, "rpn_sample_lists: bad argument");
+    k_rpn_sample_lists<<<1, 1024, 0, as_stream(stream)>>>(can_use, is_pos, n, pos_locs, neg_locs, counts);
+    return check_launch("rpn_sample_lists");
+}
+
+int frcnn_rpn_pack_targets(uint8_t* can_use, const uint8_t* is_pos, const float* bbreg, int cells, int A,
+                           const int32_t* pos_locs, int n_pos, const int32_t* off_pos, int n_off_pos,
+                           const int32_t* neg_locs, int n_neg, const int32_t* off_neg, int n_off_neg,
+                           float* y_class, float* y_bbreg, void* stream) {
+    if (!can_use || !is_pos || !bbreg || !y_class || !y_bbreg || cells <= 0 || A <= 0 || n_off_pos < 0 || n_off_neg < 0
+        || (n_off_pos > 0 && (!pos_locs || !off_pos)) || (n_off_neg > 0 && (!neg_locs || !off_neg)))
+        return fail(FRCNN_E_ARG, "rpn_pack_targets: bad argument");
+    hipStream_t s = as_stream(stream);
+    if (n_off_pos > 0) {
+        k_rpn_clear_sampled<<<(n_off_pos + 255) / 256, 256, 0, s>>>(can_use, pos_locs, n_pos, off_pos, n_off_pos);
+        if (int e = check_launch("rpn_pack_targets (positives)")) return e;
+    }
+    if (n_off_neg > 0) {
+        k_rpn_clear_sampled<<<(n_off_neg + 255) / 256, 256, 0, s>>>(can_use, neg_locs, n_neg, off_neg, n_off_neg);
+        if (int e = check_launch("rpn_pack_targets (negatives)")) return e;
+    }
+    k_rpn_pack_targets<<<(cells * A + 255) / 256, 256, 0, s>>>(can_use, is_pos, (const float4*)bbreg, cells, A, y_class, y_bbreg);
+    return check_launch("rpn_pack_targets");
+}
+
 int frcnn_decode_proposals(const float* regr, int rows, int cols, const int32_t* anchor_hw_conv_h, int A,
                            float* rois, uint8_t* valid, void* stream) {
     AnchorTable t;

@@ -9,7 +9,8 @@
 //   maximum stored in front of its planes), then
 //       ah = f16(a')                  11 significant bits, round to nearest even
 //       al = f16((a' - ah) * 2^11)    the EXACT residual (13 bits), scaled up into ah's exponent range, rounded to 11 bits
-//   so a' = ah + al * 2^-11 + eps,  |eps| <= 2^-24 |a'|  (the residual's last bit is rounded away in half of the cases); same for b.
+//   so a' = ah + al * 2^-11 + eps,  |eps| <= 2^-23 |a'|: the residual is a 13-bit multiple of a's last place; when its top bit is set
+//   (half of the cases) fp16 keeps it to two such units, i.e. the operand is off by at most ONE unit in its last place; same for b.
 //       acc0 += ah * bh               v_mfma_f32_32x32x16_f16: every product exact in f32, f32 accumulate
 //       acc1 += ah * bl + al * bh     an accumulator of its own: it carries the weight 2^-11
 //       c = (acc0 + acc1 * 2^-11) * 2^-eA * 2^-eB

@@ -3,7 +3,7 @@
 // Every operand tensor is brought into fp16's range by ONE power of two (exact):  a' = a * 2^eA  with  max|a'| in [2^14, 2^15),
 // then      ah = f16(a')                 (11 significant bits, round to nearest even)
 //           al = f16((a' - ah) * 2^11)   (the exact residual, scaled up so that it has ah's exponent range: 11 more bits)
-// so a' = ah + al * 2^-11 + eps with |eps| <= 2^-24 |a'| (one bit of the 13-bit residual is rounded away half of the time), same for b.
+// so a' = ah + al * 2^-11 + eps with |eps| <= 2^-23 |a'| (the 13-bit residual loses its last bit when its top bit is set: half of the time), same for b.
 //   acc0 += ah * bh                      (v_mfma_f32_32x32x16_f16: products exact, f32 accumulate)
 //   acc1 += ah * bl + al * bh            (its own accumulator: it carries the 2^-11 weight)
 //   [TERMS == 4:  acc2 += al * bl        (2^-22)]

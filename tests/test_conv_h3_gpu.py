@@ -223,8 +223,9 @@ def test_h3_engine_policy_scope_and_tile_choice():
 
 
 def test_h3_planes_reassemble_the_filter():
-    """frcnn_pack_conv_weights_h3: header = max|w|; hi + lo * 2^-11 under the header's scale gives every weight back to half an
-    f32 unit in its last place (2^-24 of ITS OWN magnitude; weights 2^27 under the largest one keep an absolute 2^-50 of it)."""
+    """frcnn_pack_conv_weights_h3: header = max|w|; hi + lo * 2^-11 under the header's scale gives every weight back to ONE f32
+    unit in its last place (2^-23 of ITS OWN magnitude: a 13-bit residual kept to 11 bits), half of them exactly; weights 2^27 under
+    the largest one keep an absolute 2^-49 of it."""
     from faster_rcnn_amd import _lib, ops
     rs = np.random.RandomState(21)
     for sh, mag in (((3, 3, 64, 96), 0.05), ((1, 1, 256, 1024), 3e-9), ((1, 1, 32, 8), 700.0)):
@@ -237,7 +238,7 @@ def test_h3_planes_reassemble_the_filter():
         planes = raw[16:].view(torch.float16).view(2, *pc.w.shape).double()
         back = (planes[0] + planes[1] / 2048.0) * 2.0 ** -e
         w64 = pc.w.double()
-        tol = torch.maximum(2.0 ** -24 * w64.abs(), torch.full_like(w64, 2.0 ** -49 * amax))
+        tol = torch.maximum(2.0 ** -23 * w64.abs(), torch.full_like(w64, 2.0 ** -49 * amax))
         assert bool(((back - w64).abs() <= tol).all()), float(((back - w64).abs() / tol).max())
         assert float(((back - w64).abs() > 0).double().mean()) < 0.75          # a good share of the weights come back exactly
         assert float(planes[0].abs().max()) < 32768.0 and float(planes[0].abs().max()) >= 16384.0
