@@ -636,6 +636,71 @@ def spawn_ranks(n):
 TRAIN_H, TRAIN_W = 600, 1000          # configs[2] / configs[4] are ResNet-50 at 600x1000 whatever inference config the line is for
 
 
+def train_loop_images(n_images, height, width, seed=900):
+    """`n_images` distinct in-memory frames the way the reference's loaders hand them (shapes.Image over decoded uint8 BGR pixels with
+    annotated boxes): uniform-noise pixels, 3-6 VOC-class boxes each, a few with anchor-like shapes so that positives exist."""
+    from faster_rcnn_amd import shapes
+    from faster_rcnn_amd.data.voc_data_helpers import VOC_CLASS_MAPPING
+    names = [k for k in VOC_CLASS_MAPPING if k != "bg"]
+    rs = np.random.RandomState(seed)
+    imgs = []
+    for k in range(n_images):
+        px = rs.randint(0, 256, (height, width, 3)).astype(np.uint8)
+        gts = []
+        for _ in range(rs.randint(3, 7)):
+            bw, bh = rs.choice([96, 128, 180, 256, 360]), rs.choice([96, 128, 180, 256, 360])
+            x1, y1 = rs.randint(0, max(1, width - bw - 1)), rs.randint(0, max(1, height - bh - 1))
+            gts.append(shapes.GroundTruthBox(names[rs.randint(len(names))], False, shapes.Box(int(x1), int(y1), int(min(width - 1, x1 + bw)), int(min(height - 1, y1 + bh)))))
+        imgs.append(shapes.Image(shapes.Metadata("synth%03d" % k, width, height, gts, "none"), px))
+    return imgs
+
+
+def train_loop_leg(kind, dtype="f32", n_images=32, iterations=64, warm=24, fast=True, height=None, width=None):
+    """ms per ITERATION of the reference's own training loops (train_util.train_rpn / train_detector_step2,
+    train_util.py:37-54, 100-118) over `n_images` distinct images -- image fetch, targets / proposals, sampling, the step, the
+    loss line -- beside the bare train_on_batch step bench_train.py times on one pre-staged input.  `fast`: the managers'
+    device-resident feed (train_util.FAST_FEED); False: batched_image / rpn_y_true / get_training_input as host numpy."""
+    import contextlib
+    import io
+    import random
+    from faster_rcnn_amd import det_util, resnet, rpn_util, train, train_util, util
+    from faster_rcnn_amd.data.voc_data_helpers import VOC_CLASS_MAPPING
+    from faster_rcnn_amd.weights import synthetic_resnet
+    height, width = height or TRAIN_H, width or TRAIN_W
+    anchors = util.get_anchors([128, 256, 512])
+    A, C = len(anchors), 21
+    imgs = train_loop_images(n_images, height, width)
+    random.seed(1); np.random.seed(1337)
+    reg = dict(weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
+    if kind == "rpn_step1":
+        model = resnet.resnet50_rpn(resnet.resnet50_base(weights=synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=1), dtype=dtype, **reg), anchors_per_loc=A)
+        mgr = rpn_util.RpnTrainingManager(resnet.get_conv_rows_cols, 16, resnet.preprocess, anchors)
+        loop = train_util.train_rpn
+    else:
+        frozen = resnet.resnet50_rpn(resnet.resnet50_base(weights=synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=1)), anchors_per_loc=A)
+        model = resnet.resnet50_classifier(64, C, resnet.resnet50_base(weights=synthetic_resnet(50, anchors_per_loc=A, num_classes=C, seed=2), dtype=dtype, **reg))
+        mgr = det_util.DetTrainingManager(frozen, VOC_CLASS_MAPPING, resnet.preprocess, anchor_dims=anchors)
+        loop = train_util.train_detector_step2
+    opt = train.optimizer_from_str("sgd")
+    was = train_util.FAST_FEED
+    train_util.FAST_FEED = bool(fast)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):            # (the loops print one line per iteration)
+            loop(model, imgs, mgr, opt, phases=[[warm, 1e-3]])
+            train.finish_pending_updates()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loop(model, imgs, mgr, opt, phases=[[iterations, 1e-3]])
+            train.finish_pending_updates()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+    finally:
+        train_util.FAST_FEED = was
+    return {"ms_per_iteration": round(1e3 * el / iterations, 3), "iterations": iterations, "distinct_images": n_images, "dtype": dtype,
+            "feed": "device-resident (train_util.FAST_FEED: uint8 frame up, resize / preprocess / targets on the device, next image prepared beside the step)"
+                    if fast else "host numpy (batched_image / rpn_y_true / get_training_input, the reference's calls taken literally)"}
+
+
 def train_dp_leg(anchors, rank, world, kind="rpn_step1", steps=10, warmup=10):
     """One training config inside the N > 1 line, one image per GPU per step, the flat gradient buffer through the path's
     ONE collective (dp.allreduce_sum_begin -> RCCL all-reduce over xGMI).  Every rank runs this; returns the object rank 0

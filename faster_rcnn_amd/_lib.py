@@ -33,6 +33,9 @@ SIGNATURES = {
     "frcnn_cross_ious_i16": (I, [P, I, P, I, P, P]),
     "frcnn_rpn_assign_workspace_bytes": (c_size_t, [I, I, I, I]),
     "frcnn_rpn_assign": (I, [I, I, P, I, I, P, I, I, I, P, P, P, P, P, c_size_t, P]),
+    "frcnn_rpn_sample_lists": (I, [P, P, I, P, P, P, P]),
+    "frcnn_rpn_pack_targets": (I, [P, P, P, I, I, P, I, P, I, P, I, P, I, P, P, P]),
+    "frcnn_host_mt_sample_range": (I, [P, P, I, I, I, P]),
     "frcnn_decode_proposals": (I, [P, I, I, P, I, P, P, P]),
     "frcnn_transform_inplace": (I, [P, P, I, P]),
     "frcnn_topk_workspace_bytes": (c_size_t, [I]),

@@ -48,11 +48,12 @@ class DetTrainingManager:
         return np.expand_dims(self.preprocess_func(image.data), axis=0)
 
     # ------------------------------------------------------------------ device path
-    def _proposals_dev(self, image, pre_nms, max_boxes):
+    def _proposals_dev(self, image, pre_nms, max_boxes, x=None):
         """RPN forward + decode + valid filter + descending score order + int16 cast + NMS
-        (det_util.py:44-77 / 145-156), all on the device.
+        (det_util.py:44-77 / 145-156), all on the device.  ``x``: the preprocessed image already on the device (fast path).
         Returns (rois int16 device (n,4), conv feature map device or None)."""
-        x = nets.to_device_image(self.batched_image(image))
+        if x is None:
+            x = nets.to_device_image(self.batched_image(image))
         cls, reg, feat = self.rpn_model.forward_dev(x)
         rois_all, valid = ops.decode_proposals(reg, np.asarray(self.anchor_dims) // self.stride)
         scores = cls.reshape(-1)
@@ -72,6 +73,53 @@ class DetTrainingManager:
             if feat is not None:
                 cache_obj["conv_out"] = feat.cpu().numpy()
         self._cache[image.cache_key] = cache_obj
+
+    # ------------------------------------------------------------------ device-resident fast path (train_util._train_detector)
+    # get_training_input with the LARGE tensors left on the device.  The reference's loop (train_util.py:100-118) builds the float64
+    # image on the host for the RPN pass (det_util.py:36), and again for the detector step (:127) -- or, with conv_only (step 4),
+    # copies the 9.8 MB conv4 map to numpy (:56) and train_on_batch uploads it again.  Here the decoded uint8 frame is uploaded ONCE,
+    # resized / preprocessed on the device (feed.device_image: the same float32 bits) and serves both the RPN pass and the step;
+    # the conv map never leaves the device.  The small arrays (<= 2 000 RoIs, their one-hot classes and targets) stay host numpy:
+    # the reference's np.random sampling picks among them (det_util.py:260-306) exactly as before.  ``prefetch`` holds everything
+    # that needs no random draw and may run one image AHEAD, beside the current detector step, on the manager's own stream.
+    def prefetch(self, image):
+        from . import feed
+        key = image.cache_key
+        pre = self.__dict__.setdefault("_pre", {})
+        if key in pre:
+            return
+        with self._own_stream():
+            have = key in self._cache
+            x = None if (have and self.conv_only) else feed.device_image(image, self.preprocess_func)
+            feat = None
+            if not have:
+                rois, feat = self._proposals_dev(image, 12000, 2000, x=x)
+                filtered_rois, y_class_num, y_transform = _rois_to_truth(rois, image, self.class_mapping, stride=self.stride)
+                self._cache[key] = {"rois": filtered_rois, "y_class_num": y_class_num, "y_transform": y_transform}
+            first = feat if self.conv_only else x
+            if first is not None:
+                feed.Ready.mark(first)
+            pre[key] = first
+
+    def get_training_input_dev(self, image):
+        """get_training_input whose first element is a float32 DEVICE tensor ((1,H,W,3) image, or the (1,R,C,Cf) conv map when
+        conv_only); rois / y_class_num / y_transform are the reference's numpy arrays."""
+        self.prefetch(image)
+        first = self._pre.pop(image.cache_key)
+        results = self._cache[image.cache_key]
+        if self.conv_only and first is None:                 # (a conv_only entry is consumed by its first use, det_util.py:129-130)
+            conv = results.get("conv_out")
+            first = None if conv is None else nets.to_device_image(conv)
+        if len(results["rois"]) == 0:
+            return None, None, None, None                    # (the entry stays cached, as in the reference: det_util.py:103-104)
+        rois, y_class_num, y_transform = results["rois"], results["y_class_num"], results["y_transform"]
+        sampled_idxs = _get_det_samples(y_class_num[:, -1] == 0, self.num_rois)
+        rois, y_class_num, y_transform = rois[sampled_idxs], y_class_num[sampled_idxs], y_transform[sampled_idxs]
+        if self.conv_only:
+            del self._cache[image.cache_key]
+        if first.dim() == 3:
+            first = first.unsqueeze(0)
+        return first, np.expand_dims(rois, axis=0), np.expand_dims(y_class_num, axis=0), np.expand_dims(y_transform, axis=0)
 
     def get_training_input(self, image):
         """det_util.py:90-133."""

@@ -109,6 +109,16 @@ class ImageSchedule:
         self.before_phase += self._zero_hits(self.offset, self.offset + self.steps * self.world - 1, len(self.images))
         self.offset, self.steps = num_iterations * phase_num * self.world, num_iterations
 
+    def peek(self, i):
+        """The image ``image(i)`` will return, when getting it needs no shuffle (None otherwise): what a loop may start
+        preparing AHEAD of time without touching the shuffle stream before the reference would."""
+        n = len(self.images)
+        if i >= self.steps:
+            return None
+        pos = self.offset + i * self.world + self.rank
+        hits = self.before_phase + self._zero_hits(self.offset, pos, n)
+        return self.images[pos % n] if self.applied >= hits else None
+
     def image(self, i):
         n = len(self.images)
         pos = self.offset + i * self.world + self.rank

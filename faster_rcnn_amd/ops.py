@@ -164,6 +164,30 @@ def rpn_assign(rows, cols, anchor_hw, stride, gt, img_w, img_h):
     return can_use, is_pos, bbreg, argmax
 
 
+def rpn_sample_lists(can_use, is_pos):
+    """-> (pos_locs (N,) i32, neg_locs (N,) i32, counts (2,) i32): np.where(is_pos & can_use) / np.where(~is_pos & can_use) in
+    ascending order, filled from the front, and their lengths (frcnn_rpn_sample_lists)."""
+    _require_gpu()
+    n = can_use.numel()
+    pos = torch.empty(n, dtype=torch.int32, device="cuda")
+    neg = torch.empty(n, dtype=torch.int32, device="cuda")
+    counts = torch.empty(2, dtype=torch.int32, device="cuda")
+    _lib.call("frcnn_rpn_sample_lists", _p(can_use), _p(is_pos), n, _p(pos), _p(neg), _p(counts), _stream())
+    return pos, neg, counts
+
+
+def rpn_pack_targets(can_use, is_pos, bbreg, cells, A, pos_locs, n_pos, off_pos, neg_locs, n_neg, off_neg):
+    """Switch off the sampled positions (device int32 lists or None) IN can_use, then -> (y_class (cells,2A) f32, y_bbreg
+    (cells,8A) f32) laid out like rpn_y_true's outputs (frcnn_rpn_pack_targets)."""
+    _require_gpu()
+    yc = torch.empty((cells, 2 * A), dtype=torch.float32, device="cuda")
+    yb = torch.empty((cells, 8 * A), dtype=torch.float32, device="cuda")
+    _lib.call("frcnn_rpn_pack_targets", _p(can_use), _p(is_pos), _p(bbreg), cells, A,
+              _p(pos_locs), int(n_pos), _p(off_pos), 0 if off_pos is None else off_pos.numel(),
+              _p(neg_locs), int(n_neg), _p(off_neg), 0 if off_neg is None else off_neg.numel(), _p(yc), _p(yb), _stream())
+    return yc, yb
+
+
 # ----------------------------------------------------------------------------- proposals
 def decode_proposals(regr, anchor_hw_conv):
     """regr: (1,R,C,4A) or (R,C,4A) f32 device tensor -> rois (N,4) f32, valid (N,) u8."""

@@ -6,11 +6,13 @@ regression targets run in ONE C-ABI call (frcnn_rpn_assign); the batch sampling 
 host because it consumes the global Python ``random`` stream exactly like the reference
 (rpn_util.py:324-350) -- moving it would change which anchors get sampled.
 """
+import ctypes
 import random
+from math import ceil as _ceil, log as _log
 
 import numpy as np
 
-from . import ops
+from . import _lib, ops
 from .shared_constants import DEFAULT_ANCHORS
 from .util import get_bbox_coords
 
@@ -41,6 +43,53 @@ class RpnTrainingManager:
             "is_pos": is_pos.cpu().numpy().astype(bool),
             "bbreg_targets": bbreg.cpu().numpy(),
         }
+
+    # ------------------------------------------------------------------ device-resident fast path (train_util.train_rpn)
+    # The same two calls with everything but the host RNG left on the device: ``prefetch`` is the part of batched_image +
+    # _process that needs no random draw (upload of the decoded frame, resize / preprocess, frcnn_rpn_assign, the ascending
+    # positive / negative lists) and may run a step AHEAD on the manager's own stream; ``rpn_inputs_dev`` reads the two counts
+    # (8 bytes), makes the reference's two ``random.sample`` draws in the reference's order (global ``random`` stream, _sample_off)
+    # and packs y_class / y_bbreg on the device.  What comes back are the float32 device tensors train_on_batch's feed would
+    # have built from batched_image(image) and rpn_y_true(image): 1.2 MB of masks and targets, 1 MB of packed targets and 14 MB
+    # of float64 image never cross PCIe.  tests/test_train_loop_gpu.py: same bits, same weights after N iterations.
+    def _own_stream(self):
+        import torch
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream()
+        return self._stream
+
+    def prefetch(self, image):
+        import torch
+        from . import feed
+        dev = self.__dict__.setdefault("_dev", {})
+        if image.cache_key in dev:
+            return
+        st = self._own_stream()
+        with torch.cuda.stream(st):
+            x = feed.device_image(image, self.preprocess_func)
+            conv_rows, conv_cols = self.calc_conv_dims(image.height, image.width)
+            gt = get_bbox_coords(image.gt_boxes)
+            can_use, is_pos, bbreg, _ = ops.rpn_assign(conv_rows, conv_cols, self.anchor_dims, self.stride, gt, image.width, image.height)
+            pos_locs, neg_locs, counts = ops.rpn_sample_lists(can_use, is_pos)
+            counts_host = torch.empty(2, dtype=torch.int32).pin_memory()
+            counts_host.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        dev[image.cache_key] = (x, can_use, is_pos, bbreg, pos_locs, neg_locs, counts_host, ev, conv_rows * conv_cols)
+
+    def rpn_inputs_dev(self, image):
+        """-> (x (1,H,W,3), y_class (cells,2A), y_bbreg (cells,8A)) float32 device tensors, marked with the event the step waits for."""
+        import torch
+        from . import feed
+        self.prefetch(image)
+        x, can_use, is_pos, bbreg, pos_locs, neg_locs, counts_host, ev, cells = self._dev.pop(image.cache_key)
+        ev.synchronize()
+        num_pos, num_neg = (int(v) for v in counts_host.tolist())
+        off_pos, off_neg = _sample_off(num_pos, num_neg)           # the reference's two draws, in its order (rpn_util.py:336-348)
+        with torch.cuda.stream(self._own_stream()):
+            up = lambda a: None if a is None else torch.from_numpy(a).cuda()
+            yc, yb = ops.rpn_pack_targets(can_use, is_pos, bbreg, cells, len(self.anchor_dims), pos_locs, num_pos, up(off_pos), neg_locs, num_neg, up(off_neg))
+            return feed.Ready.mark(x, yc, yb)
 
     def rpn_y_true(self, image):
         """rpn_util.py:106-140: (y_class (1,R,C,2A) bool, y_bbreg (1,R,C,8A) f32).  Like the
@@ -83,16 +132,48 @@ def _get_out_of_bounds_idxs(anchor_coords, img_width, img_height):
     return np.where((a[:, 0] < 0) | (a[:, 1] < 0) | (a[:, 2] >= img_width) | (a[:, 3] >= img_height))[0]
 
 
+FAST_SAMPLE = True          # False: the interpreter's own random.sample (what sample_range is tested against)
+
+
+def sample_range(n, k):
+    """``random.sample(range(n), k)`` -- the same list, the global ``random`` stream left in the same state -- computed by
+    frcnn_host_mt_sample_range on the interpreter's own generator state.  The reference draws 20 000-60 000 positions per
+    image this way (rpn_util.py:343-348: every usable negative but ~128 is switched OFF), 7-80 ms of interpreter time against a
+    2 ms training step; the C replay takes ~0.3 ms.  -> int32 numpy array of length k."""
+    if not FAST_SAMPLE or type(random._inst) is not random.Random or k == 0 or n >= 2 ** 31:
+        return np.asarray(random.sample(range(n), k), dtype=np.int32)
+    if not 0 <= k <= n:
+        raise ValueError("Sample larger than population or is negative")
+    setsize = 21                                             # Lib/random.py sample(): the interpreter's own arithmetic decides the branch
+    if k > 5:
+        setsize += 4 ** _ceil(_log(k * 3, 4))
+    version, internal, gauss = random.getstate()
+    state = np.array(internal[:624], dtype=np.uint32)
+    index = ctypes.c_int32(internal[624])
+    out = np.empty(k, dtype=np.int32)
+    _lib.call("frcnn_host_mt_sample_range", state.ctypes.data, ctypes.addressof(index), int(n), int(k), 1 if n <= setsize else 0, out.ctypes.data)
+    random.setstate((version, tuple(state.tolist()) + (index.value,), gauss))
+    return out
+
+
+def _sample_off(num_pos, num_neg):
+    """The two draws of rpn_util.py:336-348 given only the COUNTS: positions (in the ascending pos / neg lists) to switch off."""
+    off_pos = off_neg = None
+    if num_pos > MAX_POS_SAMPLES:
+        off_pos = sample_range(num_pos, num_pos - MAX_POS_SAMPLES)
+        num_pos = MAX_POS_SAMPLES
+    if num_neg + num_pos > SAMPLE_SIZE:
+        off_neg = sample_range(num_neg, num_neg + num_pos - SAMPLE_SIZE)
+    return off_pos, off_neg
+
+
 def _apply_sampling(is_pos, can_use):
     """rpn_util.py:324-350 (host; global ``random`` stream; mutates can_use)."""
     pos_locs = np.where(np.logical_and(is_pos == 1, can_use == 1))[0]
     neg_locs = np.where(np.logical_and(is_pos == 0, can_use == 1))[0]
-    num_pos, num_neg = len(pos_locs), len(neg_locs)
-    if num_pos > MAX_POS_SAMPLES:
-        locs_off = random.sample(range(num_pos), num_pos - MAX_POS_SAMPLES)
-        can_use[pos_locs[locs_off]] = 0
-        num_pos = MAX_POS_SAMPLES
-    if num_neg + num_pos > SAMPLE_SIZE:
-        locs_off = random.sample(range(num_neg), num_neg + num_pos - SAMPLE_SIZE)
-        can_use[neg_locs[locs_off]] = 0
+    off_pos, off_neg = _sample_off(len(pos_locs), len(neg_locs))
+    if off_pos is not None:
+        can_use[pos_locs[off_pos]] = 0
+    if off_neg is not None:
+        can_use[neg_locs[off_neg]] = 0
     return can_use

@@ -627,11 +627,26 @@ class _StepDriver:
                 # runs beside the backward pass of image i, whose short dependent launches leave most of the chip idle -- and,
                 # data parallel, beside image i's all-reduce, whose optimiser is enqueued only now (_finish_update); the
                 # main stream joins before the first trainable layer.  Same kernels, same order per tensor: bit-identical.
-                pset, views = self._stage(host_inputs)
+                # inputs that are ALREADY float32 device tensors (the managers' fast paths: rpn_util.rpn_inputs_dev,
+                # det_util.get_training_input_dev) skip the cast / staging / upload; they were produced on the manager's stream and
+                # carry the event both of this step's streams wait for
+                on_dev = [isinstance(a, torch.Tensor) and a.is_cuda for a, _ in host_inputs]
+                pset, views = self._stage([hi for hi, d in zip(host_inputs, on_dev) if not d])
                 main, side = torch.cuda.current_stream(), _prefix_stream()
                 side.wait_event(self._frozen_ready)         # the frozen layers' packed filters (lowered on the build stream)
                 with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws_prefix), ops.f32_engine(F32_ENGINE):
-                    dev = [p.to("cuda", non_blocking=True) for p in views]
+                    up = iter(views)
+                    dev = []
+                    for (a, shape), d in zip(host_inputs, on_dev):
+                        if d:
+                            assert a.dtype == torch.float32 and a.is_contiguous(), "device inputs of train_on_batch: contiguous float32"
+                            ev = getattr(a, "_ready", None)
+                            if ev is not None:
+                                side.wait_event(ev)
+                            a.record_stream(side)
+                            dev.append(a.reshape(shape))
+                        else:
+                            dev.append(next(up).to("cuda", non_blocking=True))
                     pset.mark_uploaded()
                     pre = self._frozen_prefix(dev)
                 self._finish_update()

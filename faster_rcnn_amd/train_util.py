@@ -19,8 +19,20 @@ from .loss_functions import bbreg_loss_det, bbreg_loss_rpn, cls_loss_det, cls_lo
 from .shared_constants import DEFAULT_LEARN_RATE, DEFAULT_NUM_ITERATIONS
 
 
+# The loops below feed the steps through the managers' device-resident fast paths (rpn_util.RpnTrainingManager.rpn_inputs_dev,
+# det_util.DetTrainingManager.get_training_input_dev) whenever model and manager are this package's: the same float32 inputs, built on
+# the device, with the next image's RNG-free part prepared beside the current step.  FAST_FEED = False (or a foreign model / manager)
+# takes the reference's calls literally: batched_image / rpn_y_true / get_training_input returning host numpy.
+import os as _os
+FAST_FEED = _os.environ.get("FRCNN_TRAIN_FAST_FEED", "1") != "0"
+
+
 def _is_root():
     return dp.rank() == 0
+
+
+def _fast(model, manager, method):
+    return FAST_FEED and getattr(model, "supports_deferred_losses", False) and hasattr(manager, method) and hasattr(manager, "prefetch")
 
 
 class _LossLog:
@@ -74,12 +86,19 @@ def train_rpn(rpn_model, images, training_manager, optimizer, phases=[[DEFAULT_N
         print("Starting phase {} of training: {} iterations with learning rate {}".format(phase_num, num_iterations, learn_rate))
         schedule.begin_phase(phase_num, num_iterations)
         log = _LossLog()
+        fast = _fast(rpn_model, training_manager, "rpn_inputs_dev")
         for i in range(num_iterations):
             img = schedule.image(i)
-            batched_img = training_manager.batched_image(img)
-            y_class, y_bbreg = training_manager.rpn_y_true(img)
+            if fast:
+                batched_img, y_class, y_bbreg = training_manager.rpn_inputs_dev(img)
+            else:
+                batched_img = training_manager.batched_image(img)
+                y_class, y_bbreg = training_manager.rpn_y_true(img)
             start_time = timeit.default_timer()
             loss_rpn = _enqueue_step(rpn_model, batched_img, [y_class, y_bbreg])
+            ahead = schedule.peek(i + 1) if fast else None   # (None when fetching it would shuffle: the shuffle stays where the reference has it)
+            if ahead is not None:
+                training_manager.prefetch(ahead)             # upload, resize, preprocess, anchor assignment of the NEXT image beside this step
             log.push("phase {} iteration {} image {} flipped {}: loss_rpn {} ({:.4f} s)", (phase_num, i, img.name, img.flipped), loss_rpn, start_time)
             if save_frequency and i % save_frequency == 0:
                 log.flush()
@@ -97,9 +116,10 @@ def _train_detector(detector, images, training_manager, optimizer, phases, save_
         print("Starting phase {} of training: {} iterations with learning rate {}".format(phase_num, num_iterations, learn_rate))
         schedule.begin_phase(phase_num, num_iterations)
         log = _LossLog()
+        fast = _fast(detector, training_manager, "get_training_input_dev")
         for i in range(num_iterations):
             img = schedule.image(i)
-            first_input, rois, y_class_num, y_transform = training_manager.get_training_input(img)
+            first_input, rois, y_class_num, y_transform = (training_manager.get_training_input_dev if fast else training_manager.get_training_input)(img)
             skip = rois is None
             if skip and dp.world() == 1:
                 log.flush()
@@ -107,6 +127,9 @@ def _train_detector(detector, images, training_manager, optimizer, phases, save_
                 continue
             start_time = timeit.default_timer()
             loss_frcnn = _enqueue_step(detector, [first_input, rois], [y_class_num, y_transform], skip=skip)
+            ahead = schedule.peek(i + 1) if fast else None
+            if ahead is not None:
+                training_manager.prefetch(ahead)             # the next image's RPN pass, proposals and RoI -> truth beside this step
             log.push("phase {} iteration {} image {} flipped {}: loss_frcnn {} ({:.4f} s)", (phase_num, i, img.name, img.flipped), loss_frcnn, start_time)
             if save_frequency and i % save_frequency == 0:
                 log.flush()

@@ -85,6 +85,26 @@ int frcnn_rpn_assign(int rows, int cols, const int32_t* anchor_hw_h, int A, int 
                      uint8_t* can_use, uint8_t* is_pos, float* bbreg, int32_t* argmax_gt,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* The batch sampling of rpn_y_true (rpn_util.py:106-140 over _apply_sampling, :324-350) with the host RNG kept and the tensors left on
+ * the device.  frcnn_rpn_sample_lists: the ascending lists np.where(is_pos == 1 & can_use == 1) / np.where(is_pos == 0 & can_use == 1)
+ * return (pos_locs / neg_locs, N int32 each, filled from the front) and counts = {num_pos, num_neg} -- the only two numbers
+ * `random.sample(range(num_pos), num_pos - 128)` / `random.sample(range(num_neg), num_neg + num_pos - 256)` need.
+ * frcnn_rpn_pack_targets: can_use[locs[off[j]]] = 0 for the positions the host drew (off_pos / off_neg: device int32 lists), then
+ * y_class [cells][2A] = [can_use | is_pos] and y_bbreg [cells][8A] = [(is_pos & can_use) x 4 | bbreg] as float32 -- the layout
+ * np.concatenate gives rpn_y_true's outputs, cast the way train_on_batch's feed casts them.  can_use is modified in place. */
+int frcnn_rpn_sample_lists(const uint8_t* can_use, const uint8_t* is_pos, int n, int32_t* pos_locs, int32_t* neg_locs, int32_t* counts, void* stream);
+int frcnn_rpn_pack_targets(uint8_t* can_use, const uint8_t* is_pos, const float* bbreg, int cells, int A,
+                           const int32_t* pos_locs, int n_pos, const int32_t* off_pos, int n_off_pos,
+                           const int32_t* neg_locs, int n_neg, const int32_t* off_neg, int n_off_neg,
+                           float* y_class, float* y_bbreg, void* stream);
+/* HOST function (no device call): CPython's `random.sample(range(n), k)` replayed on the interpreter's own Mersenne-Twister state
+ * (`random.getstate()`: 624 words + index, both updated in place; write them back with `random.setstate`).  The same generator words
+ * (MT19937 genrand_uint32), the same rejection loop (`_randbelow_with_getrandbits`) and the same selection (Lib/random.py sample():
+ * use_pool != 0 is its `n <= setsize` branch, decided by the caller with the interpreter's own arithmetic): out[k] equals the list the
+ * interpreter would return and the stream continues where it would.  The interpreter takes 7-80 ms for the 20 000-60 000 negative
+ * anchors of an image (rpn_util.py:343-348); this takes a few hundred microseconds. */
+int frcnn_host_mt_sample_range(uint32_t* mt_state, int32_t* mt_index, int n, int k, int use_pool, int32_t* out);
+
 /* ------------------------------------------------------------------ proposals */
 /* det_util._get_rois + _get_valid_box_idxs (det_util.py:370-380, 179-205) with
  * util.transform_np_inplace (util.py:111-142) inside: regr [rows][cols][4A] f32 ->

@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--big-tiles", action="store_true")
     ap.add_argument("--only", choices=("rpn", "det"), default=None)
     ap.add_argument("--no-split-k", action="store_true", help="dev: plain conv launches only (no split-K workspace) in the training steps")
+    ap.add_argument("--through-loop", action="store_true", help="also time train_util.train_rpn / train_detector_step2 THEMSELVES over 32 distinct images "
+                    "(image fetch, targets / proposals, host sampling, step, loss line): ms per iteration beside the bare step, with the managers' "
+                    "device-resident feed and (fewer iterations) with the reference's host-numpy calls")
     ap.add_argument("--sync-each-step", action="store_true", help="time only the plain Keras call (losses read back after every step); by default "
                     "the loop reads them one step late, the way train_util's loops do, and the per-step figure is reported beside it")
     args = ap.parse_args()
@@ -166,6 +169,14 @@ def main():
         ms = timed(step, args.steps, args.warmup)
         ms_sync = None if args.sync_each_step else timed(lambda: det.train_on_batch([x, rois], [yc, yb]), args.steps, 2)
         report("det_step2", ms, det._trainer.params, ms_sync, step)
+    if args.through_loop and world == 1:
+        import bench
+        for tag in ("rpn_step1", "det_step2"):
+            if tag in out:
+                fast = bench.train_loop_leg(tag, DT, iterations=max(32, args.steps), fast=True, height=H, width=W)
+                host = bench.train_loop_leg(tag, DT, iterations=12, warm=4, fast=False, height=H, width=W)
+                fast["bare_step_over_loop_iteration"] = round(out[tag]["ms_per_step"] / fast["ms_per_iteration"], 3)
+                out[tag]["through_loop"] = {"fast_feed": fast, "host_feed": host}
     # flat keys kept for the round-1 readers of this line
     for tag, short in (("rpn_step1", "rpn_step1"), ("det_step2", "det_step2")):
         if tag in out:
