@@ -16,6 +16,7 @@ class FrcnnError(RuntimeError):
     pass
 
 
+ABI_VERSION = 102       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
 P = c_void_p
 I = c_int
 # name -> (restype, argtypes).  Must list every symbol include/frcnn_hip.h declares
@@ -65,6 +66,7 @@ SIGNATURES = {
     "frcnn_conv2d_x6_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_fwd_x6": (I, [P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_conv2d_fwd_dual_x6": (I, [P, P, P, P, P, P, I, I, P, I, P]),
+    "frcnn_conv2d_engine": (I, [P, I, I]),
     "frcnn_conv_h3_planes_bytes": (c_size_t, [I, I]),
     "frcnn_pack_conv_weights_h3": (I, [P, I, I, P, P]),
     "frcnn_amax_record_floats": (I, []),
@@ -178,6 +180,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
+    if lib.frcnn_version() != ABI_VERSION:
+        raise FrcnnError(f"{LIB_PATH} speaks ABI revision {lib.frcnn_version()}, this binding {ABI_VERSION} (include/frcnn_hip.h "
+                         "FRCNN_ABI_VERSION): rebuild with `python -m faster_rcnn_amd.build`")
     _lib = lib
     return lib
 

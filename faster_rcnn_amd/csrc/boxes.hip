@@ -324,7 +324,7 @@ int frcnn_resize_cubic_u8(const uint8_t* src_hwc, int src_h, int src_w, const in
 }
 
 const char* frcnn_last_error(void) { return g_err; }
-int frcnn_version(void) { return 100; }
+int frcnn_version(void) { return FRCNN_ABI_VERSION; }
 int frcnn_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

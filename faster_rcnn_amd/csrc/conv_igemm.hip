@@ -2139,6 +2139,30 @@ size_t frcnn_conv2d_x6_workspace_bytes(const frcnn_conv_desc* d) {
     return SPLITK_TICKET_BYTES + tiles * splits * edge * edge * sizeof(float);
 }
 
+// ---- which matrix path a forward launch of this descriptor should take: the measured policy, for hosts in any language.
+// prefer: FRCNN_ENGINE_X6 / FRCNN_ENGINE_H3 = the split engine the caller has filter planes for (FRCNN_ENGINE_NATIVE: always native).
+// An explicit tile code picks its engine (71..78: bf16x6, 81..88: f16x3).  Otherwise a split engine takes launches with cin % 32 == 0,
+// at most 32 taps, >= 64 output columns and >= 256 output tiles of 64x64 (MI355X, configs[1] shapes, each launch alone on the chip:
+// scripts/conv_shapes.py -- the head's 14 700-row GEMMs 236 / 148 / 115 us on f16x3, 352 / 208 / 166 on bf16x6, 531 / 282 / 267 native;
+// almost every trunk layer wins by 5-15 %); smaller grids stay on the native split-K launches unless the engine's own split-K form
+// applies (>= 128 columns, a workspace at hand: rpn_conv1, stage 4's 3x3).
+enum { ENGINE_MIN_TILES = 256, ENGINE_MIN_COUT = 64 };
+
+int frcnn_conv2d_engine(const frcnn_conv_desc* d, int prefer, int workspace_present) {
+    if (!d) return fail(FRCNN_E_ARG, "conv2d_engine: null descriptor");
+    if (prefer != ENGINE_NATIVE && prefer != ENGINE_X6 && prefer != ENGINE_H3) return fail(FRCNN_E_ARG, "conv2d_engine: unknown engine %d", prefer);
+    const int t = d->tile % 100;
+    const bool splittable = d->cin > 0 && (d->cin % BK) == 0;
+    if (t >= 71 && t <= 78) return splittable ? ENGINE_X6 : ENGINE_NATIVE;
+    if (t >= 81 && t <= 88) return splittable ? ENGINE_H3 : ENGINE_NATIVE;
+    if (prefer == ENGINE_NATIVE || (t != 0 && t != 50)) return ENGINE_NATIVE;
+    if (!splittable || d->cout < ENGINE_MIN_COUT || d->kh * d->kw > 32) return ENGINE_NATIVE;
+    const long long M = (long long)d->n * d->ho * d->wo;
+    if (((M + 63) / 64) * ((d->cout + 63) / 64) >= ENGINE_MIN_TILES) return prefer;
+    const size_t need = prefer == ENGINE_X6 ? frcnn_conv2d_x6_workspace_bytes(d) : frcnn_conv2d_h3_workspace_bytes(d);
+    return (d->cout >= 128 && workspace_present && need > 0) ? prefer : ENGINE_NATIVE;
+}
+
 int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16,
                         const float* scale, const float* shift, const float* residual, const float* mask, float* y,
                         void* workspace, size_t workspace_bytes, void* stream) {

@@ -72,6 +72,20 @@ class _Slot:
                  "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed", "amax")
 
 
+def _close_slot(s):
+    """Release a captured pass NOW, from the thread that owns it: the hipGraph is destroyed here (torch.cuda.CUDAGraph.reset) and the
+    references to its tensors are dropped, so that nothing is left for a garbage-collector finalizer to do later from whatever thread
+    happens to collect (a finalizer issuing HIP calls inside another capture crashed a launch).  Idle slots only."""
+    assert not s.busy, "closing a captured pass with an image in flight"
+    if getattr(s, "graph", None) is not None:
+        s.event.synchronize()                            # its last replay (and the copies behind it) are done
+        s.graph.reset()
+    if getattr(s, "pipe", None) is not None and hasattr(s.pipe, "close"):
+        s.pipe.close()
+    for name in ("graph", "out", "out_packed", "io_dev", "x_f32", "u8_resized", "tabs", "ws", "amax", "pipe"):
+        setattr(s, name, None)
+
+
 class GraphCache:
     """Captured passes by image size, least-recently-used first out under a byte budget.  ``acquire(key, make)`` hands out
     an idle slot of that size or captures a new one; busy slots (an image in flight) are never evicted."""
@@ -118,16 +132,21 @@ class GraphCache:
                 slots.remove(s)
                 self.nbytes -= s.nbytes
                 self.evictions += 1
+                _close_slot(s)
                 dropped = True
             if not slots:
                 del self._slots[key]
             if self.nbytes <= self.byte_budget:
                 break
         if dropped:
+            s = slots = None                             # (the loop variables still hold the last slot examined: its pool must be free to go)
             torch.cuda.empty_cache()                     # a dropped graph's private pool goes back to the device
 
     def clear(self):
         assert not any(s.busy for v in self._slots.values() for s in v), "graph cache cleared with images in flight"
+        for v in self._slots.values():
+            for s in v:
+                _close_slot(s)
         self._slots.clear()
         self.nbytes = 0
         torch.cuda.empty_cache()
@@ -349,19 +368,21 @@ class DetectionEntry:
     def collect_batch(self, ticket):
         """-> [(num_rois, dets)] for the images of a ``submit_batch`` ticket."""
         s = ticket.slot
-        s.event.synchronize()
-        rev = self.rev_class_mapping
-        res = []
-        for i in range(len(ticket.image)):
-            packed = s.out_pin[i].numpy()
-            nd, n_rois = int(packed[0]), int(packed[1])
-            rows = (packed.size - 4) // 7
-            bbox = packed[4:4 + 4 * nd].reshape(nd, 4).astype(np.int64)
-            cls = packed[4 + 4 * rows:4 + 4 * rows + nd].copy()
-            prob = packed[4 + 5 * rows:4 + 5 * rows + nd].view(np.float32).copy()
-            res.append((n_rois, [{"bbox": bbox[k], "cls_name": rev[int(cls[k])], "prob": prob[k]} for k in range(nd)]))
-        s.busy = False
-        return res
+        try:
+            s.event.synchronize()
+            rev = self.rev_class_mapping
+            res = []
+            for i in range(len(ticket.image)):
+                packed = s.out_pin[i].numpy()
+                nd, n_rois = int(packed[0]), int(packed[1])
+                rows = (packed.size - 4) // 7
+                bbox = packed[4:4 + 4 * nd].reshape(nd, 4).astype(np.int64)
+                cls = packed[4 + 4 * rows:4 + 4 * rows + nd].copy()
+                prob = packed[4 + 5 * rows:4 + 5 * rows + nd].view(np.float32).copy()
+                res.append((n_rois, [{"bbox": bbox[k], "cls_name": rev[int(cls[k])], "prob": prob[k]} for k in range(nd)]))
+            return res
+        finally:
+            s.busy = False                               # whatever happened while decoding the records: the slot is free again (ADVICE r4)
 
     def collect(self, ticket):
         return self.collect_batch(ticket)[0]

@@ -393,24 +393,31 @@ class f32_engine:
         F32_ENGINE = self.prev
 
 
+_ENGINE_CODE = {"native": 0, "bf16x6": 1, "f16x3": 2}
+_ENGINE_TAG = {0: None, 1: "x6", 2: "h3"}
+
+
 def _split_engine(d, pc, tile):
     """Which split engine a forward launch takes: "x6" (bf16, six products), "h3" (fp16, three products) or None (native).
-    Explicit tile codes 71..78 / 81..88 pick the engine; otherwise ``F32_ENGINE`` and the size policy below decide (the same
-    policy for both engines: the launches where a split engine measures faster than the native kernels)."""
-    if 71 <= tile % 100 <= 78:
-        return "x6" if pc.cin % 32 == 0 else None                # explicit tile code of the split-bf16 engine
-    if 81 <= tile % 100 <= 88:
-        return "h3" if pc.cin % 32 == 0 else None
-    if F32_ENGINE == "native" or tile % 100 not in (0, 50):
-        return None
-    eng = "x6" if F32_ENGINE == "bf16x6" else "h3"
-    if pc.cin % 32 or pc.cout < X6_MIN_COUT or pc.kh * pc.kw > 32:
-        return None
-    if -(-(d.n * d.ho * d.wo) // 64) * -(-pc.cout // 64) >= X6_MIN_TILES:
-        return eng
-    # small grids with a long k loop (rpn_conv1, stage 4's 3x3): the engine's split-K form, where split-K launches are allowed
-    ok = pc.cout >= 128 and _CONV_WS is not NO_SPLIT_K and _ws_need(d, "frcnn_conv2d_%s_workspace_bytes" % eng) > 0
-    return eng if ok else None
+    The policy itself lives in the library (frcnn_conv2d_engine: explicit tile codes 71..78 / 81..88 pick their engine, otherwise
+    the engine of the ``F32_ENGINE`` scope takes the launches where it measures faster -- >= X6_MIN_TILES output tiles of 64x64
+    and >= X6_MIN_COUT columns, or its split-K form when split-K launches are allowed), so a host in another language gets the
+    same choices; memoised on the cached descriptor."""
+    key = ("engine", F32_ENGINE, _CONV_WS is not NO_SPLIT_K)
+    memo = getattr(d, "_ws", None)
+    if memo is not None and d.tile == tile and d.cout == pc.cout and d.cin == pc.cin:
+        got = memo.get(key)
+        if got is None:
+            got = memo[key] = _lib.load().frcnn_conv2d_engine(ctypes.byref(d), _ENGINE_CODE[F32_ENGINE], 1 if key[2] else 0)
+            if got < 0:
+                _lib.check(got, "frcnn_conv2d_engine")
+        return _ENGINE_TAG[got]
+    q = _lib.ConvDesc.from_buffer_copy(d)                     # (a caller asking about another tile code / filter than the descriptor's)
+    q.tile, q.cin, q.cout = tile, pc.cin, pc.cout
+    got = _lib.load().frcnn_conv2d_engine(ctypes.byref(q), _ENGINE_CODE[F32_ENGINE], 1 if key[2] else 0)
+    if got < 0:
+        _lib.check(got, "frcnn_conv2d_engine")
+    return _ENGINE_TAG[got]
 
 
 def _use_x6(d, pc, tile):

@@ -99,6 +99,16 @@ class InferencePipeline:
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
 
+    def close(self):
+        """Destroy the captured graph and drop its tensors NOW, in the calling thread (after the last replay has finished): nothing
+        is left for a finalizer to release from a collecting thread later.  The pipeline can be captured again."""
+        g = getattr(self, "_graph", None)
+        if g is not None:
+            torch.cuda.synchronize()
+            g.reset()
+        self._graph = None
+        self._static_in = self._static_out = self._conv_ws = self._amax = None
+
     def replay_u8(self, img_u8_bgr, mean_bgr=(103.939, 116.779, 123.68)):
         """Replay on a raw (H,W,3) uint8 BGR image: 3 bytes per pixel cross PCIe, resnet.preprocess runs on the device
         (bit-identical to the host path) straight into the graph's input tensor."""

@@ -71,9 +71,8 @@ class RpnTrainingManager:
             gt = get_bbox_coords(image.gt_boxes)
             can_use, is_pos, bbreg, _ = ops.rpn_assign(conv_rows, conv_cols, self.anchor_dims, self.stride, gt, image.width, image.height)
             pos_locs, neg_locs, counts = ops.rpn_sample_lists(can_use, is_pos)
-            counts_host = torch.empty(2, dtype=torch.int32).pin_memory()
+            counts_host, ev = feed.ring().host_slot((2,), torch.int32)
             counts_host.copy_(counts, non_blocking=True)
-            ev = torch.cuda.Event()
             ev.record()
         dev[image.cache_key] = (x, can_use, is_pos, bbreg, pos_locs, neg_locs, counts_host, ev, conv_rows * conv_cols)
 
@@ -87,7 +86,7 @@ class RpnTrainingManager:
         num_pos, num_neg = (int(v) for v in counts_host.tolist())
         off_pos, off_neg = _sample_off(num_pos, num_neg)           # the reference's two draws, in its order (rpn_util.py:336-348)
         with torch.cuda.stream(self._own_stream()):
-            up = lambda a: None if a is None else torch.from_numpy(a).cuda()
+            up = lambda a: None if a is None else feed.upload(a)
             yc, yb = ops.rpn_pack_targets(can_use, is_pos, bbreg, cells, len(self.anchor_dims), pos_locs, num_pos, up(off_pos), neg_locs, num_neg, up(off_neg))
             return feed.Ready.mark(x, yc, yb)
 

@@ -105,8 +105,12 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
     window = collections.deque()
 
     def finish():
-        group, ticket = window.popleft()
-        for (image, start_time), (num_boxes, dets) in zip(group, eng.collect_batch(ticket)):
+        group, ticket = window[0]                            # (taken off the window only once collected: a failing collect leaves no
+        try:                                                 #  ticket behind that nobody can see)
+            results = eng.collect_batch(ticket)
+        finally:
+            window.popleft()
+        for (image, start_time), (num_boxes, dets) in zip(group, results):
             print("num rois: {}".format(num_boxes))
             fold(image, dets, start_time)
 

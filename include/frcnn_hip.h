@@ -38,6 +38,10 @@ extern "C" {
 #define FRCNN_NMS_MAX_BOXES 12288   /* pre-NMS candidates one frcnn_nms_* call accepts */
 
 const char* frcnn_last_error(void);
+/* The ABI revision this header describes; frcnn_version() returns the library's.  A host built against another revision must not
+ * call into the library (the Python mirror checks at load): 100 = rounds 1-3; 101 = frcnn_detections takes det_threshold as a double
+ * (round 4); 102 = the f16x3 conv engine, magnitude records, frcnn_conv2d_engine, the RPN sampling entry points (round 5). */
+#define FRCNN_ABI_VERSION 102
 int frcnn_version(void);
 /* number of HIP devices visible; does not initialise a context */
 int frcnn_device_count(void);
@@ -304,6 +308,17 @@ int frcnn_conv2d_fwd_x6(const frcnn_conv_desc* d, const float* x, const void* w_
                         void* workspace, size_t workspace_bytes, void* stream);
 int frcnn_conv2d_fwd_dual_x6(const frcnn_conv_desc* d, const float* x, const void* w_planes_bf16, const float* scale, const float* shift,
                              float* y1, int n1, int act1, float* y2, int act2, void* stream);
+/* ---- which fp32 matrix path a forward launch should take (the policy behind the Python mirror's ops.f32_engine scope, for hosts in
+ * any language).  prefer: the split engine the caller holds filter planes for; returns FRCNN_ENGINE_NATIVE (frcnn_conv2d_fwd_ws),
+ * FRCNN_ENGINE_X6 (frcnn_conv2d_fwd_x6) or FRCNN_ENGINE_H3 (frcnn_conv2d_fwd_h3) for THIS descriptor: the split engines take the
+ * launches where they measure faster than the native kernels on MI355X (cin % 32 == 0, <= 32 taps, >= 64 columns, >= 256 output tiles
+ * of 64x64; or >= 128 columns with a split-K workspace at hand when the engine's own split-K form applies); an explicit tile code in
+ * d->tile (71..78 / 81..88) picks its engine.  Negative on a bad argument. */
+#define FRCNN_ENGINE_NATIVE 0
+#define FRCNN_ENGINE_X6 1
+#define FRCNN_ENGINE_H3 2
+int frcnn_conv2d_engine(const frcnn_conv_desc* d, int prefer, int workspace_present);
+
 /* ---- fp32 convolution on the fp16 matrix cores by a TWO-way operand split with a scaled low part ("f16x3", csrc/conv_h3.hip).
  * Same operation, operands, layouts and epilogue as frcnn_conv2d_fwd_x6 (resnet.py:150-176, 218-247, 508-533: Conv2D +
  * BatchNormalization(training=False) [+ Scale] [+ add] + Activation), f32 activations in and out.  Each operand tensor is scaled by

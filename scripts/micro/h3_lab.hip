@@ -38,6 +38,27 @@ constexpr int ROWB = 64;              // LDS bytes per row per plane; 16-byte sl
 __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 constexpr unsigned OOB = 0x80000000u;
 
+// The same split on the mixed-precision FMA instructions (VOP3P v_fma_mix*: each source f32 or f16, result f32 or one f16 half):
+//   ah = f16(a * s + 0)  [mixlo / mixhi: the product is exact, ONE rounding],  r = a * s - ah  [mix_f32, exact],  al = f16(r * 2048 + 0)
+// three full-rate instructions per element, no packed-f32 multiply (half rate beside MFMAs) and no separate conversions.
+__device__ __forceinline__ void split2_mix(const f32x4 v, float s, f16x4& h, f16x4& l) {
+    const float k2048 = 2048.0f;
+    unsigned hh[2], ll[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float r0, r1;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh[q]) : "v"(v[2 * q]), "s"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh[q]) : "v"(v[2 * q + 1]), "s"(s));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v[2 * q]), "s"(s), "v"(hh[q]));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v[2 * q + 1]), "s"(s), "v"(hh[q]));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(ll[q]) : "v"(r0), "s"(k2048));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(ll[q]) : "v"(r1), "s"(k2048));
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    h = __builtin_bit_cast(f16x4, (u32x2){hh[0], hh[1]});
+    l = __builtin_bit_cast(f16x4, (u32x2){ll[0], ll[1]});
+}
+
 __device__ __forceinline__ void split2(const f32x4 v, float s, f16x4& h, f16x4& l) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -120,8 +141,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_h3(const Args p) {
                 if constexpr (SKIP & 1) {                    // ladder: no split arithmetic (the same bytes stored)
                     h = __builtin_bit_cast(f16x4, __builtin_shufflevector(ra[S][i], ra[S][i], 0, 1));
                     l = __builtin_bit_cast(f16x4, __builtin_shufflevector(ra[S][i], ra[S][i], 2, 3));
-                } else
-                split2(ra[S][i], sA, h, l);
+                } else if constexpr (SKIP & 64) split2_mix(ra[S][i], sA, h, l);
+                else split2(ra[S][i], sA, h, l);
                 *reinterpret_cast<f16x4*>(base + a_lds[i]) = h;
                 *reinterpret_cast<f16x4*>(base + BM * ROWB + a_lds[i]) = l;
             }
@@ -355,6 +376,7 @@ static void accuracy() {
             run<2, 1, 2, 4, 4, 0, 0>(a, 0, ""); report("f16x4 (+ al*bl)");
             run<2, 1, 4, 4, 3, 1, 0>(a, 0, ""); report("f16x3, 16 waves double buffer");
             run<2, 1, 2, 4, 3, 0, 1>(a, 0, ""); report("f16x3, A planes from memory");
+            run<2, 1, 4, 4, 3, 1, 0, 64>(a, 0, ""); report("f16x3, split on v_fma_mix*");
             CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC)); CHECK(hipFree(dAp)); CHECK(hipFree(dBp));
         }
 }
@@ -382,6 +404,9 @@ static void rate() {
         const int R = 10;
         run<2, 1, 2, 4, 3, 0, 0>(a, R, "128x128 8w (64x32/wave), 1 buf, loads 2 ahead");
         run<2, 1, 4, 4, 3, 1, 0>(a, R, "256x128 16w, LDS double buffer");
+        run<2, 1, 4, 4, 3, 1, 0, 64>(a, R, "256x128 16w, LDS double buffer, fma_mix split");
+        run<2, 2, 4, 2, 3, 1, 0, 64>(a, R, "256x128 8w (64x64/wave) dbuf, fma_mix split");
+        run<1, 1, 2, 2, 3, 0, 0, 64>(a, R, "64x64 4w, 1 buf, fma_mix split");
         run<2, 2, 2, 2, 3, 0, 0>(a, R, "128x128 4w (64x64/wave), 1 buf");
         run<2, 2, 2, 2, 3, 1, 0>(a, R, "128x128 4w (64x64/wave), double buffer");
         run<2, 2, 4, 2, 3, 1, 0>(a, R, "256x128 8w (64x64/wave), double buffer");

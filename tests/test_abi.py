@@ -32,7 +32,8 @@ def test_library_exports_every_symbol():
     for name in header_symbols():
         assert hasattr(lib, name), name
     loaded = _lib.load()
-    assert loaded.frcnn_version() >= 100
+    hdr = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    assert loaded.frcnn_version() == _lib.ABI_VERSION == int(re.search(r"#define FRCNN_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_header_cites_reference_lines():

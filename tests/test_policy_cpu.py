@@ -71,3 +71,28 @@ def test_engine_policy_for_the_layers_of_configs1():
     d = ops._conv_desc((300, 7, 7, 512), 3, 3, 512, 1, "same", 0, 0, 0)
     assert not ops._use_x6(d, pc(3, 512, 512), 0)                          # the library default stays native
     assert ops._use_x6(d, pc(3, 512, 512), 76) and not ops._use_x6(d, pc(3, 48, 512), 76)      # an explicit tile code; never with cin % 32 != 0
+
+
+def test_engine_policy_is_the_librarys_and_serves_both_split_engines():
+    """frcnn_conv2d_engine: the policy lives behind the C ABI -- the Python scope only names the preferred engine.
+    Same answers for the f16x3 engine as for bf16x6 on the layers of configs[1]; explicit tile codes pick their engine."""
+    import ctypes
+    from faster_rcnn_amd import _lib, ops
+    lib = _lib.load()
+    q = lambda shape, k, cout, prefer, ws, stride=1, padding="same", tile=0: lib.frcnn_conv2d_engine(
+        ctypes.byref(ops._conv_desc(shape, k, k, cout, stride, padding, 0, 0, tile)), prefer, ws)
+    for prefer in (1, 2):
+        assert q((1, 149, 249, 64), 3, 64, prefer, 1) == prefer                    # stage 2 3x3
+        assert q((1, 38, 63, 1024), 1, 256, prefer, 1, padding="valid") == 0       # stage 4 2a: small grid, short k
+        assert q((1, 38, 63, 256), 3, 256, prefer, 1) == prefer and q((1, 38, 63, 256), 3, 256, prefer, 0) == 0     # only as split-K
+        assert q((1, 38, 63, 512), 1, 36, prefer, 1, padding="valid") == 0         # under 64 columns
+        assert q((1, 600, 1000, 3), 7, 64, prefer, 1, stride=2) == 0               # the stem
+    assert q((300, 7, 7, 512), 3, 512, 0, 1) == 0                                  # prefer native: native
+    assert q((300, 7, 7, 512), 3, 512, 0, 1, tile=76) == 1 and q((300, 7, 7, 512), 3, 512, 0, 1, tile=86) == 2
+    assert q((300, 7, 7, 512), 3, 512, 2, 1, tile=21) == 0                         # an explicit native tile code stays native
+    assert lib.frcnn_conv2d_engine(None, 1, 1) < 0 and q((300, 7, 7, 512), 3, 512, 7, 1) < 0
+    pc = lambda k, cin, cout: type("PC", (), {"kh": k, "kw": k, "cin": cin, "cout": cout})()
+    with ops.f32_engine("f16x3"):
+        d = ops._conv_desc((300, 7, 7, 512), 3, 3, 512, 1, "same", 0, 0, 0)
+        assert ops._split_engine(d, pc(3, 512, 512), 0) == "h3" and not ops._use_x6(d, pc(3, 512, 512), 0)
+    assert (ops.X6_MIN_TILES, ops.X6_MIN_COUT) == (256, 64)                        # the constants bench.py prints are the library's

@@ -40,7 +40,7 @@ def test_rpn_inputs_dev_equal_the_host_feed(case):
     if case == "resized":
         imgs = frames(2, 320, 448, seed=3, src=(200, 280))
     elif case == "many_positives":
-        imgs = frames(2, 480, 640, seed=4, boxes=40)             # > 128 usable positives: the first draw happens too
+        imgs = frames(2, 480, 640, seed=4, boxes=260)            # > 128 usable positives (every box makes its best anchor one): the first draw happens too
     else:
         imgs = frames(2, 320, 448, seed=5)
     if case == "flipped":

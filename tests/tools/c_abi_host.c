@@ -5,6 +5,8 @@
  *   rpn_util._get_all_anchor_coords (rpn_util.py:276-298)   frcnn_anchors_image
  *   util.cross_ious (util.py:146-177)                        frcnn_cross_ious_f32
  *   det_util.nms (det_util.py:209-256)                       frcnn_nms_f64
+ *   one Conv2D + folded BatchNorm + ReLU group (resnet.py:150-176) on the matrix path the library's own policy names
+ *   (frcnn_conv2d_engine -> frcnn_pack_conv_weights_h3, frcnn_amax_f32, frcnn_conv2d_fwd_h3), against a double-precision loop
  * Build (tests/test_abi_host_gpu.py does it):  gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/tools/c_abi_host.c
  *        -Lfaster_rcnn_amd -lfrcnn_hip -L/opt/rocm/lib -lamdhip64 -lm -o c_abi_host
  * Exit code 0 = every check passed. */
@@ -97,6 +99,56 @@ int main(void) {
     }
     if (n_keep != nw) { printf("nms kept %d, expected %d\n", n_keep, nw); ++fails; }
     for (int k = 0; k < nw && k < n_keep; ++k) if (keep[k] != want_keep[k]) { if (fails < 5) printf("nms pick %d: %d vs %d\n", k, keep[k], want_keep[k]); ++fails; }
+
+    /* ---- one 1x1 convolution + per-channel scale / shift + ReLU over 12 288 pixels (64 -> 128 channels): the engine the POLICY picks
+     * for a host that holds f16x3 planes, its filter planes, the input's magnitude record, the launch; y against a double loop */
+    {
+        const int cn = 1, ch = 96, cw = 128, cin = 64, cout = 128, M = cn * ch * cw;
+        frcnn_conv_desc d;
+        memset(&d, 0, sizeof d);
+        d.n = cn; d.h = ch; d.w = cw; d.cin = cin; d.cout = cout; d.kh = d.kw = 1; d.stride = 1; d.ho = ch; d.wo = cw; d.act = FRCNN_ACT_RELU;
+        const int engine = frcnn_conv2d_engine(&d, FRCNN_ENGINE_H3, 0);
+        if (engine != FRCNN_ENGINE_H3) { printf("policy: engine %d for a 12 288 x 128 launch, expected f16x3\n", engine); ++fails; }
+        frcnn_conv_desc small = d; small.h = 16; small.w = 16; small.ho = 16; small.wo = 16;
+        if (frcnn_conv2d_engine(&small, FRCNN_ENGINE_H3, 0) != FRCNN_ENGINE_NATIVE || frcnn_conv2d_engine(&d, FRCNN_ENGINE_NATIVE, 1) != FRCNN_ENGINE_NATIVE
+            || frcnn_conv2d_engine(&d, FRCNN_ENGINE_X6, 0) != FRCNN_ENGINE_X6 || frcnn_conv2d_engine(NULL, 0, 0) >= 0) { printf("policy: small grid / native / x6 answers differ\n"); ++fails; }
+        const int kp = frcnn_conv_packed_k(1, 1, cin);
+        float* x = (float*)malloc((size_t)M * cin * 4); float* wv = (float*)malloc((size_t)cin * cout * 4);
+        float sc[128], sh[128];
+        for (int i = 0; i < M * cin; ++i) x[i] = ((int)(rnd() % 2001) - 1000) * 1e-3f;
+        for (int i = 0; i < cin * cout; ++i) wv[i] = ((int)(rnd() % 2001) - 1000) * 1e-4f;          /* HWIO: [cin][cout] for 1x1 */
+        for (int c = 0; c < cout; ++c) { sc[c] = 1.f + (int)(rnd() % 100) * 1e-3f; sh[c] = ((int)(rnd() % 200) - 100) * 1e-3f; }
+        float *dx, *dw, *dpk, *dsc, *dsh, *dy, *drec; void* dplanes;
+        const size_t rec_bytes = (size_t)frcnn_amax_record_floats() * 4;
+        CHECK_HIP(hipMalloc((void**)&dx, (size_t)M * cin * 4)); CHECK_HIP(hipMalloc((void**)&dw, (size_t)cin * cout * 4)); CHECK_HIP(hipMalloc((void**)&dpk, (size_t)cout * kp * 4));
+        CHECK_HIP(hipMalloc((void**)&dsc, cout * 4)); CHECK_HIP(hipMalloc((void**)&dsh, cout * 4)); CHECK_HIP(hipMalloc((void**)&dy, (size_t)M * cout * 4));
+        CHECK_HIP(hipMalloc((void**)&drec, 2 * rec_bytes)); CHECK_HIP(hipMalloc(&dplanes, frcnn_conv_h3_planes_bytes(cout, kp)));
+        CHECK_HIP(hipMemcpyAsync(dx, x, (size_t)M * cin * 4, hipMemcpyHostToDevice, stream)); CHECK_HIP(hipMemcpyAsync(dw, wv, (size_t)cin * cout * 4, hipMemcpyHostToDevice, stream));
+        CHECK_HIP(hipMemcpyAsync(dsc, sc, cout * 4, hipMemcpyHostToDevice, stream)); CHECK_HIP(hipMemcpyAsync(dsh, sh, cout * 4, hipMemcpyHostToDevice, stream));
+        CHECK_FR(frcnn_pack_conv_weights(dw, 1, 1, cin, cout, dpk, stream));
+        CHECK_FR(frcnn_pack_conv_weights_h3(dpk, cout, kp, dplanes, stream));
+        CHECK_FR(frcnn_amax_clear(drec, 2, stream));
+        CHECK_FR(frcnn_amax_f32(dx, (size_t)M * cin, drec, stream));
+        float* y_rec = drec + frcnn_amax_record_floats();
+        CHECK_FR(frcnn_conv2d_fwd_h3(&d, dx, drec, dplanes, dsc, dsh, NULL, NULL, dy, y_rec, NULL, 0, stream));
+        float* y = (float*)malloc((size_t)M * cout * 4); float* rec = (float*)malloc(rec_bytes);
+        CHECK_HIP(hipMemcpyAsync(y, dy, (size_t)M * cout * 4, hipMemcpyDeviceToHost, stream)); CHECK_HIP(hipMemcpyAsync(rec, y_rec, rec_bytes, hipMemcpyDeviceToHost, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        double worst = 0; float ymax = 0, recmax = 0;
+        for (int m = 0; m < M; m += 7) for (int c = 0; c < cout; ++c) {                                  /* every seventh pixel */
+            double acc = 0, mag = 0;
+            for (int k = 0; k < cin; ++k) { const double t = (double)x[(size_t)m * cin + k] * wv[(size_t)k * cout + c]; acc += t; mag += fabs(t); }
+            double want = acc * sc[c] + sh[c]; if (want < 0) want = 0;
+            const double e = fabs(y[(size_t)m * cout + c] - want) / (mag * fabs(sc[c]) + 1e-30);
+            if (e > worst) worst = e;
+        }
+        for (size_t i = 0; i < (size_t)M * cout; ++i) if (y[i] > ymax) ymax = y[i];
+        for (int i = 0; i < frcnn_amax_record_floats(); ++i) if (rec[i] > recmax) recmax = rec[i];
+        if (worst > 4e-7) { printf("conv (f16x3): error %.3g of sum|ab|\n", worst); ++fails; }
+        if (recmax != ymax) { printf("conv (f16x3): record holds %.9g, max|y| is %.9g\n", recmax, ymax); ++fails; }
+        if (frcnn_conv2d_fwd_h3(&d, dx, NULL, dplanes, dsc, dsh, NULL, NULL, dy, NULL, NULL, 0, stream) == FRCNN_OK) { printf("conv (f16x3): a launch without a magnitude record was accepted\n"); ++fails; }
+        printf("c_abi_host: conv 12288x128x64 on the f16x3 engine, max error %.3g of sum|ab|\n", worst);
+    }
 
     /* ---- error path: a refused call leaves a message and no exception */
     if (frcnn_nms_f64(NULL, d_n, K, thresh, max_boxes, d_keep, d_nkeep, d_ws, ws_bytes, stream) == FRCNN_OK || !frcnn_last_error()[0]) { printf("null boxes accepted\n"); ++fails; }
