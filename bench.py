@@ -655,11 +655,14 @@ def train_loop_images(n_images, height, width, seed=900):
     return imgs
 
 
-def train_loop_leg(kind, dtype="f32", n_images=32, iterations=64, warm=24, fast=True, height=None, width=None):
+def train_loop_leg(kind, dtype="f32", n_images=32, iterations=64, warm=64, fast=True, height=None, width=None):
     """ms per ITERATION of the reference's own training loops (train_util.train_rpn / train_detector_step2,
     train_util.py:37-54, 100-118) over `n_images` distinct images -- image fetch, targets / proposals, sampling, the step, the
     loss line -- beside the bare train_on_batch step bench_train.py times on one pre-staged input.  `fast`: the managers'
-    device-resident feed (train_util.FAST_FEED); False: batched_image / rpn_y_true / get_training_input as host numpy."""
+    device-resident feed (train_util.FAST_FEED); False: batched_image / rpn_y_true / get_training_input as host numpy.
+    `warm` untimed iterations first (two walks over the image list by default: allocator pools of three streams, pinned staging
+    areas and kernel images are first-use costs -- with 24 warm iterations the timed RPN loop read 2.7 ms per iteration, 2.03 once
+    warm, scripts/dev/loop_profile.py)."""
     import contextlib
     import io
     import random

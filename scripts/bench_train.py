@@ -174,7 +174,7 @@ def main():
         for tag in ("rpn_step1", "det_step2"):
             if tag in out:
                 fast = bench.train_loop_leg(tag, DT, iterations=max(32, args.steps), fast=True, height=H, width=W)
-                host = bench.train_loop_leg(tag, DT, iterations=12, warm=4, fast=False, height=H, width=W)
+                host = bench.train_loop_leg(tag, DT, iterations=12, warm=6, fast=False, height=H, width=W)
                 fast["bare_step_over_loop_iteration"] = round(out[tag]["ms_per_step"] / fast["ms_per_iteration"], 3)
                 out[tag]["through_loop"] = {"fast_feed": fast, "host_feed": host}
     # flat keys kept for the round-1 readers of this line

@@ -63,9 +63,12 @@ def test_rpn_inputs_dev_equal_the_host_feed(case):
         assert np.array_equal(yc_d.cpu().numpy().reshape(yc_h.shape), yc_h.astype(np.float32))
         assert np.array_equal(yb_d.cpu().numpy().reshape(yb_h.shape), yb_h.astype(np.float32))
         n_pos = int((yc_h[..., :A] & yc_h[..., A:]).sum())
-        assert int(yc_h[..., :A].sum()) == 256 and n_pos <= 128
+        used = int(yc_h[..., :A].sum())
+        assert used <= 256 and n_pos <= 128
         if case == "many_positives":
-            assert n_pos == 128, n_pos
+            assert n_pos == 128, n_pos                            # (260 boxes leave hardly an anchor under 0.3 IoU with all of them: few negatives)
+        else:
+            assert used == 256
         assert not dev_mgr._dev                                   # the entry is consumed, like the reference's cache (rpn_util.py:121-123)
 
 
