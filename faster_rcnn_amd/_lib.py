@@ -77,6 +77,7 @@ SIGNATURES = {
     "frcnn_conv2d_h3_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_fwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_conv2d_fwd_dual_h3": (I, [P, P, P, P, P, P, P, I, I, P, P, I, P, P]),
+    "frcnn_conv2d_fwd_h3_planes": (I, [P, P, P, P, P, P, P, P, P, P, P, P, ctypes.c_float, ctypes.c_float, P]),
     "frcnn_conv2d_fwd_ws_amax": (I, [P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_pack_conv_weights_dgrad": (I, [P, P, I, I, I, I, P, P]),
     "frcnn_conv2d_wgrad_workspace_bytes": (c_size_t, [P]),
@@ -152,6 +153,11 @@ class WgradJob(ctypes.Structure):
 class X6Job(ctypes.Structure):
     """frcnn_x6_job (include/frcnn_hip.h)."""
     _fields_ = [("w_packed", c_void_p), ("planes_bf16", c_void_p), ("rows", ctypes.c_int32), ("kpad", ctypes.c_int32)]
+
+
+class H3Planes(ctypes.Structure):
+    """frcnn_h3_planes (include/frcnn_hip.h)."""
+    _fields_ = [("planes", c_void_p), ("exponent", c_void_p)]
 
 
 class ColsumJob(ctypes.Structure):

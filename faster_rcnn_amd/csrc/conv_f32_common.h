@@ -35,6 +35,10 @@ struct ConvArgs {
     // it stores into y_amax (y2_amax: the second layer of a paired launch); the f16x3 engine (conv_h3.hip) reads x_amax -- an UPPER
     // BOUND of |x| -- to bring the activations into fp16's range by one power of two.
     const float* x_amax; float* y_amax; float* y2_amax;
+    // Activations as two fp16 planes (conv_h3.hip, the 256x128 forms): x_planes [2][rows][Cin] read INSTEAD of x, scaled by 2^*x_pexp;
+    // y_planes [2][M][Cout] written beside / instead of y under the scale 2^eY, eY from the bound bound_c * max|x| + bound_d
+    // (+ max|residual|, res_amax) that every workgroup derives from the same device words; *y_pexp = eY.
+    const void* x_planes; const int* x_pexp; void* y_planes; int* y_pexp; const float* res_amax; float bound_c, bound_d;
 };
 
 // ---- magnitude records.  A record is AMAX_SLOTS floats, one per 128-byte line: a launch has hundreds to thousands of waves and a
@@ -258,8 +262,11 @@ struct X6Tile {
 // The 16-byte epilogue of conv_f32_common.h (epilogue_vec: same arithmetic per element, same order) with the tile turned through
 // LDS one WAVE-ROW at a time: pass h stages the 32 TM rows owned by the waves with wm == h, every thread then owns 16-byte pieces
 // of whole rows (scale / shift / residual / mask / y as b128, out-of-range pieces on the buffer descriptors).
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh, float* smem) {
+// PLANES (conv_h3.hip): the tile also leaves as two fp16 planes under the scale y_scale (a power of two): ah = f16(v * s), al = f16((v * s - ah) * 2^11),
+// 8-byte pieces at [plane][row][column]; the f32 store is skipped when the launch has no f32 output.
+template <int TM, int TN, int WM, int WN, bool PLANES = false>
+__device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh, float* smem,
+                                                float y_scale = 1.0f) {
     constexpr int NT = 64 * WM * WN, BN = 32 * TN * WN, HB = 32 * TM, LD = BN + 4, C4 = BN / 4, RPP = NT / C4, PASSES = HB / RPP;
     static_assert(HB % RPP == 0 && NT % C4 == 0 && PASSES >= 1 && PASSES <= 8, "epilogue passes");
     const bool second = p.n_split && n0 >= p.n_split;       // two layers in one launch: the tile belongs to ONE of them (host guarantees it)
@@ -267,6 +274,7 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
     const int y_ld = second ? p.ldy2 : p.ldy, y_act = second ? p.act2 : p.act, y_n0 = second ? p.n_split : 0;
     const int y_cols = p.n_split ? (second ? p.Cout - p.n_split : p.n_split) : p.Cout;
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yb, 0, (int)((size_t)p.M * y_ld * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(PLANES ? p.y_planes : (void*)yb, 0, PLANES ? (int)((size_t)2 * p.M * p.Cout * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.residual ? p.residual : p.x), 0, p.residual ? (int)((size_t)p.M * p.ldres * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -318,8 +326,22 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
             const int ym = m0 + h * HB + q * RPP + prow, yn = n0 - y_n0 + pcol;
             const bool in = ym < p.M && yn < y_cols;
             const unsigned yoff = in ? (unsigned)(((size_t)ym * y_ld + yn) * 4) : OOB_OFFSET;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, yoff, 0, 0);
+            if (!PLANES || yb) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), yrsrc, yoff, 0, 0);
             if (in) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            if constexpr (PLANES) {
+                typedef _Float16 f16x4e __attribute__((ext_vector_type(4)));
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                f16x4e h, l;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float xs = v[c] * y_scale;
+                    const _Float16 a1 = (_Float16)xs;
+                    h[c] = a1; l[c] = (_Float16)((xs - (float)a1) * 2048.0f);
+                }
+                const unsigned poff = in ? (unsigned)(((size_t)ym * p.Cout + yn) * 2) : OOB_OFFSET;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, h), prsrc, poff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, l), prsrc, poff == OOB_OFFSET ? OOB_OFFSET : poff + (unsigned)((size_t)p.M * p.Cout * 2), 0, 0);
+            }
         }
     }
     if (float* rec = second ? p.y2_amax : p.y_amax) amax_publish(rec, vmax);

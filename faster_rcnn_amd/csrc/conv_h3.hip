@@ -355,10 +355,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3(const ConvArgs p
 // requested (k_conv_igemm_x6_db's loop).  <2,1,4,4>: sixteen waves of 64x32; <2,2,4,2>: eight waves of 64x64 (eight fragment reads
 // per twelve MFMAs instead of six per six).  Lab (scripts/micro/h3_lab.hip, the head's 3x3 / 512->2048 / 2048->512 GEMMs alone on
 // the chip): 246 / 127 / 104 us and 242 / 118 / 107 us against 345 / 172 / 160 for k_conv_igemm_x6_db on the same box.
-template <int TM, int TN, int WM, int WN>
+// APLANES: the activations arrive ALREADY split -- two fp16 planes [2][rows][Cin] a producing launch's epilogue wrote under the scale
+// 2^*x_pexp (ConvArgs.x_planes): 16-byte pieces go from memory to LDS unchanged, no conversion and no arithmetic in the loader (lab:
+// the head's 3x3 / 512 -> 2048 / 2048 -> 512 GEMMs 195 / 103 / 89 us against 246 / 127 / 104 with the split in the loader).
+template <int TM, int TN, int WM, int WN, bool APLANES = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArgs p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
-    constexpr int RPP = NT / 8, PA = BM / RPP;            // A: NT / 8 rows per pass
+    constexpr int RPP = APLANES ? NT / 4 : NT / 8, PA = APLANES ? (2 * BM) / RPP : BM / RPP;      // A: rows staged per pass (planes: 4 pieces of 16 B per row per plane)
     constexpr int NBP = 2 * BN * 4;                       // 16-byte pieces of the two filter planes per chunk
     constexpr int PBT = (NBP + NT - 1) / NT;
     constexpr int BUFB = 2 * (BM + BN) * X6_ROWB;
@@ -374,23 +377,30 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const size_t plane_bytes = (size_t)p.Cout * p.Kpad * 2;
     const char* wbase = reinterpret_cast<const char*>(p.w);
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x), 0, (int)((size_t)p.n_img * p.H * p.W * p.Cin * 4), 0x00020000);
+    const size_t x_elems = (size_t)p.n_img * p.H * p.W * p.Cin;
+    const __amdgpu_buffer_rsrc_t xrsrc = APLANES
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x_planes), 0, (int)(x_elems * 4), 0x00020000)      // two planes of 2 bytes
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(x_elems * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase + H3_HEADER_BYTES), 0, (int)(2 * plane_bytes), 0x00020000);
 
-    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    // f32 activations: a lane stages 4 channels (16 bytes of f32) of one row, 8 lanes per row; planes: 8 channels (16 bytes of fp16) of
+    // one row of one plane, 4 lanes per row, the second half of the passes takes the low plane
+    constexpr int ESZ = APLANES ? 2 : 4;
+    const int lrow = APLANES ? tid >> 2 : tid >> 3, lcol = APLANES ? (tid & 3) * 8 : (tid & 7) * 4;
     int a_h[PA], a_w[PA], a_off[PA], a_lds[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int row = lrow + RPP * i, m = m0 + row, g = tid & 7;
-        a_lds[i] = row * X6_ROWB + 16 * ((g >> 1) ^ x6_swz(row)) + 8 * (g & 1);
+        const int pl = APLANES ? (lrow + RPP * i) / BM : 0;
+        const int row = lrow + RPP * i - pl * BM, m = m0 + row;
+        if constexpr (APLANES) a_lds[i] = pl * BM * X6_ROWB + row * X6_ROWB + 16 * ((tid & 3) ^ x6_swz(row));
+        else { const int g = tid & 7; a_lds[i] = row * X6_ROWB + 16 * ((g >> 1) ^ x6_swz(row)) + 8 * (g & 1); }
         if (m < p.M) {
             int wo, ho, img;
             if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
             else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
             a_h[i] = ho * p.stride - p.pad_top;
             a_w[i] = wo * p.stride - p.pad_left;
-            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * 4;
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + lcol) * ESZ + (int)(pl * x_elems * 2);
         } else {
             a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
         }
@@ -415,7 +425,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     auto load_next = [&]() {
         const int tap = __builtin_ctz(rem);
         const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
-        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 4;
+        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * ESZ;
         const int w_off = w_grp + tap * (BK * 2);
 #pragma unroll
         for (int i = 0; i < PBT; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0));
@@ -432,17 +442,28 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
         w_grp += wrap * (RS * BK * 2);
     };
     load_next();                                          // chunk 0: in flight while the two scales are fetched
-    const int eA = h3_exponent(amax_read(p.x_amax));
+    const float x_max = amax_read(p.x_amax);
+    const int eA = APLANES ? *p.x_pexp : h3_exponent(x_max);
     const int eB = h3_exponent(*reinterpret_cast<const float*>(wbase));
     const float sA = h3_pow2(eA);
+    // the output's planes: |y| <= bound_c * max|x| + bound_d (+ max|residual|) whatever the data, so that bound's exponent cannot overflow
+    int eY = 0;
+    if (p.y_planes) {
+        eY = h3_exponent(p.bound_c * x_max + p.bound_d + (p.res_amax ? amax_read(p.res_amax) : 0.0f));
+        if (blockIdx.x == 0 && tid == 0) *p.y_pexp = eY;
+    }
     auto store = [&](int buf) {
         char* base = lds + buf * BUFB;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            f16x4 h, l;
-            h3_split(ra[i], sA, h, l);
-            *reinterpret_cast<f16x4*>(base + a_lds[i]) = h;
-            *reinterpret_cast<f16x4*>(base + BM * X6_ROWB + a_lds[i]) = l;
+            if constexpr (APLANES) {
+                *reinterpret_cast<f32x4*>(base + a_lds[i]) = ra[i];
+            } else {
+                f16x4 h, l;
+                h3_split(ra[i], sA, h, l);
+                *reinterpret_cast<f16x4*>(base + a_lds[i]) = h;
+                *reinterpret_cast<f16x4*>(base + BM * X6_ROWB + a_lds[i]) = l;
+            }
         }
 #pragma unroll
         for (int i = 0; i < PBT; ++i)
@@ -488,7 +509,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     }
     h3_combine<TM, TN>(acc0, acc1);
     h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
-    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    if (p.y_planes) x6_epilogue_vec<TM, TN, WM, WN, true>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds), h3_pow2(eY));
+    else if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
     else epilogue<TM, TN>(acc0, p, m0, n0, wm, wn, li, lh);
 }
 
@@ -500,7 +522,12 @@ static int launch_h3_db(const ConvArgs& a, hipStream_t s) {
     p.tiles_n = (p.Cout + BN - 1) / BN;
     constexpr size_t lds = (size_t)2 * 2 * (BM + BN) * X6_ROWB;
     static_assert(lds >= X6Tile<TM, TN, WM, WN, 2>::epi, "the epilogue's wave-row must fit in the operand buffers");
-    static std::atomic<uint64_t> lds_seen{0};
+    static std::atomic<uint64_t> lds_seen{0}, lds_seen_planes{0};
+    if (p.x_planes) {
+        if (int e = raise_lds_once(lds_seen_planes, (const void*)k_conv_igemm_h3_db<TM, TN, WM, WN, true>, lds, "conv2d_h3")) return e;
+        k_conv_igemm_h3_db<TM, TN, WM, WN, true><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
+        return check_launch("conv2d_fwd_h3 (planes in)");
+    }
     if (int e = raise_lds_once(lds_seen, (const void*)k_conv_igemm_h3_db<TM, TN, WM, WN>, lds, "conv2d_h3")) return e;
     k_conv_igemm_h3_db<TM, TN, WM, WN><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
     return check_launch("conv2d_fwd_h3");

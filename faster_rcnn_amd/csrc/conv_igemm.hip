@@ -2064,7 +2064,12 @@ struct DualOut { int n1; int act1; float* y2; int act2; };      // frcnn_conv2d_
 
 // which matrix path a forward launch takes, and the magnitude records that ride along (all NULL: nothing is tracked)
 enum { ENGINE_NATIVE = 0, ENGINE_X6 = 1, ENGINE_H3 = 2 };
-struct ConvRange { const float* x_amax; float* y_amax; float* y2_amax; };
+struct ConvRange {
+    const float* x_amax; float* y_amax; float* y2_amax;
+    // f16x3 engine, activations as fp16 planes (frcnn_conv2d_fwd_h3_planes); all null / 0 otherwise
+    const void* x_planes = nullptr; const int* x_pexp = nullptr; void* y_planes = nullptr; int* y_pexp = nullptr; const float* res_amax = nullptr;
+    float bound_c = 0.0f, bound_d = 0.0f;
+};
 
 static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                          const float* scale, const float* shift, const float* residual, const float* mask, float* y,
@@ -2260,6 +2265,23 @@ int frcnn_conv2d_fwd_dual_h3(const frcnn_conv_desc* d, const float* x, const flo
     return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_f16), scale, shift, nullptr, nullptr, y1, &dual, nullptr, 0, stream, ENGINE_H3, &rg);
 }
 
+int frcnn_conv2d_fwd_h3_planes(const frcnn_conv_desc* d, const float* x, const frcnn_h3_planes* x_planes, const float* x_amax, const void* w_planes_f16,
+                               const float* scale, const float* shift, const float* residual, const float* residual_amax,
+                               float* y, float* y_amax, const frcnn_h3_planes* y_planes, float bound_c, float bound_d, void* stream) {
+    if (!x_amax) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: the input's magnitude record is required");
+    if ((x != nullptr) == (x_planes != nullptr)) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: exactly one of x / x_planes");
+    if (!y && !y_planes) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: no output");
+    if (x_planes && (!x_planes->planes || !x_planes->exponent)) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: incomplete input planes");
+    if (y_planes && (!y_planes->planes || !y_planes->exponent || !(bound_c >= 0.0f) || !(bound_d >= 0.0f) || (residual && !residual_amax)))
+        return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: output planes need their buffers, the filter's bound constants and, with a residual, its magnitude record");
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if ((x_planes && !al16(x_planes->planes)) || (y_planes && !al16(y_planes->planes))) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: 16-byte aligned planes required");
+    ConvRange rg = {x_amax, y_amax, nullptr};
+    if (x_planes) { rg.x_planes = x_planes->planes; rg.x_pexp = x_planes->exponent; }
+    if (y_planes) { rg.y_planes = y_planes->planes; rg.y_pexp = y_planes->exponent; rg.res_amax = residual ? residual_amax : nullptr; rg.bound_c = bound_c; rg.bound_d = bound_d; }
+    return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_f16), scale, shift, residual, nullptr, y, nullptr, nullptr, 0, stream, ENGINE_H3, &rg);
+}
+
 // the native launches of frcnn_conv2d_fwd_ws / frcnn_conv2d_fwd_dual that also leave max|y| in a magnitude record: what feeds an
 // f16x3 launch from a layer that stays on the native kernels (the 3-channel stem, stage 4's 256-column 1x1 layers)
 int frcnn_conv2d_fwd_ws_amax(const frcnn_conv_desc* d, const float* x, const float* w_packed,
@@ -2298,7 +2320,8 @@ int frcnn_conv2d_fwd_dual(const frcnn_conv_desc* d, const float* x, const float*
 static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
                          const float* scale, const float* shift, const float* residual, const float* mask, float* y,
                          const DualOut* dual, void* workspace, size_t workspace_bytes, void* stream, int engine, const ConvRange* range) {
-    if (!d || !x || !w_packed || !y) return fail(FRCNN_E_ARG, "conv2d_fwd: null pointer");
+    const bool planes_io = range && (range->x_planes || range->y_planes);
+    if (!d || !w_packed || (!planes_io && (!x || !y))) return fail(FRCNN_E_ARG, "conv2d_fwd: null pointer");
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->ho <= 0 || d->wo <= 0)
         return fail(FRCNN_E_ARG, "conv2d_fwd: bad shape");
     ConvArgs a;
@@ -2311,6 +2334,9 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
     a.act = d->act; a.ldy = d->ldy > 0 ? d->ldy : d->cout; a.ldres = d->ldres > 0 ? d->ldres : d->cout;
     a.n_split = 0; a.y2 = nullptr; a.ldy2 = 0; a.act2 = 0;
     a.x_amax = range ? range->x_amax : nullptr; a.y_amax = range ? range->y_amax : nullptr; a.y2_amax = range ? range->y2_amax : nullptr;
+    a.x_planes = range ? range->x_planes : nullptr; a.x_pexp = range ? range->x_pexp : nullptr;
+    a.y_planes = range ? range->y_planes : nullptr; a.y_pexp = range ? range->y_pexp : nullptr;
+    a.res_amax = range ? range->res_amax : nullptr; a.bound_c = range ? range->bound_c : 0.0f; a.bound_d = range ? range->bound_d : 0.0f;
     if (dual) { a.n_split = dual->n1; a.act = dual->act1; a.ldy = dual->n1; a.y2 = dual->y2; a.ldy2 = d->cout - dual->n1; a.act2 = dual->act2; }
     a.tiles_m = a.tiles_n = 0;
     a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
@@ -2331,6 +2357,18 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
         if ((size_t)2 * d->cout * a.Kpad * 2 >= 0x7fffffffull) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3: filter planes over 2 GiB");
         if (reinterpret_cast<uintptr_t>(w_packed) & 15) return fail(FRCNN_E_ARG, "conv2d_fwd_h3: 16-byte aligned filter planes required");
         const int hcfg = h3_config(d, dual ? dual->n1 : 0);
+        if (planes_io) {
+            // activations as fp16 planes: the double-buffered 256x128 forms only, 16-byte epilogue, one layer, no mask
+            if ((hcfg != 86 && hcfg != 82) || dual || mask || !a.vec_epi && y || d->ldy > 0)
+                return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3_planes: needs the 256x128 tile (>= 256 output tiles of 128x128; frcnn_conv2d_h3_config 86 / 82), a dense single-layer launch without a mask");
+            if ((d->cout & 3) || (d->cin & 7)) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3_planes: cin %% 8 == 0 and cout %% 4 == 0");
+            if ((size_t)M * d->cout * 4 >= 0x7fffffffull || (size_t)d->n * d->h * d->w * d->cin * 4 >= 0x7fffffffull)
+                return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3_planes: tensor planes over 2 GiB");
+            if (!y) a.vec_epi = 1;
+            const int bn = h3_tile_width(hcfg);
+            a.group_m = g_group_m >= 0 ? g_group_m : (d->cout > bn ? 1 : 0);
+            return launch_conv_h3(a, hcfg, s);
+        }
         if (workspace && !dual) {
             const size_t need = frcnn_conv2d_h3_workspace_bytes(d);
             if (need) {

@@ -53,15 +53,16 @@ class ConvUnit:
         self.pc = packer(*self.folded())
         return self
 
-    def __call__(self, x, residual=None, out=None, act="unit", layout=0):
+    def __call__(self, x, residual=None, out=None, act="unit", layout=0, planes_out=False):
         """``act`` overrides the unit's activation for this call ("unit" = keep it); ``layout`` 1 = position-major
-        tensors (h,w,n,c), see frcnn_conv_desc.layout."""
+        tensors (h,w,n,c), see frcnn_conv_desc.layout; ``planes_out``: ops.conv2d (f32 path: the result may come back as an
+        ops.PlaneTensor for the next convolution)."""
         if self.pc is None:
             self.lower()
         act = self.act if act == "unit" else act
         if self.dtype == "bf16":
             return ops.conv2d_bf16(x, self.pc, self.stride, self.padding, act, residual, self.out_f32, self.tile, layout)
-        return ops.conv2d(x, self.pc, self.stride, self.padding, act, residual, out, self.tile, layout)
+        return ops.conv2d(x, self.pc, self.stride, self.padding, act, residual, out, self.tile, layout, planes_out)
 
 
 class DualUnit:
@@ -130,15 +131,21 @@ def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dt
     return u
 
 
-def run_block(u, x, layout=0):
-    """identity_block / conv_block (resnet.py:114-247) and their TimeDistributed twins (:250-392)."""
+HEAD_PLANES = True      # dev knob (tests): False keeps every tensor of the detector head f32
+
+
+def run_block(u, x, layout=0, planes=False):
+    """identity_block / conv_block (resnet.py:114-247) and their TimeDistributed twins (:250-392).  ``planes``: branch2a's and
+    branch2b's outputs have ONE reader each, the next convolution of the block: on the f16x3 engine they are handed on as the fp16
+    planes that convolution multiplies (ops.PlaneTensor), so its loader splits nothing."""
+    planes = planes and HEAD_PLANES
     pair = _pair(u["2a"], u["1"]) if "1" in u else None
     if pair is not None:                                    # branch2a and the shortcut conv read x: one launch
         t, shortcut = pair(x, layout=layout)
     else:
         shortcut = u["1"](x, layout=layout) if "1" in u else x
-        t = u["2a"](x, layout=layout)
-    t = u["2b"](t, layout=layout)
+        t = u["2a"](x, layout=layout, planes_out=planes)
+    t = u["2b"](t, layout=layout, planes_out=planes)
     return u["2c"](t, residual=shortcut, layout=layout)
 
 
@@ -302,7 +309,7 @@ class ResNetHead:
         L = self.layout
         t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)
         s = resize(v, rois, self.pool, fill=a["1"].pc.shift, layout=L)
-        return a["2c"](a["2b"](t, layout=L), residual=s, layout=L)
+        return a["2c"](a["2b"](t, layout=L, planes_out=self.dtype == "f32" and HEAD_PLANES), residual=s, layout=L)
 
     def __call__(self, feat, rois):
         resize = ops.roi_crop_resize_bf16 if self.dtype == "bf16" else ops.roi_crop_resize
@@ -314,7 +321,7 @@ class ResNetHead:
             x = resize(feat, rois, self.pool, layout=L)     # (n,7,7,1024), or (7,7,n,1024) position-major
             rest = self.blocks
         for b in rest:
-            x = run_block(b, x, L)
+            x = run_block(b, x, L, planes=self.dtype == "f32")
         if self.dtype == "bf16":
             return self.dense(ops.avgpool_bf16(x, 7, L))   # pooled features and the dense layers stay f32
         if L:

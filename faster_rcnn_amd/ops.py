@@ -358,6 +358,37 @@ class PackedConv:
         return planes
 
 
+    def h3_bound(self):
+        """(bound_c, bound_d) of frcnn_conv2d_fwd_h3_planes: |y| <= bound_c * max|x| + bound_d for ANY input -- the largest
+        |scale[c]| * sum |w[.,.,.,c]| over the output channels and the largest |shift[c]| (host floats, computed once per filter)."""
+        b = getattr(self, "_h3_bound", None)
+        if b is None or getattr(self, "_h3_bound_src", None) is not self.w:
+            l1 = self.w.abs().sum(dim=1)
+            if self.scale is not None:
+                l1 = l1 * self.scale.abs()
+            b = (float(l1.max().item()), 0.0 if self.shift is None else float(self.shift.abs().max().item()))
+            self._h3_bound, self._h3_bound_src = b, self.w
+        return b
+
+
+class PlaneTensor:
+    """An activation tensor the way the f16x3 engine multiplies it: two fp16 planes (2, *shape) -- hi = f16(v * 2^e), lo = f16((v * 2^e
+    - hi) * 2^11) -- and the device int32 ``exponent`` e, written by the launch that produced it (frcnn_conv2d_fwd_h3_planes).  Only
+    convolutions read it (``conv2d`` accepts it in place of the f32 tensor); ``_amax`` is the producer's magnitude record."""
+    is_planes = True
+
+    def __init__(self, shape):
+        self.shape = tuple(int(v) for v in shape)
+        self.planes = torch.empty((2,) + self.shape, dtype=torch.float16, device="cuda")
+        self.exponent = torch.empty(1, dtype=torch.int32, device="cuda")
+        self._amax = None
+
+    def float(self):
+        """The f32 values (hi + lo * 2^-11) * 2^-e, on the device (tests / debugging: torch arithmetic)."""
+        e = self.exponent.to(torch.float64)
+        return ((self.planes[0].double() + self.planes[1].double() / 2048.0) * torch.pow(torch.tensor(2.0, dtype=torch.float64, device="cuda"), -e)).float()
+
+
 # ---- which matrix path an fp32 convolution takes.
 # "native": v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip).  "bf16x6": the same GEMM on the bf16 matrix cores by exact
 # three-way operand splitting (csrc/conv_x6.hip) for the launches where it measures faster -- large row counts, cin % 32 == 0;
@@ -618,14 +649,55 @@ def _conv_launch(d, x, w, scale, shift, residual, mask, out, y_amax=None):
     return (fn, args), ws
 
 
-def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0, layout=0):
+def _conv2d_h3_planes(d, x, pc, residual, oshape, planes_out, act):
+    """frcnn_conv2d_fwd_h3_planes: x a PlaneTensor or an f32 tensor, the result a PlaneTensor (planes_out) or an f32 tensor."""
+    x_in = isinstance(x, PlaneTensor)
+    xp = _lib.H3Planes(planes=x.planes.data_ptr(), exponent=x.exponent.data_ptr()) if x_in else None
+    y = PlaneTensor(oshape) if planes_out else torch.empty(oshape, dtype=torch.float32, device="cuda")
+    yp = _lib.H3Planes(planes=y.planes.data_ptr(), exponent=y.exponent.data_ptr()) if planes_out else None
+    ya = _amax_new()
+    bc, bd = pc.h3_bound() if planes_out else (0.0, 0.0)
+    args = (ctypes.byref(d), None if x_in else _p(x), ctypes.byref(xp) if x_in else None, _p(amax_of(x)), _p(pc.h3_planes()), _p(pc.scale), _p(pc.shift),
+            _p(residual), _p(amax_of(residual)) if (residual is not None and planes_out) else None,
+            None if planes_out else _p(y), _p(ya), ctypes.byref(yp) if planes_out else None, bc, bd)
+    _lib.call("frcnn_conv2d_fwd_h3_planes", *args, _stream())
+    y._amax = ya
+    if CONV_PROFILE is not None:
+        keep = (d, x, pc, residual, y, ya, xp, yp)
+        CONV_PROFILE.append({"kernel": _h3_name(d) + (" planes-in" if x_in else "") + (" planes-out" if planes_out else ""),
+                             "flops": 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin,
+                             "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, d.stride),
+                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_h3_planes", *args, _stream())})
+    return y
+
+
+def _planes_ok(d, pc, eng):
+    """A launch may read / write fp16 planes: the f16x3 engine on its double-buffered 256x128 tile, un-split, channel counts the 16- and
+    8-byte pieces divide."""
+    return (eng == "h3" and _lib.load().frcnn_conv2d_h3_config(ctypes.byref(d), 0) in (86, 82) and pc.cout % 4 == 0 and pc.cin % 8 == 0
+            and (_CONV_WS is NO_SPLIT_K or _ws_need(d, "frcnn_conv2d_h3_workspace_bytes") == 0))
+
+
+def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, tile=0, layout=0, planes_out=False):
     """x: (n,h,w,cin) f32 NHWC device tensor; pc: PackedConv -> (n,ho,wo,cout).
-    layout=1: position-major tensors, x (h,w,n,cin) -> (ho,wo,n,cout) (frcnn_conv_desc.layout)."""
+    layout=1: position-major tensors, x (h,w,n,cin) -> (ho,wo,n,cout) (frcnn_conv_desc.layout).
+    ``planes_out``: a REQUEST to hand the result on as a PlaneTensor (the caller knows its only readers are f16x3 convolutions of the
+    detector head's size); honoured when this launch runs on the engine's 256x128 tile, otherwise the f32 tensor comes back as usual.
+    x may be a PlaneTensor (then the launch must be such a one: anything else raises)."""
     _require_gpu()
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == pc.cin, (x.shape, pc.cin)
+    x_planes = isinstance(x, PlaneTensor)
+    assert (x_planes or (x.dtype == torch.float32 and x.is_contiguous())) and x.shape[-1] == pc.cin, (x.shape, pc.cin)
     d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act], layout, tile or AUTO_TILE)
     n, ho, wo = d.n, d.ho, d.wo
     oshape = (ho, wo, n, pc.cout) if layout else (n, ho, wo, pc.cout)
+    if x_planes or planes_out:
+        ok = out is None and _planes_ok(d, pc, _split_engine(d, pc, tile or AUTO_TILE))
+        if x_planes and not ok:
+            raise _lib.FrcnnError("conv2d: a PlaneTensor input needs an f16x3 launch on the 256x128 tile (frcnn_conv2d_fwd_h3_planes)")
+        if ok:
+            if residual is not None:
+                assert tuple(residual.shape) == tuple(oshape) and residual.is_contiguous()
+            return _conv2d_h3_planes(d, x, pc, residual, oshape, planes_out, act)
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device="cuda")
     else:

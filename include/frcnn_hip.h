@@ -354,6 +354,23 @@ int frcnn_conv2d_fwd_h3(const frcnn_conv_desc* d, const float* x, const float* x
 int frcnn_conv2d_fwd_dual_h3(const frcnn_conv_desc* d, const float* x, const float* x_amax, const void* w_planes_f16,
                              const float* scale, const float* shift, float* y1, int n1, int act1, float* y1_amax,
                              float* y2, int act2, float* y2_amax, void* stream);
+/* A chain of f16x3 layers may hand its activations on ALREADY split: `y_planes` makes the launch write two fp16 planes [2][M][cout]
+ * (hi, lo as the engine splits them) under the scale 2^*exponent beside -- or, with y == NULL, instead of -- the f32 tensor, and a
+ * following launch given them as `x_planes` (x == NULL) stages them into LDS unchanged: no conversion and no arithmetic in its loader
+ * (the detector head's 14 700-row GEMMs, resnet.py:508-533: 195 / 103 / 89 us instead of 246 / 127 / 104).  The producer cannot know
+ * max|y| before it has finished, so it scales by a bound every workgroup derives alike: |y| <= bound_c * max|x| + bound_d (+ max|residual|),
+ * bound_c = max over output channels of |scale[c]| * sum |w[.,.,.,c]|, bound_d = max |shift[c]| (host constants of the filter) -- it cannot
+ * overflow whatever the data, and it is loose by about sqrt(K) (2^4..2^6 for these layers), which costs nothing (see above).  The
+ * 256x128 tile forms only (frcnn_conv2d_h3_config 86 / 82), dense single layers, no mask; x_amax is always required; residual needs its
+ * record when planes are written. */
+typedef struct frcnn_h3_planes {
+    void* planes;                  /* [2][rows][channels] fp16, 16-byte aligned */
+    int32_t* exponent;             /* device int32: stored value = true value * 2^exponent (written by the producing launch) */
+} frcnn_h3_planes;
+int frcnn_conv2d_fwd_h3_planes(const frcnn_conv_desc* d, const float* x, const frcnn_h3_planes* x_planes, const float* x_amax,
+                               const void* w_planes_f16, const float* scale, const float* shift,
+                               const float* residual, const float* residual_amax,
+                               float* y, float* y_amax, const frcnn_h3_planes* y_planes, float bound_c, float bound_d, void* stream);
 /* frcnn_conv2d_fwd_ws (the native f32 MFMA kernels) that also folds max|y| into y_amax: a layer that stays on the native path
  * (the 3-channel stem, small grids) in front of an f16x3 layer. */
 int frcnn_conv2d_fwd_ws_amax(const frcnn_conv_desc* d, const float* x, const float* w_packed,

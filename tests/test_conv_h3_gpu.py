@@ -279,3 +279,70 @@ def test_h3_split_k_small_grid_long_k():
         got = ops.conv2d(torch.from_numpy(x).cuda(), pc, 1, "same", None, tile=88)
     ref, mag = ref_conv(x, wt, 1, "same")
     assert err(got.cpu().numpy(), ref, mag) <= 5e-7 and not ws.buf[:16384].any().item()
+
+
+def test_h3_plane_tensors_between_layers():
+    """frcnn_conv2d_fwd_h3_planes: a 1x1 -> 3x3 -> 1x1 (+ residual) chain over 300 position-major RoI crops -- the detector head's
+    block (resnet.py:282-313) -- with the two inner tensors handed on as fp16 planes, against the same chain through f32 tensors and
+    against fp64: same bars.  The planes ARE the producer's f32 values to one unit in the last place, their exponent comes from the
+    bound (never from the data), and a PlaneTensor offered to a launch that cannot read it is refused."""
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(31)
+    n, cin, c1, c3 = 300, 64, 384, 512
+    x = np.maximum(rs.randn(7, 7, n, cin), 0).astype(np.float32)                 # position-major, post-ReLU like the crops
+    w1 = (rs.randn(1, 1, cin, c1) * np.sqrt(2.0 / cin)).astype(np.float32)
+    w2 = (rs.randn(3, 3, c1, c1) * np.sqrt(2.0 / (9 * c1))).astype(np.float32)
+    w3 = (rs.randn(1, 1, c1, c3) * np.sqrt(2.0 / c1)).astype(np.float32)
+    sb = lambda c: ((1 + 0.1 * rs.randn(c)).astype(np.float32), (0.1 * rs.randn(c)).astype(np.float32))
+    (s1, h1), (s2, h2), (s3, h3) = sb(c1), sb(c1), sb(c3)
+    p1, p2, p3 = ops.PackedConv(w1, s1, h1), ops.PackedConv(w2, s2, h2), ops.PackedConv(w3, s3, h3)
+    res = rs.randn(7, 7, n, c3).astype(np.float32)
+    xd, rd = torch.from_numpy(x).cuda(), torch.from_numpy(res).cuda()
+    with ops.f32_engine("f16x3"), ops.conv_workspace(ops.NO_SPLIT_K):
+        a1 = ops.conv2d(xd, p1, 1, "valid", "relu", layout=1)
+        a2 = ops.conv2d(a1, p2, 1, "same", "relu", layout=1)
+        a3 = ops.conv2d(a2, p3, 1, "valid", "relu", residual=rd, layout=1)
+        ops.CONV_PROFILE = []
+        try:
+            b1 = ops.conv2d(xd, p1, 1, "valid", "relu", layout=1, planes_out=True)
+            b2 = ops.conv2d(b1, p2, 1, "same", "relu", layout=1, planes_out=True)
+            b3 = ops.conv2d(b2, p3, 1, "valid", "relu", residual=rd, layout=1)
+            names = [r["kernel"] for r in ops.CONV_PROFILE]
+            for r in ops.CONV_PROFILE:
+                r["relaunch"]()
+        finally:
+            ops.CONV_PROFILE = None
+        # a launch that cannot take planes (64x64 tiles): the request is ignored on the way out, refused on the way in
+        small = ops.conv2d(torch.from_numpy(x[:, :, :40]).cuda().contiguous(), p1, 1, "valid", "relu", layout=1, planes_out=True)
+        assert isinstance(small, torch.Tensor)
+        with pytest.raises(_lib.FrcnnError):
+            ops.conv2d(b1, ops.PackedConv((rs.randn(1, 1, c1, 32) * 0.05).astype(np.float32)), 1, "valid", layout=1)
+    assert isinstance(b1, ops.PlaneTensor) and isinstance(b2, ops.PlaneTensor) and isinstance(b3, torch.Tensor)
+    assert names == ["k_conv_igemm_h3_db<2,1,4,4> planes-out", "k_conv_igemm_h3_db<2,1,4,4> planes-in planes-out", "k_conv_igemm_h3_db<2,1,4,4> planes-in"], names
+    # the planes are the producer's values (one unit in the last place; exact zeros stay zeros)
+    v1, f1 = b1.float().double(), a1.double()
+    assert bool(((v1 - f1).abs() <= 2.0 ** -23 * f1.abs() + 2.0 ** -40 * f1.abs().max()).all())
+    assert float(b1._amax.max()) == float(a1.abs().max())
+    bc, bd = p1.h3_bound()
+    bound = bc * float(xd.abs().max()) + bd
+    e = int(b1.exponent.item())
+    assert 2.0 ** 14 <= bound * 2.0 ** e < 2.0 ** 15 and float(a1.abs().max()) <= bound
+    assert float(b1.planes[0].abs().max()) < 32768.0
+    # the chain: same bars against fp64 as the f32-tensor chain, and the two agree far inside them
+    def ref_chain():
+        t = np.transpose(x, (2, 0, 1, 3))
+        r1, _ = ref_conv(t, w1, 1, "valid", s1, h1, None, "relu")
+        r2, _ = ref_conv(r1.astype(np.float64), w2, 1, "same", s2, h2, None, "relu")
+        r3, m3 = ref_conv(r2, w3, 1, "valid", s3, h3, np.transpose(res, (2, 0, 1, 3)), "relu")
+        return r3, m3
+    r3, m3 = ref_chain()
+    to_nhwc = lambda t: t.permute(2, 0, 1, 3).cpu().numpy()
+    e_f32, e_pl = err(to_nhwc(a3), r3, m3), err(to_nhwc(b3), r3, m3)
+    print("chain error vs fp64: f32 tensors %.3g, plane tensors %.3g" % (e_f32, e_pl))
+    assert e_pl <= max(1.5 * e_f32, 6e-7)
+    assert float((a3 - b3).abs().max() / a3.abs().max()) < 2e-6
+    # bitwise reproducible
+    with ops.f32_engine("f16x3"), ops.conv_workspace(ops.NO_SPLIT_K):
+        c1_ = ops.conv2d(xd, p1, 1, "valid", "relu", layout=1, planes_out=True)
+        c3_ = ops.conv2d(ops.conv2d(c1_, p2, 1, "same", "relu", layout=1, planes_out=True), p3, 1, "valid", "relu", residual=rd, layout=1)
+    assert torch.equal(c3_, b3) and torch.equal(c1_.planes, b1.planes)
