@@ -664,7 +664,8 @@ def _conv2d_h3_planes(d, x, pc, residual, oshape, planes_out, act):
     y._amax = ya
     if CONV_PROFILE is not None:
         keep = (d, x, pc, residual, y, ya, xp, yp)
-        CONV_PROFILE.append({"kernel": _h3_name(d) + (" planes-in" if x_in else "") + (" planes-out" if planes_out else ""),
+        # (the instantiation that reads planes is a kernel of its own; writing planes is a run-time branch of either's epilogue)
+        CONV_PROFILE.append({"kernel": _h3_name(d).replace(">", ",planes>") if x_in else _h3_name(d), "planes_out": bool(planes_out),
                              "flops": 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin,
                              "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, d.stride),
                              "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_h3_planes", *args, _stream())})
