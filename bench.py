@@ -983,7 +983,7 @@ def main():
     # the engine policy of this PROCESS (captures, the per-launch roofline pass and the parity checkers below all see the same
     # launch forms); the training legs of an N > 1 line run on the native engine
     from faster_rcnn_amd import ops as _ops
-    _ops.F32_ENGINE = args.f32_engine
+    _ops.F32_ENGINE = args.f32_engine if DTYPE == "f32" else "native"      # (a bf16 run has a handful of small f32 layers: native)
     pipe, weights, anchors = build_pipeline()
     if args.unit_tiles:
         want = dict(kv.split("=") for kv in args.unit_tiles.split(","))

@@ -465,11 +465,15 @@ class AmaxArena:
         _require_gpu()
         self.floats = _lib.load().frcnn_amax_record_floats()
         self.buf = torch.zeros((n, self.floats), dtype=torch.float32, device="cuda")
-        self.i = 0
+        self.i = self.high_water = 0
 
     def begin(self):
+        """Clear the records the passes so far have used (all of them were zero at allocation; a captured pass bakes in the count of
+        its warm-up passes, which walk the same launches): ~60 records = 240 KB for a ResNet-50 pass instead of the whole pool."""
+        self.high_water = max(self.high_water, self.i)
         self.i = 0
-        _lib.call("frcnn_amax_clear", _p(self.buf), self.buf.shape[0], _stream())
+        if self.high_water:
+            _lib.call("frcnn_amax_clear", _p(self.buf), self.high_water, _stream())
 
     def take(self):
         assert self.i < self.buf.shape[0], "AmaxArena: more tracked tensors in a pass than records"
@@ -504,10 +508,16 @@ def amax_begin():
         _AMAX_ARENA.begin()
 
 
-def _amax_new():
+def _amax_new(optional=False):
+    """A cleared record: from the active arena, or (eager launches) a fresh allocation.  A capture without an arena cannot have one
+    (a zero-filling allocation would put a memset node into the graph): an error for an f16x3 launch, None for a native layer that
+    would merely have left its record for a layer behind it (``optional``)."""
     if _AMAX_ARENA is not None:
         return _AMAX_ARENA.take()
-    assert not torch.cuda.is_current_stream_capturing(), "f16x3 launches inside a capture need an ops.amax_arena"
+    if torch.cuda.is_current_stream_capturing():
+        if optional:
+            return None
+        raise _lib.FrcnnError("f16x3 launches inside a capture need an ops.amax_arena (pipeline.InferencePipeline.capture makes one)")
     return torch.zeros(_lib.load().frcnn_amax_record_floats(), dtype=torch.float32, device="cuda")
 
 
@@ -732,7 +742,7 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
                                  "shape": (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
                                  "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_x6", *args, _stream())})
         return out
-    ya = _amax_new() if (_tracking() and pc.cout >= 32) else None      # a native layer in an f16x3 pass leaves max|y| for the layer behind it
+    ya = _amax_new(optional=True) if (_tracking() and pc.cout >= 32) else None      # a native layer in an f16x3 pass leaves max|y| for the layer behind it
     (fn, args), ws = _conv_launch(d, x, pc.w, pc.scale, pc.shift, residual, None, out, ya)
     if ya is not None:
         out._amax = ya

@@ -210,14 +210,16 @@ class BatchedInferencePipeline(InferencePipeline):
     def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=False, throughput=True):
         self._static_in = torch.zeros((self.batch, height, width, 3), dtype=torch.float32, device="cuda")
         self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
+        self._amax = ops.AmaxArena() if ops.F32_ENGINE == "f16x3" else None       # (the few f32 layers of a bf16 pass under an f16x3 scope)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.amax_arena(self._amax):
             for _ in range(warmup):
                 self.forward_dev(self._static_in, resize_ratio)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with no_gc(), torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput):
+        with no_gc(), torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), \
+                ops.amax_arena(self._amax):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self
