@@ -213,7 +213,7 @@ def conv_roofline(pipe, x, reps=10, split_k=True, throughput=False, images=1, en
         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic,
         "traffic_source": "profiles/traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch of this kernel, from the committed rocprofv3 --pmc "
-                          "passes of scripts/profile_round4.sh (counters cannot be read from inside this process; null if the kernel is not in the file)",
+                          "passes of scripts/profile_round5.sh (counters cannot be read from inside this process; null if the kernel is not in the file)",
         "launches_per_image": dom[2], "images_per_launch": images, "avg_launch_us": round(1e3 * dom[1] / dom[2], 2),
         "gflop_per_launch_avg": round(dom[0] / dom[2] / 1e9, 3),
         "share_of_conv_time": round(dom[1] / images / tot_ms, 3),
