@@ -375,10 +375,19 @@ def e2e_drift_bf16(pipe, weights, anchors, oracle_runs):
         c["matched_frac"] = round(m / max(t, 1), 4)
         res[tag] = c
     bars = {"head_as_drawn": DRIFT_BARS_AS_DRAWN, "head_calibrated": DRIFT_BARS_CALIBRATED}
+    map_bar = drift_map_bar(len(oracle_runs))
     res["bars"] = {k: "detections matched (class, IoU >= 0.5) >= %g of the larger set, mean score difference of the pairs <= %g; "
-                      "map_pair_delta is reported, not barred (see bench.py)" % v for k, v in bars.items() if k in res}
-    res["ok"] = bool(all(res[k]["matched_frac"] >= m and res[k]["matched_score_diff"]["mean"] <= d for k, (m, d) in bars.items() if k in res))
+                      "map_pair_delta <= %g for %d frames (bench.DRIFT_MAP_BARS)" % (v + (map_bar, len(oracle_runs))) for k, v in bars.items() if k in res}
+    res["ok"] = bool(all(res[k]["matched_frac"] >= m and res[k]["matched_score_diff"]["mean"] <= d and res[k]["map_pair_delta"] <= map_bar
+                         for k, (m, d) in bars.items() if k in res))
     return res
+
+
+def drift_map_bar(frames):
+    """The bound on `map_pair_delta` of a bf16 run against the fp32 oracle for a sample of `frames` frames (DRIFT_MAP_BARS)."""
+    key = "configs[3]" if DEPTH == 101 else "configs[1] shapes"
+    many, few = DRIFT_MAP_BARS[key]
+    return many if frames >= 32 else few
 
 
 # Bars (matched fraction, mean score difference of the matched pairs).  Measured on MI355X, round 4: head as drawn -- configs[3]
@@ -391,6 +400,14 @@ def e2e_drift_bf16(pipe, weights, anchors, oracle_runs):
 # `parity.e2e`.)  With trained weights -- absent offline -- the delta would be the number to bar.
 DRIFT_BARS_AS_DRAWN = (0.90, 5e-3)
 DRIFT_BARS_CALIBRATED = (0.80, 2e-2)
+# Round 5: the pair's mAP delta over 32 frames with a bootstrap over frames (scripts/drift_bf16.py,
+# profiles/round5_drift_bf16_*.json).  configs[3] (ResNet-101 600x1500): head as drawn 0.039 over all frames (bootstrap mean 0.056,
+# 97.5 % 0.171), calibrated head 0.103 (0.094 +- 0.026, 97.5 % 0.142); configs[1] shapes on the bf16 engine: 0.142 / 0.152 (97.5 %
+# 0.279 / 0.268).  A sample of n frames spreads like 1 / sqrt(n): the bar for >= 32 frames is the bootstrap's 97.5th percentile
+# rounded up, the bar for the 4-8 frames of bench.py's own leg adds 2 sigma of an 8x smaller sample.  It bounds THIS metric on THESE
+# weights (one pseudo ground-truth box per class and image, an untrained head whose winning margins are a few 1e-4 of probability);
+# it is a regression bound for the bf16 path, not a statement about a trained model's mAP.
+DRIFT_MAP_BARS = {"configs[3]": (0.20, 0.40), "configs[1] shapes": (0.32, 0.55)}
 E2E_MAP_BAR = 1e-3        # measured on MI355X: 0.0 (2700/2700 proposals, 2382/2382 detections identical over 9 frames)
 
 

@@ -72,11 +72,15 @@ SIGNATURES = {
     "frcnn_amax_record_floats": (I, []),
     "frcnn_amax_clear": (I, [P, I, P]),
     "frcnn_amax_f32": (I, [P, c_size_t, P, P]),
-    "frcnn_amax_merge": (I, [P, P, ctypes.c_float, P]),
+    "frcnn_amax_merge": (I, [P, P, ctypes.c_float, P, P]),
+    "frcnn_roi_crop_resize_fwd_planes": (I, [P, I, I, I, P, I, I, P, I, I, P, P]),
     "frcnn_conv2d_h3_config": (I, [P, I]),
     "frcnn_conv2d_h3_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_fwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_conv2d_fwd_dual_h3": (I, [P, P, P, P, P, P, P, I, I, P, P, I, P, P]),
+    "frcnn_stem_h3_packed_bytes": (c_size_t, []),
+    "frcnn_pack_stem_weights_h3": (I, [P, P, P]),
+    "frcnn_stem_h3_fwd": (I, [P, P, I, I, I, P, P, P, P, P, P]),
     "frcnn_conv2d_fwd_h3_planes": (I, [P, P, P, P, P, P, P, P, P, P, P, P, ctypes.c_float, ctypes.c_float, P]),
     "frcnn_conv2d_fwd_ws_amax": (I, [P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_pack_conv_weights_dgrad": (I, [P, P, I, I, I, I, P, P]),

@@ -599,9 +599,12 @@ __global__ void __launch_bounds__(256) k_amax_f32(const float* x, size_t n, floa
 
 // dst := max(dst, max over src's slots, floor): the bound of a tensor made from `src`'s tensor by a map that cannot exceed
 // max(|input|, floor) -- max-pooling, the bilinear RoI resampling with a fill vector, ReLU
-__global__ void __launch_bounds__(64) k_amax_merge(float* dst, const float* src, float floor_value) {
-    const float v = fmaxf(src ? amax_read(src) : 0.0f, floor_value);
-    if (threadIdx.x == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+__global__ void __launch_bounds__(64) k_amax_merge(float* dst, const float* src, float floor_value, int* exponent_out) {
+    const float v = fmaxf(fmaxf(src ? amax_read(src) : 0.0f, floor_value), amax_read(dst));
+    if (threadIdx.x == 0) {
+        if (v > 0.0f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+        if (exponent_out) *exponent_out = h3_exponent(v);       // the scale of planes written under this bound (frcnn_roi_crop_resize_fwd_planes)
+    }
 }
 
 }  // namespace frcnn
@@ -650,8 +653,8 @@ extern "C" int frcnn_amax_f32(const float* x, size_t n, float* record, void* str
     return check_launch("amax_f32");
 }
 
-extern "C" int frcnn_amax_merge(float* dst_record, const float* src_record, float floor_value, void* stream) {
+extern "C" int frcnn_amax_merge(float* dst_record, const float* src_record, float floor_value, int32_t* exponent_out, void* stream) {
     if (!dst_record || !(floor_value >= 0.0f)) return fail(FRCNN_E_ARG, "amax_merge: bad argument");
-    k_amax_merge<<<1, 64, 0, as_stream(stream)>>>(dst_record, src_record, floor_value);
+    k_amax_merge<<<1, 64, 0, as_stream(stream)>>>(dst_record, src_record, floor_value, exponent_out);
     return check_launch("amax_merge");
 }

@@ -69,6 +69,50 @@ __global__ void __launch_bounds__(256) k_roi_fwd(const float4* feat, int rows, i
     }
 }
 
+// The same resampling with the result written as the f16x3 engine's two fp16 planes (conv_h3.hip; frcnn_h3_planes): hi = f16(v * 2^e),
+// lo = f16((v * 2^e - hi) * 2^11), e = *pexp -- derived BEFORE this launch from the map's magnitude record (a bilinear sample is a
+// convex combination of map values and a rejected RoI yields the fill vector: max(|map|, |fill|) bounds every output,
+// frcnn_amax_merge).  The consumer, res5a_branch2b's 3x3 over the crops (resnet.py:508-512), then stages the planes unchanged.
+__global__ void __launch_bounds__(256) k_roi_fwd_planes(const float4* feat, int rows, int cols, int C4, const float4* rois, int pool,
+                                                        const float4* fill, int relu, int pos_major, const int* pexp,
+                                                        _Float16* planes, size_t plane_elems) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int pix = blockIdx.x;
+    const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
+    const size_t orow = pos_major ? (size_t)(py * pool + px) * (gridDim.x / (pool * pool)) + r : (size_t)pix;
+    const int e = *pexp;
+    unsigned sb = (unsigned)(e + 127) << 23;
+    float s;
+    __builtin_memcpy(&s, &sb, 4);
+    f16x4* hi = reinterpret_cast<f16x4*>(planes + orow * C4 * 4);
+    f16x4* lo = reinterpret_cast<f16x4*>(planes + plane_elems + orow * C4 * 4);
+    const float4* tl = feat + ((size_t)t.y_lo * cols + t.x_lo) * C4;
+    const float4* tr = feat + ((size_t)t.y_lo * cols + t.x_hi) * C4;
+    const float4* bl = feat + ((size_t)t.y_hi * cols + t.x_lo) * C4;
+    const float4* br = feat + ((size_t)t.y_hi * cols + t.x_hi) * C4;
+    for (int c = threadIdx.x; c < C4; c += blockDim.x) {
+        float4 v;
+        if (!t.ok) {
+            v = fill ? fill[c] : make_float4(0, 0, 0, 0);
+        } else {
+            const float4 a = tl[c], b = tr[c], d = bl[c], g = br[c];
+#define LERP2(f) { const float top = a.f + (b.f - a.f) * t.tx; const float bot = d.f + (g.f - d.f) * t.tx; v.f = top + (bot - top) * t.ty; }
+            LERP2(x) LERP2(y) LERP2(z) LERP2(w)
+#undef LERP2
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        const float xs[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+        f16x4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const _Float16 a1 = (_Float16)xs[q];
+            h[q] = a1; l[q] = (_Float16)((xs[q] - (float)a1) * 2048.0f);
+        }
+        hi[c] = h; lo[c] = l;
+    }
+}
+
 // Gradient w.r.t. the feature map as a GATHER: one workgroup per feature cell lists the RoIs whose box contains the
 // cell (ascending), walks those RoIs' pool x pool samples and lists the corner taps that land on the cell -- sample-major,
 // then top-left, top-right, bottom-left, bottom-right: the order in which TF's CPU ResizeBilinearGrad walks them -- and
@@ -183,6 +227,17 @@ int frcnn_roi_crop_resize_fwd_ex(const float* feat, int rows, int cols, int C, c
     k_roi_fwd<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool,
                                                               (const float4*)fill, relu, layout, (float4*)out);
     return check_launch("roi_crop_resize_fwd");
+}
+
+int frcnn_roi_crop_resize_fwd_planes(const float* feat, int rows, int cols, int C, const float* rois, int n, int pool,
+                                     const float* fill, int relu, int layout, const frcnn_h3_planes* out, void* stream) {
+    if (n < 0 || rows <= 0 || cols <= 0 || C <= 0 || (C & 3) || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_planes: bad shape (C %% 4 == 0)");
+    if (n == 0) return FRCNN_OK;
+    if (!feat || !rois || !out || !out->planes || !out->exponent) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_planes: null pointer");
+    if (reinterpret_cast<uintptr_t>(out->planes) & 15) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_planes: 16-byte aligned planes required");
+    k_roi_fwd_planes<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool, (const float4*)fill,
+                                                                    relu, layout, out->exponent, (_Float16*)out->planes, (size_t)n * pool * pool * C);
+    return check_launch("roi_crop_resize_fwd_planes");
 }
 
 int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C, const float* rois, int n, int pool,

@@ -104,6 +104,7 @@ class DualUnit:
 
 FUSE_PAIRS = True       # dev knob (tests): False launches every layer on its own
 FUSED_BF16_STEM = True  # dev knob (tests): False = f32 stem conv + f32 pool + cast in front of a bf16 trunk
+FUSED_F32_STEM = True   # dev knob (tests): False = conv1 and the max-pool as two launches also under the f16x3 engine
 
 
 def _pair(first, second):
@@ -144,9 +145,18 @@ def run_block(u, x, layout=0, planes=False):
         t, shortcut = pair(x, layout=layout)
     else:
         shortcut = u["1"](x, layout=layout) if "1" in u else x
-        t = u["2a"](x, layout=layout, planes_out=planes)
-    t = u["2b"](t, layout=layout, planes_out=planes)
+        t = u["2a"](x, layout=layout, planes_out=planes and _reads_planes(u["2b"], x.shape[:-1] + (u["2a"].pc.cout,), layout))
+    t = u["2b"](t, layout=layout, planes_out=planes and _reads_planes(u["2c"], t.shape, layout))
     return u["2c"](t, residual=shortcut, layout=layout)
+
+
+def _reads_planes(unit, x_shape, layout):
+    """Will ``unit`` read a tensor of this shape as fp16 planes (ops.conv_accepts_planes)?  (stride-1 layers of a head block)"""
+    if unit.dtype != "f32":
+        return False
+    if unit.pc is None:
+        unit.lower()
+    return ops.conv_accepts_planes(tuple(x_shape), unit.pc, unit.stride, unit.padding, unit.act, layout, unit.tile)
 
 
 class ResNetBase:
@@ -174,6 +184,7 @@ class ResNetBase:
         arrays' id(), which a freed-and-reallocated generation of arrays can repeat: ADVICE r3)."""
         if only is None or self.stem.conv in only or self.stem.bn in only or self.stem.scale_name in only:
             self._stem_bf16 = None
+            self._stem_h3 = None
 
     def lower_fused_stem(self):
         """The packed form frcnn_stem_bf16_fwd reads (None on an f32 base); built once, dropped by invalidate_fused."""
@@ -184,12 +195,21 @@ class ResNetBase:
             self._stem_bf16, self._stem_src = ops.PackedStemBf16(*self.stem.folded()), src
         return self._stem_bf16
 
+    def lower_fused_stem_h3(self):
+        """The packed form frcnn_stem_h3_fwd reads; built once per generation of conv1's arrays, dropped by invalidate_fused."""
+        src = tuple(id(a) for name in (self.stem.conv, self.stem.bn, self.stem.scale_name) if name for a in self.weights[name])
+        if getattr(self, "_stem_h3", None) is None or self._stem_h3_src != src:
+            self._stem_h3, self._stem_h3_src = ops.PackedStemH3(*self.stem.folded()), src
+        return self._stem_h3
+
     def stem_pool(self, x):
         """conv1 + BN (+ Scale) + ReLU + MaxPooling2D((3,3), strides=(2,2)) (resnet.py:408-412).  bf16 path: ONE launch on
         the bf16 matrix cores with the pool and the bf16 store fused (frcnn_stem_bf16_fwd); ``FUSED_BF16_STEM = False``
         keeps the round-1/2 form (f32 conv, f32 pool, cast)."""
         if self.dtype == "bf16" and FUSED_BF16_STEM:
             return ops.stem_bf16(x, self.lower_fused_stem())
+        if self.dtype == "f32" and FUSED_F32_STEM and ops.F32_ENGINE == "f16x3" and x.shape[1] >= 7 and x.shape[2] >= 7:
+            return ops.stem_h3(x, self.lower_fused_stem_h3())   # the fp32 twin on the f16x3 engine (round 5): one launch, no 38 MB conv map
         x = ops.pool2d(self.stem(x), 3, 2, True)
         return ops.cast_bf16(x) if self.dtype == "bf16" else x
 
@@ -307,9 +327,15 @@ class ResNetHead:
             v = a["1"](fmap)                                # shortcut conv + BN
         # an invalid (empty) RoI crops to zeros in the reference order, which these layers map to their BN shift
         L = self.layout
-        t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)
+        planes = self.dtype == "f32" and HEAD_PLANES
+        n = rois.reshape(-1, 4).shape[0]
+        crop_shape = (self.pool, self.pool, n, u.shape[-1]) if L else (n, self.pool, self.pool, u.shape[-1])
+        if planes and _reads_planes(a["2b"], crop_shape, L):     # the crops go to res5a_branch2b as the planes it multiplies
+            t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L, planes_out=True)
+        else:
+            t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)
         s = resize(v, rois, self.pool, fill=a["1"].pc.shift, layout=L)
-        return a["2c"](a["2b"](t, layout=L, planes_out=self.dtype == "f32" and HEAD_PLANES), residual=s, layout=L)
+        return a["2c"](a["2b"](t, layout=L, planes_out=planes and _reads_planes(a["2c"], crop_shape[:-1] + (a["2b"].pc.cout,), L)), residual=s, layout=L)
 
     def __call__(self, feat, rois):
         resize = ops.roi_crop_resize_bf16 if self.dtype == "bf16" else ops.roi_crop_resize

@@ -266,16 +266,30 @@ def roi_targets(rois_i16, gt_f32, gt_f64, gt_cls, bg_idx):
 
 
 # ----------------------------------------------------------------------------- RoI crop/resize
-def roi_crop_resize(feat, rois, pool, fill=None, relu=False, layout=0):
+def roi_crop_resize(feat, rois, pool, fill=None, relu=False, layout=0, planes_out=False):
     """feat: (R,C,Cf) f32 (or (1,R,C,Cf)); rois: (n,4) f32 -> (n,pool,pool,Cf) f32, or (pool,pool,n,Cf) with layout=1.
-    fill (Cf,) = value of an invalid RoI (default zeros); relu clamps the output (frcnn_roi_crop_resize_fwd_ex)."""
+    fill (Cf,) = value of an invalid RoI (default zeros); relu clamps the output (frcnn_roi_crop_resize_fwd_ex).
+    ``planes_out``: the result as a PlaneTensor for an f16x3 convolution behind it (frcnn_roi_crop_resize_fwd_planes); needs the
+    map's magnitude record (its producer's), otherwise the f32 tensor comes back."""
     _require_gpu()
     src = feat
     feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
     rows, cols, C = feat.shape
     rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
     n = rois.shape[0]
-    out = torch.empty((pool, pool, n, C) if layout else (n, pool, pool, C), dtype=torch.float32, device="cuda")
+    oshape = (pool, pool, n, C) if layout else (n, pool, pool, C)
+    if planes_out and _tracking() and getattr(src, "_amax", None) is not None and C % 4 == 0 and n > 0:
+        floor = 0.0
+        if fill is not None:
+            floor = getattr(fill, "_absmax", None)
+            if floor is None:
+                floor = float(fill.abs().max().item())
+        out = PlaneTensor(oshape)
+        amax_carry(out, src, floor, exponent_out=out.exponent)    # the bound and, from it, the planes' scale: known before the launch
+        yp = _lib.H3Planes(planes=out.planes.data_ptr(), exponent=out.exponent.data_ptr())
+        _lib.call("frcnn_roi_crop_resize_fwd_planes", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, ctypes.byref(yp), _stream())
+        return out
+    out = torch.empty(oshape, dtype=torch.float32, device="cuda")
     _lib.call("frcnn_roi_crop_resize_fwd_ex", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, _p(out), _stream())
     if _tracking() and getattr(src, "_amax", None) is not None:
         # a bilinear sample is a convex combination of map values; a rejected RoI yields the fill vector
@@ -526,29 +540,40 @@ def _tracking():
 
 
 def amax_of(x):
-    """The magnitude record of tensor ``x``: the one its producer attached, or a measured one (one pass over x)."""
+    """The magnitude record of tensor ``x``: the one its producer attached, or a MEASURED one (one pass over x).  A measured record is
+    not kept on the tensor: a tensor nobody produced is somebody's input buffer, rewritten between passes (a captured pass's static
+    input), and its record lives in an arena that the next pass clears."""
     rec = getattr(x, "_amax", None)
     if rec is None:
         global AMAX_MEASURED
         AMAX_MEASURED += 1
         rec = _amax_new()
         _lib.call("frcnn_amax_f32", _p(x), x.numel(), _p(rec), _stream())
-        x._amax = rec
     return rec
 
 
-def amax_carry(dst, src, floor=0.0):
+def amax_carry(dst, src, floor=0.0, exponent_out=None):
     """``dst`` was derived from ``src`` by a map that cannot exceed max(|src|, floor) (a view, max-pooling, ReLU, the bilinear RoI
-    resampling with a fill vector): it inherits the bound.  floor > 0 needs a record of its own (frcnn_amax_merge)."""
+    resampling with a fill vector): it inherits the bound.  floor > 0 (or a request for the bound's plane exponent) needs a record
+    of its own (frcnn_amax_merge)."""
     rec = getattr(src, "_amax", None)
     if rec is None:
         return dst
-    if floor > 0.0:
+    if floor > 0.0 or exponent_out is not None:
         merged = _amax_new()
-        _lib.call("frcnn_amax_merge", _p(merged), _p(rec), float(floor), _stream())
+        _lib.call("frcnn_amax_merge", _p(merged), _p(rec), float(floor), _p(exponent_out), _stream())
         rec = merged
     dst._amax = rec
     return dst
+
+
+def conv_accepts_planes(x_shape, pc, stride=1, padding="valid", act=None, layout=0, tile=0):
+    """Would ``conv2d`` of a tensor of this shape read fp16 planes (the f16x3 engine on its 256x128 tile, un-split)?  Producers ask
+    before they hand a PlaneTensor on."""
+    if F32_ENGINE != "f16x3" or not isinstance(pc, PackedConv):
+        return False
+    d = _conv_desc(tuple(x_shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act], layout, tile or AUTO_TILE)
+    return _planes_ok(d, pc, _split_engine(d, pc, tile or AUTO_TILE))
 
 
 H3_KERNEL_NAMES = {81: "k_conv_igemm_h3<2,1,2,4>", 82: "k_conv_igemm_h3_db<2,2,4,2>", 83: "k_conv_igemm_h3<2,2,2,2>", 84: "k_conv_igemm_h3<1,1,2,2>",
@@ -1174,4 +1199,37 @@ def stem_bf16(x, ps):
     ho, wo = (h + 1) // 2, (w + 1) // 2
     out = torch.empty((n, (ho - 3) // 2 + 1, (wo - 3) // 2 + 1, 64), dtype=torch.bfloat16, device="cuda")
     _lib.call("frcnn_stem_bf16_fwd", _p(x), n, h, w, _p(ps.w), _p(ps.scale), _p(ps.shift), _p(out), _stream())
+    return out
+
+
+class PackedStemH3:
+    """The fused f32 stem's parameters (frcnn_stem_h3_fwd): conv1's 7x7x3x64 filter as a header + two fp16 planes [2][64][176] and the
+    folded f32 scale / shift of bias + BatchNorm (+ Scale)."""
+
+    def __init__(self, w_hwio, scale, shift):
+        _require_gpu()
+        w = _dev(w_hwio, torch.float32)
+        assert tuple(w.shape) == (7, 7, 3, 64), "the fused stem is conv1 of the ResNets: 7x7x3 -> 64"
+        self.w = torch.empty(_lib.load().frcnn_stem_h3_packed_bytes(), dtype=torch.uint8, device="cuda")
+        _lib.call("frcnn_pack_stem_weights_h3", _p(w), _p(self.w), _stream())
+        self.scale, self.shift = _dev(scale, torch.float32), _dev(shift, torch.float32)
+        torch.cuda.current_stream().synchronize()            # w may be a temporary
+
+
+def stem_h3(x, ps):
+    """(n,H,W,3) f32 preprocessed images -> (n,Hp,Wp,64) f32: conv1 + BN (+Scale) + ReLU + 3x3/2 max-pool in ONE f16x3 launch; the
+    result carries its magnitude record."""
+    _require_gpu()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[-1] == 3
+    n, h, w, _ = x.shape
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    out = torch.empty((n, (ho - 3) // 2 + 1, (wo - 3) // 2 + 1, 64), dtype=torch.float32, device="cuda")
+    ya = _amax_new()
+    args = (_p(x), _p(amax_of(x)), n, h, w, _p(ps.w), _p(ps.scale), _p(ps.shift), _p(out), _p(ya))
+    _lib.call("frcnn_stem_h3_fwd", *args, _stream())
+    out._amax = ya
+    if CONV_PROFILE is not None:
+        keep = (x, ps, out, ya)
+        CONV_PROFILE.append({"kernel": "k_stem_h3", "flops": 2.0 * n * ho * wo * 64 * 147, "shape": (n * ho * wo, 64, 147, 2),
+                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_stem_h3_fwd", *args, _stream())})
     return out

@@ -332,7 +332,8 @@ int frcnn_conv2d_engine(const frcnn_conv_desc* d, int prefer, int workspace_pres
  * frcnn_amax_record_floats() floats (several atomic slots; a reader takes their maximum; 16-byte aligned).  frcnn_amax_clear zeroes
  * records (a kernel, safe inside a captured graph); every frcnn_conv2d_fwd_h3 / _dual_h3 / frcnn_conv2d_fwd_ws_amax launch folds
  * max|y| of what it stores into y_amax (NULL: not tracked), so a chain of layers carries its bounds along without extra passes;
- * frcnn_amax_f32 measures a tensor that has no producer record; frcnn_amax_merge(dst, src, floor) sets dst = max(dst, src, floor)
+ * frcnn_amax_f32 measures a tensor that has no producer record; frcnn_amax_merge(dst, src, floor, exponent_out) sets dst = max(dst, src, floor)
+ * (and, when exponent_out is given, writes the power of two planes under that bound are scaled by: frcnn_roi_crop_resize_fwd_planes)
  * for tensors derived by maps that cannot exceed max(|input|, floor): max-pooling (resnet.py:412), the bilinear RoI resampling
  * with a fill vector (custom_layers.py:35-56), ReLU.  A bound that is too LARGE by up to 2^8 costs no precision; one that is too
  * small overflows fp16 (inf / NaN in the output, as an f32 overflow would give).
@@ -345,7 +346,7 @@ int frcnn_pack_conv_weights_h3(const float* w_packed, int cout, int packed_k, vo
 int frcnn_amax_record_floats(void);
 int frcnn_amax_clear(float* records, int n_records, void* stream);
 int frcnn_amax_f32(const float* x, size_t n, float* record, void* stream);
-int frcnn_amax_merge(float* dst_record, const float* src_record, float floor_value, void* stream);
+int frcnn_amax_merge(float* dst_record, const float* src_record, float floor_value, int32_t* exponent_out, void* stream);
 int frcnn_conv2d_h3_config(const frcnn_conv_desc* d, int n1);
 size_t frcnn_conv2d_h3_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_fwd_h3(const frcnn_conv_desc* d, const float* x, const float* x_amax, const void* w_planes_f16,
@@ -354,6 +355,16 @@ int frcnn_conv2d_fwd_h3(const frcnn_conv_desc* d, const float* x, const float* x
 int frcnn_conv2d_fwd_dual_h3(const frcnn_conv_desc* d, const float* x, const float* x_amax, const void* w_planes_f16,
                              const float* scale, const float* shift, float* y1, int n1, int act1, float* y1_amax,
                              float* y2, int act2, float* y2_amax, void* stream);
+/* The ResNet stem as ONE f16x3 launch: conv1 7x7 / 2 'same' (3 -> 64) + BatchNormalization (+ Scale) + ReLU + MaxPooling2D((3,3),
+ * strides (2,2)) (resnet.py:408-412, :565-568), f32 image in, f32 pooled map [n][hp][wp][64] out (hp = ((h+1)/2 - 3)/2 + 1), max|y| into
+ * y_amax.  The fp32 twin of frcnn_stem_bf16_fwd: per conv pixel the arithmetic of frcnn_conv2d_fwd_h3 (the image split into two fp16
+ * planes in LDS under the scale its magnitude record x_amax gives), the pool taken in LDS on f32 values; replaces a
+ * frcnn_conv2d_fwd_ws + frcnn_pool2d_fwd pair whose 38 MB intermediate map does not stay in L2 with several images in flight.
+ * frcnn_pack_stem_weights_h3: HWIO [7][7][3][64] f32 -> 16-byte header (max|w|) + two fp16 planes (frcnn_stem_h3_packed_bytes). */
+size_t frcnn_stem_h3_packed_bytes(void);
+int frcnn_pack_stem_weights_h3(const float* w_hwio, void* packed, void* stream);
+int frcnn_stem_h3_fwd(const float* x, const float* x_amax, int n, int h, int w, const void* w_packed, const float* scale, const float* shift,
+                      float* out, float* y_amax, void* stream);
 /* A chain of f16x3 layers may hand its activations on ALREADY split: `y_planes` makes the launch write two fp16 planes [2][M][cout]
  * (hi, lo as the engine splits them) under the scale 2^*exponent beside -- or, with y == NULL, instead of -- the f32 tensor, and a
  * following launch given them as `x_planes` (x == NULL) stages them into LDS unchanged: no conversion and no arithmetic in its loader
@@ -371,6 +382,12 @@ int frcnn_conv2d_fwd_h3_planes(const frcnn_conv_desc* d, const float* x, const f
                                const void* w_planes_f16, const float* scale, const float* shift,
                                const float* residual, const float* residual_amax,
                                float* y, float* y_amax, const frcnn_h3_planes* y_planes, float bound_c, float bound_d, void* stream);
+/* RoiResizeConv (custom_layers.py:35-56; frcnn_roi_crop_resize_fwd_ex) writing its result as f16x3 planes for the convolution behind it
+ * (res5a_branch2b's 3x3 over the crops, resnet.py:508-512).  out->exponent is an INPUT here: the scale comes from a bound known before the
+ * launch -- a bilinear sample cannot exceed the map's largest magnitude, a rejected RoI yields `fill` -- i.e. from
+ * frcnn_amax_merge(record, map_record, max|fill|, out->exponent) issued in front of it on the same stream. */
+int frcnn_roi_crop_resize_fwd_planes(const float* feat, int rows, int cols, int c, const float* rois, int n, int pool,
+                                     const float* fill, int relu, int layout, const frcnn_h3_planes* out, void* stream);
 /* frcnn_conv2d_fwd_ws (the native f32 MFMA kernels) that also folds max|y| into y_amax: a layer that stays on the native path
  * (the 3-channel stem, small grids) in front of an f16x3 layer. */
 int frcnn_conv2d_fwd_ws_amax(const frcnn_conv_desc* d, const float* x, const float* w_packed,

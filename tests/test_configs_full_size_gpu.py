@@ -316,7 +316,9 @@ def test_bf16_drift_from_the_fp32_reference_graph(config, dtype, frames):
     frames -- configs[3] (ResNet-101, 600x1500) and configs[1]'s shapes on the bf16 engine.  Bars (bench.DRIFT_BARS_*):
     head as drawn >= 0.90 of the detections paired by class and IoU >= 0.5, mean score difference of the pairs <= 5e-3; the
     calibrated head (~20 classes firing on margins below one bf16 rounding) is the stress case: >= 0.80, <= 2e-2.  The pair's
-    mAP delta is printed, not asserted (bench.py says why).  bench.py prints the same object (`parity.e2e_vs_fp32`)."""
+    mAP delta is BOUNDED since round 5 (bench.DRIFT_MAP_BARS: from a 32-frame run with a bootstrap over frames,
+    scripts/drift_bf16.py / profiles/round5_drift_bf16_*.json; the few frames of this test get the small-sample bar).
+    bench.py prints the same object (`parity.e2e_vs_fp32`)."""
     import bench
     saved = {k: getattr(bench, k) for k in ("HEIGHT", "WIDTH", "SCALES", "NUM_CLASSES", "DEPTH", "DTYPE", "WORKLOAD")}
     try:
@@ -339,3 +341,5 @@ def test_bf16_drift_from_the_fp32_reference_graph(config, dtype, frames):
     same, total = (int(v) for v in drawn["proposals_identical"].split("/"))
     assert same >= 0.7 * total
     assert drawn["matched_score_diff"]["mean"] < 5e-3 and cal["matched_score_diff"]["mean"] < 2e-2
+    bar = bench.DRIFT_MAP_BARS["configs[3]" if config == "c4" else "configs[1] shapes"][0 if frames >= 32 else 1]
+    assert drawn["map_pair_delta"] <= bar and cal["map_pair_delta"] <= bar, (drawn["map_pair_delta"], cal["map_pair_delta"], bar)

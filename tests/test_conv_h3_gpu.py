@@ -116,11 +116,13 @@ def test_h3_magnitude_bound_may_be_loose_but_not_wrong():
     xd = torch.from_numpy(x).cuda()
     ref, mag = ref_conv(x, wt, 1, "same")
     tight = ops.conv2d(xd, pc, 1, "same", tile=84)
+    assert getattr(xd, "_amax", None) is None                     # a measured record is not kept on an input buffer
+    xd._amax = ops.amax_of(xd)
     assert float(xd._amax.max()) == float(np.abs(x).max())       # measured (no producer): exact
     e_tight = err(tight.cpu().numpy(), ref, mag)
     loose_in = torch.from_numpy(x).cuda()
     rec = torch.zeros_like(xd._amax)
-    _lib.call("frcnn_amax_merge", rec.data_ptr(), xd._amax.data_ptr(), 256.0 * float(np.abs(x).max()), None)
+    _lib.call("frcnn_amax_merge", rec.data_ptr(), xd._amax.data_ptr(), 256.0 * float(np.abs(x).max()), None, None)
     loose_in._amax = rec
     loose = ops.conv2d(loose_in, pc, 1, "same", tile=84)
     e_loose = err(loose.cpu().numpy(), ref, mag)
@@ -346,3 +348,64 @@ def test_h3_plane_tensors_between_layers():
         c1_ = ops.conv2d(xd, p1, 1, "valid", "relu", layout=1, planes_out=True)
         c3_ = ops.conv2d(ops.conv2d(c1_, p2, 1, "same", "relu", layout=1, planes_out=True), p3, 1, "valid", "relu", residual=rd, layout=1)
     assert torch.equal(c3_, b3) and torch.equal(c1_.planes, b1.planes)
+
+
+@pytest.mark.parametrize("size", [(160, 224), (161, 227), (600, 1000), (37, 29)])
+def test_h3_fused_stem_equals_conv_plus_pool(size):
+    """frcnn_stem_h3_fwd: conv1 7x7 / 2 'same' + folded BatchNorm + ReLU + MaxPooling2D((3,3), (2,2)) in one f16x3 launch (resnet.py:408-412)
+    against the two-launch form (native f32 conv, then the pool) and against fp64: the conv values within the engine's bar, the pool
+    exact on them -- even and odd sizes (TF 'same' pads one side only on even sizes), patches that hang over the image edge."""
+    from faster_rcnn_amd import ops
+    h, w = size
+    rs = np.random.RandomState(h * 1000 + w)
+    x = (rs.randint(0, 256, (2, h, w, 3)).astype(np.float64) - np.array([103.939, 116.779, 123.68])).astype(np.float32)
+    wt = (rs.randn(7, 7, 3, 64) * np.sqrt(2.0 / 147)).astype(np.float32)
+    scale = (1 + 0.1 * rs.randn(64)).astype(np.float32)
+    shift = (0.5 * rs.randn(64)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    got = ops.stem_h3(xd, ops.PackedStemH3(wt, scale, shift))
+    two = ops.pool2d(ops.conv2d(xd, ops.PackedConv(wt, scale, shift), 2, "same", "relu"), 3, 2, True)
+    assert got.shape == two.shape
+    conv64, mag = ref_conv(x, wt, 2, "same", scale, shift, None, "relu")
+    t = torch.from_numpy(conv64).permute(0, 3, 1, 2)
+    pool64 = torch.nn.functional.max_pool2d(t, 3, 2).permute(0, 2, 3, 1).numpy()
+    magp = torch.nn.functional.max_pool2d(torch.from_numpy(mag).permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1).numpy()     # (an upper bound of the selected pixel's)
+    e_fused = float((np.abs(got.cpu().numpy() - pool64) / np.maximum(magp, 1e-30)).max())
+    e_two = float((np.abs(two.cpu().numpy() - pool64) / np.maximum(magp, 1e-30)).max())
+    print(size, "fused f16x3 stem %.3g, native conv + pool %.3g" % (e_fused, e_two))
+    assert e_fused <= max(1.5 * e_two, 4e-7)
+    assert float((got - two).abs().max() / two.abs().max()) < 1e-5
+    assert float(got._amax.max()) == float(got.abs().max())
+    assert torch.equal(ops.stem_h3(xd, ops.PackedStemH3(wt, scale, shift)), got)          # bitwise reproducible
+
+
+def test_h3_roi_resampling_writes_the_planes_the_next_conv_reads():
+    """frcnn_roi_crop_resize_fwd_planes: the crops of RoiResizeConv (custom_layers.py:35-56) as fp16 planes under the scale the map's
+    record gives BEFORE the launch (a bilinear sample cannot exceed the map's maximum; a rejected RoI yields the fill vector): the
+    planes equal the f32 crops to one unit in the last place, and the 3x3 convolution behind them gives what it gives on the f32 crops."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(41)
+    rows, cols, C, n = 38, 63, 512, 300
+    with ops.f32_engine("f16x3"), ops.conv_workspace(ops.NO_SPLIT_K):
+        base = torch.from_numpy(rs.randn(1, rows, cols, 64).astype(np.float32)).cuda()
+        feat = ops.conv2d(base, ops.PackedConv((rs.randn(1, 1, 64, C) * 0.2).astype(np.float32)), 1, "valid")       # a producer: the map has a record
+        x1 = rs.randint(0, cols - 3, n); y1 = rs.randint(0, rows - 3, n)
+        rois = np.stack([x1, y1, np.minimum(cols - 1, x1 + 2 + rs.randint(0, 20, n)), np.minimum(rows - 1, y1 + 2 + rs.randint(0, 14, n))], axis=1).astype(np.float32)
+        rois[7] = [5, 5, 5, 5]                                               # an empty RoI: the fill vector
+        rd = torch.from_numpy(rois).cuda()
+        fill = torch.from_numpy((rs.randn(C) * 3).astype(np.float32)).cuda()
+        f32 = ops.roi_crop_resize(feat, rd, 7, fill=fill, relu=True, layout=1)
+        pl = ops.roi_crop_resize(feat, rd, 7, fill=fill, relu=True, layout=1, planes_out=True)
+        assert isinstance(pl, ops.PlaneTensor) and pl.shape == tuple(f32.shape)
+        v, f = pl.float().double(), f32.double()
+        assert bool(((v - f).abs() <= 2.0 ** -23 * f.abs() + 2.0 ** -40 * f.abs().max()).all())
+        bound = max(float(feat.abs().max()), float(fill.abs().max()))
+        assert float(pl._amax.max()) == bound and 2.0 ** 14 <= bound * 2.0 ** int(pl.exponent.item()) < 2.0 ** 15
+        pc = ops.PackedConv((rs.randn(3, 3, C, C) * np.sqrt(2.0 / (9 * C))).astype(np.float32))
+        assert ops.conv_accepts_planes(pl.shape, pc, 1, "same", "relu", 1)
+        a = ops.conv2d(f32, pc, 1, "same", "relu", layout=1)
+        b = ops.conv2d(pl, pc, 1, "same", "relu", layout=1)
+        assert float((a - b).abs().max() / a.abs().max()) < 2e-6
+        # without a record on the map the request falls back to the f32 tensor
+        plain = ops.roi_crop_resize(feat.clone(), rd, 7, fill=fill, relu=True, layout=1, planes_out=True)
+        assert isinstance(plain, torch.Tensor) and torch.equal(plain, f32)
