@@ -145,9 +145,15 @@ def run_block(u, x, layout=0, planes=False):
         t, shortcut = pair(x, layout=layout)
     else:
         shortcut = u["1"](x, layout=layout) if "1" in u else x
-        t = u["2a"](x, layout=layout, planes_out=planes and _reads_planes(u["2b"], x.shape[:-1] + (u["2a"].pc.cout,), layout))
+        t = u["2a"](x, layout=layout, planes_out=planes and _reads_planes(u["2b"], tuple(x.shape[:-1]) + (_cout(u["2a"]),), layout))
     t = u["2b"](t, layout=layout, planes_out=planes and _reads_planes(u["2c"], t.shape, layout))
     return u["2c"](t, residual=shortcut, layout=layout)
+
+
+def _cout(unit):
+    if unit.pc is None:
+        unit.lower()
+    return unit.pc.cout
 
 
 def _reads_planes(unit, x_shape, layout):
@@ -335,7 +341,7 @@ class ResNetHead:
         else:
             t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)
         s = resize(v, rois, self.pool, fill=a["1"].pc.shift, layout=L)
-        return a["2c"](a["2b"](t, layout=L, planes_out=planes and _reads_planes(a["2c"], crop_shape[:-1] + (a["2b"].pc.cout,), L)), residual=s, layout=L)
+        return a["2c"](a["2b"](t, layout=L, planes_out=planes and _reads_planes(a["2c"], crop_shape[:-1] + (_cout(a["2b"]),), L)), residual=s, layout=L)
 
     def __call__(self, feat, rois):
         resize = ops.roi_crop_resize_bf16 if self.dtype == "bf16" else ops.roi_crop_resize

@@ -692,13 +692,14 @@ def _conv2d_h3_planes(d, x, pc, residual, oshape, planes_out, act):
     yp = _lib.H3Planes(planes=y.planes.data_ptr(), exponent=y.exponent.data_ptr()) if planes_out else None
     ya = _amax_new()
     bc, bd = pc.h3_bound() if planes_out else (0.0, 0.0)
-    args = (ctypes.byref(d), None if x_in else _p(x), ctypes.byref(xp) if x_in else None, _p(amax_of(x)), _p(pc.h3_planes()), _p(pc.scale), _p(pc.shift),
-            _p(residual), _p(amax_of(residual)) if (residual is not None and planes_out) else None,
-            None if planes_out else _p(y), _p(ya), ctypes.byref(yp) if planes_out else None, bc, bd)
+    xa = amax_of(x)                                              # (a measured record is a temporary: it must outlive the launch and its re-launches)
+    ra = amax_of(residual) if (residual is not None and planes_out) else None
+    args = (ctypes.byref(d), None if x_in else _p(x), ctypes.byref(xp) if x_in else None, _p(xa), _p(pc.h3_planes()), _p(pc.scale), _p(pc.shift),
+            _p(residual), _p(ra), None if planes_out else _p(y), _p(ya), ctypes.byref(yp) if planes_out else None, bc, bd)
     _lib.call("frcnn_conv2d_fwd_h3_planes", *args, _stream())
     y._amax = ya
     if CONV_PROFILE is not None:
-        keep = (d, x, pc, residual, y, ya, xp, yp)
+        keep = (d, x, pc, residual, y, ya, xp, yp, xa, ra)
         # (the instantiation that reads planes is a kernel of its own; writing planes is a run-time branch of either's epilogue)
         CONV_PROFILE.append({"kernel": _h3_name(d).replace(">", ",planes>") if x_in else _h3_name(d), "planes_out": bool(planes_out),
                              "flops": 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin,
@@ -743,13 +744,13 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
     eng = _split_engine(d, pc, tile or AUTO_TILE)
     if eng == "h3":
         ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_h3_workspace_bytes"))
-        ya = _amax_new()
-        args = (ctypes.byref(d), _p(x), _p(amax_of(x)), _p(pc.h3_planes()), _p(pc.scale), _p(pc.shift), _p(residual), None, _p(out), _p(ya),
+        ya, xa = _amax_new(), amax_of(x)
+        args = (ctypes.byref(d), _p(x), _p(xa), _p(pc.h3_planes()), _p(pc.scale), _p(pc.shift), _p(residual), None, _p(out), _p(ya),
                 _p(ws), ws.numel() if ws is not None else 0)
         _lib.call("frcnn_conv2d_fwd_h3", *args, _stream())
         out._amax = ya
         if CONV_PROFILE is not None:
-            keep = (d, x, pc, residual, out, ws, ya)
+            keep = (d, x, pc, residual, out, ws, ya, xa)
             CONV_PROFILE.append({"kernel": "k_conv_igemm_h3<1,1,2,2> split-K" if ws is not None else _h3_name(d),
                                  "flops": 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin,
                                  "shape": (n * ho * wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
@@ -794,13 +795,13 @@ def conv2d_dual(x, pc, n1, stride=1, padding="valid", act1=None, act2=None, layo
     y2 = torch.empty(lead + (pc.cout - n1,), dtype=torch.float32, device="cuda")
     eng = _split_engine(d, pc, tile or AUTO_TILE)
     if eng == "h3":
-        a1, a2 = _amax_new(), _amax_new()
-        args = (ctypes.byref(d), _p(x), _p(amax_of(x)), _p(pc.h3_planes()), _p(pc.scale), _p(pc.shift), _p(y1), n1, ACT[act1], _p(a1),
+        a1, a2, xa = _amax_new(), _amax_new(), amax_of(x)
+        args = (ctypes.byref(d), _p(x), _p(xa), _p(pc.h3_planes()), _p(pc.scale), _p(pc.shift), _p(y1), n1, ACT[act1], _p(a1),
                 _p(y2), ACT[act2], _p(a2))
         _lib.call("frcnn_conv2d_fwd_dual_h3", *args, _stream())
         y1._amax, y2._amax = a1, a2
         if CONV_PROFILE is not None:
-            keep = (d, x, pc, y1, y2, a1, a2)
+            keep = (d, x, pc, y1, y2, a1, a2, xa)
             CONV_PROFILE.append({"kernel": _h3_name(d, n1), "flops": 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin,
                                  "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, stride),
                                  "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_dual_h3", *args, _stream())})
@@ -1224,12 +1225,12 @@ def stem_h3(x, ps):
     n, h, w, _ = x.shape
     ho, wo = (h + 1) // 2, (w + 1) // 2
     out = torch.empty((n, (ho - 3) // 2 + 1, (wo - 3) // 2 + 1, 64), dtype=torch.float32, device="cuda")
-    ya = _amax_new()
-    args = (_p(x), _p(amax_of(x)), n, h, w, _p(ps.w), _p(ps.scale), _p(ps.shift), _p(out), _p(ya))
+    ya, xa = _amax_new(), amax_of(x)
+    args = (_p(x), _p(xa), n, h, w, _p(ps.w), _p(ps.scale), _p(ps.shift), _p(out), _p(ya))
     _lib.call("frcnn_stem_h3_fwd", *args, _stream())
     out._amax = ya
     if CONV_PROFILE is not None:
-        keep = (x, ps, out, ya)
+        keep = (x, ps, out, ya, xa)
         CONV_PROFILE.append({"kernel": "k_stem_h3", "flops": 2.0 * n * ho * wo * 64 * 147, "shape": (n * ho * wo, 64, 147, 2),
                              "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_stem_h3_fwd", *args, _stream())})
     return out
