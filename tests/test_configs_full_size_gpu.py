@@ -80,8 +80,10 @@ def test_config1_resnet50_600x1000_inference_fp32(engine):
     # rpn_conv1 (k 9 216).  Native (8): the stem, stage 4's 256-column 1x1 layers, the RPN output pair, the dense pair.
     if engine == "native":
         assert n_x6 == 0 and n_sk == 0, (n_x6, n_sk, kernels)
-    else:
+    elif engine == "bf16x6":
         assert n_sk == 7 and n_x6 == 37 and n_native == 8, (engine, n_x6, n_sk, n_native, kernels)
+    else:                                                    # f16x3: the stem too (k_stem_h3: conv1 + BN + ReLU + max-pool in one launch)
+        assert n_sk == 7 and n_x6 == 38 and n_native == 7 and kernels[0] == "k_stem_h3", (engine, n_x6, n_sk, n_native, kernels)
     if engine == "f16x3":                                    # every tensor a split launch read carried its producer's magnitude record:
         assert res["amax_measured"] <= 1, res                # nothing but (at most) the network input was measured by a pass of its own
 
