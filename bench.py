@@ -971,7 +971,9 @@ def main():
     if args.batch > 1 and (not bf16_run or args.config == "c1" or args.no_graph):
         ap.error("--batch needs the bf16 conv path and hipGraph replay")
     if args.streams <= 0:
-        args.streams = 8 if not bf16_run else 4       # configs[3] sweep (round 3, batch 8): 4 graphs 982-994 img/s, 3 975-985, 5 933-943, 2 952; 8 hw queues 939-944
+        # fp32: 12 images in flight on 12 hardware queues since round 5 (f16x3 engine: 8 / 12 / 16 streams 472 / 481 / 480 img/s, twice each in
+        # one session -- the launches are shorter now and more of them are latency-bound; the native engine showed no difference)
+        args.streams = 12 if not bf16_run else 4      # configs[3] sweep (round 3, batch 8): 4 graphs 982-994 img/s, 3 975-985, 5 933-943, 2 952; 8 hw queues 939-944
     # ROCm maps a process's streams onto 4 hardware queues unless told otherwise; more than four images in flight need
     # a queue each or they queue behind one another (measured on MI355X: 8 streams on 8 queues 245.6 img/s, 8 streams on
     # 4 queues 241.4, 4 on 4 240.7, 4 on 8 217.0; configs[3] (bf16) is fastest with 4 on 4).  Read when the HIP runtime

@@ -208,7 +208,7 @@ def main(argv=None):
     from .util import get_anchors, resize_imgs
     args = build_parser().parse_args(argv)
     # eight images in flight want eight hardware queues; read when the HIP runtime starts, an explicit setting wins
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     test_imgs = base_paths_to_imgs(args.voc_path, img_set=args.img_set, do_flip=False)
     anchors = get_anchors(anchor_scales_from_str(args.anchor_scales))
     print("num test_imgs: ", len(test_imgs))
