@@ -22,7 +22,7 @@ python3 $R/scripts/bench_train.py --bf16 --through-loop > $OUT/bench_train_mixed
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-io --conv-table > /dev/null 2> $OUT/bench_default_conv_table.err
 grep "^conv" $OUT/bench_default_conv_table.err > $OUT/bench_default_conv_table.txt
 # ---- kernel traces (the profiler starts the runtime before bench.py does: ask for the queues here)
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=12
 export FRCNN_BENCH_NO_ENTRY=1
 export FRCNN_BENCH_NO_NATIVE=1       # the traces hold the timed launch forms only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-io > $OUT/trace_default.log 2>&1

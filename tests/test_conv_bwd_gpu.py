@@ -183,3 +183,91 @@ def test_wgrad_batch_is_bitwise_the_single_layer_calls(wgrad_engine):
     ops.conv2d_wgrad_batch(jobs)
     for j, want in zip(jobs, single):
         assert torch.equal(j[-1], want)
+
+
+def _dgrad_x6(gy, pd, padding, residual, mask, tile):
+    """frcnn_conv2d_fwd_x6 on the dgrad descriptor with an explicit tile code (ops.conv2d_dgrad passes 0 = the policy's choice)."""
+    import ctypes
+    from faster_rcnn_amd import _lib, ops
+    n, ho, wo, _ = gy.shape
+    d = ops._conv_desc((n, ho, wo, pd.cin), pd.kh, pd.kw, pd.cout, 1, padding, 0, 0, tile)
+    out = torch.full((n, ho, wo, pd.cout), float("nan"), dtype=torch.float32, device="cuda")
+    need = _lib.load().frcnn_conv2d_x6_workspace_bytes(ctypes.byref(d))
+    ws = torch.zeros(max(need // 4, 1), dtype=torch.float32, device="cuda") if need else None
+    _lib.call("frcnn_conv2d_fwd_x6", ctypes.byref(d), ops._p(gy), ops._p(pd.x6_planes()), None, None, ops._p(residual), ops._p(mask), ops._p(out),
+              ops._p(ws), ws.numel() if ws is not None else 0, ops._stream())
+    if ws is not None:
+        torch.cuda.synchronize()
+        assert not ws[:4096].view(torch.int32).any().item()          # tickets back to zero
+    return out
+
+
+X6_DGRAD = [  # n,h,w, cin_fwd, cout_fwd, k, padding, tile  (dgrad: rows = n*h*w, reduction over k*k*cout_fwd, columns = cin_fwd)
+    (1, 38, 63, 256, 256, 3, "same", 71),        # vector epilogue, 128x128
+    (1, 38, 63, 128, 256, 1, "valid", 74),       # 64x64
+    (2, 23, 31, 96, 64, 3, "same", 76),          # sixteen waves, ragged rows and columns
+    (1, 38, 63, 1024, 512, 3, "same", 171),      # split-K forms: the last arriver applies residual and mask
+    (1, 38, 63, 256, 256, 3, "same", 174),
+    (1, 19, 31, 192, 2048, 1, "valid", 174),
+    (1, 38, 63, 66, 256, 1, "valid", 74),        # columns not a multiple of four: the scalar epilogue
+    (1, 38, 63, 70, 128, 3, "same", 174),        # ... of the split-K reduction
+]
+
+
+@pytest.mark.parametrize("case", X6_DGRAD)
+def test_split_engine_input_gradient_with_mask_and_residual(case):
+    """The split-bf16 engine as train.py uses it for input gradients (ops.conv2d_dgrad under F32_ENGINE='bf16x6'): residual added and the
+    ReLU mask applied in the engine's own epilogues -- vector, scalar and both split-K reductions -- against fp64 in units of
+    sum |gy w|, bit-identical on a second run, and equal to the native kernel's result to f32 rounding."""
+    from faster_rcnn_amd import ops
+    n, h, w, cin, cout, k, padding, tile = case
+    rs = np.random.RandomState(abs(hash(case)) % (2 ** 31))
+    x = torch.from_numpy(rs.randn(n, h, w, cin)).double().requires_grad_(True)
+    wt = torch.from_numpy(rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).double()
+    scale = torch.from_numpy(1 + 0.1 * rs.randn(cout)).double()
+    y = ref_conv(torch.relu(x), wt, 1, padding) * scale
+    gy = torch.from_numpy(rs.randn(*y.shape)).double()
+    res = torch.from_numpy(rs.randn(n, h, w, cin)).double()
+    (y * gy).sum().backward()
+    keep = (x.detach() > 0)
+    want = x.grad + res * keep
+    xa = x.detach().abs().requires_grad_(True)                       # magnitude: |gy| convT |w scale| (+ |residual|), where the mask keeps
+    (ref_conv(xa, wt.abs(), 1, padding) * scale.abs() * gy.abs()).sum().backward()
+    mag = (xa.grad + res.abs()).clamp(min=1e-30)
+    dev = lambda t: t.detach().float().cuda().contiguous()
+    pd = ops.PackedDgrad(dev(wt), dev(scale))
+    g, r, m = dev(gy), dev(res), dev(x)
+    got = _dgrad_x6(g, pd, padding, r, m, tile)
+    again = _dgrad_x6(g, pd, padding, r, m, tile)
+    assert torch.equal(got, again)
+    e = ((got.cpu().double() - want).abs() / mag)[keep].max().item()
+    assert e <= 5e-7, e
+    assert not got.cpu()[~keep].any().item()                         # masked elements are exactly zero
+    with ops.f32_engine("native"):
+        native = ops.conv2d_dgrad(g, pd, padding, residual=r, mask=m)
+    e_native = ((native.cpu().double() - want).abs() / mag)[keep].max().item()
+    assert e <= max(e_native, 3e-7), (e, e_native)
+
+
+@pytest.mark.parametrize("engine", ["native", "bf16x6"])
+def test_conv2d_dgrad_under_both_engines(engine):
+    """ops.conv2d_dgrad itself (tile 0: the policy picks the launch form) under the library default and under train.py's setting."""
+    from faster_rcnn_amd import ops
+    for (n, h, w, cin, cout, k, padding) in ((1, 38, 63, 256, 256, 3, "same"), (1, 38, 63, 1024, 256, 1, "valid"), (1, 13, 17, 64, 128, 3, "same")):
+        rs = np.random.RandomState(cin + cout + k)
+        x = torch.from_numpy(rs.randn(n, h, w, cin)).double().requires_grad_(True)
+        wt = torch.from_numpy(rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).double()
+        scale = torch.from_numpy(1 + 0.1 * rs.randn(cout)).double()
+        y = ref_conv(torch.relu(x), wt, 1, padding) * scale
+        gy = torch.from_numpy(rs.randn(*y.shape)).double()
+        res = torch.from_numpy(rs.randn(n, h, w, cin)).double()
+        (y * gy).sum().backward()
+        want = x.grad + res * (x.detach() > 0)
+        dev = lambda t: t.detach().float().cuda().contiguous()
+        pd = ops.PackedDgrad(dev(wt), dev(scale))
+        with ops.f32_engine(engine), ops.conv_workspace(ops.ConvWorkspace()):
+            dx = ops.conv2d_dgrad(dev(gy), pd, padding, residual=dev(res), mask=dev(x))
+            d = ops._conv_desc((n, h, w, pd.cin), k, k, pd.cout, 1, padding, 0, 0, 0)
+            assert ops._use_x6(d, pd, 0) == (engine == "bf16x6" and h * w >= 2000)      # (the small case stays native under either setting)
+        e = ((dx.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
+        assert e < 1e-5, e
