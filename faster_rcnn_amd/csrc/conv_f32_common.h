@@ -82,13 +82,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// fused epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-template <int TM, int TN>
+// fused epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+// S16 (conv_h3.hip): the 32x32 block was accumulated as FOUR 16x16 blocks of v_mfma_f32_16x16x32 (element e: block e >> 2 = 2 * row half +
+// column half; inside it col = lane & 15, row = 4 * (lane >> 4) + (e & 3)): a lane owns two columns (16 apart) and eight rows.
+template <int TM, int TN, bool S16 = false>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int wm, int wn, int li, int lh) {
     float vmax1 = 0.0f, vmax2 = 0.0f;                               // max |y| this lane stored, per layer of a paired launch
+    const int lane = li + 32 * lh;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + li;
+    for (int jc = 0; jc < (S16 ? 2 * TN : TN); ++jc) {
+        const int j = S16 ? jc >> 1 : jc, ci = S16 ? jc & 1 : 0;
+        const int n = n0 + wn * TN * 32 + j * 32 + (S16 ? 16 * ci + (lane & 15) : li);
         if (n >= p.Cout) continue;
         const float sc = p.scale ? p.scale[n] : 1.0f;
         const float sh = p.shift ? p.shift[n] : 0.0f;
@@ -97,10 +101,11 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const ConvArgs& 
         const int ld = second ? p.ldy2 : p.ldy, act = second ? p.act2 : p.act, nn = second ? n - p.n_split : n;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
+            const int mb = m0 + wm * TM * 32 + i * 32 + (S16 ? 4 * (lane >> 4) : 4 * lh);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (S16 && ((e >> 2) & 1) != ci) continue;              // the other column of this lane
+                const int m = S16 ? mb + 16 * (e >> 3) + (e & 3) : mb + (e & 3) + 8 * (e >> 2);
                 if (m < p.M) {
                     float v = acc[i][j][e] * sc + sh;
                     if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
@@ -264,7 +269,7 @@ struct X6Tile {
 // of whole rows (scale / shift / residual / mask / y as b128, out-of-range pieces on the buffer descriptors).
 // PLANES (conv_h3.hip): the tile also leaves as two fp16 planes under the scale y_scale (a power of two): ah = f16(v * s), al = f16((v * s - ah) * 2^11),
 // 8-byte pieces at [plane][row][column]; the f32 store is skipped when the launch has no f32 output.
-template <int TM, int TN, int WM, int WN, bool PLANES = false>
+template <int TM, int TN, int WM, int WN, bool PLANES = false, bool S16 = false>
 __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const ConvArgs& p, int m0, int n0, int tid, int wm, int wn, int li, int lh, float* smem,
                                                 float y_scale = 1.0f) {
     constexpr int NT = 64 * WM * WN, BN = 32 * TN * WN, HB = 32 * TM, LD = BN + 4, C4 = BN / 4, RPP = NT / C4, PASSES = HB / RPP;
@@ -305,9 +310,16 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float* dst = smem + (i * 32 + 4 * lh) * LD + wn * TN * 32 + j * 32 + li;
+                    if constexpr (S16) {                     // four 16x16 blocks (epilogue()'s note): block e >> 2, col = lane & 15, row = 4 * (lane >> 4) + (e & 3)
+                        const int lane = li + 32 * lh;
+                        float* dst = smem + (i * 32 + 4 * (lane >> 4)) * LD + wn * TN * 32 + j * 32 + (lane & 15);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * LD] = acc[i][j][e];
+                        for (int e = 0; e < 16; ++e) dst[(16 * (e >> 3) + (e & 3)) * LD + 16 * ((e >> 2) & 1)] = acc[i][j][e];
+                    } else {
+                        float* dst = smem + (i * 32 + 4 * lh) * LD + wn * TN * 32 + j * 32 + li;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * LD] = acc[i][j][e];
+                    }
                 }
         }
         __syncthreads();

@@ -38,6 +38,59 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int H3_HEADER_BYTES = 16;       // in front of a filter's two planes: word 0 = max|w| of the packed filter (f32)
 
+// The matrix instruction.  S16: v_mfma_f32_16x16x32_f16 -- one instruction spans the whole 32-deep chunk of a 16x16 block; a wave's 32x32
+// block is four of them.  Same products, same LDS bytes and the same cycles per product as two k-steps of v_mfma_f32_32x32x16_f16, but
+// under load the chip holds a higher clock on this shape (MI355X_MICROARCH.md 'DVFS give-back' item 7; lab, scripts/micro/h3_lab.hip
+// `ring`: the head's 3x3 GEMM's LDS-read + MFMA loop 166 -> 149 us on random operands).  Every launch form uses the SAME shape, so a
+// layer's result does not depend on the tile that computed it (the bitwise tests across tiles, layouts and split-K hold).
+constexpr bool H3_S16 = true;
+// 16-byte slot s of LDS row r is stored at slot s ^ h3_swz(r).  f = [0, 2, 3, 1] over the row's group of four (r >> 2 & 3): under it BOTH
+// shapes' fragment reads are conflict-free (ds_read_b128 serves four groups of 16 lanes; with the 16x16x32 fragment -- lane l: row l & 15,
+// slot l >> 4 -- the identity map of conv_x6.hip would put rows 0-3 / slot 0 and rows 4-7 / slot 1 of one group on the same banks).
+__device__ __forceinline__ int h3_swz(int row) { return H3_S16 ? (0x1320 >> (4 * ((row >> 2) & 3))) & 3 : (row >> 2) & 3; }
+
+// One 32-deep chunk of a wave's TM x TN blocks of 32x32 from the four LDS planes (a_hi / b_hi: this wave's first row of the high planes;
+// the low planes lie a_lo / b_lo bytes behind).  acc0 += ah bh; acc1 += al bh + ah bl.  Accumulator element e of a block -- S16: 16x16
+// block e >> 2 (2 * row half + column half), col = lane & 15, row = 4 * (lane >> 4) + (e & 3); else the 32x32 map (epilogue()).
+template <int TM, int TN>
+__device__ __forceinline__ void h3_chunk(const char* a_hi, int a_lo, const char* b_hi, int b_lo, int lane, f32x4 (&s0)[TM][TN][4], f32x4 (&s1)[TM][TN][4]) {
+    static_assert(H3_S16, "the 16x16x32 form");
+    const int r = lane & 15, off = r * X6_ROWB + 16 * ((lane >> 4) ^ h3_swz(r));      // (block bases are multiples of 16 rows: the swizzle is the lane's)
+    f16x8 fb[2][TN][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) fb[pl][j][ci] = *reinterpret_cast<const f16x8*>(b_hi + pl * b_lo + (j * 32 + ci * 16) * X6_ROWB + off);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(a_hi + (i * 32 + ri * 16) * X6_ROWB + off);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(a_hi + a_lo + (i * 32 + ri * 16) * X6_ROWB + off);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    f32x4& c1 = s1[i][j][ri * 2 + ci];
+                    f32x4& c0 = s0[i][j][ri * 2 + ci];
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, fb[0][j][ci], c1, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, fb[1][j][ci], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, fb[0][j][ci], c0, 0, 0, 0);
+                }
+        }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void h3_gather(const f32x4 (&s)[TM][TN][4], f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = s[i][j][e >> 2][e & 3];
+}
+
 // e with amax * 2^e in [2^14, 2^15); clamped so that 2^e, 2^(e + 11) and 2^-e are normal f32 numbers whatever amax is
 __host__ __device__ __forceinline__ int h3_exponent(float amax) {
     unsigned b;
@@ -114,7 +167,8 @@ __device__ __forceinline__ unsigned h3_tap_mask(const ConvArgs& p, int m0, int B
 // ONE LDS buffer (four planes), the next two chunks waiting in registers, two barriers per chunk: k_conv_igemm_x6's loop.
 // SPLITK: the f32 kernel's protocol (write-through partial tiles, a ticket per tile, the last arriver sums the slabs in slice order).
 template <int TM, int TN, int WM, int WN, bool SPLITK = false>
-__global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3(const ConvArgs p) {
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(TM * TN == 1 ? 4 : 1)))      // (the 64x64 tile: four waves per SIMD, as with the 32x32x16 form)
+k_conv_igemm_h3(const ConvArgs p) {
     using T = X6Tile<TM, TN, WM, WN, 2>;
     constexpr int NT = T::NT, BM = T::BM, BN = T::BN;
     constexpr int RPP = NT / 8;                           // tile rows staged per pass of A (8 lanes x 16 B of f32 per row)
@@ -227,7 +281,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3(const ConvArgs p
             f16x4 h, l;
             h3_split(ra[S][i], sA, h, l);
             const int row = lrow + RPP * i, g = tid & 7;
-            char* dst = As + row * X6_ROWB + 16 * ((g >> 1) ^ x6_swz(row)) + 8 * (g & 1);
+            char* dst = As + row * X6_ROWB + 16 * ((g >> 1) ^ h3_swz(row)) + 8 * (g & 1);
             *reinterpret_cast<f16x4*>(dst) = h;
             *reinterpret_cast<f16x4*>(dst + BM * X6_ROWB) = l;
         }
@@ -235,21 +289,29 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3(const ConvArgs p
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                *reinterpret_cast<f32x4*>(Bs + pl * BN * X6_ROWB + (brow + RPB * i) * X6_ROWB + 16 * ((tid & 3) ^ x6_swz(brow + RPB * i))) = rb[S][pl][i];
+                *reinterpret_cast<f32x4*>(Bs + pl * BN * X6_ROWB + (brow + RPB * i) * X6_ROWB + 16 * ((tid & 3) ^ h3_swz(brow + RPB * i))) = rb[S][pl][i];
     };
 
     f32x16 acc0[TM][TN], acc1[TM][TN];
+    f32x4 s0[TM][TN][4], s1[TM][TN][4];                   // (S16) the same accumulators as sixteen-row blocks
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.0f; acc1[i][j][e] = 0.0f; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s0[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; s1[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+        }
 
     const char* abase = As + (wm * TM * 32 + li) * X6_ROWB;
     const char* bbase = Bs + (wn * TN * 32 + li) * X6_ROWB;
-    const int koff[2] = {16 * (lh ^ x6_swz(li)), 16 * ((2 + lh) ^ x6_swz(li))};       // k-step s reads logical slot 2 s + lh (tile bases are multiples of 32 rows)
+    const int koff[2] = {16 * (lh ^ h3_swz(li)), 16 * ((2 + lh) ^ h3_swz(li))};       // k-step s reads logical slot 2 s + lh (tile bases are multiples of 32 rows)
     auto compute = [&]() {
+        if constexpr (H3_S16) {
+            h3_chunk<TM, TN>(As + wm * TM * 32 * X6_ROWB, BM * X6_ROWB, Bs + wn * TN * 32 * X6_ROWB, BN * X6_ROWB, lane, s0, s1);
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                     // two k-steps of 16 per 32-channel chunk
             f16x8 fa[2][TM], fb[2][TN];
@@ -294,6 +356,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3(const ConvArgs p
         compute();
         __syncthreads();                                  // the epilogue reuses the buffer
     }
+    if constexpr (H3_S16) { h3_gather<TM, TN>(s0, acc0); h3_gather<TM, TN>(s1, acc1); }
     h3_combine<TM, TN>(acc0, acc1);
     if constexpr (SPLITK) {
         // publish this slice's partial tile WRITE-THROUGH (sc1 stores need no release fence), thread-major 16-byte rows
@@ -346,8 +409,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3(const ConvArgs p
         __syncthreads();                                       // the flag word is read; the epilogue reuses the buffer
     }
     h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
-    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
-    else epilogue<TM, TN>(acc0, p, m0, n0, wm, wn, li, lh);
+    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN, false, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN, H3_S16>(acc0, p, m0, n0, wm, wn, li, lh);
 }
 
 // ---- ONE workgroup per CU, TWO LDS buffers (96 KB for a 256x128 tile) and ONE barrier per chunk: chunk kt multiplies from buffer
@@ -392,8 +455,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     for (int i = 0; i < PA; ++i) {
         const int pl = APLANES ? (lrow + RPP * i) / BM : 0;
         const int row = lrow + RPP * i - pl * BM, m = m0 + row;
-        if constexpr (APLANES) a_lds[i] = pl * BM * X6_ROWB + row * X6_ROWB + 16 * ((tid & 3) ^ x6_swz(row));
-        else { const int g = tid & 7; a_lds[i] = row * X6_ROWB + 16 * ((g >> 1) ^ x6_swz(row)) + 8 * (g & 1); }
+        if constexpr (APLANES) a_lds[i] = pl * BM * X6_ROWB + row * X6_ROWB + 16 * ((tid & 3) ^ h3_swz(row));
+        else { const int g = tid & 7; a_lds[i] = row * X6_ROWB + 16 * ((g >> 1) ^ h3_swz(row)) + 8 * (g & 1); }
         if (m < p.M) {
             int wo, ho, img;
             if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
@@ -412,7 +475,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
         const int q = tid + NT * i, pl = q / (BN * 4), r = q % (BN * 4), row = r >> 2, g = r & 3;
         const bool ok = q < NBP && n0 + row < p.Cout;
         b_off[i] = ok ? (unsigned)(((size_t)(n0 + row) * p.Kpad + g * 8) * 2 + pl * plane_bytes) : OOB_OFFSET;
-        b_lds[i] = q < NBP ? 2 * BM * X6_ROWB + pl * BN * X6_ROWB + row * X6_ROWB + 16 * (g ^ x6_swz(row)) : -1;
+        b_lds[i] = q < NBP ? 2 * BM * X6_ROWB + pl * BN * X6_ROWB + row * X6_ROWB + 16 * (g ^ h3_swz(row)) : -1;
     }
 
     const int RS = p.R * p.S;
@@ -470,14 +533,18 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
             if (b_lds[i] >= 0) *reinterpret_cast<f32x4*>(base + b_lds[i]) = rb[i];
     };
     f32x16 acc0[TM][TN], acc1[TM][TN];
+    f32x4 s0[TM][TN][4], s1[TM][TN][4];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.0f; acc1[i][j][e] = 0.0f; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s0[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; s1[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+        }
     const int aoff = (wm * TM * 32 + li) * X6_ROWB, boff = 2 * BM * X6_ROWB + (wn * TN * 32 + li) * X6_ROWB;
-    const int koff[2] = {16 * (lh ^ x6_swz(li)), 16 * ((2 + lh) ^ x6_swz(li))};
+    const int koff[2] = {16 * (lh ^ h3_swz(li)), 16 * ((2 + lh) ^ h3_swz(li))};
     auto kstep = [&](int buf, int s) {
         const char* base = lds + buf * BUFB;
         f16x8 fa[2][TM], fb[2][TN];
@@ -503,15 +570,21 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) { store(buf ^ 1); load_next(); }
-        kstep(buf, 0);
-        kstep(buf, 1);
+        if constexpr (H3_S16) {
+            const char* base = lds + buf * BUFB;
+            h3_chunk<TM, TN>(base + wm * TM * 32 * X6_ROWB, BM * X6_ROWB, base + 2 * BM * X6_ROWB + wn * TN * 32 * X6_ROWB, BN * X6_ROWB, lane, s0, s1);
+        } else {
+            kstep(buf, 0);
+            kstep(buf, 1);
+        }
         __syncthreads();
     }
+    if constexpr (H3_S16) { h3_gather<TM, TN>(s0, acc0); h3_gather<TM, TN>(s1, acc1); }
     h3_combine<TM, TN>(acc0, acc1);
     h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
-    if (p.y_planes) x6_epilogue_vec<TM, TN, WM, WN, true>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds), h3_pow2(eY));
-    else if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
-    else epilogue<TM, TN>(acc0, p, m0, n0, wm, wn, li, lh);
+    if (p.y_planes) x6_epilogue_vec<TM, TN, WM, WN, true, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds), h3_pow2(eY));
+    else if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN, false, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN, H3_S16>(acc0, p, m0, n0, wm, wn, li, lh);
 }
 
 template <int TM, int TN, int WM, int WN>

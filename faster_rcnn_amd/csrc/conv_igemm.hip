@@ -2222,7 +2222,7 @@ static int choose_splits_h3(const frcnn_conv_desc* d) {
     if (tiles * sizeof(unsigned) > SPLITK_TICKET_BYTES) return 1;
     int s = d->tile / 100;
     if (s <= 0) {
-        if (tiles64 >= 640 || nk < 64) return 1;
+        if (tiles64 >= 640 || nk < 32 || (nk < 64 && tiles64 >= 256)) return 1;       // (short reductions: only grids that leave most CUs idle -- stage 4's 1x1 1024 -> 256 at 152 tiles: 21.9 us native split-K, 19.0 here)
         if (edge == 128) s = (int)(512 / tiles);
         else s = tiles >= 100 ? 3 : (int)((768 + tiles - 1) / tiles);
         if (s > nk / 8) s = nk / 8;

@@ -71,6 +71,9 @@ __device__ __forceinline__ void split2(const f32x4 v, float s, f16x4& h, f16x4& 
 
 // MODE 0: ONE LDS buffer (four planes), two staging register sets, loads requested two chunks ahead, two barriers per chunk
 //         (the product's k_conv_igemm_x6 loop).  MODE 1: TWO LDS buffers, one register set, ONE barrier per chunk (k_conv_igemm_x6_db).
+// MODE 2: MODE 1's buffers with the fragment reads software-pipelined ACROSS the barrier: two fragment register sets; the barrier sits
+//         between the chunk's two k-steps, so a wave leaves it with twelve MFMAs in hand (k-step 1, read before the barrier) while the
+//         next chunk's k-step 0 fragments come in -- no wave ever waits on an LDS read with an empty matrix pipe.
 template <int TM, int TN, int WM, int WN, int TERMS, int MODE, int ASRC, int SKIP = 0>
 __global__ void __launch_bounds__(64 * WM * WN) k_gemm_h3(const Args p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
@@ -191,7 +194,53 @@ __global__ void __launch_bounds__(64 * WM * WN) k_gemm_h3(const Args p) {
         }
     };
     auto sync = [&]() { if constexpr (!(SKIP & 8)) __syncthreads(); };
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 2) {
+        f16x8 fa[2][2][TM], fb[2][2][TN];
+        auto readF = [&](auto setc, int buf, int s) {
+            constexpr int S = decltype(setc)::value;
+            const char* base = lds + buf * BUFB;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[S][pl][i] = *reinterpret_cast<const f16x8*>(base + aoff + pl * BM * ROWB + i * 32 * ROWB + koff[s]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[S][pl][j] = *reinterpret_cast<const f16x8*>(base + boff + pl * BN * ROWB + j * 32 * ROWB + koff[s]);
+            }
+        };
+        auto mfma = [&](auto setc) {
+            constexpr int S = decltype(setc)::value;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][1][i], fb[S][0][j], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][0][i], fb[S][1][j], acc1[i][j], 0, 0, 0);
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][0][i], fb[S][0][j], acc0[i][j], 0, 0, 0);
+                }
+        };
+        using J0 = std::integral_constant<int, 0>;
+        using J1 = std::integral_constant<int, 1>;
+        load(0, I0{});
+        store(I0{}, 0);
+        if (nk > 1) load(1, I0{});
+        __syncthreads();
+        readF(J0{}, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            readF(J1{}, buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(J0{});
+            if (kt + 1 < nk) {
+                store(I0{}, buf ^ 1);
+                load(kt + 2 < nk ? kt + 2 : 0, I0{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sync();
+            if (kt + 1 < nk) readF(J0{}, buf ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(J1{});
+        }
+    } else if constexpr (MODE == 1) {
         load(0, I0{});
         store(I0{}, 0);
         if (nk > 1) load(1, I0{});
@@ -292,8 +341,185 @@ static float run(const Args& a0, int reps, const char* name) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     Args a = a0;
     a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * ROWB * (MODE == 1 ? 2 : 1);
+    const size_t lds = (size_t)2 * (BM + BN) * ROWB * (MODE >= 1 ? 2 : 1);
     auto kern = k_gemm_h3<TM, TN, WM, WN, TERMS, MODE, ASRC, SKIP>;
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    kern<<<a.tiles_m * a.tiles_n, 64 * WM * WN, lds>>>(a);
+    CHECK(hipGetLastError());
+    CHECK(hipDeviceSynchronize());
+    if (reps <= 0) return 0.0f;
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) kern<<<a.tiles_m * a.tiles_n, 64 * WM * WN, lds>>>(a);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / reps, tf = 2.0 * a.M * a.N * a.K / us / 1e6;
+    printf("  %-46s %8.1f us  %7.1f TFLOP/s fp32-eq  (%d workgroups, %zu B LDS)\n", name, us, tf, a.tiles_m * a.tiles_n, lds);
+    fflush(stdout);
+    return (float)us;
+}
+
+
+// ---- RING: both operands as fp16 planes, brought in by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write), a ring
+// of STAGES chunk buffers (chunk kt + STAGES - 1 requested while chunk kt multiplies, ONE barrier per chunk), and -- S16 -- the
+// 16x16x32 MFMA shape on the same wave tile (same LDS bytes, same products; the chip holds a higher clock on it under load).
+// A wave-instruction fills 16 consecutive 64-byte rows (1 KB): lane l -> row l >> 2, physical slot l & 3 = logical slot ^ f(row >> 2 & 3).
+__device__ __forceinline__ int swz16(int g) { return (0x1320 >> (4 * (g & 3))) & 3; }      // f = [0, 2, 3, 1]: conflict-free for both MFMA shapes' reads
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int TM, int TN, int WM, int WN, int S16, int STAGES, int SKIP = 0>
+__global__ void __launch_bounds__(64 * WM * WN) k_gemm_h3_ring(const Args p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN, NW = WM * WN;
+    constexpr int STAGEB = 2 * (BM + BN) * ROWB;          // A hi, A lo, B hi, B lo
+    constexpr int NA = 2 * BM / 16, NI = 2 * (BM + BN) / 16;      // 1 KB pieces per stage: the first NA belong to A
+    constexpr int PI = (NI + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = p.tiles_m * p.tiles_n, q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int tm = bid / p.tiles_n, tn = bid % p.tiles_n, m0 = tm * BM, n0 = tn * BN;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Ap), 0, (int)((size_t)2 * p.M * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.Bp), 0, (int)((size_t)2 * p.N * p.K * 2), 0x00020000);
+    // this wave's pieces: j = wave + NW * i
+    unsigned g_off[PI];
+    const int lrow = lane >> 2, lp = (lane & 3) ^ (S16 ? swz16(lane >> 4) : ((lane >> 4) & 3));
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int j = wave + NW * i;
+        if (j < NA) {
+            const int pl = j / (BM / 16), row = (j % (BM / 16)) * 16 + lrow;
+            g_off[i] = (m0 + row < p.M) ? (unsigned)(((size_t)pl * p.M * p.K + (size_t)(m0 + row) * p.K + lp * 8) * 2) : OOB;
+        } else {
+            const int jb = j - NA, pl = jb / (BN / 16), row = (jb % (BN / 16)) * 16 + lrow;
+            g_off[i] = (j < NI && n0 + row < p.N) ? (unsigned)(((size_t)pl * p.N * p.K + (size_t)(n0 + row) * p.K + lp * 8) * 2) : OOB;
+        }
+    }
+    auto issue = [&](int kt, int stage) {
+        if constexpr (SKIP & 4) return;
+        char* base = lds + stage * STAGEB;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int j = wave + NW * i;
+            if (j < NA) __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lds_ptr_t)(base + j * 1024), 16, g_off[i], kt * (BK * 2), 0, 0);
+            else if (j < NI) __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (lds_ptr_t)(base + j * 1024), 16, g_off[i], kt * (BK * 2), 0, 0);
+        }
+#endif
+    };
+    const int nk = p.K / BK;
+    constexpr int SM = S16 ? 2 * TM : TM, SN = S16 ? 2 * TN : TN;       // sub-tiles per wave
+    typedef float accv __attribute__((ext_vector_type(S16 ? 4 : 16)));
+    accv acc0[SM][SN], acc1[SM][SN];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < SN; ++j)
+#pragma unroll
+            for (int e = 0; e < (S16 ? 4 : 16); ++e) { acc0[i][j][e] = 0.0f; acc1[i][j][e] = 0.0f; }
+    const int li = lane & 31, lh = lane >> 5, l16 = lane & 15, lq = lane >> 4;
+    auto compute = [&](int stage) {
+        const char* base = lds + stage * STAGEB;
+        if constexpr (S16) {
+            const int aoff = (wm * TM * 32 + l16) * ROWB + 16 * (lq ^ swz16(l16 >> 2));
+            const int boff = 2 * BM * ROWB + (wn * TN * 32 + l16) * ROWB + 16 * (lq ^ swz16(l16 >> 2));
+            f16x8 fa[2][SM], fb[2][SN];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int j = 0; j < SN; ++j) fb[pl][j] = *reinterpret_cast<const f16x8*>(base + boff + pl * BN * ROWB + j * 16 * ROWB);
+#pragma unroll
+                for (int i = 0; i < SM; ++i) fa[pl][i] = *reinterpret_cast<const f16x8*>(base + aoff + pl * BM * ROWB + i * 16 * ROWB);
+            }
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int j = 0; j < SN; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][i], fb[0][j], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[1][j], acc1[i][j], 0, 0, 0);
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][i], fb[0][j], acc0[i][j], 0, 0, 0);
+                }
+        } else {
+            const int aoff = (wm * TM * 32 + li) * ROWB, boff = 2 * BM * ROWB + (wn * TN * 32 + li) * ROWB;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ko = 16 * ((2 * s + lh) ^ swz(li));
+                f16x8 fa[2][TM], fb[2][TN];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const f16x8*>(base + aoff + pl * BM * ROWB + i * 32 * ROWB + ko);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[pl][j] = *reinterpret_cast<const f16x8*>(base + boff + pl * BN * ROWB + j * 32 * ROWB + ko);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][j], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][j], acc1[i][j], 0, 0, 0);
+                        acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][j], acc0[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    };
+    // prologue: STAGES - 1 chunks in flight
+#pragma unroll
+    for (int c = 0; c < STAGES - 1; ++c) if (c < nk) issue(c, c);
+    // chunk 0 landed = all but the newest (STAGES - 2) chunks' pieces of this wave (short loops: wait for everything)
+    if (nk >= STAGES - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((STAGES - 2) * PI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int st = 0, st_in = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, st_in);       // into the stage chunk kt - 1 was read from: everyone passed the last barrier
+        compute(st);
+        // chunk kt + 1 landed: at most the (STAGES - 2) newer chunks of this wave may stay in flight (fewer near the end: wait for all)
+        if (kt + STAGES - 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"((STAGES - 2) * PI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (!(SKIP & 8)) __builtin_amdgcn_s_barrier();
+        st = st + 1 == STAGES ? 0 : st + 1;
+        st_in = st_in + 1 == STAGES ? 0 : st_in + 1;
+    }
+    const float w1 = 1.0f / 2048.0f;
+    if constexpr (S16) {
+#pragma unroll
+        for (int j = 0; j < SN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 16 + l16;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int i = 0; i < SM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + wm * TM * 32 + i * 16 + 4 * lq + e;
+                    if (m < p.M) p.C[(size_t)m * p.N + n] = ((acc0[i][j][e] + acc1[i][j][e] * w1) * p.inv_sA) * p.inv_sB;
+                }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 32 + li;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm * TM * 32 + i * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+                    if (m < p.M) p.C[(size_t)m * p.N + n] = ((acc0[i][j][e] + acc1[i][j][e] * w1) * p.inv_sA) * p.inv_sB;
+                }
+        }
+    }
+}
+
+template <int TM, int TN, int WM, int WN, int S16, int STAGES, int SKIP = 0>
+static float run_ring(const Args& a0, int reps, const char* name) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    Args a = a0;
+    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * ROWB * STAGES;
+    auto kern = k_gemm_h3_ring<TM, TN, WM, WN, S16, STAGES, SKIP>;
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     kern<<<a.tiles_m * a.tiles_n, 64 * WM * WN, lds>>>(a);
@@ -419,6 +645,20 @@ static void rate() {
         run<2, 1, 2, 4, 3, 0, 1>(a, R, "128x128 8w, A as fp16 planes from memory");
         run<2, 1, 4, 4, 3, 1, 1>(a, R, "256x128 16w dbuf, A as fp16 planes");
         run<2, 2, 4, 2, 3, 1, 1>(a, R, "256x128 8w (64x64/wave) dbuf, A as fp16 planes");
+        std::vector<float> c1((size_t)s.M * s.N), c2((size_t)s.M * s.N);
+        CHECK(hipMemcpy(c1.data(), dC, c1.size() * 4, hipMemcpyDeviceToHost));
+        run<2, 2, 4, 2, 3, 2, 1>(a, R, "PIPE 256x128 8w (64x64/wave), A planes");
+        CHECK(hipMemcpy(c2.data(), dC, c2.size() * 4, hipMemcpyDeviceToHost));
+        printf("    pipelined == double-buffer result bitwise: %s\n", memcmp(c1.data(), c2.data(), c1.size() * 4) ? "NO" : "yes");
+        run<2, 2, 2, 4, 3, 2, 1>(a, R, "PIPE 128x256 8w (64x64/wave), A planes");
+        run<2, 2, 4, 2, 3, 2, 0>(a, R, "PIPE 256x128 8w (64x64/wave), f32 A");
+        run<2, 2, 2, 4, 3, 2, 0>(a, R, "PIPE 128x256 8w (64x64/wave), f32 A");
+        run<2, 1, 4, 4, 3, 2, 1>(a, R, "PIPE 256x128 16w (64x32/wave), A planes");
+        run<2, 1, 4, 4, 3, 2, 0>(a, R, "PIPE 256x128 16w (64x32/wave), f32 A");
+        run<2, 2, 2, 2, 3, 2, 1>(a, R, "PIPE 128x128 4w (64x64/wave), A planes");
+        run<2, 2, 4, 2, 3, 2, 1, 14>(a, R, "  ladder PIPE 256x128 8w: LDS reads + MFMAs only");
+        run<2, 2, 4, 2, 3, 2, 1, 6>(a, R, "  ladder PIPE 256x128 8w: no loads, no stores");
+        run<2, 2, 4, 2, 3, 1, 1, 14>(a, R, "  ladder dbuf 256x128 8w: LDS reads + MFMAs only");
         run<2, 1, 4, 4, 3, 1, 0, 1>(a, R, "  ladder 256x128 16w: no split arithmetic");
         run<2, 1, 4, 4, 3, 1, 0, 2>(a, R, "  ladder 256x128 16w: no LDS stores");
         run<2, 1, 4, 4, 3, 1, 0, 6>(a, R, "  ladder 256x128 16w: no loads, no stores");
@@ -427,9 +667,57 @@ static void rate() {
     }
 }
 
+
+static void ring() {
+    struct Shape { int M, N, K; const char* what; } shapes[] = {
+        {14700, 512, 4608, "head 3x3 512->512 as a GEMM"}, {14700, 2048, 512, "head 512->2048"}, {14700, 512, 2048, "head 2048->512"},
+        {37101, 256, 64, "stage 2 64->256"}, {9375, 512, 128, "stage 3 128->512"}, {2394, 2560, 1024, "hoisted pair 1024->2560"}};
+    for (const Shape& s : shapes) {
+        float *dA, *dC; _Float16 *dAp, *dBp;
+        CHECK(hipMalloc(&dA, (size_t)s.M * s.K * 4)); CHECK(hipMalloc(&dC, (size_t)s.M * s.N * 4));
+        CHECK(hipMalloc(&dAp, (size_t)2 * s.M * s.K * 2)); CHECK(hipMalloc(&dBp, (size_t)2 * s.N * s.K * 2));
+        std::vector<float> A((size_t)s.M * s.K), B((size_t)s.N * s.K);
+        srand(3);
+        for (size_t i = 0; i < A.size(); ++i) A[i] = (float)nrand();
+        for (size_t i = 0; i < B.size(); ++i) B[i] = (float)(nrand() * 0.05);
+        const int eA = scale_exp(A), eB = scale_exp(B);
+        std::vector<_Float16> Ap, Bp;
+        split_host(A, eA, Ap); split_host(B, eB, Bp);
+        CHECK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dAp, Ap.data(), Ap.size() * 2, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dBp, Bp.data(), Bp.size() * 2, hipMemcpyHostToDevice));
+        Args a = {dA, dAp, dBp, dC, s.M, s.N, s.K, 0, 0, pow2f(eA), pow2f(-eA), pow2f(-eB)};
+        printf("%s  M=%d N=%d K=%d  (random normal operands)\n", s.what, s.M, s.N, s.K);
+        const int R = 20;
+        std::vector<float> c1((size_t)s.M * s.N), c2((size_t)s.M * s.N);
+        auto same = [&](const char* what) {
+            CHECK(hipMemcpy(c2.data(), dC, c2.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0; size_t diff = 0;
+            for (size_t i = 0; i < c1.size(); ++i) { diff += c1[i] != c2[i]; worst = fmax(worst, fabs((double)c1[i] - c2[i]) / fmax(1e-6, fabs((double)c1[i]))); }
+            printf("    %s vs double-buffer result: %zu / %zu elements differ, worst relative %.3g\n", what, diff, c1.size(), worst);
+        };
+        run<2, 1, 4, 4, 3, 1, 1>(a, R, "256x128 16w dbuf, A as fp16 planes (product)");
+        CHECK(hipMemcpy(c1.data(), dC, c1.size() * 4, hipMemcpyDeviceToHost));
+        run<2, 2, 4, 2, 3, 1, 1>(a, R, "256x128 8w (64x64/wave) dbuf, A planes");
+        run_ring<2, 1, 4, 4, 0, 2>(a, R, "RING 256x128 16w 32x32x16, 2 stages"); same("ring 32x32x16");
+        run_ring<2, 1, 4, 4, 0, 3>(a, R, "RING 256x128 16w 32x32x16, 3 stages");
+        run_ring<2, 1, 4, 4, 1, 3>(a, R, "RING 256x128 16w 16x16x32, 3 stages"); same("ring 16x16x32");
+        run_ring<2, 2, 4, 2, 0, 3>(a, R, "RING 256x128 8w (64x64) 32x32x16, 3 stages");
+        run_ring<2, 2, 4, 2, 1, 3>(a, R, "RING 256x128 8w (64x64) 16x16x32, 3 stages"); same("ring 8w 16x16x32");
+        run_ring<2, 2, 2, 4, 1, 3>(a, R, "RING 128x256 8w (64x64) 16x16x32, 3 stages");
+        run_ring<2, 1, 2, 4, 1, 4>(a, R, "RING 128x128 8w (64x32) 16x16x32, 4 stages");
+        run_ring<2, 1, 2, 4, 1, 2>(a, R, "RING 128x128 8w (64x32) 16x16x32, 2 stages (2 wg/CU)");
+        run_ring<2, 1, 4, 4, 0, 3, 12>(a, R, "  ladder RING 16w 32x32x16: LDS reads + MFMAs only");
+        run_ring<2, 1, 4, 4, 1, 3, 12>(a, R, "  ladder RING 16w 16x16x32: LDS reads + MFMAs only");
+        run_ring<2, 2, 4, 2, 1, 3, 12>(a, R, "  ladder RING 8w 16x16x32: LDS reads + MFMAs only");
+        run_ring<2, 1, 4, 4, 1, 3, 4>(a, R, "  ladder RING 16w 16x16x32: no DMA (barriers kept)");
+        CHECK(hipFree(dA)); CHECK(hipFree(dC)); CHECK(hipFree(dAp)); CHECK(hipFree(dBp));
+    }
+}
+
 int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
     if (!strcmp(what, "acc") || !strcmp(what, "all")) accuracy();
     if (!strcmp(what, "rate") || !strcmp(what, "all")) rate();
+    if (!strcmp(what, "ring")) ring();
     return 0;
 }

@@ -82,8 +82,9 @@ def test_config1_resnet50_600x1000_inference_fp32(engine):
         assert n_x6 == 0 and n_sk == 0, (n_x6, n_sk, kernels)
     elif engine == "bf16x6":
         assert n_sk == 7 and n_x6 == 37 and n_native == 8, (engine, n_x6, n_sk, n_native, kernels)
-    else:                                                    # f16x3: the stem too (k_stem_h3: conv1 + BN + ReLU + max-pool in one launch)
-        assert n_sk == 7 and n_x6 == 38 and n_native == 7 and kernels[0] == "k_stem_h3", (engine, n_x6, n_sk, n_native, kernels)
+    else:                                                    # f16x3: the stem too (k_stem_h3: conv1 + BN + ReLU + max-pool in one launch), and stage 4's five
+        # 1x1 1024 -> 256 layers on the engine's own split-K (k 1 024: its rule starts at 32 chunks for grids under 256 tiles); native: the RPN output pair, the dense pair
+        assert n_sk == 12 and n_x6 == 38 and n_native == 2 and kernels[0] == "k_stem_h3", (engine, n_x6, n_sk, n_native, kernels)
     if engine == "f16x3":                                    # every tensor a split launch read carried its producer's magnitude record:
         assert res["amax_measured"] <= 1, res                # nothing but (at most) the network input was measured by a pass of its own
 

@@ -246,7 +246,7 @@ def test_split_engine_input_gradient_with_mask_and_residual(case):
     with ops.f32_engine("native"):
         native = ops.conv2d_dgrad(g, pd, padding, residual=r, mask=m)
     e_native = ((native.cpu().double() - want).abs() / mag)[keep].max().item()
-    assert e <= max(e_native, 3e-7), (e, e_native)
+    assert e <= max(e_native, 5e-7), (e, e_native)                   # (the bar tests/test_conv_x6_gpu.py holds the engine's forward launches to)
 
 
 @pytest.mark.parametrize("engine", ["native", "bf16x6"])
