@@ -83,7 +83,10 @@ def test_engine_policy_is_the_librarys_and_serves_both_split_engines():
         ctypes.byref(ops._conv_desc(shape, k, k, cout, stride, padding, 0, 0, tile)), prefer, ws)
     for prefer in (1, 2):
         assert q((1, 149, 249, 64), 3, 64, prefer, 1) == prefer                    # stage 2 3x3
-        assert q((1, 38, 63, 1024), 1, 256, prefer, 1, padding="valid") == 0       # stage 4 2a: small grid, short k
+        # stage 4 2a (152 tiles, k = 32 chunks): the f16x3 engine's own split-K starts there on small grids, the bf16x6 one's at 64 chunks
+        assert q((1, 38, 63, 1024), 1, 256, prefer, 1, padding="valid") == (2 if prefer == 2 else 0)
+        assert q((1, 38, 63, 1024), 1, 256, prefer, 0, padding="valid") == 0
+        assert q((1, 75, 125, 128), 3, 128, prefer, 1) == prefer                   # (stage 3's 3x3: 294 tiles, plain launches on either engine)
         assert q((1, 38, 63, 256), 3, 256, prefer, 1) == prefer and q((1, 38, 63, 256), 3, 256, prefer, 0) == 0     # only as split-K
         assert q((1, 38, 63, 512), 1, 36, prefer, 1, padding="valid") == 0         # under 64 columns
         assert q((1, 600, 1000, 3), 7, 64, prefer, 1, stride=2) == 0               # the stem
