@@ -63,6 +63,7 @@ SIGNATURES = {
     "frcnn_conv2d_x6_config": (I, [P, I]),
     "frcnn_pack_conv_weights_x6": (I, [P, I, I, P, P]),
     "frcnn_refresh_x6_planes": (I, [P, I, P]),
+    "frcnn_refresh_h3_planes": (I, [P, I, P]),
     "frcnn_conv2d_x6_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_fwd_x6": (I, [P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_conv2d_fwd_dual_x6": (I, [P, P, P, P, P, P, I, I, P, I, P]),

@@ -654,6 +654,46 @@ __global__ void __launch_bounds__(256) k_pack_h3(const float* w, size_t n, const
     }
 }
 
+// the same for MANY filters (a training step re-derives the planes of every trainable layer's forward and input-gradient filter after the
+// optimiser has rewritten the f32 forms; conv_x6.hip k_pack_x6_batch): a workgroup finds its job by the block prefix.  Three launches
+// per table: headers to zero, max|w| per filter, the two planes under that maximum's scale.
+constexpr int H3_REFRESH_JOBS = 48;
+struct H3RefreshTable { const float* w[H3_REFRESH_JOBS]; char* out[H3_REFRESH_JOBS]; unsigned long long n[H3_REFRESH_JOBS]; int first_block[H3_REFRESH_JOBS + 1]; int jobs; };
+__global__ void __launch_bounds__(256) k_h3_refresh_clear(const H3RefreshTable t) {
+    const int j = threadIdx.x >> 2;
+    if (j < t.jobs) reinterpret_cast<float*>(t.out[j])[threadIdx.x & 3] = 0.0f;
+}
+__global__ void __launch_bounds__(256) k_h3_refresh_wmax(const H3RefreshTable t) {
+    int j = 0;
+    while (j + 1 < t.jobs && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
+    const size_t n = t.n[j];
+    const int nb = t.first_block[j + 1] - t.first_block[j], b = (int)blockIdx.x - t.first_block[j];
+    const float* w = t.w[j];
+    float v = 0.0f;
+    for (size_t i = ((size_t)b * 256 + threadIdx.x) * 4; i < n; i += (size_t)nb * 256 * 4) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(w + i);
+        v = fmaxf(fmaxf(v, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
+    }
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0 && v > 0.0f) atomicMax(reinterpret_cast<unsigned*>(t.out[j]), __float_as_uint(v));
+}
+__global__ void __launch_bounds__(256) k_h3_refresh_pack(const H3RefreshTable t) {
+    int j = 0;
+    while (j + 1 < t.jobs && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
+    const size_t n = t.n[j];
+    const int nb = t.first_block[j + 1] - t.first_block[j], b = (int)blockIdx.x - t.first_block[j];
+    const float* w = t.w[j];
+    const float s = h3_pow2(h3_exponent(*reinterpret_cast<const float*>(t.out[j])));
+    _Float16* out = reinterpret_cast<_Float16*>(t.out[j] + H3_HEADER_BYTES);
+    for (size_t i = ((size_t)b * 256 + threadIdx.x) * 4; i < n; i += (size_t)nb * 256 * 4) {       // n % 4 == 0 (packed k is a multiple of 32)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + i);
+        f16x4 h, l;
+        h3_split(v, s, h, l);
+        *reinterpret_cast<f16x4*>(out + i) = h;
+        *reinterpret_cast<f16x4*>(out + n + i) = l;
+    }
+}
+
 // ---- magnitude records
 __global__ void __launch_bounds__(256) k_amax_clear(float* rec, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) rec[i] = 0.0f;
@@ -703,6 +743,33 @@ extern "C" int frcnn_pack_conv_weights_h3(const float* w_packed, int cout, int k
     k_pack_h3<<<grid, 256, 0, s>>>(w_packed, n, reinterpret_cast<const float*>(planes_f16),
                                    reinterpret_cast<_Float16*>(reinterpret_cast<char*>(planes_f16) + H3_HEADER_BYTES));
     return check_launch("pack_conv_weights_h3");
+}
+
+extern "C" int frcnn_refresh_h3_planes(const frcnn_x6_job* jobs, int n_jobs, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(FRCNN_E_ARG, "refresh_h3_planes: bad argument");
+    for (int i = 0; i < n_jobs; ++i)
+        if (!jobs[i].w_packed || !jobs[i].planes_bf16 || jobs[i].rows <= 0 || jobs[i].kpad <= 0 || (jobs[i].kpad % 32)
+            || (reinterpret_cast<uintptr_t>(jobs[i].w_packed) & 15) || (reinterpret_cast<uintptr_t>(jobs[i].planes_bf16) & 15))
+            return fail(FRCNN_E_ARG, "refresh_h3_planes: job %d is malformed (packed k must be a multiple of 32, 16-byte aligned buffers)", i);
+    hipStream_t s = as_stream(stream);
+    for (int b = 0; b < n_jobs; b += H3_REFRESH_JOBS) {
+        H3RefreshTable t;
+        const int n = n_jobs - b < H3_REFRESH_JOBS ? n_jobs - b : H3_REFRESH_JOBS;
+        int blocks = 0;
+        for (int i = 0; i < H3_REFRESH_JOBS; ++i) {
+            const frcnn_x6_job& j = jobs[b + (i < n ? i : 0)];
+            t.w[i] = j.w_packed; t.out[i] = reinterpret_cast<char*>(j.planes_bf16); t.n[i] = (unsigned long long)j.rows * j.kpad;
+            t.first_block[i] = blocks;
+            if (i < n) { const unsigned long long g = (t.n[i] + 4095) / 4096; blocks += (int)(g < 1 ? 1 : (g > 512 ? 512 : g)); }      // 16 elements per thread
+        }
+        t.first_block[H3_REFRESH_JOBS] = blocks;
+        t.jobs = n;
+        k_h3_refresh_clear<<<1, 256, 0, s>>>(t);
+        k_h3_refresh_wmax<<<blocks, 256, 0, s>>>(t);
+        k_h3_refresh_pack<<<blocks, 256, 0, s>>>(t);
+        if (int e = check_launch("refresh_h3_planes")) return e;
+    }
+    return FRCNN_OK;
 }
 
 extern "C" int frcnn_amax_record_floats(void) { return AMAX_SLOTS * AMAX_STRIDE; }

@@ -955,6 +955,7 @@ class PackedDgrad:
         self.scale = self.shift = None
 
     x6_planes = PackedConv.x6_planes                         # the same [rows][packed k] f32 layout: the same three-plane form
+    h3_planes = PackedConv.h3_planes                         # ... and the same header + two fp16 planes
 
 
 def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
@@ -972,12 +973,23 @@ def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
     d = _conv_desc((n, ho, wo, pd.cin), pd.kh, pd.kw, pd.cout, 1, padding, 0, 0, 0)      # (see conv2d_dgrad_bf16)
     assert (d.pad_top, d.pad_left, d.ho, d.wo) == (pt, pl, ho, wo)
     gy = gy.contiguous()
-    if _use_x6(d, pd, 0):                                       # the split engine's policy, as for a forward launch of this geometry
+    eng = _split_engine(d, pd, 0)                               # the split engines' policy, as for a forward launch of this geometry
+    if eng == "x6":
         ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_x6_workspace_bytes"))
         _lib.call("frcnn_conv2d_fwd_x6", ctypes.byref(d), _p(gy), _p(pd.x6_planes()), None, None, _p(residual), _p(mask), _p(out),
                   _p(ws), ws.numel() if ws is not None else 0, _stream())
         return out
-    _conv_launch(d, gy, pd.w, None, None, residual, mask, out)
+    if eng == "h3":                                             # the gradient's magnitude record: its producer's (the dgrad launch behind it) or measured
+        ws = _split_k_ws(_ws_need(d, "frcnn_conv2d_h3_workspace_bytes"))
+        ya, ga = _amax_new(), amax_of(gy)
+        _lib.call("frcnn_conv2d_fwd_h3", ctypes.byref(d), _p(gy), _p(ga), _p(pd.h3_planes()), None, None, _p(residual), _p(mask), _p(out), _p(ya),
+                  _p(ws), ws.numel() if ws is not None else 0, _stream())
+        out._amax = ya                                          # (residual and mask are applied before the epilogue takes the maximum)
+        return out
+    ya = _amax_new(optional=True) if (_tracking() and pd.cout >= 32) else None
+    _conv_launch(d, gy, pd.w, None, None, residual, mask, out, ya)
+    if ya is not None:
+        out._amax = ya
     return out
 
 

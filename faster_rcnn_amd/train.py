@@ -209,6 +209,13 @@ WGRAD_ENGINE = __import__("os").environ.get("FRCNN_TRAIN_WGRAD", "bf16x6")
 # The forward convolutions of an f32 step (the frozen stages of the next image and the trainable layers) under ops.f32_engine: the
 # split engine's launch policy applies as in inference (stages 2-3 on 64x64 tiles, stage 4's wide 1x1, rpn_conv1 / 3x3 split-K);
 # a trainable layer's three filter planes are re-derived after every update.  RPN step 2.32 -> 2.26 ms, detector step 4.39 -> 4.22.
+# Round 5: FRCNN_TRAIN_F32_ENGINE=f16x3 puts the forward AND the input-gradient launches on the f16x3 engine (three matrix instructions
+# per block of products instead of six): a gradient tensor carries the magnitude record its producing launch published, like an
+# activation; the records of a step come from two arenas (one per stream); header + two fp16 planes of every trainable filter are
+# re-derived after the update (frcnn_refresh_h3_planes).  Measured 1.97 / 3.62 ms against 2.04 / 3.71 (a step's launches are the
+# 2 394- / 3 136-row split-K forms: latency- and L2-bound, not MFMA-bound), and NOT the default: under ONE power-of-two scale per
+# tensor an element below 2^-22 of the tensor's largest vanishes -- harmless in activations, but a gradient tensor's rows (one RoI's
+# against another's) can lie further apart than that, and the exact split keeps every element's 24 bits.
 F32_ENGINE = __import__("os").environ.get("FRCNN_TRAIN_F32_ENGINE", "bf16x6")
 _WGRAD_STREAM = None
 
@@ -568,6 +575,28 @@ class _StepDriver:
         # the packed f32 filters were rewritten IN PLACE: bf16 planes derived from them for the split-bf16 engine
         # (ops.PackedConv.x6_planes, cached on tensor identity) are stale now
         self._refresh_x6()
+        self._refresh_h3()
+
+    def _refresh_h3(self):
+        """The f16x3 engine's twin of _refresh_x6: header (max|w|) + two fp16 planes of every filter that has them, three launches."""
+        live = [pk for c in self._tconvs() for pk in (c.pc, getattr(c, "pd", None)) if getattr(pk, "_h3", None) is not None and pk._h3_src is pk.w]
+        key = tuple(id(pk._h3) for pk in live)
+        if getattr(self, "_h3_key", None) != key:
+            jobs = (_lib.X6Job * max(1, len(live)))()
+            for j, pk in zip(jobs, live):
+                j.w_packed, j.planes_bf16, j.rows, j.kpad = pk.w.data_ptr(), pk._h3.data_ptr(), pk.w.shape[0], pk.w.shape[1]
+            self._h3_key, self._h3_jobs = key, jobs
+        if live:
+            _lib.call("frcnn_refresh_h3_planes", self._h3_jobs, len(live), _stream())
+
+    def _amax_arenas(self):
+        """(prefix stream's, main stream's) magnitude-record arenas of a step under the f16x3 engine.  Records never cross the two
+        streams (the frozen prefix's output is measured again by its first reader): the next step's prefix clears ITS arena while this
+        step's main part may still be running."""
+        a = getattr(self, "_amax", None)
+        if a is None:
+            a = self._amax = (ops.AmaxArena(256), ops.AmaxArena(256))
+        return a
 
     def _refresh_x6(self):
         """The packed f32 filters were rewritten IN PLACE: the three bf16 planes the split-bf16 engine multiplies with
@@ -634,7 +663,9 @@ class _StepDriver:
                 pset, views = self._stage([hi for hi, d in zip(host_inputs, on_dev) if not d])
                 main, side = torch.cuda.current_stream(), _prefix_stream()
                 side.wait_event(self._frozen_ready)         # the frozen layers' packed filters (lowered on the build stream)
-                with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws_prefix), ops.f32_engine(F32_ENGINE):
+                arena_pre, arena_main = self._amax_arenas() if F32_ENGINE == "f16x3" else (None, None)
+                with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws_prefix), ops.f32_engine(F32_ENGINE), ops.amax_arena(arena_pre):
+                    ops.amax_begin()
                     up = iter(views)
                     dev = []
                     for (a, shape), d in zip(host_inputs, on_dev):
@@ -649,11 +680,14 @@ class _StepDriver:
                             dev.append(next(up).to("cuda", non_blocking=True))
                     pset.mark_uploaded()
                     pre = self._frozen_prefix(dev)
+                    if pre is not None and getattr(pre, "_amax", None) is not None:
+                        pre._amax = None                    # (a record of the prefix arena: not read on the main stream)
                 self._finish_update()
                 main.wait_stream(side)
                 for t in dev + ([pre] if pre is not None else []):
                     t.record_stream(main)                   # allocated on the side stream, read (and released) under the main one
-                with ops.conv_workspace(self._conv_ws), ops.f32_engine(F32_ENGINE):
+                with ops.conv_workspace(self._conv_ws), ops.f32_engine(F32_ENGINE), ops.amax_arena(arena_main):
+                    ops.amax_begin()
                     self._device_step(dev, out, pre)
         finally:
             # a step that died half way (OOM, FrcnnError) must not leave its queued weight-gradient jobs to the next

@@ -299,6 +299,9 @@ typedef struct frcnn_x6_job {
     int32_t rows, kpad;            /* kpad % 32 == 0 */
 } frcnn_x6_job;
 int frcnn_refresh_x6_planes(const frcnn_x6_job* jobs, int n_jobs, void* stream);
+/* The f16x3 engine's twin (frcnn_pack_conv_weights_h3 per job, three launches per 48 jobs): `planes_bf16` of a job points at
+ * frcnn_conv_h3_planes_bytes(rows, kpad) bytes, 16-byte aligned -- the 16-byte header (max|w|, re-measured) and the two fp16 planes. */
+int frcnn_refresh_h3_planes(const frcnn_x6_job* jobs, int n_jobs, void* stream);
 /* The tile code (71..77) frcnn_conv2d_fwd_x6 / frcnn_conv2d_fwd_dual_x6 (n1 > 0) run for this descriptor when no split-K workspace
  * applies: profiling tools name the kernel with it. */
 int frcnn_conv2d_x6_config(const frcnn_conv_desc* d, int n1);

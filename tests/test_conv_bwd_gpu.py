@@ -249,9 +249,10 @@ def test_split_engine_input_gradient_with_mask_and_residual(case):
     assert e <= max(e_native, 5e-7), (e, e_native)                   # (the bar tests/test_conv_x6_gpu.py holds the engine's forward launches to)
 
 
-@pytest.mark.parametrize("engine", ["native", "bf16x6"])
-def test_conv2d_dgrad_under_both_engines(engine):
-    """ops.conv2d_dgrad itself (tile 0: the policy picks the launch form) under the library default and under train.py's setting."""
+@pytest.mark.parametrize("engine", ["native", "bf16x6", "f16x3"])
+def test_conv2d_dgrad_under_every_engine(engine):
+    """ops.conv2d_dgrad itself (tile 0: the policy picks the launch form) under the library default, the exact bf16 split and train.py's
+    setting (f16x3: the gradient's magnitude record is measured here -- nothing produced it -- and the result carries its own)."""
     from faster_rcnn_amd import ops
     for (n, h, w, cin, cout, k, padding) in ((1, 38, 63, 256, 256, 3, "same"), (1, 38, 63, 1024, 256, 1, "valid"), (1, 13, 17, 64, 128, 3, "same")):
         rs = np.random.RandomState(cin + cout + k)
@@ -267,7 +268,13 @@ def test_conv2d_dgrad_under_both_engines(engine):
         pd = ops.PackedDgrad(dev(wt), dev(scale))
         with ops.f32_engine(engine), ops.conv_workspace(ops.ConvWorkspace()):
             dx = ops.conv2d_dgrad(dev(gy), pd, padding, residual=dev(res), mask=dev(x))
+            again = ops.conv2d_dgrad(dev(gy), pd, padding, residual=dev(res), mask=dev(x))
             d = ops._conv_desc((n, h, w, pd.cin), k, k, pd.cout, 1, padding, 0, 0, 0)
-            assert ops._use_x6(d, pd, 0) == (engine == "bf16x6" and h * w >= 2000)      # (the small case stays native under either setting)
+            tag = {"native": None, "bf16x6": "x6", "f16x3": "h3"}[engine]
+            assert ops._split_engine(d, pd, 0) == (tag if h * w >= 2000 else None)      # (the small case stays native under every setting)
         e = ((dx.cpu().double() - want).abs() / want.abs().clamp(min=1.0)).max().item()
         assert e < 1e-5, e
+        assert torch.equal(dx, again)
+        if engine == "f16x3":                                           # the record bounds the result (residual added, mask applied)
+            rec = dx._amax.view(32, -1)[:, 0].max().item()
+            assert rec == dx.abs().max().item(), (rec, dx.abs().max().item())

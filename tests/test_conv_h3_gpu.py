@@ -409,3 +409,31 @@ def test_h3_roi_resampling_writes_the_planes_the_next_conv_reads():
         # without a record on the map the request falls back to the f32 tensor
         plain = ops.roi_crop_resize(feat.clone(), rd, 7, fill=fill, relu=True, layout=1, planes_out=True)
         assert isinstance(plain, torch.Tensor) and torch.equal(plain, f32)
+
+
+def test_refresh_h3_planes_equals_the_single_filter_pack():
+    """frcnn_refresh_h3_planes (a training step's re-derivation of every trainable filter's planes after the update): header and both
+    planes of many packed filters in three launches == frcnn_pack_conv_weights_h3 per filter, bit for bit -- also after the weights
+    have CHANGED in place (the header's maximum is measured again, a smaller one too); malformed jobs are refused."""
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(23)
+    shapes = [(3, 3, 64, 96), (1, 1, 256, 1024), (1, 1, 32, 8), (3, 3, 512, 512)] * 15          # 60 jobs: more than one table
+    packs = [ops.PackedConv((rs.randn(*sh) * 0.05 * (1 + i % 5)).astype(np.float32)) for i, sh in enumerate(shapes)]
+    outs = [torch.full_like(pc.h3_planes(), 7) for pc in packs]
+    jobs = (_lib.X6Job * len(packs))()
+    for j, pc, o in zip(jobs, packs, outs):
+        j.w_packed, j.planes_bf16, j.rows, j.kpad = pc.w.data_ptr(), o.data_ptr(), pc.w.shape[0], pc.w.shape[1]
+    for scale in (1.0, 0.125, 3.0):
+        for pc in packs:
+            pc.w.mul_(scale)                                        # in place, like the optimiser's re-pack
+            pc._h3 = None                                           # (the single-filter form derives its planes afresh)
+        want = [pc.h3_planes().clone() for pc in packs]
+        _lib.call("frcnn_refresh_h3_planes", jobs, len(packs), None)
+        torch.cuda.synchronize()
+        for o, w_ in zip(outs, want):
+            assert torch.equal(o, w_)
+            assert float(o[:4].view(torch.float32).item()) > 0       # the header: max|w|
+    jobs[1].kpad = 48
+    with pytest.raises(_lib.FrcnnError):
+        _lib.call("frcnn_refresh_h3_planes", jobs, 2, None)
+    _lib.call("frcnn_refresh_h3_planes", None, 0, None)              # nothing to do is fine

@@ -493,3 +493,47 @@ def test_many_steps_keep_device_memory_flat():
             torch.cuda.synchronize()
             reserved.append(torch.cuda.memory_reserved())
     assert reserved[1] <= reserved[0], reserved
+
+
+def test_rpn_steps_on_the_f16x3_engine_track_the_exact_split():
+    """train.F32_ENGINE = "f16x3" (opt-in): forward and input-gradient launches on the f16x3 engine with per-step magnitude-record
+    arenas and the batched plane refresh -- two SGD steps on a 320x480 image (stages 2-3 and the RPN layers pass the engine's policy)
+    against the same steps on the default exact split: losses to 1e-5, weight updates to 1e-3 of each tensor's (Frobenius)."""
+    from faster_rcnn_amd import ops, resnet, train
+    from faster_rcnn_amd.weights import synthetic_resnet
+    A = 9
+    w0 = synthetic_resnet(50, anchors_per_loc=A, seed=7)
+    x = image(320, 480)
+    rows, cols = resnet.get_conv_rows_cols(320, 480)
+    y_class, y_bbreg = rpn_targets(rows, cols, A)
+    res = {}
+    for eng in ("bf16x6", "f16x3"):
+        prev, train.F32_ENGINE = train.F32_ENGINE, eng
+        try:
+            base = resnet.resnet50_base(weights={k: [a.copy() for a in v] for k, v in w0.items()},
+                                        weight_regularizer=resnet.WEIGHT_REGULARIZER, bias_regularizer=resnet.BIAS_REGULARIZER)
+            rpn = resnet.resnet50_rpn(base, anchors_per_loc=A)
+            tr = train.RpnTrainer(rpn, l2=1e-4)
+            tr.compile(train.SGD(lr=1e-3, momentum=0.9))
+            measured0 = ops.AMAX_MEASURED
+            losses = [tr.train_on_batch(x, [y_class, y_bbreg]) for _ in range(2)]
+            tr.sync_weights()
+            res[eng] = (losses, {k: [np.array(a, np.float64) for a in v] for k, v in rpn.weights.items()}, ops.AMAX_MEASURED - measured0)
+            if eng == "f16x3":
+                live = [pk for c in tr._tconvs() for pk in (c.pc, getattr(c, "pd", None)) if getattr(pk, "_h3", None) is not None]
+                assert len(live) >= 10                               # trainable filters did run on the engine, forward and backward
+                for pk in live[:6]:                                  # ... and their planes are those of the UPDATED weights
+                    have = pk._h3.clone()
+                    pk._h3 = None
+                    assert torch.equal(have, pk.h3_planes())
+        finally:
+            train.F32_ENGINE = prev
+    (la, wa, _), (lb, wb, measured) = res["bf16x6"], res["f16x3"]
+    for a, b in zip(np.ravel(la), np.ravel(lb)):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (la, lb)
+    assert 0 < measured <= 2 * 12, measured                          # a few tensors per step have no producing conv launch (the image, loss gradients)
+    for k in wa:
+        for o, a, b in zip(w0[k], wa[k], wb[k]):
+            da, db = a - np.asarray(o, np.float64), b - np.asarray(o, np.float64)
+            if np.abs(da).max() > 0:
+                assert np.sqrt(((da - db) ** 2).sum() / (da ** 2).sum()) < 1e-3, k
