@@ -39,7 +39,8 @@ class DetTrainingManager:
         trained (steps 2 / 4 freeze it: train_det_step2.py / step4), and a detector trainer writes only its own master
         and packed buffers, so nothing this stream reads is written by the step beside it."""
         if self._stream is None:
-            self._stream = torch.cuda.Stream()
+            from . import feed
+            self._stream = feed.manager_stream()                        # (one per process: see feed.manager_stream)
         if getattr(self.rpn_model, "_trainer", None) is not None and getattr(self.rpn_model, "_dirty", False):
             self._stream.wait_stream(torch.cuda.current_stream())       # (a trained RPN model: order behind its last step)
         return torch.cuda.stream(self._stream)

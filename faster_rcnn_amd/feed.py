@@ -7,6 +7,7 @@ same float32 tensor is produced ON the device from the decoded uint8 frame: one 
 flip of ``shapes.Image.data`` (frcnn_resize_cubic_u8, the same integers as the host restatement) and frcnn_preprocess_u8 (bit for
 bit float32(float64(pixel) - mean)).  tests/test_train_loop_gpu.py holds the two feeds to the same bits.
 """
+import os
 import numpy as np
 import torch
 
@@ -103,3 +104,61 @@ class Ready:
         for t in tensors:
             t._ready = ev
         return tensors
+
+
+# ---- the stream the training managers' device work runs on (rpn_util.RpnTrainingManager, det_util.DetTrainingManager).  ONE per process,
+# and one that shares a hardware queue with NEITHER the caller's stream NOR the training step's weight-gradient and prefix streams.
+# HIP deals its hardware queues (GPU_MAX_HW_QUEUES, 4 by default) to streams as they are created; once they are taken, streams share.
+# A manager stream that shares with the weight-gradient stream has its launches -- and the event the host waits on for the sampling
+# counts -- queued behind the previous step's batched weight gradients: 2.7 ms per fp32 RPN iteration instead of 2.05, decided by how
+# many streams the process happened to have created before (scripts/dev/stream_probe.py prints the sharing matrix: the same loop leg
+# fast or slow by its place in the process).  So candidates are PROBED: a ~3 ms spin on the other stream, an event on the candidate --
+# a candidate whose event completes while the spin is still running is independent of it.  More queues are NOT the answer: with
+# GPU_MAX_HW_QUEUES = 8 / 12 the same loops ran at 2.5 (mixed) / 3.9 ms (fp32) per iteration.
+# FRCNN_MANAGER_STREAM: "own" (default: the probed stream) | "prefix" (train._prefix_stream()) | "main" (the caller's stream).
+_MANAGER_STREAM = None
+MANAGER_STREAM = os.environ.get("FRCNN_MANAGER_STREAM", "own")
+
+
+def _runs_beside(busy_stream, stream):
+    """Does an event on ``stream`` complete while ``busy_stream`` spins?  (~3 ms per question.)"""
+    first = torch.cuda.Event()
+    first.record(stream)
+    first.synchronize()                                      # (a stream's queue is set up at its first use: not inside the measurement)
+    with torch.cuda.stream(busy_stream):
+        torch.cuda._sleep(4_000_000)
+        busy = torch.cuda.Event()
+        busy.record(busy_stream)
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    ev.synchronize()
+    beside = not busy.query()
+    busy.synchronize()
+    return beside
+
+
+def manager_stream():
+    global _MANAGER_STREAM
+    if MANAGER_STREAM == "main":
+        return torch.cuda.current_stream()
+    if MANAGER_STREAM == "prefix":
+        from . import train
+        return train._prefix_stream()
+    if _MANAGER_STREAM is None:
+        from . import train
+        cur = torch.cuda.current_stream()
+        cur.synchronize()
+        others = [cur, train._wgrad_stream(), train._prefix_stream()]       # (created now if the process has not trained yet: the order is fixed here)
+        tried, best = [], None
+        for _ in range(8):
+            cand = torch.cuda.Stream()
+            tried.append(cand)                               # (kept alive: a released stream's queue slot would be dealt out again)
+            free = [_runs_beside(o, cand) for o in others]
+            if all(free):
+                best = cand
+                break
+            if best is None and free[0] and free[1]:
+                best = cand                                  # sharing with the prefix stream only: 2.10 against 2.05 ms
+        _MANAGER_STREAM = best if best is not None else tried[-1]
+        manager_stream.tried = tried
+    return _MANAGER_STREAM

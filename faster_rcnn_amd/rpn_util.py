@@ -53,10 +53,8 @@ class RpnTrainingManager:
     # have built from batched_image(image) and rpn_y_true(image): 1.2 MB of masks and targets, 1 MB of packed targets and 14 MB
     # of float64 image never cross PCIe.  tests/test_train_loop_gpu.py: same bits, same weights after N iterations.
     def _own_stream(self):
-        import torch
-        if getattr(self, "_stream", None) is None:
-            self._stream = torch.cuda.Stream()
-        return self._stream
+        from . import feed
+        return feed.manager_stream()                          # (one per process: see feed.manager_stream)
 
     def prefetch(self, image):
         import torch

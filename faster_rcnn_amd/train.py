@@ -220,13 +220,17 @@ F32_ENGINE = __import__("os").environ.get("FRCNN_TRAIN_F32_ENGINE", "bf16x6")
 _WGRAD_STREAM = None
 
 
-def _launch_pending_wgrads():
+def _wgrad_stream():
     global _WGRAD_STREAM
-    if not _PENDING_WGRAD:
-        return
     if _WGRAD_STREAM is None:
         _WGRAD_STREAM = torch.cuda.Stream()
-    side, cur = _WGRAD_STREAM, torch.cuda.current_stream()
+    return _WGRAD_STREAM
+
+
+def _launch_pending_wgrads():
+    if not _PENDING_WGRAD:
+        return
+    side, cur = _wgrad_stream(), torch.cuda.current_stream()
     side.wait_stream(cur)                                   # the operands were produced on the main stream
     prev, ops.WGRAD_ENGINE = ops.WGRAD_ENGINE, WGRAD_ENGINE
     try:
