@@ -258,7 +258,7 @@ def backbone_in_flight(pipe, n_images, base_gflop, steps=20, batch=1, engine="na
         return net(x)
     for i, st in enumerate(streams):
         x = torch.from_numpy(np.concatenate([synth_image(200 + i * batch + j) for j in range(batch)])).cuda()
-        ws = ops.ConvWorkspace() if batch == 1 else ops.NO_SPLIT_K
+        ws = ops.ConvWorkspace() if (batch == 1 or os.environ.get("FRCNN_BENCH_BATCH_SPLITK")) else ops.NO_SPLIT_K
         arena = ops.AmaxArena() if engine == "f16x3" else None
         shared = n_images > 1 or batch > 1
         st.wait_stream(torch.cuda.current_stream())
@@ -948,10 +948,10 @@ def main():
     ap.add_argument("--no-io", action="store_true",
                     help="skip the second, I/O-inclusive timing (fresh uint8 images from pinned host memory in, detections out)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="images in flight per GPU (one hipGraph + HIP stream each); default: 8 for the fp32 config, 4 for bf16")
+                    help="captured passes in flight per GPU (one hipGraph + HIP stream each); default: 4 (12 for fp32 with --batch 1)")
     ap.add_argument("--batch", type=int, default=0,
                     help="images per hipGraph (BatchedInferencePipeline: trunk at batch B, one detector-head pass over B x 300 RoIs); "
-                         "default: 8 for configs[3] (bf16), 1 otherwise")
+                         "default: 8 for configs[3] (bf16), 4 for configs[1] (fp32; 1 when --streams is given), 1 for configs[0]")
     ap.add_argument("--unit-tiles", default="", help="dev: tile codes for named conv layers, e.g. res5a_branch2c=26,res5b_branch2c=26")
     ap.add_argument("--conv-table", action="store_true", help="print every distinct conv launch's duration alone on the chip to stderr")
     ap.add_argument("--f32-engine", choices=("native", "bf16x6", "f16x3"), default="f16x3",
@@ -967,13 +967,16 @@ def main():
     select_config(args.config)
     bf16_run = not (DTYPE == "f32" and args.dtype in ("config", "f32"))
     if args.batch <= 0:
-        args.batch = 8 if (bf16_run and args.config != "c1" and not args.no_graph) else 1
-    if args.batch > 1 and (not bf16_run or args.config == "c1" or args.no_graph):
-        ap.error("--batch needs the bf16 conv path and hipGraph replay")
+        # fp32 (round 5): four images per pass, four passes in flight -- the trunk's launches are latency-bound at one image (matrix pipe
+        # 8 % busy on its 64x64 tiles), B times taller they fill the chip: trunk 0.59 -> 0.445 ms per image in flight, end to end 502 ->
+        # 540 img/s (B x passes: 2x6 516, 3x4 522, 4x3 540, 4x4 541, 5x3 550, 6x3 542, 8x2 534, 8x3 547; `one_image_per_pass` in the line)
+        args.batch = (8 if bf16_run else 4) if (args.config != "c1" and not args.no_graph and (args.streams <= 0 or bf16_run)) else 1
+    if args.batch > 1 and args.config == "c1":
+        ap.error("--batch needs a detector (c2 / c4)")
     if args.streams <= 0:
         # fp32: 12 images in flight on 12 hardware queues since round 5 (f16x3 engine: 8 / 12 / 16 streams 472 / 481 / 480 img/s, twice each in
         # one session -- the launches are shorter now and more of them are latency-bound; the native engine showed no difference)
-        args.streams = 12 if not bf16_run else 4      # configs[3] sweep (round 3, batch 8): 4 graphs 982-994 img/s, 3 975-985, 5 933-943, 2 952; 8 hw queues 939-944
+        args.streams = 12 if (not bf16_run and args.batch == 1) else 4      # configs[3] sweep (round 3, batch 8): 4 graphs 982-994 img/s, 3 975-985, 5 933-943, 2 952; 8 hw queues 939-944
     # ROCm maps a process's streams onto 4 hardware queues unless told otherwise; more than four images in flight need
     # a queue each or they queue behind one another (measured on MI355X: 8 streams on 8 queues 245.6 img/s, 8 streams on
     # 4 queues 241.4, 4 on 4 240.7, 4 on 8 217.0; configs[3] (bf16) is fastest with 4 on 4).  Read when the HIP runtime
@@ -1012,6 +1015,7 @@ def main():
                     u.tile = int(want[u.conv])
     B = args.batch                                  # images per hipGraph (1 = InferencePipeline, one image per graph)
     synth_batch = lambda first: torch.from_numpy(np.concatenate([synth_image(first + j) for j in range(B)])).cuda()
+    pipe1 = pipe                                    # the one-image pipeline: what the parity checkers walk stage by stage
     if B > 1:
         from faster_rcnn_amd.pipeline import BatchedInferencePipeline
         raw_dense = getattr(pipe, "raw_dense_class", None)
@@ -1034,7 +1038,7 @@ def main():
         pipes = [pipe] + [more() for _ in range(S - 1)]
         streams = [torch.cuda.Stream() for _ in range(S)]
         for i, (pl, st) in enumerate(zip(pipes, streams)):
-            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1 or B > 1, **({"f32_engine": args.f32_engine} if B == 1 else {}))
+            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1 or B > 1, **({"f32_engine": args.f32_engine} if (B == 1 or not bf16_run) else {}))
             pl._static_in.copy_(synth_batch((rank * S + i) * B))
         torch.cuda.synchronize()
 
@@ -1097,15 +1101,35 @@ def main():
     # v_mfma_f32_32x32x2_f32; `bf16x6_exact_split` (f16x3 runs): the exact three-way bf16 split of round 4.
     native = x6_alt = None
 
-    def time_engine(engine, what):
-        npipes = [more() for _ in range(S)]
+    def per_image_outputs(pls, batch):
+        """{image id: (det_bbox, det_cls, det_prob, n_dets)} of captured pipelines; image id = pipeline index * batch + position in the pass"""
+        res = {}
+        for i, pl in enumerate(pls):
+            o = pl._static_out
+            for j in range(batch):
+                pick = lambda k: o[k][j] if isinstance(o[k], list) else o[k]
+                res[i * batch + j] = (pick("det_bbox"), pick("det_cls"), pick("det_prob"), pick("n_dets"))
+        return res
+
+    def time_engine(engine, what, batch=None, n_streams=None):
+        """The same steps with other captured passes: another matrix path (``engine``) and / or another pass shape (``batch`` images
+        per pass, ``n_streams`` passes in flight); image g of this run is image g of the value run."""
+        from faster_rcnn_amd.pipeline import BatchedInferencePipeline, InferencePipeline
+        b = B if batch is None else batch
+        ns = S if n_streams is None else n_streams
+        make = lambda: (RpnOnlyPipeline(pipe.rpn) if DEPTH == 16 else
+                        BatchedInferencePipeline(pipe.rpn, pipe.det, anchors, b, max_proposals=PROPOSALS) if b > 1 else
+                        InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS))
+        npipes = [make() for _ in range(ns)]
+        nstreams = streams[:ns] + [torch.cuda.Stream() for _ in range(max(0, ns - len(streams)))]
+        sk = args.split_k == "on" or (args.split_k == "auto" and b == 1 and (ns == 1 or DTYPE == "f32"))
         for i, pl in enumerate(npipes):
-            pl.capture(HEIGHT, WIDTH, split_k=split_k, throughput=S > 1, f32_engine=engine)
-            pl._static_in.copy_(synth_batch((rank * S + i) * B))
+            pl.capture(HEIGHT, WIDTH, split_k=sk, throughput=ns > 1 or b > 1, f32_engine=engine)
+            pl._static_in.copy_(torch.from_numpy(np.concatenate([synth_image(rank * S * B + i * b + j) for j in range(b)])).cuda())
         torch.cuda.synchronize()
 
         def nstep():
-            for pl, st in zip(npipes, streams):
+            for pl, st in zip(npipes, nstreams):
                 with torch.cuda.stream(st):
                     pl._graph.replay()
         for _ in range(args.warmup):
@@ -1116,22 +1140,45 @@ def main():
             nstep()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        res = {"value": round(S * args.steps / el, 3), "unit": "img/s", "ms_per_step": round(1e3 * el / args.steps, 4), "what": what % args.steps}
+        res = {"value": round(ns * b * args.steps / el, 3), "unit": "img/s", "ms_per_step": round(1e3 * el / args.steps, 4), "what": what % args.steps}
+        if (b, ns) != (B, S):
+            res.update({"images_per_graph": b, "graphs_in_flight": ns})
         if "det_bbox" in pipes[0]._static_out:
-            same = all(torch.equal(a._static_out["det_bbox"], b._static_out["det_bbox"]) and torch.equal(a._static_out["det_cls"], b._static_out["det_cls"])
-                       for a, b in zip(pipes, npipes))
-            res["same_boxes_and_classes_as_value_run"] = bool(same)
-            res["max_score_difference_from_value_run"] = float(max((a._static_out["det_prob"] - b._static_out["det_prob"]).abs().max() for a, b in zip(pipes, npipes)))
+            # detection by detection: a (class, box) pair of the value run that the other run has too is IDENTICAL; its scores are compared.
+            # (Two fp32 summation orders differ by ~1e-6 in a score or a regression: over thousands of boxes one integer box edge lands
+            # on the other side of a .5, or two near-tied scores swap places in an NMS -- counted here, not hidden.)
+            mine, theirs = per_image_outputs(pipes, B), per_image_outputs(npipes, b)
+            common = sorted(set(mine) & set(theirs))
+            n_mine = n_theirs = n_same = 0
+            worst = 0.0
+            for g in common:
+                (ba, ca, pa, na), (bb, cb, pb, nb) = ([t.cpu().numpy() for t in mine[g]], [t.cpu().numpy() for t in theirs[g]])
+                na, nb = int(na.reshape(-1)[0]), int(nb.reshape(-1)[0])
+                da = {(int(c),) + tuple(int(v) for v in bx): float(p) for bx, c, p in zip(ba.reshape(-1, 4)[:na], ca.reshape(-1)[:na], pa.reshape(-1)[:na])}
+                db = {(int(c),) + tuple(int(v) for v in bx): float(p) for bx, c, p in zip(bb.reshape(-1, 4)[:nb], cb.reshape(-1)[:nb], pb.reshape(-1)[:nb])}
+                n_mine += len(da); n_theirs += len(db)
+                for k, p in da.items():
+                    if k in db:
+                        n_same += 1
+                        worst = max(worst, abs(p - db[k]))
+            res["same_boxes_and_classes_as_value_run"] = bool(n_same == n_mine == n_theirs)
+            res["detections_identical_to_value_run"] = "%d/%d" % (n_same, max(n_mine, n_theirs))
+            res["max_score_difference_from_value_run"] = worst
+            res["images_compared"] = len(common)
         else:                                               # configs[0]: RPN outputs only
-            res["max_rpn_cls_difference_from_value_run"] = float(max((a._static_out["rpn_cls"] - b._static_out["rpn_cls"]).abs().max() for a, b in zip(pipes, npipes)))
+            res["max_rpn_cls_difference_from_value_run"] = float(max((a._static_out["rpn_cls"] - b_._static_out["rpn_cls"]).abs().max() for a, b_ in zip(pipes, npipes)))
         del npipes
         torch.cuda.empty_cache()
         return res
-    if not args.no_graph and args.f32_engine != "native" and DTYPE == "f32" and B == 1 and world == 1 and not force_dist and "FRCNN_BENCH_NO_NATIVE" not in os.environ:
+    single = None
+    if not args.no_graph and args.f32_engine != "native" and DTYPE == "f32" and world == 1 and not force_dist and "FRCNN_BENCH_NO_NATIVE" not in os.environ:
         native = time_engine("native", "the same %d steps with every fp32 convolution on v_mfma_f32_32x32x2_f32 (--f32-engine native)")
         if args.f32_engine == "f16x3":
             x6_alt = time_engine("bf16x6", "the same %d steps with the split launches on the bf16 matrix cores by EXACT three-way operand splitting, six matrix "
                                            "instructions per block of products (--f32-engine bf16x6: round 4's headline path)")
+        if B > 1 and DEPTH != 16:
+            # the pass shape of rounds 1-5a: ONE image per captured pass, twelve in flight -- the same images, the same engine
+            single = time_engine(args.f32_engine, "the same images, ONE per captured pass, 12 passes in flight, %d steps (the headline's pass shape until round 5)", batch=1, n_streams=12)
 
     # ---- the same K steps again with the host on both ends (voc_dets.get_dets' contract: image in, detections out,
     # voc_dets.py:20-88): per image a FRESH uint8 BGR frame leaves pinned host memory (1.8 MB over PCIe), resnet.preprocess
@@ -1265,6 +1312,8 @@ def main():
             line["native_f32_mfma"] = native
         if x6_alt is not None:
             line["bf16x6_exact_split"] = x6_alt
+        if single is not None:
+            line["one_image_per_pass"] = single
         if io is not None:
             line["with_host_io"] = io
         if via_entry is not None:
@@ -1311,11 +1360,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline(weights, anchors, runs=oracle_runs, alt_dense_class=getattr(pipe, "raw_dense_class", None) if DTYPE != "f32" else None)
             if DTYPE == "f32":
                 try:
-                    line["parity"] = full_size_parity(pipe, weights, anchors)
+                    line["parity"] = full_size_parity(pipe1, weights, anchors)
                 except Exception as e:                              # the checker must not cost the bench line
                     line["parity"] = {"ok": False, "error": repr(e)[:200]}
                 try:
-                    line["parity"]["e2e"] = e2e_parity(pipe, weights, anchors, oracle_runs)
+                    line["parity"]["e2e"] = e2e_parity(pipe1, weights, anchors, oracle_runs)
                 except Exception as e:
                     line["parity"]["e2e"] = {"ok": False, "error": repr(e)[:300]}
             else:                                                       # configs[1] shapes on the bf16 engine (off-contract run)

@@ -75,6 +75,7 @@ SIGNATURES = {
     "frcnn_amax_f32": (I, [P, c_size_t, P, P]),
     "frcnn_amax_merge": (I, [P, P, ctypes.c_float, P, P]),
     "frcnn_roi_crop_resize_fwd_planes": (I, [P, I, I, I, P, I, I, P, I, I, P, P]),
+    "frcnn_roi_crop_resize_fwd_batch": (I, [P, I, I, I, P, I, I, I, P, I, I, P, P, P]),
     "frcnn_conv2d_h3_config": (I, [P, I]),
     "frcnn_conv2d_h3_workspace_bytes": (c_size_t, [P]),
     "frcnn_conv2d_fwd_h3": (I, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),

@@ -38,10 +38,12 @@ __device__ __forceinline__ Taps roi_taps(const float4 roi, int py, int px, int p
 // for the hoisted detector head (nets.ResNetHead): a 1x1 conv + folded BatchNorm commutes with this resampling
 // (interpolation weights sum to 1), so the head applies res5a_branch2a / branch1 ONCE to the conv4 map and
 // resamples their outputs; an all-zero crop would have produced the BatchNorm shift there.
+// n_per_img > 0: `feat` holds one map per IMAGE, RoI r crops image r / n_per_img's (frcnn_roi_crop_resize_fwd_batch)
 __global__ void __launch_bounds__(256) k_roi_fwd(const float4* feat, int rows, int cols, int C4,
-                                                 const float4* rois, int pool, const float4* fill, int relu, int pos_major, float4* out) {
+                                                 const float4* rois, int pool, const float4* fill, int relu, int pos_major, float4* out, int n_per_img) {
     const int pix = blockIdx.x;                 // (roi, py, px)
     const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    if (n_per_img > 0) feat += (size_t)(r / n_per_img) * rows * cols * C4;
     const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
     // pos_major: out[py][px][roi][c] (frcnn_conv_desc.layout == 1) instead of out[roi][py][px][c]
     const size_t orow = pos_major ? (size_t)(py * pool + px) * (gridDim.x / (pool * pool)) + r : (size_t)pix;
@@ -75,10 +77,11 @@ __global__ void __launch_bounds__(256) k_roi_fwd(const float4* feat, int rows, i
 // frcnn_amax_merge).  The consumer, res5a_branch2b's 3x3 over the crops (resnet.py:508-512), then stages the planes unchanged.
 __global__ void __launch_bounds__(256) k_roi_fwd_planes(const float4* feat, int rows, int cols, int C4, const float4* rois, int pool,
                                                         const float4* fill, int relu, int pos_major, const int* pexp,
-                                                        _Float16* planes, size_t plane_elems) {
+                                                        _Float16* planes, size_t plane_elems, int n_per_img) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int pix = blockIdx.x;
     const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
+    if (n_per_img > 0) feat += (size_t)(r / n_per_img) * rows * cols * C4;
     const Taps t = roi_taps(rois[r], py, px, pool, rows, cols);
     const size_t orow = pos_major ? (size_t)(py * pool + px) * (gridDim.x / (pool * pool)) + r : (size_t)pix;
     const int e = *pexp;
@@ -225,7 +228,7 @@ int frcnn_roi_crop_resize_fwd_ex(const float* feat, int rows, int cols, int C, c
     if (n == 0) return FRCNN_OK;
     if (!feat || !rois || !out) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd: null pointer");
     k_roi_fwd<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool,
-                                                              (const float4*)fill, relu, layout, (float4*)out);
+                                                              (const float4*)fill, relu, layout, (float4*)out, 0);
     return check_launch("roi_crop_resize_fwd");
 }
 
@@ -236,8 +239,26 @@ int frcnn_roi_crop_resize_fwd_planes(const float* feat, int rows, int cols, int 
     if (!feat || !rois || !out || !out->planes || !out->exponent) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_planes: null pointer");
     if (reinterpret_cast<uintptr_t>(out->planes) & 15) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_planes: 16-byte aligned planes required");
     k_roi_fwd_planes<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool, (const float4*)fill,
-                                                                    relu, layout, out->exponent, (_Float16*)out->planes, (size_t)n * pool * pool * C);
+                                                                    relu, layout, out->exponent, (_Float16*)out->planes, (size_t)n * pool * pool * C, 0);
     return check_launch("roi_crop_resize_fwd_planes");
+}
+
+int frcnn_roi_crop_resize_fwd_batch(const float* feat, int rows, int cols, int C, const float* rois, int n, int n_per_img, int pool,
+                                    const float* fill, int relu, int layout, float* out, const frcnn_h3_planes* planes_out, void* stream) {
+    if (n < 0 || n_per_img <= 0 || rows <= 0 || cols <= 0 || C <= 0 || (C & 3) || pool <= 0) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_batch: bad shape (C %% 4 == 0, n_per_img > 0)");
+    if ((out != nullptr) == (planes_out != nullptr)) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_batch: exactly one of out / planes_out");
+    if (n == 0) return FRCNN_OK;
+    if (!feat || !rois) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_batch: null pointer");
+    if (out) {
+        k_roi_fwd<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool,
+                                                                  (const float4*)fill, relu, layout, (float4*)out, n_per_img);
+        return check_launch("roi_crop_resize_fwd_batch");
+    }
+    if (!planes_out->planes || !planes_out->exponent || (reinterpret_cast<uintptr_t>(planes_out->planes) & 15))
+        return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_batch: planes and exponent required, planes 16-byte aligned");
+    k_roi_fwd_planes<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool, (const float4*)fill,
+                                                                    relu, layout, planes_out->exponent, (_Float16*)planes_out->planes, (size_t)n * pool * pool * C, n_per_img);
+    return check_launch("roi_crop_resize_fwd_batch (planes)");
 }
 
 int frcnn_roi_crop_resize_bwd(const float* dout, int rows, int cols, int C, const float* rois, int n, int pool,

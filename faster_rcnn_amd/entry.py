@@ -49,13 +49,22 @@ def _default_budget():
 
 
 def default_in_flight(dtype="f32"):
-    """Images in flight for get_dets_by_cls: one per hardware queue (fp32 wants 8-12 streams on as many queues, the
+    """Captured passes in flight for get_dets_by_cls: one per hardware queue (fp32 wants 8-12 streams on as many queues, the
     power-limited bf16 path 4 on 4); ROCm gives a process 4 queues unless GPU_MAX_HW_QUEUES says otherwise."""
     env = int(os.environ.get("FRCNN_ENTRY_IN_FLIGHT", "0"))
     if env > 0:
         return env
     queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
-    return min(queues, 12) if (queues >= 8 and dtype == "f32") else 4      # (round 5: 12 on 12 queues, +2 % over 8 on 8 with the f16x3 engine)
+    # fp32: 12 on 12 queues (+2 % over 8 on 8 for one-image passes, the shape every odd-sized image takes; four-image passes are flat
+    # from 3 to 6 in flight: 540 / 541 / 528 / 539 img/s)
+    return min(queues, 12) if (queues >= 8 and dtype == "f32") else 4
+
+
+def default_batch(dtype="f32"):
+    """Images per captured pass where neighbouring images share a geometry (FRCNN_ENTRY_BATCH / FRCNN_ENTRY_BATCH_F32)."""
+    if dtype == "bf16":
+        return max(1, int(os.environ.get("FRCNN_ENTRY_BATCH", "8")))
+    return max(1, int(os.environ.get("FRCNN_ENTRY_BATCH_F32", "4")))
 
 
 # The reference pads the last batch of 64 RoIs with copies of its first RoI and scores the copies too (voc_dets.py:42-51).  A copy
@@ -174,11 +183,12 @@ class DetectionEntry:
         self.num_rois, self.stride, self.in_flight = int(num_rois), stride, max(1, int(in_flight))
         # images per captured pass.  The bf16 detector makes ONE head pass over the RoIs of eight images and runs its trunk at batch
         # eight (pipeline.BatchedInferencePipeline: what configs[3]'s headline times); get_dets_by_cls groups neighbouring images of
-        # one size into such passes.  The f32 models keep one image per pass (a batched fp32 head gains nothing).
+        # one size into such passes.  The f32 ResNet models take four per pass since round 5 (the TRUNK is what gains: its launches are
+        # latency-bound at one image -- 0.59 -> 0.445 ms per image at four; the head is unchanged, as DESIGN 11 found in round 2).
         head = getattr(detector, "head", None)
         self.batch = 1
-        if getattr(head, "dtype", "f32") == "bf16" and hasattr(head, "forward_batched"):
-            self.batch = max(1, int(os.environ.get("FRCNN_ENTRY_BATCH", "8")))
+        if hasattr(head, "forward_batched") and getattr(head, "hoist", False):
+            self.batch = default_batch(getattr(head, "dtype", "f32"))
         from . import resnet, vgg
         self.device_preprocess = manager.preprocess_func in (resnet.preprocess, vgg.preprocess)
         self.rev_class_mapping = dict((v, k) for k, v in manager.class_mapping.items())
@@ -274,7 +284,7 @@ class DetectionEntry:
         # (fp32 models keep split-K also beside other passes, as bench.py's headline does: the small grids of rpn_conv1 / stage 4 then run
         # the split engine's split-K form; the bf16 engine loses with it when several passes share the chip)
         dtype = getattr(getattr(self.detector, "head", None), "dtype", "f32")
-        s.ws = ops.NO_SPLIT_K if (shared and (dtype == "bf16" or os.environ.get("FRCNN_ENTRY_NO_SPLITK"))) else ops.ConvWorkspace()
+        s.ws = ops.NO_SPLIT_K if ((shared and (dtype == "bf16" or os.environ.get("FRCNN_ENTRY_NO_SPLITK"))) or B > 1) else ops.ConvWorkspace()
         s.io_dev.copy_(s.io_pin)
         s.amax = ops.AmaxArena() if self.f32_engine == "f16x3" else None      # the pass's magnitude records (fixed addresses across replays)
         side = torch.cuda.Stream()

@@ -324,7 +324,10 @@ class ResNetHead:
 
     def _first_block_hoisted(self, feat, rois, resize):
         a = self.blocks[0]
-        fmap = ops.amax_carry(feat.reshape(1, feat.shape[-3], feat.shape[-2], feat.shape[-1]), feat)    # (a view keeps its magnitude record)
+        if feat.dim() == 4 and feat.shape[0] > 1:               # a batch of maps (forward_batched): `resize` knows which RoI crops which
+            fmap = feat
+        else:
+            fmap = ops.amax_carry(feat.reshape(1, feat.shape[-3], feat.shape[-2], feat.shape[-1]), feat)    # (a view keeps its magnitude record)
         pair = _pair(a["2a"], a["1"])
         if pair is not None:
             u, v = pair(fmap, act1=None)                    # one launch: conv + BN of both on the map
@@ -363,10 +366,20 @@ class ResNetHead:
 
 
     def forward_batched(self, feat, rois, n_per_img):
-        """The head over the RoIs of a BATCH of images in one pass: feat (B,R,C,Cf) bf16, rois (B*n_per_img,4) (RoI r belongs
+        """The head over the RoIs of a BATCH of images in one pass: feat (B,R,C,Cf) (bf16 or f32 model), rois (B*n_per_img,4) (RoI r belongs
         to image r // n_per_img) -> (class probabilities (B*n,C), regressions).  Same layers, same per-row arithmetic as
         ``__call__`` per image; the GEMMs are B times taller (one launch per layer for the whole batch)."""
-        assert self.dtype == "bf16" and self.hoist, "batched head: bf16, hoisted order"
+        assert self.hoist, "batched head: hoisted order"
+        if self.dtype == "f32":                                 # the same code path as one image: only the resampling knows about the batch
+            import functools
+            L = self.layout
+            x = self._first_block_hoisted(feat, rois, functools.partial(ops.roi_crop_resize, n_per_img=n_per_img))
+            for b in self.blocks[1:]:
+                x = run_block(b, x, L, planes=True)
+            if L:
+                return self.dense(ops.avgpool_pos_major(x))
+            x = ops.pool2d(x, 7, 7, False)
+            return self.dense(x.reshape(x.shape[0], -1))
         L, a = self.layout, self.blocks[0]
         u = a["2a"](feat, act=None)                         # conv + BN on every image's map (M = B * rows * cols)
         v = a["1"](feat)

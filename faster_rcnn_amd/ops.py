@@ -266,15 +266,20 @@ def roi_targets(rois_i16, gt_f32, gt_f64, gt_cls, bg_idx):
 
 
 # ----------------------------------------------------------------------------- RoI crop/resize
-def roi_crop_resize(feat, rois, pool, fill=None, relu=False, layout=0, planes_out=False):
+def roi_crop_resize(feat, rois, pool, fill=None, relu=False, layout=0, planes_out=False, n_per_img=0):
     """feat: (R,C,Cf) f32 (or (1,R,C,Cf)); rois: (n,4) f32 -> (n,pool,pool,Cf) f32, or (pool,pool,n,Cf) with layout=1.
     fill (Cf,) = value of an invalid RoI (default zeros); relu clamps the output (frcnn_roi_crop_resize_fwd_ex).
     ``planes_out``: the result as a PlaneTensor for an f16x3 convolution behind it (frcnn_roi_crop_resize_fwd_planes); needs the
-    map's magnitude record (its producer's), otherwise the f32 tensor comes back."""
+    map's magnitude record (its producer's), otherwise the f32 tensor comes back.
+    ``n_per_img`` > 0: feat (B,R,C,Cf) holds one map per image and RoI r crops image r // n_per_img's (frcnn_roi_crop_resize_fwd_batch)."""
     _require_gpu()
     src = feat
-    feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
-    rows, cols, C = feat.shape
+    if n_per_img > 0:
+        assert feat.dim() == 4 and feat.is_contiguous() and rois.reshape(-1, 4).shape[0] <= feat.shape[0] * n_per_img
+        rows, cols, C = feat.shape[1:]
+    else:
+        feat = feat.reshape(feat.shape[-3], feat.shape[-2], feat.shape[-1]).contiguous()
+        rows, cols, C = feat.shape
     rois = rois.reshape(-1, 4).to(torch.float32).contiguous()
     n = rois.shape[0]
     oshape = (pool, pool, n, C) if layout else (n, pool, pool, C)
@@ -287,10 +292,16 @@ def roi_crop_resize(feat, rois, pool, fill=None, relu=False, layout=0, planes_ou
         out = PlaneTensor(oshape)
         amax_carry(out, src, floor, exponent_out=out.exponent)    # the bound and, from it, the planes' scale: known before the launch
         yp = _lib.H3Planes(planes=out.planes.data_ptr(), exponent=out.exponent.data_ptr())
-        _lib.call("frcnn_roi_crop_resize_fwd_planes", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, ctypes.byref(yp), _stream())
+        if n_per_img > 0:
+            _lib.call("frcnn_roi_crop_resize_fwd_batch", _p(feat), rows, cols, C, _p(rois), n, n_per_img, pool, _p(fill), 1 if relu else 0, layout, None, ctypes.byref(yp), _stream())
+        else:
+            _lib.call("frcnn_roi_crop_resize_fwd_planes", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, ctypes.byref(yp), _stream())
         return out
     out = torch.empty(oshape, dtype=torch.float32, device="cuda")
-    _lib.call("frcnn_roi_crop_resize_fwd_ex", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, _p(out), _stream())
+    if n_per_img > 0:
+        _lib.call("frcnn_roi_crop_resize_fwd_batch", _p(feat), rows, cols, C, _p(rois), n, n_per_img, pool, _p(fill), 1 if relu else 0, layout, _p(out), None, _stream())
+    else:
+        _lib.call("frcnn_roi_crop_resize_fwd_ex", _p(feat), rows, cols, C, _p(rois), n, pool, _p(fill), 1 if relu else 0, layout, _p(out), _stream())
     if _tracking() and getattr(src, "_amax", None) is not None:
         # a bilinear sample is a convex combination of map values; a rejected RoI yields the fill vector
         floor = 0.0

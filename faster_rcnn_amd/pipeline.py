@@ -160,7 +160,7 @@ class BatchedInferencePipeline(InferencePipeline):
     def __init__(self, rpn_model, det_model, anchor_dims, batch, **kw):
         super().__init__(rpn_model, det_model, anchor_dims, **kw)
         self.batch = int(batch)
-        assert getattr(det_model.head, "dtype", "f32") == "bf16" and hasattr(det_model.head, "forward_batched"), "batched pipeline: bf16 ResNet head"
+        assert hasattr(det_model.head, "forward_batched") and getattr(det_model.head, "hoist", False), "batched pipeline: a ResNet head in the hoisted order"
         # the per-image stages (proposal selection: ~10 short dependent launches; detection post-process: one workgroup) of the
         # B images are independent chains.  FRCNN_PAR_BRANCHES=1 runs each on its own stream, forked from and joined into the
         # pass's stream, so a captured graph holds them as B parallel branches: ONE graph in flight gains (B = 8: 663 -> 740
@@ -207,19 +207,22 @@ class BatchedInferencePipeline(InferencePipeline):
             res[k] = [d[k] for d in dets]
         return res
 
-    def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=False, throughput=True):
+    def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=False, throughput=True, f32_engine=None):
+        """``f32_engine``: None = the ambient ops.F32_ENGINE scope (bf16 models: their few f32 layers); an fp32 model names its engine
+        like InferencePipeline.capture does ("f16x3": the pass owns an ops.AmaxArena sized for B images' records)."""
+        engine = ops.F32_ENGINE if f32_engine is None else f32_engine
         self._static_in = torch.zeros((self.batch, height, width, 3), dtype=torch.float32, device="cuda")
         self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
-        self._amax = ops.AmaxArena() if ops.F32_ENGINE == "f16x3" else None       # (the few f32 layers of a bf16 pass under an f16x3 scope)
+        self._amax = ops.AmaxArena(192 + 16 * self.batch) if engine == "f16x3" else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.amax_arena(self._amax):
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), ops.f32_engine(engine), ops.amax_arena(self._amax):
             for _ in range(warmup):
                 self.forward_dev(self._static_in, resize_ratio)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with no_gc(), torch.cuda.graph(self._graph, capture_error_mode="thread_local"), ops.conv_workspace(self._conv_ws), ops.tile_policy(throughput), \
-                ops.amax_arena(self._amax):
+                ops.f32_engine(engine), ops.amax_arena(self._amax):
             self._static_out = self.forward_dev(self._static_in, resize_ratio)
         return self

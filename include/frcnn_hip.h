@@ -391,6 +391,12 @@ int frcnn_conv2d_fwd_h3_planes(const frcnn_conv_desc* d, const float* x, const f
  * frcnn_amax_merge(record, map_record, max|fill|, out->exponent) issued in front of it on the same stream. */
 int frcnn_roi_crop_resize_fwd_planes(const float* feat, int rows, int cols, int c, const float* rois, int n, int pool,
                                      const float* fill, int relu, int layout, const frcnn_h3_planes* out, void* stream);
+/* The RoIs of a BATCH of images in one launch (fp32 twin of frcnn_roi_crop_resize_fwd_bf16_batch): `feat` holds one (rows, cols, C) map per
+ * image, RoI r crops the map of image r / n_per_img.  Exactly one of `out` (f32, as frcnn_roi_crop_resize_fwd_ex) and `planes_out` (two fp16
+ * planes under *exponent, as frcnn_roi_crop_resize_fwd_planes: the exponent of the bound over ALL the maps) is given.  Per RoI the
+ * arithmetic is the single-image call's. */
+int frcnn_roi_crop_resize_fwd_batch(const float* feat, int rows, int cols, int C, const float* rois, int n, int n_per_img, int pool,
+                                    const float* fill, int relu, int layout, float* out, const frcnn_h3_planes* planes_out, void* stream);
 /* frcnn_conv2d_fwd_ws (the native f32 MFMA kernels) that also folds max|y| into y_amax: a layer that stays on the native path
  * (the 3-channel stem, small grids) in front of an f16x3 layer. */
 int frcnn_conv2d_fwd_ws_amax(const frcnn_conv_desc* d, const float* x, const float* w_packed,

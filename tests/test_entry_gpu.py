@@ -358,3 +358,30 @@ def test_file_backed_images_are_resized_on_the_device_and_match_the_eager_path(m
         assert list(per_img) == ["f%d" % i for i in range(6) if "f%d" % i in per_img]
         for name, dets in per_img.items():
             same_dets(dets, [d for d in one if d["cls_name"] == cls_name], tol=1e-4)
+
+
+def test_get_dets_by_cls_fp32_four_image_passes(models):
+    """Neighbouring fp32 frames of one size go through four-image captured passes (entry.default_batch("f32"); round 5): ten frames of
+    one size and two of another -> two whole passes, one padded pass of two (half a batch), two single passes.  Same dict, same
+    order and progress lines as the eager one-by-one path; scores to 1e-4, classes and boxes identical."""
+    from faster_rcnn_amd import entry, voc_dets
+    mgr, det, _, _ = models
+    images = [named_image("f%02d" % i, synth_pixels(320, 480 if i < 10 else 544, 170 + i)) for i in range(12)]
+    ratios = [1.0 + 0.01 * i for i in range(len(images))]
+    fast, eager, out_fast, out_eager = both_paths(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.0)
+    assert list(fast) == list(eager) and sum(len(v) for c in eager.values() for v in c.values()) > 0
+    for cls_name in eager:
+        assert list(fast[cls_name]) == list(eager[cls_name])
+        for img_name in eager[cls_name]:
+            same_dets(fast[cls_name][img_name], eager[cls_name][img_name])
+    strip = lambda s_: [ln.split(" ran in ")[0] for ln in s_.splitlines()]
+    assert strip(out_fast) == strip(out_eager)
+    eng = entry.for_models(mgr, det, 64, 16, entry.default_in_flight("f32"))
+    st = eng.stats()
+    assert st["images_per_pass"] == 4, st
+    # the same list again: every pass is a cache hit and returns the same bits
+    again, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.0)
+    for cls_name in again:
+        for img_name in again[cls_name]:
+            same_dets(again[cls_name][img_name], fast[cls_name][img_name], tol=0.0)
+    assert not any(sl.busy for v in eng.cache._slots.values() for sl in v)
