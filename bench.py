@@ -868,6 +868,19 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
     finally:
         voc_dets.FAST_ENTRY = True
     same = all(k in dets and all(len(v[i]) == len(dets[k][i]) for i in v) for k, v in dets_eager.items())
+    # detection by detection (a captured four-image pass and an eager one-image launch sum some layers in another order: ~1e-6 in a
+    # score, now and then a box edge on the other side of a .5 or two near-tied boxes swapped in an NMS)
+    n_eager = n_same = 0
+    worst = 0.0
+    for k, v in dets_eager.items():
+        for i, lst in v.items():
+            mine = {tuple(int(c) for c in d["bbox"]): float(d["prob"]) for d in dets.get(k, {}).get(i, [])}
+            n_eager += len(lst)
+            for d in lst:
+                key = tuple(int(c) for c in d["bbox"])
+                if key in mine:
+                    n_same += 1
+                    worst = max(worst, abs(mine[key] - float(d["prob"])))
     # ---- the same call on FILES: the VOC frame as voc_dets.main feeds it (a 500x375 JPEG on disk, metadata resized to 800x600):
     # JPEG decode on a few host threads, the decoded frame uploaded, INTER_CUBIC resize + preprocess + network on the device;
     # the eager path beside it decodes and resizes on the host the way the reference does (cv2 there, integer numpy here)
@@ -908,6 +921,7 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
                       "what": "the same call with voc_dets.FAST_ENTRY = False: get_det_inputs returns the conv map and the RoIs as numpy "
                               "(det_util.py:136-158), the detector takes them back (voc_dets.py:49), one image at a time"},
             "same_detection_counts_as_eager": bool(same),
+            "detections_identical_to_eager": "%d/%d" % (n_same, n_eager), "max_score_difference_from_eager": worst,
             "what": "voc_dets.get_dets_by_cls(DetTrainingManager, detector, ratios, images) over %d distinct %dx%d uint8 frames in host memory, "
                     "%d captured passes in flight x %d image(s) per pass, list of detection dicts out; wall clock of the whole call.  The captured passes score the %d kept proposals (the "
                     "reference's padded copies of a batch's first RoI, voc_dets.py:42-51, have their original's box, class and score: the per-class NMS "

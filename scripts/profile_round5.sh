@@ -13,6 +13,7 @@ python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 $R/bench.py --f32-engine native --steps 50 --warmup 10 > $OUT/bench_native_f32_mfma.json 2> $OUT/bench_native.err
 python3 $R/bench.py --f32-engine bf16x6 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_bf16x6_exact_split.json 2> $OUT/bench_bf16x6.err
 python3 $R/bench.py --steps 50 --warmup 10 --streams 1 > $OUT/bench_streams1.json 2> $OUT/bench_streams1.err
+python3 $R/bench.py --steps 50 --warmup 10 --batch 1 --streams 12 --no-cpu-baseline > $OUT/bench_batch1_streams12.json 2> $OUT/bench_batch1_streams12.err
 python3 $R/bench.py --config c1 --steps 50 --warmup 10 > $OUT/bench_c1_vgg16_rpn.json 2> $OUT/bench_c1.err
 python3 $R/bench.py --config c4 --steps 50 --warmup 10 --conv-table > $OUT/bench_c4_default.json 2> $OUT/bench_c4.err
 grep "^conv" $OUT/bench_c4.err > $OUT/bench_c4_conv_table.txt
@@ -21,12 +22,10 @@ python3 $R/scripts/bench_train.py --through-loop > $OUT/bench_train_f32.json 2> 
 python3 $R/scripts/bench_train.py --bf16 --through-loop > $OUT/bench_train_mixed_bf16.json 2>> $OUT/bench_train.err
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-io --conv-table > /dev/null 2> $OUT/bench_default_conv_table.err
 grep "^conv" $OUT/bench_default_conv_table.err > $OUT/bench_default_conv_table.txt
-# ---- kernel traces (the profiler starts the runtime before bench.py does: ask for the queues here)
-export GPU_MAX_HW_QUEUES=12
+# ---- kernel traces (fp32 default: four passes of four images on the runtime's four queues)
 export FRCNN_BENCH_NO_ENTRY=1
 export FRCNN_BENCH_NO_NATIVE=1       # the traces hold the timed launch forms only
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-io > $OUT/trace_default.log 2>&1
-unset GPU_MAX_HW_QUEUES
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_streams1 -- python3 $R/bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-io > $OUT/trace_streams1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c4 -- python3 $R/bench.py --config c4 --steps 20 --warmup 5 --no-cpu-baseline --no-io > $OUT/trace_c4.log 2>&1
 unset FRCNN_BENCH_NO_ENTRY FRCNN_BENCH_NO_NATIVE
@@ -35,12 +34,12 @@ rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train_f32 -- python3 
 python3 $R/scripts/trace_by_grid.py $OUT/trace_train_f32 60 > $OUT/train_f32_trace_by_grid.txt 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train_mixed -- python3 $R/scripts/bench_train.py --bf16 --steps 10 --warmup 5 > $OUT/trace_train_mixed.log 2>&1
 python3 $R/scripts/trace_by_grid.py $OUT/trace_train_mixed 60 > $OUT/train_mixed_bf16_trace_by_grid.txt 2>&1
-# ---- PMC: separate passes, eager single stream with the launch forms of the default (multi-image) run
+# ---- PMC: separate passes, eager single stream with the launch forms of the default run (four images per pass)
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" \
             "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-graph --shared-tiles > $OUT/pmc$i.log 2>&1
+  rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --batch 4 --no-cpu-baseline --no-graph --shared-tiles > $OUT/pmc$i.log 2>&1
 done
 # configs[3]: the batched pass, eager (one batch of eight per step)
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
