@@ -7,6 +7,8 @@ per-channel scale/shift, the shortcut add and the activation run in registers.
 No tracing compiler: a forward pass is a fixed sequence of C-ABI calls on one HIP stream,
 which ``InferenceGraph`` (pipeline.py) captures into a hipGraph.
 """
+import os as _os
+
 import numpy as np
 import torch
 
@@ -313,7 +315,7 @@ class ResNetHead:
         self.dtype, self.hoist = dtype, hoist
         # RoI crops kept as [7][7][roi][c]: a 128-row conv tile then covers one or two output positions and the 3x3
         # layers skip the filter taps that only meet zero padding (14 % of their chunks; bit-identical results)
-        self.layout = 1 if pos_major else 0
+        self.layout = 1 if (pos_major and _os.environ.get("FRCNN_HEAD_POS_MAJOR", "1") != "0") else 0      # (dev knob: 0 = [roi][7][7][c] crops)
         self.blocks = [_block_units(weights, 5, b, b == "a", 1, r101, dtype) for b in "abc"]
         self.dense = _MergedDense(weights, num_classes)
 
