@@ -16,7 +16,7 @@ class FrcnnError(RuntimeError):
     pass
 
 
-ABI_VERSION = 102       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
+ABI_VERSION = 103       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
 P = c_void_p
 I = c_int
 # name -> (restype, argtypes).  Must list every symbol include/frcnn_hip.h declares
