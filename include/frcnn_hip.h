@@ -40,7 +40,8 @@ extern "C" {
 const char* frcnn_last_error(void);
 /* The ABI revision this header describes; frcnn_version() returns the library's.  A host built against another revision must not
  * call into the library (the Python mirror checks at load): 100 = rounds 1-3; 101 = frcnn_detections takes det_threshold as a double
- * (round 4); 102 = the f16x3 conv engine, magnitude records, frcnn_conv2d_engine, the RPN sampling entry points (round 5). */
+ * (round 4); 102 = the f16x3 conv engine, magnitude records, frcnn_conv2d_engine, the RPN sampling entry points (round 5);
+ * 103 = frcnn_refresh_h3_planes, frcnn_roi_crop_resize_fwd_batch (additions only). */
 #define FRCNN_ABI_VERSION 103
 int frcnn_version(void);
 /* number of HIP devices visible; does not initialise a context */
