@@ -89,6 +89,48 @@ def test_config1_resnet50_600x1000_inference_fp32(engine):
         assert res["amax_measured"] <= 1, res                # nothing but (at most) the network input was measured by a pass of its own
 
 
+def test_config1_four_image_pass_against_one_image_passes():
+    """The pass shape bench.py times since round 5 -- FOUR 600x1000 images per pass on the f16x3 engine, plain launches -- against the
+    one-image pipeline (split-K on the small grids) that `test_config1_resnet50_600x1000_inference_fp32` holds to the oracle: the
+    continuous stages within 1e-4 (north_star's bar), at least 299 of each image's 300 proposals identical, and of the detections at
+    least 99 % identical in class and box with scores within 1e-4 (a different summation order moves a score by ~1e-6: now and then a
+    box edge falls on the other side of a .5 or two near-tied boxes swap in an NMS)."""
+    import bench
+    from faster_rcnn_amd import ops
+    from faster_rcnn_amd.pipeline import BatchedInferencePipeline
+    B = 4
+    with ops.f32_engine("f16x3"):
+        pipe, weights, anchors = bench.build_pipeline()
+        x = torch.from_numpy(np.concatenate([bench.synth_image(300 + j) for j in range(B)])).cuda()
+        arena = ops.AmaxArena(256)
+        with ops.conv_workspace(ops.NO_SPLIT_K), ops.tile_policy(True), ops.amax_arena(arena):
+            out = BatchedInferencePipeline(pipe.rpn, pipe.det, anchors, B, max_proposals=bench.PROPOSALS).forward_dev(x)
+        torch.cuda.synchronize()
+        per = []
+        for j in range(B):
+            with ops.conv_workspace(ops.ConvWorkspace()), ops.amax_arena(ops.AmaxArena(256)):
+                per.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in pipe.forward_dev(x[j:j + 1].contiguous()).items()})
+        torch.cuda.synchronize()
+    n_same = n_all = 0
+    for j, o in enumerate(per):
+        for k in ("rpn_cls", "rpn_reg", "feat"):
+            assert rel(out[k][j].cpu().numpy(), o[k][0].cpu()) < 1e-4, (j, k)
+        assert int(out["n_rois"][j]) == int(o["n_rois"]) == 300
+        a, b = out["rois"][j].cpu().numpy(), o["rois"].cpu().numpy()
+        assert (a == b).all(axis=1).sum() >= 299, j
+        na, nb = int(out["n_dets"][j]), int(o["n_dets"])
+        da = {(int(c),) + tuple(int(v) for v in bx): float(p) for bx, c, p in zip(out["det_bbox"][j].cpu().numpy()[:na], out["det_cls"][j].cpu().numpy()[:na], out["det_prob"][j].cpu().numpy()[:na])}
+        db = {(int(c),) + tuple(int(v) for v in bx): float(p) for bx, c, p in zip(o["det_bbox"].cpu().numpy()[:nb], o["det_cls"].cpu().numpy()[:nb], o["det_prob"].cpu().numpy()[:nb])}
+        assert na > 50 and nb > 50
+        for key, p in da.items():
+            if key in db:
+                n_same += 1
+                assert abs(p - db[key]) <= 1e-4, (j, key, p, db[key])
+        n_all += max(na, nb)
+    print("four-image pass vs one-image passes: %d/%d detections identical" % (n_same, n_all))
+    assert n_same >= 0.99 * n_all, (n_same, n_all)
+
+
 def test_config1_end_to_end_pair_and_map_delta():
     """configs[1], oracle END TO END vs device END TO END (SURVEY 8(d) "box mAP delta"): two synthetic 600x1000 frames and
     the real VOC_test/000005 (600x800 after util.resize_imgs) each run through the CPU restatement on its own and through
