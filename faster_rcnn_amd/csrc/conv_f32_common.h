@@ -253,7 +253,11 @@ __device__ __forceinline__ void epilogue_vec(f32x16 (&acc)[TM][TN], const ConvAr
 // an operand plane -- unpadded 64-byte rows (32 k of 2 bytes), the 16-byte slot s of row r stored at slot s ^ ((r >> 2) & 3) -- the
 // tile's LDS budget, and the 16-byte epilogue that turns the tile through that LDS one wave-row at a time.
 constexpr int X6_ROWB = 64;           // LDS bytes per row per plane
-__device__ __forceinline__ int x6_swz(int row) { return (row >> 2) & 3; }
+// 16-byte slot s of LDS row r is stored at slot s ^ x6_swz(r): f = [0, 2, 3, 1] over the row's group of four (r >> 2 & 3).  Under f the
+// fragment reads of BOTH matrix-instruction shapes are conflict-free (ds_read_b128 serves four groups of 16 lanes; with the 16x16x32
+// fragment -- lane l: row l & 15, slot l >> 4 -- the identity map would put rows 0-3 / slot 0 and rows 4-7 / slot 1 of one group on the
+// same banks); writers cover whole rows, so any per-group bijection costs them nothing.
+__device__ __forceinline__ int x6_swz(int row) { return (0x1320 >> (4 * ((row >> 2) & 3))) & 3; }
 
 
 template <int TM, int TN, int WM, int WN, int PLANES = 3>

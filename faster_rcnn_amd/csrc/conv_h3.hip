@@ -44,10 +44,8 @@ constexpr int H3_HEADER_BYTES = 16;       // in front of a filter's two planes: 
 // `ring`: the head's 3x3 GEMM's LDS-read + MFMA loop 166 -> 149 us on random operands).  Every launch form uses the SAME shape, so a
 // layer's result does not depend on the tile that computed it (the bitwise tests across tiles, layouts and split-K hold).
 constexpr bool H3_S16 = true;
-// 16-byte slot s of LDS row r is stored at slot s ^ h3_swz(r).  f = [0, 2, 3, 1] over the row's group of four (r >> 2 & 3): under it BOTH
-// shapes' fragment reads are conflict-free (ds_read_b128 serves four groups of 16 lanes; with the 16x16x32 fragment -- lane l: row l & 15,
-// slot l >> 4 -- the identity map of conv_x6.hip would put rows 0-3 / slot 0 and rows 4-7 / slot 1 of one group on the same banks).
-__device__ __forceinline__ int h3_swz(int row) { return H3_S16 ? (0x1320 >> (4 * ((row >> 2) & 3))) & 3 : (row >> 2) & 3; }
+// (LDS slot swizzle: conv_f32_common.h x6_swz, conflict-free for this fragment)
+__device__ __forceinline__ int h3_swz(int row) { return x6_swz(row); }
 
 // One 32-deep chunk of a wave's TM x TN blocks of 32x32 from the four LDS planes (a_hi / b_hi: this wave's first row of the high planes;
 // the low planes lie a_lo / b_lo bytes behind).  acc0 += ah bh; acc1 += al bh + ah bl.  Accumulator element e of a block -- S16: 16x16

@@ -31,6 +31,48 @@
 
 namespace frcnn {
 
+// The matrix instruction (conv_h3.hip H3_S16's note): v_mfma_f32_16x16x32_bf16 -- one instruction spans the 32-deep chunk of a 16x16 block, a
+// wave's 32x32 block is four of them; the chip holds a higher clock on this shape under load.  Every launch form of the engine uses it.
+constexpr bool X6_S16 = true;
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+// one chunk of a wave's TM x TN blocks from the six LDS planes; the six products of a block in the engine's order (smallest first)
+template <int TM, int TN>
+__device__ __forceinline__ void x6_chunk(const char* a0, int a_plane, const char* b0, int b_plane, int lane, f32x4 (&s)[TM][TN][4]) {
+    const int r = lane & 15, off = r * X6_ROWB + 16 * ((lane >> 4) ^ x6_swz(r));
+    bf16x8s fb[3][TN][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) fb[pl][j][ci] = *reinterpret_cast<const bf16x8s*>(b0 + pl * b_plane + (j * 32 + ci * 16) * X6_ROWB + off);
+    constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri) {
+            bf16x8s fa[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fa[pl] = *reinterpret_cast<const bf16x8s*>(a0 + pl * a_plane + (i * 32 + ri * 16) * X6_ROWB + off);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci)
+                        s[i][j][ri * 2 + ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[IA[t]], fb[IB[t]][j][ci], s[i][j][ri * 2 + ci], 0, 0, 0);
+        }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void x6_gather(const f32x4 (&s)[TM][TN][4], f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = s[i][j][e >> 2][e & 3];
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -49,7 +91,8 @@ __device__ __forceinline__ void x6_split(const f32x4 v, bf16x4& h, bf16x4& m, bf
 // `splits` slices, one workgroup each; the f32 kernel's protocol (conv_igemm.hip): write-through partial tiles, a ticket per
 // tile, the last arriver sums the slabs in slice order (bitwise reproducible) and runs the epilogue.
 template <int TM, int TN, int WM, int WN, bool SPLITK = false>
-__global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p) {
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu((TM * TN == 1 || (TM * TN == 2 && WM * WN == 8)) ? 4 : 1)))      // (64x64 and the two-workgroup 128x128 tile: four waves per SIMD, as with the 32x32x16 form)
+k_conv_igemm_x6(const ConvArgs p) {
     using T = X6Tile<TM, TN, WM, WN>;
     constexpr int NT = T::NT, BM = T::BM, BN = T::BN;
     constexpr int RPP = NT / 8;                           // tile rows staged per pass of A (8 lanes x 16 B of f32 per row)
@@ -196,10 +239,21 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    f32x4 s16[TM][TN][4];                                 // (X6_S16) the same accumulators as sixteen-row blocks
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s16[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const char* abase = As + (wm * TM * 32 + li) * X6_ROWB;
     const char* bbase = Bs + (wn * TN * 32 + li) * X6_ROWB;
     const int koff[2] = {16 * (lh ^ x6_swz(li)), 16 * ((2 + lh) ^ x6_swz(li))};       // k-step s reads logical slot 2 s + lh (tile bases are multiples of 32 rows)
     auto compute = [&]() {
+        if constexpr (X6_S16) {
+            x6_chunk<TM, TN>(As + wm * TM * 32 * X6_ROWB, BM * X6_ROWB, Bs + wn * TN * 32 * X6_ROWB, BN * X6_ROWB, lane, s16);
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                     // two k-steps of 16 per 32-channel chunk
             bf16x8 fa[3][TM], fb[3][TN];
@@ -247,6 +301,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p
         compute();
         __syncthreads();                                  // the epilogue reuses the buffer
     }
+    if constexpr (X6_S16) x6_gather<TM, TN>(s16, acc);
     if constexpr (SPLITK) {
         // publish this slice's partial tile WRITE-THROUGH (sc1 stores need no release fence), thread-major 16-byte rows
         const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -297,8 +352,8 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_x6(const ConvArgs p
         }
         __syncthreads();                                       // the flag word is read; the epilogue reuses the buffer
     }
-    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
-    else epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN, false, X6_S16>(acc, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN, X6_S16>(acc, p, m0, n0, wm, wn, li, lh);
 }
 
 // ---- the same engine as ONE 16-wave workgroup per CU (tile code 76): 256x128 tile, four waves per SIMD from one workgroup, TWO LDS
@@ -422,6 +477,13 @@ __global__ void __launch_bounds__(1024) k_conv_igemm_x6_db(const ConvArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    f32x4 s16[TM][TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s16[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const int aoff = (wm * TM * 32 + li) * X6_ROWB, boff = 3 * BM * X6_ROWB + (wn * TN * 32 + li) * X6_ROWB;
     const int koff[2] = {16 * (lh ^ x6_swz(li)), 16 * ((2 + lh) ^ x6_swz(li))};
     auto kstep = [&](int buf, int s) {
@@ -450,12 +512,18 @@ __global__ void __launch_bounds__(1024) k_conv_igemm_x6_db(const ConvArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) { store(buf ^ 1); load_next(); }
-        kstep(buf, 0);
-        kstep(buf, 1);
+        if constexpr (X6_S16) {
+            const char* base = lds + buf * BUFB;
+            x6_chunk<TM, TN>(base + wm * TM * 32 * X6_ROWB, BM * X6_ROWB, base + 3 * BM * X6_ROWB + wn * TN * 32 * X6_ROWB, BN * X6_ROWB, lane, s16);
+        } else {
+            kstep(buf, 0);
+            kstep(buf, 1);
+        }
         __syncthreads();
     }
-    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN>(acc, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
-    else epilogue<TM, TN>(acc, p, m0, n0, wm, wn, li, lh);
+    if constexpr (X6_S16) x6_gather<TM, TN>(s16, acc);
+    if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN, false, X6_S16>(acc, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN, X6_S16>(acc, p, m0, n0, wm, wn, li, lh);
 }
 
 static int launch_x6_db(const ConvArgs& a, hipStream_t s) {

@@ -371,7 +371,12 @@ def test_rpn_adam_one_step_moments_and_update():
         # fresh moments at t = 2: m = 0.1 g, v = 0.001 g^2  ->  step = -lr * 0.7444 * |g| / (|g| + 1e-8 / sqrt(0.001)) * sign(g)
         want = -1e-4 * scale_t2 * g / (np.abs(g) + 1e-8 / np.sqrt(0.001))
         assert big.mean() > 0.3
-        assert (np.maximum(np.abs(step - want) - 2 * ulp, 0)[big] < 0.02 * 1e-4).all(), n      # lr alone (t restarted) would be off by 0.26 lr
+        # lr alone (t restarted) would be off by 0.26 lr.  Per element: within 0.02 lr -- except for a handful of elements (fewer than
+        # one in ten thousand) whose f32 gradient has the other SIGN than the f64 oracle's: Adam's step is lr-sized whatever |g| is, and
+        # one pre-activation that lands within f32 rounding of zero takes the other ReLU branch than the oracle (check_updates' note:
+        # which one depends on the summation order of the matrix engine in use)
+        err = np.maximum(np.abs(step - want) - 2 * ulp, 0)[big]
+        assert (err < 0.02 * 1e-4).mean() > 0.9999 and err.max() < 2 * 1e-4, (n, err.max(), (err < 0.02 * 1e-4).mean())
         assert np.abs(np.abs(step[np.abs(g) > 1e-4]).mean() / 1e-4 - scale_t2) < 0.01          # the 0.744, not 1.0
 
 
