@@ -943,6 +943,22 @@ def claim_stdout():
     return _JSON_OUT
 
 
+def default_pass_shape(config, bf16_run, batch=0, streams=0, no_graph=False):
+    """(images per captured pass, passes in flight) for the flags given (<= 0: not given).
+    fp32 detector configs (round 5): four images per pass, four passes in flight -- the trunk's launches are latency-bound at one image
+    (matrix pipe 8 % busy on its 64x64 tiles), four times taller they fill the chip: trunk 0.59 -> 0.445 ms per image in flight, end to end
+    502 -> 540 img/s (B x passes: 2x6 516, 3x4 522, 4x3 540, 4x4 541, 5x3 550, 6x3 542, 8x2 534, 8x3 547; `one_image_per_pass` in the line).
+    A run that names `--streams` but not `--batch` keeps one image per pass (`--streams 1`: the latency form).  One-image fp32 passes:
+    12 in flight on 12 hardware queues (8 / 12 / 16 streams 472 / 481 / 480 img/s with the f16x3 engine).  bf16: eight images per pass,
+    four passes (configs[3] sweep, round 3: 4 graphs 982-994 img/s, 3 975-985, 5 933-943, 2 952; on 8 hardware queues 939-944).
+    configs[0] (no detector) and eager runs: one image per pass."""
+    if batch <= 0:
+        batch = (8 if bf16_run else 4) if (config != "c1" and not no_graph and (streams <= 0 or bf16_run)) else 1
+    if streams <= 0:
+        streams = 12 if (not bf16_run and batch == 1) else 4
+    return batch, streams
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -980,17 +996,9 @@ def main():
     global HOIST, DTYPE, WORKLOAD
     select_config(args.config)
     bf16_run = not (DTYPE == "f32" and args.dtype in ("config", "f32"))
-    if args.batch <= 0:
-        # fp32 (round 5): four images per pass, four passes in flight -- the trunk's launches are latency-bound at one image (matrix pipe
-        # 8 % busy on its 64x64 tiles), B times taller they fill the chip: trunk 0.59 -> 0.445 ms per image in flight, end to end 502 ->
-        # 540 img/s (B x passes: 2x6 516, 3x4 522, 4x3 540, 4x4 541, 5x3 550, 6x3 542, 8x2 534, 8x3 547; `one_image_per_pass` in the line)
-        args.batch = (8 if bf16_run else 4) if (args.config != "c1" and not args.no_graph and (args.streams <= 0 or bf16_run)) else 1
     if args.batch > 1 and args.config == "c1":
         ap.error("--batch needs a detector (c2 / c4)")
-    if args.streams <= 0:
-        # fp32: 12 images in flight on 12 hardware queues since round 5 (f16x3 engine: 8 / 12 / 16 streams 472 / 481 / 480 img/s, twice each in
-        # one session -- the launches are shorter now and more of them are latency-bound; the native engine showed no difference)
-        args.streams = 12 if (not bf16_run and args.batch == 1) else 4      # configs[3] sweep (round 3, batch 8): 4 graphs 982-994 img/s, 3 975-985, 5 933-943, 2 952; 8 hw queues 939-944
+    args.batch, args.streams = default_pass_shape(args.config, bf16_run, args.batch, args.streams, args.no_graph)
     # ROCm maps a process's streams onto 4 hardware queues unless told otherwise; more than four images in flight need
     # a queue each or they queue behind one another (measured on MI355X: 8 streams on 8 queues 245.6 img/s, 8 streams on
     # 4 queues 241.4, 4 on 4 240.7, 4 on 8 217.0; configs[3] (bf16) is fastest with 4 on 4).  Read when the HIP runtime

@@ -32,3 +32,20 @@ def test_gpus_flag_gloo_still_needs_a_device():
         pytest.skip("a device is visible")
     r = _run({"FRCNN_BENCH_BACKEND": "gloo"})
     assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_default_pass_shape():
+    """What `python bench.py` (the driver's command) and its documented variants replay: images per captured pass x passes in flight."""
+    sys.path.insert(0, ROOT)
+    import bench
+    f = bench.default_pass_shape
+    assert f("c2", False) == (4, 4)                           # the headline: four fp32 images per pass, four passes
+    assert f("c2", False, streams=1) == (1, 1)                # --streams 1: the latency form, one image
+    assert f("c2", False, streams=12) == (1, 12)              # naming --streams keeps one image per pass
+    assert f("c2", False, batch=1) == (1, 12)                 # --batch 1: twelve one-image passes on twelve queues
+    assert f("c2", False, batch=8, streams=3) == (8, 3)
+    assert f("c2", False, no_graph=True) == (1, 12)           # eager runs: one image per pass unless --batch says otherwise
+    assert f("c2", False, batch=4, streams=1, no_graph=True) == (4, 1)     # (the PMC passes of scripts/profile_round5.sh)
+    assert f("c4", True) == (8, 4) and f("c2", True) == (8, 4)             # bf16: eight per pass, four passes
+    assert f("c4", True, streams=4) == (8, 4)
+    assert f("c1", False) == (1, 12)                          # configs[0]: RPN only, no batched pass
