@@ -296,6 +296,9 @@ class _MergedDense:
         return ops.dense_heads_split(y, self.C)                 # softmax | regressions, one launch, no torch kernels
 
 
+BATCHED_F32_HEAD_LAYOUT = int(_os.environ.get("FRCNN_BATCHED_HEAD_LAYOUT", "0"))       # dev knob: 1 = position-major crops in the batched fp32 pass too
+
+
 class ResNetHead:
     """RoiResizeConv -> stage 5 (TimeDistributed) -> AveragePooling2D(7) -> dense x2
     (resnet50_classifier resnet.py:489-548, resnet101_classifier :631-686).
@@ -324,7 +327,7 @@ class ResNetHead:
             yield from b.values()
         yield self.dense.unit
 
-    def _first_block_hoisted(self, feat, rois, resize):
+    def _first_block_hoisted(self, feat, rois, resize, layout=None):
         a = self.blocks[0]
         if feat.dim() == 4 and feat.shape[0] > 1:               # a batch of maps (forward_batched): `resize` knows which RoI crops which
             fmap = feat
@@ -337,7 +340,7 @@ class ResNetHead:
             u = a["2a"](fmap, act=None)                     # conv + BN on the map; its ReLU follows the resampling
             v = a["1"](fmap)                                # shortcut conv + BN
         # an invalid (empty) RoI crops to zeros in the reference order, which these layers map to their BN shift
-        L = self.layout
+        L = self.layout if layout is None else layout
         planes = self.dtype == "f32" and HEAD_PLANES
         n = rois.reshape(-1, 4).shape[0]
         crop_shape = (self.pool, self.pool, n, u.shape[-1]) if L else (n, self.pool, self.pool, u.shape[-1])
@@ -374,8 +377,12 @@ class ResNetHead:
         assert self.hoist, "batched head: hoisted order"
         if self.dtype == "f32":                                 # the same code path as one image: only the resampling knows about the batch
             import functools
-            L = self.layout
-            x = self._first_block_hoisted(feat, rois, functools.partial(ops.roi_crop_resize, n_per_img=n_per_img))
+            # [roi][7][7][c] crops for the batched pass: a tile's nine taps then re-read the tile's OWN rows (L2) instead of the
+            # neighbouring positions' (fabric: 2.4x the algorithmic bytes per launch in the position-major form); no tap can be skipped
+            # (14 % more chunks), each launch alone is 0.5 % slower -- and four passes in flight 0.9 % faster (549-551 against 545-546
+            # img/s, three alternating runs).  One-image passes tie (507 / 507) and the latency form loses 2 %: they keep position-major.
+            L = BATCHED_F32_HEAD_LAYOUT if self.layout else 0
+            x = self._first_block_hoisted(feat, rois, functools.partial(ops.roi_crop_resize, n_per_img=n_per_img), layout=L)
             for b in self.blocks[1:]:
                 x = run_block(b, x, L, planes=True)
             if L:
