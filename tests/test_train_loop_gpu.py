@@ -143,3 +143,18 @@ def test_train_detector_loop_fast_feed_is_bit_identical(step, tmp_path):
     _weights_equal(res[True][0], res[False][0])
     assert np.array_equal(res[True][1], res[False][1]) and res[True][2] == res[False][2]
     assert not np.array_equal(res[True][0]["res5a_branch2a"][0], synthetic_resnet(50, anchors_per_loc=9, num_classes=21, seed=12)["res5a_branch2a"][0])
+
+
+def test_manager_stream_shares_no_queue_with_the_steps_streams():
+    """feed.manager_stream(): ONE stream per process, chosen by probing -- work on it completes while the caller's stream, the step's
+    weight-gradient stream and (if a candidate allows) its prefix stream are busy; a stream is never beside itself."""
+    from faster_rcnn_amd import feed, train
+    cur = torch.cuda.current_stream()
+    assert not feed._runs_beside(cur, cur)
+    s = feed.manager_stream()
+    assert s is feed.manager_stream() and s is not cur
+    assert feed._runs_beside(cur, s) and feed._runs_beside(train._wgrad_stream(), s)
+    assert 1 <= len(feed.manager_stream.tried) <= 8
+    from faster_rcnn_amd import resnet, rpn_util, util
+    mgr = rpn_util.RpnTrainingManager(resnet.get_conv_rows_cols, 16, resnet.preprocess, util.get_anchors([128, 256, 512]))
+    assert mgr._own_stream() is s                                  # every manager object of the process uses it
