@@ -80,3 +80,21 @@ def test_batched_f32_pipeline_equals_per_image_pipeline(engine):
         assert torch.equal(bp._static_out["det_bbox"][i], want["det_bbox"][i]) and torch.equal(bp._static_out["det_prob"][i], want["det_prob"][i])
         assert torch.equal(bp._static_out["cls"][i], want["cls"][i])
     bp.close()
+
+
+def test_batched_roi_resize_refuses_malformed_calls():
+    """frcnn_roi_crop_resize_fwd_batch: exactly one of the two outputs, a positive RoI count per image, channels in fours."""
+    import ctypes
+    from faster_rcnn_amd import _lib, ops
+    feat = torch.zeros((2, 5, 6, 8), device="cuda")
+    rois = torch.tensor([[0, 0, 2, 2]] * 4, dtype=torch.float32, device="cuda")
+    out = torch.zeros((4, 7, 7, 8), device="cuda")
+    pt = ops.PlaneTensor((4, 7, 7, 8))
+    yp = _lib.H3Planes(planes=pt.planes.data_ptr(), exponent=pt.exponent.data_ptr())
+    call = lambda n_per, C, o, p: _lib.call("frcnn_roi_crop_resize_fwd_batch", ops._p(feat), 5, 6, C, ops._p(rois), 4, n_per, 7, None, 0, 0, o, p, None)
+    for bad in ((2, 8, None, None), (2, 8, ops._p(out), ctypes.byref(yp)), (0, 8, ops._p(out), None), (2, 6, ops._p(out), None)):
+        with pytest.raises(_lib.FrcnnError):
+            call(*bad)
+    call(2, 8, ops._p(out), None)
+    call(2, 8, None, ctypes.byref(yp))
+    torch.cuda.synchronize()
