@@ -297,6 +297,7 @@ class _MergedDense:
 
 
 BATCHED_F32_HEAD_LAYOUT = int(_os.environ.get("FRCNN_BATCHED_HEAD_LAYOUT", "0"))       # dev knob: 1 = position-major crops in the batched fp32 pass too
+BATCHED_BF16_HEAD_LAYOUT = int(_os.environ.get("FRCNN_BATCHED_HEAD_LAYOUT_BF16", "1"))  # dev knob: 0 = [roi][7][7][c] crops in the batched bf16 pass
 
 
 class ResNetHead:
@@ -389,7 +390,7 @@ class ResNetHead:
                 return self.dense(ops.avgpool_pos_major(x))
             x = ops.pool2d(x, 7, 7, False)
             return self.dense(x.reshape(x.shape[0], -1))
-        L, a = self.layout, self.blocks[0]
+        L, a = (self.layout and BATCHED_BF16_HEAD_LAYOUT), self.blocks[0]
         u = a["2a"](feat, act=None)                         # conv + BN on every image's map (M = B * rows * cols)
         v = a["1"](feat)
         t = ops.roi_crop_resize_bf16_batch(u, rois, n_per_img, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)
