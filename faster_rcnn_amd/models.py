@@ -100,6 +100,7 @@ class _Model:
             # training continues from the loaded values: new master buffers and packed filters; the optimiser object
             # (with its step counter) and its slots carry over, as in Keras, where load_weights touches neither
             old = self._trainer
+            old.drop_step_graphs()                          # (captured steps hold the old packed filters: destroy them here, not in a finalizer)
             self._trainer = self._new_trainer()
             if old.optimizer is not None:
                 self._trainer.compile(old.optimizer)

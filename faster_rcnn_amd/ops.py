@@ -1052,6 +1052,7 @@ def conv2d_wgrad_batch(jobs):
         j.in_bf16 = 1 if x.dtype == torch.bfloat16 else 0
     ws = _ws(_lib.load().frcnn_conv2d_wgrad_batch_workspace_bytes(arr, len(jobs)))
     _lib.call("frcnn_conv2d_wgrad_batch", arr, len(jobs), _p(ws), ws.numel(), _stream())
+    return ws, keep                                              # (a capturing caller keeps the launch's buffers from being recycled)
 
 
 # ----------------------------------------------------------------------------- bf16 conv path

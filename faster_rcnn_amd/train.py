@@ -217,6 +217,12 @@ WGRAD_ENGINE = __import__("os").environ.get("FRCNN_TRAIN_WGRAD", "bf16x6")
 # tensor an element below 2^-22 of the tensor's largest vanishes -- harmless in activations, but a gradient tensor's rows (one RoI's
 # against another's) can lie further apart than that, and the exact split keeps every element's 24 bits.
 F32_ENGINE = __import__("os").environ.get("FRCNN_TRAIN_F32_ENGINE", "bf16x6")
+# A step on an input shape seen more than STEP_GRAPH_AFTER times replays from captured hipGraphs (_StepDriver._capture_step): the
+# ~110 launches of a mixed-precision RPN step took ~1.15 ms of Python to enqueue against 1.27 ms of kernels.  At most
+# STEP_GRAPH_SHAPES shapes stay captured (least recently used first out); FRCNN_TRAIN_GRAPH=0 keeps every step eager.
+STEP_GRAPHS = __import__("os").environ.get("FRCNN_TRAIN_GRAPH", "1") != "0"
+STEP_GRAPH_AFTER = int(__import__("os").environ.get("FRCNN_TRAIN_GRAPH_AFTER", "2"))
+STEP_GRAPH_SHAPES = int(__import__("os").environ.get("FRCNN_TRAIN_GRAPH_SHAPES", "8"))
 _WGRAD_STREAM = None
 
 
@@ -230,10 +236,22 @@ def _wgrad_stream():
 def _launch_pending_wgrads():
     if not _PENDING_WGRAD:
         return
-    side, cur = _wgrad_stream(), torch.cuda.current_stream()
-    side.wait_stream(cur)                                   # the operands were produced on the main stream
     prev, ops.WGRAD_ENGINE = ops.WGRAD_ENGINE, WGRAD_ENGINE
     try:
+        rec = _RECORDER
+        if rec is not None:
+            # a step being captured (_StepDriver._capture_step): the batch becomes a graph of its own, replayed on the weight-gradient
+            # stream.  The pieces are captured one after the other on ONE stream, so the allocator sees a single timeline: whatever
+            # this batch reads or uses as workspace must stay allocated until the whole capture ends, or a later piece of the main
+            # lane -- which runs BESIDE this one at replay -- would be handed the same memory
+            rec.cut("wgrad")
+            rec.keep.append(ops.conv2d_wgrad_batch(_PENDING_WGRAD))
+            rec.keep.append(list(_PENDING_WGRAD))
+            rec.cut("main")
+            _PENDING_WGRAD.clear()
+            return
+        side, cur = _wgrad_stream(), torch.cuda.current_stream()
+        side.wait_stream(cur)                               # the operands were produced on the main stream
         with torch.cuda.stream(side):
             ops.conv2d_wgrad_batch(_PENDING_WGRAD)
     finally:
@@ -249,7 +267,7 @@ def flush_weight_grads():
     bias gradients (dbias[co] = scale[co] * sum_m g[m][co]) in one launch.  Launched one by one (round 1) each of these
     small GEMMs paid its own ramp, tail and reduction launch: 44 + 2 launches per RPN step, now a handful."""
     _launch_pending_wgrads()
-    if _WGRAD_STREAM is not None:
+    if _WGRAD_STREAM is not None and _RECORDER is None:     # (a replayed step joins the lanes after its last piece)
         torch.cuda.current_stream().wait_stream(_WGRAD_STREAM)
     if not _PENDING_BIAS:
         return
@@ -261,6 +279,46 @@ def flush_weight_grads():
         j.g_is_bf16 = 1 if g.dtype == torch.bfloat16 else 0
     _lib.call("frcnn_colsum_batch", jobs, len(_PENDING_BIAS), _stream())
     _PENDING_BIAS.clear()
+
+
+_RECORDER = None
+_TICK = __import__("os").environ.get("FRCNN_TICK", "0") != "0"
+
+
+class _Pieces:
+    """A run of LINEAR hipGraphs captured one after the other on the current (side) stream into one memory pool; ``cut(lane)`` ends
+    the piece being captured and starts the next.  Why pieces and not one graph with a forked branch: the runtime spreads a graph's
+    parallel branches over its hardware queues, the prefix stream's among them -- the NEXT image's frozen stages then queue behind
+    this step's backward pass instead of running beside it (rocprofv3 timeline, round 6) -- while a linear graph stays on the queue
+    of the stream it is replayed on."""
+
+    def __init__(self):
+        self.pool, self.items, self.cur, self.keep = None, [], None, []
+
+    def begin(self, lane):
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")   # (another thread -- an RCCL watchdog -- may call into HIP meanwhile)
+        self.cur = (lane, g)
+
+    def end(self):
+        lane, g = self.cur
+        self.cur = None
+        g.capture_end()
+        self.items.append((lane, g))
+
+    def cut(self, lane):
+        self.end()
+        self.begin(lane)
+
+    def abort(self):
+        if self.cur is not None:
+            try:
+                self.cur[1].capture_end()
+            except Exception:
+                pass
+            self.cur = None
 
 
 def make_refresh_jobs(tconvs):
@@ -496,6 +554,8 @@ class _StepDriver:
         self._loss_ring = [None] * LOSS_RING          # steps whose three scalars are still on their way to the host
         self._loss_pos = 0
         self._pending_update = None                   # (all-reduce handle, 1/world, optimiser) of a step whose update is not enqueued yet
+        self._cur = None
+        self._graphs = {"graphs": __import__("collections").OrderedDict(), "seen": {}, "epoch": None, "token": None}
         _LIVE_DRIVERS.add(self)
         self._lower_frozen()
 
@@ -536,15 +596,29 @@ class _StepDriver:
         three scalars leave for pinned host memory on a stream of their own.  train_on_batch's return value is therefore
         available after the FORWARD pass; the backward pass and the update run on while the caller reads the losses and
         stages the next image (Keras semantics kept: every way of reading weights back is stream-ordered behind the step)."""
-        out3, slot = self._cur
+        self._l2_sum()
+        self._send_losses()
+
+    def _l2_sum(self):
         if self.l2:
-            self.params.sumsq(out=out3[2:3])
+            self.params.sumsq(out=self._cur[0][2:3])
+
+    def _send_losses(self):
+        out3, slot = self._cur
         main, side = torch.cuda.current_stream(), _loss_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
             slot[0].copy_(out3, non_blocking=True)
             slot[1].record()
         out3.record_stream(side)
+
+    def _device_step(self, dev, out, pre=None):
+        """The device part of one step on the current stream: forward + losses, the three scalars on their way to the host,
+        backward, update.  (A captured step replays ``_fwd_part`` and ``_bwd_part`` from two hipGraphs: _StepGraph.)"""
+        self._fwd_part(dev, out, pre)
+        self._publish_losses()
+        self._bwd_part()
+        self._update()
 
     def _update(self, sq_out=None):
         """After the backward pass: the ONE exchange of the flat gradient buffer, optimiser, re-pack.
@@ -556,6 +630,9 @@ class _StepDriver:
         and those launches run BESIDE the collective instead of behind it), or any read-out of the weights
         (sync_weights / compile).  Same kernels in the same order per tensor: bit-identical to the serial form."""
         flush_weight_grads()
+        self._exchange_and_apply()
+
+    def _exchange_and_apply(self):
         handle, scale = _sync_grads_begin(self.params)
         if handle is None:
             self._apply_update(scale)
@@ -638,15 +715,17 @@ class _StepDriver:
         Returns Keras' [total, loss 1, loss 2] -- or, with ``defer``, a PendingLosses whose ``result()`` is that list: the
         step is then only ENQUEUED when this returns, and the caller may prepare the next image meanwhile."""
         assert self.optimizer is not None, "call compile() first"
-        out3 = torch.zeros(3, dtype=torch.float32, device="cuda")                          # loss 1, loss 2, sum of squares
-        out = [out3[0:1], out3[1:2], out3[2:3]]
+        sg = self._step_graph(host_inputs) if (STEP_GRAPHS and not skip) else None
+        if sg is None:
+            out3 = torch.zeros(3, dtype=torch.float32, device="cuda")                      # loss 1, loss 2, sum of squares
+            out = [out3[0:1], out3[1:2], out3[2:3]]
         slot = self._loss_ring[self._loss_pos]
         if slot is None:
             slot = self._loss_ring[self._loss_pos] = [torch.empty(3, dtype=torch.float32).pin_memory(), torch.cuda.Event(), None]
         elif slot[2] is not None and slot[2]() is not None:
             slot[2]().result()                          # the ring wrapped around an unread step: read it before its slot is reused
         self._loss_pos = (self._loss_pos + 1) % LOSS_RING
-        self._cur = (out3, slot)
+        self._cur = (out3, slot) if sg is None else None
         try:
             if skip:
                 self._finish_update()
@@ -664,35 +743,10 @@ class _StepDriver:
                 # det_util.get_training_input_dev) skip the cast / staging / upload; they were produced on the manager's stream and
                 # carry the event both of this step's streams wait for
                 on_dev = [isinstance(a, torch.Tensor) and a.is_cuda for a, _ in host_inputs]
-                pset, views = self._stage([hi for hi, d in zip(host_inputs, on_dev) if not d])
-                main, side = torch.cuda.current_stream(), _prefix_stream()
-                side.wait_event(self._frozen_ready)         # the frozen layers' packed filters (lowered on the build stream)
-                arena_pre, arena_main = self._amax_arenas() if F32_ENGINE == "f16x3" else (None, None)
-                with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws_prefix), ops.f32_engine(F32_ENGINE), ops.amax_arena(arena_pre):
-                    ops.amax_begin()
-                    up = iter(views)
-                    dev = []
-                    for (a, shape), d in zip(host_inputs, on_dev):
-                        if d:
-                            assert a.dtype == torch.float32 and a.is_contiguous(), "device inputs of train_on_batch: contiguous float32"
-                            ev = getattr(a, "_ready", None)
-                            if ev is not None:
-                                side.wait_event(ev)
-                            a.record_stream(side)
-                            dev.append(a.reshape(shape))
-                        else:
-                            dev.append(next(up).to("cuda", non_blocking=True))
-                    pset.mark_uploaded()
-                    pre = self._frozen_prefix(dev)
-                    if pre is not None and getattr(pre, "_amax", None) is not None:
-                        pre._amax = None                    # (a record of the prefix arena: not read on the main stream)
-                self._finish_update()
-                main.wait_stream(side)
-                for t in dev + ([pre] if pre is not None else []):
-                    t.record_stream(main)                   # allocated on the side stream, read (and released) under the main one
-                with ops.conv_workspace(self._conv_ws), ops.f32_engine(F32_ENGINE), ops.amax_arena(arena_main):
-                    ops.amax_begin()
-                    self._device_step(dev, out, pre)
+                if sg is not None:
+                    self._replay_step(sg, host_inputs, on_dev, slot)
+                else:
+                    self._eager_step(host_inputs, on_dev, out)
         finally:
             # a step that died half way (OOM, FrcnnError) must not leave its queued weight-gradient jobs to the next
             # step -- possibly another model's -- to launch into this step's buffers
@@ -702,6 +756,246 @@ class _StepDriver:
         pending = PendingLosses(slot[0], slot[1], self.l2, self.frozen_sumsq)
         slot[2] = weakref.ref(pending)
         return pending if defer else pending.result()
+
+
+    def _eager_step(self, host_inputs, on_dev, out):
+        pset, views = self._stage([hi for hi, d in zip(host_inputs, on_dev) if not d])
+        main, side = torch.cuda.current_stream(), _prefix_stream()
+        side.wait_event(self._frozen_ready)         # the frozen layers' packed filters (lowered on the build stream)
+        arena_pre, arena_main = self._amax_arenas() if F32_ENGINE == "f16x3" else (None, None)
+        with torch.cuda.stream(side), ops.conv_workspace(self._conv_ws_prefix), ops.f32_engine(F32_ENGINE), ops.amax_arena(arena_pre):
+            ops.amax_begin()
+            up = iter(views)
+            dev = []
+            for (a, shape), d in zip(host_inputs, on_dev):
+                if d:
+                    assert a.dtype == torch.float32 and a.is_contiguous(), "device inputs of train_on_batch: contiguous float32"
+                    ev = getattr(a, "_ready", None)
+                    if ev is not None:
+                        side.wait_event(ev)
+                    a.record_stream(side)
+                    dev.append(a.reshape(shape))
+                else:
+                    dev.append(next(up).to("cuda", non_blocking=True))
+            pset.mark_uploaded()
+            pre = self._frozen_prefix(dev)
+            if pre is not None and getattr(pre, "_amax", None) is not None:
+                pre._amax = None                    # (a record of the prefix arena: not read on the main stream)
+        self._finish_update()
+        main.wait_stream(side)
+        for t in dev + ([pre] if pre is not None else []):
+            t.record_stream(main)                   # allocated on the side stream, read (and released) under the main one
+        with ops.conv_workspace(self._conv_ws), ops.f32_engine(F32_ENGINE), ops.amax_arena(arena_main):
+            ops.amax_begin()
+            self._device_step(dev, out, pre)
+
+    # ------------------------------------------------------------------ the step as three hipGraphs
+    def _graph_key(self, host_inputs):
+        return (tuple(shape for _, shape in host_inputs), F32_ENGINE, WGRAD_ENGINE, WGRAD_FLUSH_JOBS, ops.AUTO_TILE,
+                id(self._conv_ws), id(self._conv_ws_prefix))
+
+    def _frozen_token(self):
+        return tuple(id(u.pc) for u in self._frozen_units())
+
+    def _step_graph(self, host_inputs):
+        """The captured form of a step on these input shapes, or None (the step then runs eagerly): a shape is captured on its
+        (STEP_GRAPH_AFTER + 1)-th step -- the eager ones before it have lowered every lazily built filter form and sized the
+        split-K workspaces, so the capture allocates nothing that must outlive it and contains no set-up launch."""
+        from . import models
+        st = self._graphs
+        epoch = models.weights_epoch()
+        if st["epoch"] != epoch:
+            # some model re-lowered layers since the last step.  A trainer's own packed filters never move (TConv), the frozen
+            # layers' could (set_weights on a frozen layer): the captured prefix holds their addresses
+            token = self._frozen_token()
+            if st["token"] is not None and st["token"] != token:
+                self.drop_step_graphs()
+            st["epoch"], st["token"] = epoch, token
+        key = self._graph_key(host_inputs)
+        sg = st["graphs"].get(key)
+        if sg is not None:
+            if next(reversed(st["graphs"])) != key:
+                st["graphs"].move_to_end(key)
+            return sg
+        seen = st["seen"].get(key, 0) + 1
+        if seen <= STEP_GRAPH_AFTER:
+            if len(st["seen"]) > 4096:
+                st["seen"].clear()
+            st["seen"][key] = seen
+            return None
+        while len(st["graphs"]) >= STEP_GRAPH_SHAPES:
+            _, old = st["graphs"].popitem(last=False)
+            old.close()
+        st["seen"].pop(key, None)
+        sg = st["graphs"][key] = self._capture_step([shape for _, shape in host_inputs])
+        return sg
+
+    def drop_step_graphs(self):
+        """Destroy every captured step (their memory pools go back to the allocator); the next steps run eagerly and re-capture."""
+        for sg in self._graphs["graphs"].values():
+            sg.close()
+        self._graphs["graphs"].clear()
+        self._graphs["seen"].clear()
+
+    def _capture_step(self, shapes):
+        """Capture the device part of a step on inputs of ``shapes`` (see _StepGraph)."""
+        from .pipeline import no_gc
+        self._finish_update()
+        torch.cuda.synchronize()
+        sg = _StepGraph()
+        has_prefix = getattr(self, "base", None) is not None
+        sg.inbox = [torch.empty(shape, dtype=torch.float32, device="cuda") for shape in shapes]
+        # the image is read by the prefix graph only, straight from where the feed wrote it; everything else (and the first
+        # input of a base-less detector) is read by the step's main part and moves into its own copy at the start of G1
+        sg.static = [t if (i == 0 and has_prefix) else torch.empty_like(t) for i, t in enumerate(sg.inbox)]
+        sg.out3 = torch.zeros(3, dtype=torch.float32, device="cuda")
+        out = [sg.out3[0:1], sg.out3[1:2], sg.out3[2:3]]
+        arena_pre, arena_main = self._amax_arenas() if F32_ENGINE == "f16x3" else (None, None)
+        global _RECORDER
+        cur_saved = self._cur
+        recs = []
+        try:
+            with no_gc(), torch.cuda.stream(_capture_stream()):
+                pre_stage = None
+                if has_prefix:
+                    rec0 = _Pieces()                        # (a pool of its own: G0 of the next image runs beside this step's backward pass)
+                    recs.append(rec0)
+                    with ops.conv_workspace(self._conv_ws_prefix), ops.f32_engine(F32_ENGINE), ops.amax_arena(arena_pre):
+                        rec0.begin("prefix")
+                        ops.amax_begin()
+                        pre_stage = self._frozen_prefix(sg.static)
+                        rec0.end()
+                    sg.g0, sg.pre_stage = rec0.items[0][1], pre_stage
+                rec = _Pieces()
+                recs.append(rec)
+                with ops.conv_workspace(self._conv_ws), ops.f32_engine(F32_ENGINE), ops.amax_arena(arena_main):
+                    rec.begin("main")
+                    for dst, src in zip(sg.static, sg.inbox):
+                        if dst is not src:
+                            dst.copy_(src)
+                    pre = None
+                    if pre_stage is not None:
+                        pre = torch.empty_like(pre_stage)   # the prefix graph of the NEXT image overwrites pre_stage during this step's backward pass
+                        pre.copy_(pre_stage)
+                    sg.out3.zero_()
+                    ops.amax_begin()
+                    self._cur = (sg.out3, None)
+                    self._fwd_part(sg.static, out, pre)
+                    self._l2_sum()
+                    rec.end()
+                    sg.g1 = rec.items[0][1]
+                    rec.begin("main")
+                    _RECORDER = rec
+                    self._bwd_part()
+                    flush_weight_grads()
+                    _RECORDER = None
+                    rec.end()
+                sg.bwd = rec.items[1:]
+                rec.keep.clear()
+        except BaseException:
+            _RECORDER = None
+            for r in recs:
+                r.abort()
+            _PENDING_WGRAD.clear()
+            _PENDING_BIAS.clear()
+            sg.close()
+            raise
+        finally:
+            self._cur = cur_saved
+        torch.cuda.synchronize()
+        sg.fwd_done = torch.cuda.Event()
+        return sg
+
+    def _replay_step(self, sg, host_inputs, on_dev, slot):
+        """One step from its captured form: the inputs move into the graphs' input buffers, then G0 (frozen prefix, prefix stream)
+        -> G1 (trainable forward, losses, L2 sum) -> the three scalars leave -> the backward pieces (input-gradient chain on this
+        stream, each weight-gradient batch on the weight-gradient stream behind the piece that produced its operands) -> exchange,
+        optimiser, re-pack (eager launches: the optimiser's scalars and step counter stay ordinary arguments)."""
+        pset, views = self._stage([hi for hi, d in zip(host_inputs, on_dev) if not d])
+        main, side = torch.cuda.current_stream(), _prefix_stream()
+        side.wait_event(self._frozen_ready)
+        if sg.used:
+            side.wait_event(sg.fwd_done)            # the previous replay's G1 has taken its inputs and the prefix output
+        with torch.cuda.stream(side):
+            up = iter(views)
+            for (a, shape), d, dst in zip(host_inputs, on_dev, sg.inbox):
+                if d:
+                    assert a.dtype == torch.float32 and a.is_contiguous(), "device inputs of train_on_batch: contiguous float32"
+                    ev = getattr(a, "_ready", None)
+                    if ev is not None:
+                        side.wait_event(ev)
+                    a.record_stream(side)
+                    dst.copy_(a.reshape(shape))
+                else:
+                    dst.copy_(next(up), non_blocking=True)
+            pset.mark_uploaded()
+            if sg.g0 is not None:
+                sg.g0.replay()
+        self._finish_update()
+        main.wait_stream(side)
+        if sg.loss_sent is not None:
+            main.wait_event(sg.loss_sent)           # the previous replay's scalars have left out3
+        sg.g1.replay()
+        if _TICK:
+            sg.out3[2:3].add_(0.0)
+        sg.fwd_done.record(main)
+        sg.used = True
+        self._cur = (sg.out3, slot)
+        self._send_losses()
+        sg.loss_sent = slot[1]
+        wside = None
+        for lane, g in sg.bwd:
+            if lane == "wgrad":
+                wside = _wgrad_stream()
+                wside.wait_stream(main)
+                with torch.cuda.stream(wside):
+                    g.replay()
+            else:
+                g.replay()
+        if wside is not None:
+            main.wait_stream(wside)
+        with ops.conv_workspace(self._conv_ws):
+            self._exchange_and_apply()
+
+
+class _StepGraph:
+    """A training step on one set of input shapes as a handful of LINEAR hipGraphs (see _Pieces).
+
+    G0 (own memory pool): stem + frozen stages of the image in ``inbox[0]`` -> ``pre_stage``; replayed on the prefix stream, beside
+    the previous step's backward pass.  G1: the other inputs ``inbox[k]`` -> ``static[k]`` and ``pre_stage`` -> a copy of its own (so
+    the next image's G0 and input copies may start as soon as G1 has run: ``fwd_done``), trainable forward, the two loss kernels
+    (value + gradient), the L2 sum -> ``out3``.  ``bwd`` (G1's pool: they read G1's activations): the input-gradient chain cut at
+    every weight-gradient flush, alternating with the weight-gradient batches, which replay on the weight-gradient stream; the bias
+    gradients end the last main piece.  Same kernels, same arguments, same order per tensor as the eager step: the weights after N
+    replayed steps equal the eager ones bit for bit (tests/test_train_graph_gpu.py)."""
+
+    def __init__(self):
+        self.g0 = self.g1 = None
+        self.bwd = []
+        self.inbox = self.static = self.out3 = self.pre_stage = None
+        self.fwd_done = self.loss_sent = None
+        self.used = False
+
+    def close(self):
+        graphs = [g for _, g in reversed(self.bwd)] + [self.g1, self.g0]
+        if any(g is not None for g in graphs):
+            torch.cuda.synchronize()
+        for g in graphs:
+            if g is not None:
+                g.reset()
+        self.g0 = self.g1 = None
+        self.bwd = []
+        self.inbox = self.static = self.out3 = self.pre_stage = None
+
+
+_CAPTURE_STREAM = None
+
+
+def _capture_stream():
+    global _CAPTURE_STREAM
+    if _CAPTURE_STREAM is None:
+        _CAPTURE_STREAM = torch.cuda.Stream()
+    return _CAPTURE_STREAM
 
 
 class _PinnedSet:
@@ -856,7 +1150,7 @@ class RpnTrainer(_StepDriver):
         cells = int(np.prod(np.shape(y[0])[:-1]))
         return self._run_step([(x, (1,) + tuple(np.shape(x)[-3:])), (y[0], (cells, 2 * self.A)), (y[1], (cells, 8 * self.A))], False, defer)
 
-    def _device_step(self, dev, out, pre=None):
+    def _fwd_part(self, dev, out, pre=None):
         xd, yc, yr = dev
         loss1, loss2, sq = out
         cls, reg, h = self.forward(xd, pre)
@@ -867,7 +1161,10 @@ class RpnTrainer(_StepDriver):
         half = ctypes.c_void_p(ws.data_ptr() + ws.numel() // 2)
         _lib.call("frcnn_loss_rpn_cls_ws", _p(yc), _p(cls), cells, self.A, _p(loss1), _p(g_cls), _p(ws), _stream())
         _lib.call("frcnn_loss_rpn_reg_ws", _p(yr), _p(reg), cells, self.A, _p(loss2), _p(g_reg), half, _stream())
-        self._publish_losses()
+        self._bwd_state = (g_cls, g_reg, h)
+
+    def _bwd_part(self):
+        (g_cls, g_reg, h), self._bwd_state = self._bwd_state, None
         self.rpn_cls.wgrad(g_cls)
         self.rpn_reg.wgrad(g_reg)
         tmp = self.rpn_cls.dgrad(g_cls)
@@ -877,7 +1174,6 @@ class RpnTrainer(_StepDriver):
         self.rpn_conv.wgrad(gh)
         if self.base_trains:
             self.base.backward(self.rpn_conv.dgrad(gh, mask=self.feat))
-        self._update()
 
     def sync_weights(self):
         """Write the trained master weights back into the model's Keras-keyed weight dict.  Only the layers that train
@@ -1011,7 +1307,7 @@ class DetTrainer(_StepDriver):
         n, C, K4 = int(np.size(x[1])) // 4, self.C, 4 * (self.C - 1)
         return self._run_step([(x[0], (1,) + tuple(np.shape(x[0])[-3:])), (x[1], (n, 4)), (y[0], (n, C)), (y[1], (n, 2 * K4))], False, defer)
 
-    def _device_step(self, dev, out, pre=None):
+    def _fwd_part(self, dev, out, pre=None):
         xd, rois, yc, yr = dev
         loss1, loss2, sq = out
         n, C, K4 = rois.shape[0], self.C, 4 * (self.C - 1)
@@ -1019,7 +1315,11 @@ class DetTrainer(_StepDriver):
         g = torch.empty((n, C + K4), dtype=torch.float32, device="cuda")     # [d logits | d reg]
         _lib.call("frcnn_loss_det_cls", _p(yc), _p(cls), n, C, _p(loss1), _p(g), C + K4, _stream())
         _lib.call("frcnn_loss_det_reg", _p(yr), _p(reg), n, C - 1, _p(loss2), ctypes.c_void_p(g.data_ptr() + 4 * C), C + K4, _stream())
-        self._publish_losses()
+        self._bwd_state = (g, rois)
+
+    def _bwd_part(self):
+        (g, rois), self._bwd_state = self._bwd_state, None
+        n, C, K4 = rois.shape[0], self.C, 4 * (self.C - 1)
         g4 = g.reshape(n, 1, 1, C + K4)
         self.dense.wgrad(g4)
         gcrop = self.head.backward(self.dense.dgrad(g4))
@@ -1031,7 +1331,6 @@ class DetTrainer(_StepDriver):
             gfeat = ops.roi_crop_resize_bwd(gcrop, rois, self.feat.shape[1], self.feat.shape[2])
             _lib.call("frcnn_relu_bwd_inplace", _p(gfeat), _p(self.feat), gfeat.numel(), _stream())
             self.base.backward(gfeat.reshape(self.feat.shape))
-        self._update()
 
     def sync_weights(self):
         self._finish_update()
