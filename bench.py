@@ -931,6 +931,72 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
 _JSON_OUT = None
 
 
+# ---- the other BASELINE configs in the driver's N=1 line (`extra`): each runs as a CHILD process of this command line, started and
+# finished BEFORE this process makes its first HIP call (a process that has initialised the runtime starts no GPU children), one after
+# the other, so each has the chip to itself exactly as when run by hand.
+EXTRA_LEGS = (
+    ("c0_vgg16_rpn", ["bench.py", "--config", "c1", "--no-extra", "--no-cpu-baseline", "--no-io", "--steps", "30", "--warmup", "5"]),
+    ("c3_r101_bf16", ["bench.py", "--config", "c4", "--no-extra", "--no-cpu-baseline", "--no-io", "--steps", "12", "--warmup", "3"]),
+    ("train_steps_f32", [os.path.join("scripts", "bench_train.py"), "--through-loop", "--no-host-feed", "--steps", "60", "--warmup", "40"]),
+    ("train_steps_mixed_bf16", [os.path.join("scripts", "bench_train.py"), "--bf16", "--through-loop", "--no-host-feed", "--steps", "60", "--warmup", "40"]),
+)
+
+
+def compact_inference_leg(line):
+    """What `extra` keeps of a child's bench line (configs[0] / configs[3]): the value with its config and its rooflines."""
+    roof = line.get("roofline") or {}
+    keep = {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"],
+            "warmup": line["warmup"], "dtype": line["dtype"], "data": line["data"],
+            "config": {k: line["config"].get(k) for k in ("workload", "images_per_step_per_gpu", "graphs_in_flight", "images_per_graph", "hw_queues", "launch", "split_k")},
+            "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "error") if k in roof}}
+    for part in ("all_conv_launches", "backbone_conv"):
+        if isinstance(roof.get(part), dict):
+            keep["roofline"][part] = {k: roof[part].get(k) for k in ("achieved", "frac", "gflop_per_image", "in_flight") if k in roof[part]}
+    if "end_to_end_conv_tflops" in roof:
+        keep["roofline"]["end_to_end_conv_tflops"] = roof["end_to_end_conv_tflops"]
+    return keep
+
+
+def compact_train_leg(line):
+    """What `extra` keeps of scripts/bench_train.py's line: per step kind the bare step, the loop iteration and the roofline."""
+    keep = {"dtype": line["dtype"], "workload": line["workload"], "losses_read": line["losses_read"], "step_launch": line.get("step_launch")}
+    for tag in ("rpn_step1", "det_step2"):
+        if tag in line:
+            t = line[tag]
+            keep[tag] = {"ms_per_step": t["ms_per_step"], "img_s": t["img_s"], "ms_per_step_losses_read_every_step": t.get("ms_per_step_losses_read_every_step"),
+                         "roofline": t["roofline"]}
+            loop = (t.get("through_loop") or {}).get("fast_feed")
+            if loop:
+                keep[tag]["through_train_util_loop"] = {k: loop.get(k) for k in ("ms_per_iteration", "iterations", "distinct_images", "bare_step_over_loop_iteration")}
+    return keep
+
+
+def other_config_legs(timeout_s=170.0):
+    """Run EXTRA_LEGS (see above) and return {name: compact result or {"error": ...}}; `seconds` per leg says what the line cost."""
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, FRCNN_BENCH_NO_ENTRY="1", FRCNN_BENCH_NO_NATIVE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FRCNN_BENCH_FORCE_DIST", "GPU_MAX_HW_QUEUES"):
+        env.pop(k, None)
+    out = {}
+    for name, argv in EXTRA_LEGS:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable] + argv, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": "exit code %d: %s" % (r.returncode, r.stderr.strip()[-300:])}
+            else:
+                line = json.loads(lines[-1])
+                out[name] = (compact_train_leg if name.startswith("train_") else compact_inference_leg)(line)
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "timed out after %.0f s" % timeout_s}
+        except Exception as e:
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out[name]["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def claim_stdout():
     """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to fd 1 when
     its communicator goes away; eval_dets prints progress): from here on fd 1 IS stderr for everybody, and the JSON line goes
@@ -989,10 +1055,16 @@ def main():
                          "three-way operand splitting (csrc/conv_x6.hip, six matrix instructions per block of products); f16x3 = the same launches on "
                          "the fp16 matrix cores by a two-way split with a scaled low part (csrc/conv_h3.hip, three).  fp32-grade results either way")
     ap.add_argument("--no-train-dp", action="store_true", help="N > 1: leave the data-parallel training steps (`train_dp`) out of the line")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1, --config c2: leave the other BASELINE configs (`extra`: configs[0], configs[3], the "
+                    "training steps of configs[2] / [4]) out of the line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)                      # does not return
     json_out = claim_stdout()
+    extra = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "c2" and not args.no_extra and args.dtype == "config"
+            and not args.no_graph and os.environ.get("FRCNN_BENCH_FORCE_DIST", "0") == "0"):
+        extra = other_config_legs()                 # children first: this process has not touched the GPU yet
     global HOIST, DTYPE, WORKLOAD
     select_config(args.config)
     bf16_run = not (DTYPE == "f32" and args.dtype in ("config", "f32"))
@@ -1342,6 +1414,8 @@ def main():
             line["via_reference_entry"] = via_entry
         if train_dp is not None:
             line["train_dp"] = train_dp
+        if extra is not None:
+            line["extra"] = extra
         if roof is None:
             line["roofline"] = {"bound": "mfma", "error": roof_error}
         if roof is not None and HOIST and DEPTH != 16:   # what the same image costs in the reference's layer order (res5a_branch2a / branch1 on every crop)

@@ -282,6 +282,7 @@ def flush_weight_grads():
 
 
 _RECORDER = None
+_DBG = __import__("os").environ.get("FRCNN_DBG", "")
 _TICK = __import__("os").environ.get("FRCNN_TICK", "0") != "0"
 
 
@@ -914,11 +915,13 @@ class _StepDriver:
         pset, views = self._stage([hi for hi, d in zip(host_inputs, on_dev) if not d])
         main, side = torch.cuda.current_stream(), _prefix_stream()
         side.wait_event(self._frozen_ready)
-        if sg.used:
+        if sg.used and "nowait" not in _DBG:
             side.wait_event(sg.fwd_done)            # the previous replay's G1 has taken its inputs and the prefix output
         with torch.cuda.stream(side):
             up = iter(views)
             for (a, shape), d, dst in zip(host_inputs, on_dev, sg.inbox):
+                if "nocopy" in _DBG:
+                    continue
                 if d:
                     assert a.dtype == torch.float32 and a.is_contiguous(), "device inputs of train_on_batch: contiguous float32"
                     ev = getattr(a, "_ready", None)

@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--through-loop", action="store_true", help="also time train_util.train_rpn / train_detector_step2 THEMSELVES over 32 distinct images "
                     "(image fetch, targets / proposals, host sampling, step, loss line): ms per iteration beside the bare step, with the managers' "
                     "device-resident feed and (fewer iterations) with the reference's host-numpy calls")
+    ap.add_argument("--no-host-feed", action="store_true", help="with --through-loop: only the device-resident feed (the loops' default), not the reference's host-numpy calls")
     ap.add_argument("--sync-each-step", action="store_true", help="time only the plain Keras call (losses read back after every step); by default "
                     "the loop reads them one step late, the way train_util's loops do, and the per-step figure is reported beside it")
     args = ap.parse_args()
@@ -105,7 +106,9 @@ def main():
     rows, cols = resnet.get_conv_rows_cols(H, W)
     out = {"world": world, "dtype": DT, "backend": (torch.distributed.get_backend() if world > 1 else None),
            "workload": "ResNet-50 600x1000, 1 image per GPU per step, SGD momentum 0.9, l2 1e-4, synthetic data",
-           "losses_read": "after every step" if args.sync_each_step else "one step late (train_util's loops), all inside the timed region"}
+           "losses_read": "after every step" if args.sync_each_step else "one step late (train_util's loops), all inside the timed region",
+           "step_launch": ("hipGraph replay: prefix / forward / backward pieces / weight-gradient batches as linear graphs on three streams (train._StepGraph), "
+                           "optimiser + re-pack eager" if train.STEP_GRAPHS else "eager launches (FRCNN_TRAIN_GRAPH=0)")}
 
     def report(tag, ms, params, ms_sync=None, step=None):
         ar = allreduce_ms(params)
@@ -174,9 +177,10 @@ def main():
         for tag in ("rpn_step1", "det_step2"):
             if tag in out:
                 fast = bench.train_loop_leg(tag, DT, iterations=max(32, args.steps), fast=True, height=H, width=W)
-                host = bench.train_loop_leg(tag, DT, iterations=12, warm=6, fast=False, height=H, width=W)
                 fast["bare_step_over_loop_iteration"] = round(out[tag]["ms_per_step"] / fast["ms_per_iteration"], 3)
-                out[tag]["through_loop"] = {"fast_feed": fast, "host_feed": host}
+                out[tag]["through_loop"] = {"fast_feed": fast}
+                if not args.no_host_feed:
+                    out[tag]["through_loop"]["host_feed"] = bench.train_loop_leg(tag, DT, iterations=12, warm=6, fast=False, height=H, width=W)
     # flat keys kept for the round-1 readers of this line
     for tag, short in (("rpn_step1", "rpn_step1"), ("det_step2", "det_step2")):
         if tag in out:

@@ -49,3 +49,29 @@ def test_default_pass_shape():
     assert f("c4", True) == (8, 4) and f("c2", True) == (8, 4)             # bf16: eight per pass, four passes
     assert f("c4", True, streams=4) == (8, 4)
     assert f("c1", False) == (1, 12)                          # configs[0]: RPN only, no batched pass
+
+
+def test_extra_legs_are_compacted_and_survive_a_failed_child(monkeypatch):
+    """`python bench.py` (N = 1, configs[1]) carries the other BASELINE configs under `extra`: child processes, started before the parent
+    touches the GPU.  Here (no GPU) every child fails: each leg must come back as {"error": ..., "seconds": ...}, never an exception; the
+    compaction of a child's line keeps value / config / roofline and drops the rest."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "EXTRA_LEGS", (("c0_vgg16_rpn", ["bench.py", "--config", "c1", "--no-extra", "--steps", "1", "--warmup", "0"]),
+                                             ("train_steps_f32", ["-c", "import sys; sys.exit(3)"])))
+    got = bench.other_config_legs(timeout_s=120)
+    assert set(got) == {"c0_vgg16_rpn", "train_steps_f32"}
+    for leg in got.values():
+        assert "error" in leg and "seconds" in leg
+    line = {"metric": "m", "value": 1.0, "unit": "img/s", "ms_per_step": 2.0, "steps": 3, "warmup": 1, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "w", "graphs_in_flight": 4, "n_rois_kept": 300},
+            "roofline": {"bound": "mfma", "achieved": 10.0, "peak": 2500.0, "frac": 0.004, "unit": "TFLOP/s", "kernel": "k",
+                         "all_conv_launches": {"achieved": 5.0, "frac": 0.002, "launches": [1, 2, 3]}, "end_to_end_conv_tflops": 7.0},
+            "with_host_io": {"value": 0.5}}
+    c = bench.compact_inference_leg(line)
+    assert c["value"] == 1.0 and c["config"]["workload"] == "w" and "n_rois_kept" not in c["config"] and "with_host_io" not in c
+    assert c["roofline"]["frac"] == 0.004 and c["roofline"]["all_conv_launches"] == {"achieved": 5.0, "frac": 0.002}
+    t = bench.compact_train_leg({"dtype": "f32", "workload": "w", "losses_read": "late", "step_launch": "g",
+                                 "rpn_step1": {"ms_per_step": 2.0, "img_s": 500.0, "roofline": {"frac": 0.5}, "grad_payload_MB": 47.3,
+                                               "through_loop": {"fast_feed": {"ms_per_iteration": 2.1, "iterations": 64, "distinct_images": 32}}}})
+    assert t["rpn_step1"]["through_train_util_loop"]["ms_per_iteration"] == 2.1 and "det_step2" not in t and "grad_payload_MB" not in t["rpn_step1"]
