@@ -16,7 +16,7 @@ class FrcnnError(RuntimeError):
     pass
 
 
-ABI_VERSION = 103       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
+ABI_VERSION = 104       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
 P = c_void_p
 I = c_int
 # name -> (restype, argtypes).  Must list every symbol include/frcnn_hip.h declares
@@ -74,6 +74,7 @@ SIGNATURES = {
     "frcnn_amax_clear": (I, [P, I, P]),
     "frcnn_amax_f32": (I, [P, c_size_t, P, P]),
     "frcnn_amax_merge": (I, [P, P, ctypes.c_float, P, P]),
+    "frcnn_amax_status": (I, [P, I, P, P]),
     "frcnn_roi_crop_resize_fwd_planes": (I, [P, I, I, I, P, I, I, P, I, I, P, P]),
     "frcnn_roi_crop_resize_fwd_batch": (I, [P, I, I, I, P, I, I, I, P, I, I, P, P, P]),
     "frcnn_conv2d_h3_config": (I, [P, I]),
@@ -161,9 +162,12 @@ class X6Job(ctypes.Structure):
     _fields_ = [("w_packed", c_void_p), ("planes_bf16", c_void_p), ("rows", ctypes.c_int32), ("kpad", ctypes.c_int32)]
 
 
+H3_UNDER, H3_SATURATED, H3_NONFINITE = 1, 2, 4      # FRCNN_H3_* status bits (include/frcnn_hip.h)
+
+
 class H3Planes(ctypes.Structure):
     """frcnn_h3_planes (include/frcnn_hip.h)."""
-    _fields_ = [("planes", c_void_p), ("exponent", c_void_p)]
+    _fields_ = [("planes", c_void_p), ("exponent", c_void_p), ("status", c_void_p)]
 
 
 class ColsumJob(ctypes.Structure):

@@ -67,6 +67,46 @@ __device__ __forceinline__ float amax_read(const float* rec) {
     return wave_max(lane < AMAX_SLOTS ? rec[lane * AMAX_STRIDE] : 0.0f);
 }
 
+// ---- the f16x3 engine's fences (include/frcnn_hip.h "Status word of a magnitude record").  Word 1 of a record is a STICKY status word
+// (cleared with the record by frcnn_amax_clear): a launch that scales a tensor into fp16's range under that record ORs in
+//   H3_UNDER      a value at or above 2^15 after scaling: the record was not an upper bound (stale, or a producer's bug),
+//   H3_SATURATED  ... and at fp16's largest finite value: the conversion was CLAMPED to +-65504 (MODE.FP16_OVFL), the result is finite but
+//                 wrong there,
+//   H3_NONFINITE  an infinity or a NaN went by (their fp16 patterns lie above 65504's), or the record itself is not finite.
+// The kernels watch the HIGH fp16 plane they produce anyway: a running packed maximum of |h| (one v_and + one v_pk_max_u16 per PAIR of
+// values), folded over the wave at the end of the launch.  frcnn_amax_status gathers the words of a pass's records into one word that
+// travels with the outputs.
+constexpr unsigned H3_UNDER = 1u, H3_SATURATED = 2u, H3_NONFINITE = 4u;
+__device__ __forceinline__ void h3_fp16_saturate() {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1u);         // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: an overflowing f16 result clamps to +-MAX, true infinities stay
+}
+__device__ __forceinline__ void h3_see(unsigned& seen, unsigned hpair) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 m = __builtin_elementwise_max(__builtin_bit_cast(u16x2, seen), __builtin_bit_cast(u16x2, hpair & 0x7fff7fffu));
+    seen = __builtin_bit_cast(unsigned, m);
+}
+__device__ __forceinline__ void h3_see(unsigned& seen, _Float16 h) {
+    unsigned short b;
+    __builtin_memcpy(&b, &h, 2);
+    h3_see(seen, (unsigned)b);
+}
+__device__ __forceinline__ unsigned h3_status_bits(unsigned m16) {      // m16: the largest |h| bit pattern seen
+    return m16 > 0x7bffu ? (H3_UNDER | H3_SATURATED | H3_NONFINITE) : m16 == 0x7bffu ? (H3_UNDER | H3_SATURATED) : m16 >= 0x7800u ? H3_UNDER : 0u;
+}
+__device__ __forceinline__ void h3_report(const float* rec, unsigned seen) {
+    unsigned m = seen & 0xffffu;
+    m = m > (seen >> 16) ? m : (seen >> 16);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned t = __shfl_xor(m, o); m = m > t ? m : t; }
+    const unsigned bits = h3_status_bits(m);
+    if ((threadIdx.x & 63) == 0 && bits) atomicOr(reinterpret_cast<unsigned*>(const_cast<float*>(rec)) + 1, bits);
+}
+// a record that is not finite (an Inf in the tensor it was measured on): flagged; the launch goes on under a meaningless scale
+__device__ __forceinline__ void h3_check_record(const float* rec, float bound) {
+    if (!(bound < __builtin_inff()) && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicOr(reinterpret_cast<unsigned*>(const_cast<float*>(rec)) + 1, H3_NONFINITE);
+}
+
 constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;     // floats per LDS row (144 B)
 
@@ -296,6 +336,7 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
     }
     f32x4 rres[PASSES], rmask[PASSES];
     float vmax = 0.0f;
+    unsigned pseen = 0u;
     auto fetch = [&](int h) {                                // the global reads of wave-row h: in flight while it goes through LDS
 #pragma unroll
         for (int q = 0; q < PASSES; ++q) {
@@ -354,13 +395,17 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
                     const _Float16 a1 = (_Float16)xs;
                     h[c] = a1; l[c] = (_Float16)((xs - (float)a1) * 2048.0f);
                 }
+                if (in) { const i32x2 hp = __builtin_bit_cast(i32x2, h); h3_see(pseen, (unsigned)hp[0]); h3_see(pseen, (unsigned)hp[1]); }
                 const unsigned poff = in ? (unsigned)(((size_t)ym * p.Cout + yn) * 2) : OOB_OFFSET;
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, h), prsrc, poff, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, l), prsrc, poff == OOB_OFFSET ? OOB_OFFSET : poff + (unsigned)((size_t)p.M * p.Cout * 2), 0, 0);
             }
         }
     }
-    if (float* rec = second ? p.y2_amax : p.y_amax) amax_publish(rec, vmax);
+    if (float* rec = second ? p.y2_amax : p.y_amax) {
+        amax_publish(rec, vmax);
+        if constexpr (PLANES) h3_report(rec, pseen);      // planes written under a bound (bound_c * max|x| + bound_d) that the values exceeded
+    }
 }
 
 

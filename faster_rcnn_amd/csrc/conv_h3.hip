@@ -103,7 +103,10 @@ __host__ __device__ __forceinline__ float h3_pow2(int e) {
     return f;
 }
 
-__device__ __forceinline__ void h3_split(const f32x4 v, float s, f16x4& h, f16x4& l) {
+// `seen`: the running packed maximum of |h| (conv_f32_common.h h3_see / h3_report: a high part at or above 2^15 means the record the scale
+// came from was not an upper bound).  With MODE.FP16_OVFL set (h3_fp16_saturate) a conversion that overflows clamps to +-65504 instead of
+// turning into an infinity whose residual is a NaN.
+__device__ __forceinline__ void h3_split(const f32x4 v, float s, f16x4& h, f16x4& l, unsigned& seen) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float x = v[e] * s;                             // exact: s is a power of two
@@ -111,6 +114,10 @@ __device__ __forceinline__ void h3_split(const f32x4 v, float s, f16x4& h, f16x4
         const float r = x - (float)a1;                        // exact
         h[e] = a1; l[e] = (_Float16)(r * 2048.0f);
     }
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const i32x2 hp = __builtin_bit_cast(i32x2, h);
+    h3_see(seen, (unsigned)hp[0]);
+    h3_see(seen, (unsigned)hp[1]);
 }
 
 // the two scaled accumulators -> the f32 sum of products the epilogues expect
@@ -268,16 +275,20 @@ k_conv_igemm_h3(const ConvArgs p) {
     load_next(I1{});                                      // chunk 1: both in flight while the two scales are fetched
 
     // the two power-of-two scales (every wave derives the same numbers from the same words)
-    const int eA = h3_exponent(amax_read(p.x_amax));
+    h3_fp16_saturate();
+    const float x_max = amax_read(p.x_amax);
+    const int eA = h3_exponent(x_max);
     const int eB = h3_exponent(*reinterpret_cast<const float*>(wbase));
     const float sA = h3_pow2(eA);
+    h3_check_record(p.x_amax, x_max);
+    unsigned seen = 0u;
 
     auto store = [&](auto setc) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             f16x4 h, l;
-            h3_split(ra[S][i], sA, h, l);
+            h3_split(ra[S][i], sA, h, l, seen);
             const int row = lrow + RPP * i, g = tid & 7;
             char* dst = As + row * X6_ROWB + 16 * ((g >> 1) ^ h3_swz(row)) + 8 * (g & 1);
             *reinterpret_cast<f16x4*>(dst) = h;
@@ -354,6 +365,7 @@ k_conv_igemm_h3(const ConvArgs p) {
         compute();
         __syncthreads();                                  // the epilogue reuses the buffer
     }
+    h3_report(p.x_amax, seen);
     if constexpr (H3_S16) { h3_gather<TM, TN>(s0, acc0); h3_gather<TM, TN>(s1, acc1); }
     h3_combine<TM, TN>(acc0, acc1);
     if constexpr (SPLITK) {
@@ -503,10 +515,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
         w_grp += wrap * (RS * BK * 2);
     };
     load_next();                                          // chunk 0: in flight while the two scales are fetched
+    h3_fp16_saturate();
     const float x_max = amax_read(p.x_amax);
     const int eA = APLANES ? *p.x_pexp : h3_exponent(x_max);
     const int eB = h3_exponent(*reinterpret_cast<const float*>(wbase));
     const float sA = h3_pow2(eA);
+    if constexpr (!APLANES) h3_check_record(p.x_amax, x_max);
+    unsigned seen = 0u;
     // the output's planes: |y| <= bound_c * max|x| + bound_d (+ max|residual|) whatever the data, so that bound's exponent cannot overflow
     int eY = 0;
     if (p.y_planes) {
@@ -521,7 +536,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
                 *reinterpret_cast<f32x4*>(base + a_lds[i]) = ra[i];
             } else {
                 f16x4 h, l;
-                h3_split(ra[i], sA, h, l);
+                h3_split(ra[i], sA, h, l, seen);
                 *reinterpret_cast<f16x4*>(base + a_lds[i]) = h;
                 *reinterpret_cast<f16x4*>(base + BM * X6_ROWB + a_lds[i]) = l;
             }
@@ -577,6 +592,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
         }
         __syncthreads();
     }
+    if constexpr (!APLANES) h3_report(p.x_amax, seen);
     if constexpr (H3_S16) { h3_gather<TM, TN>(s0, acc0); h3_gather<TM, TN>(s1, acc1); }
     h3_combine<TM, TN>(acc0, acc1);
     h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
@@ -646,7 +662,8 @@ __global__ void __launch_bounds__(256) k_pack_h3(const float* w, size_t n, const
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {       // n % 4 == 0
         const f32x4 v = *reinterpret_cast<const f32x4*>(w + i);
         f16x4 h, l;
-        h3_split(v, s, h, l);
+        unsigned unused = 0u;                                 // (the scale comes from the maximum of these very values)
+        h3_split(v, s, h, l, unused);
         *reinterpret_cast<f16x4*>(out + i) = h;
         *reinterpret_cast<f16x4*>(out + n + i) = l;
     }
@@ -686,7 +703,8 @@ __global__ void __launch_bounds__(256) k_h3_refresh_pack(const H3RefreshTable t)
     for (size_t i = ((size_t)b * 256 + threadIdx.x) * 4; i < n; i += (size_t)nb * 256 * 4) {       // n % 4 == 0 (packed k is a multiple of 32)
         const f32x4 v = *reinterpret_cast<const f32x4*>(w + i);
         f16x4 h, l;
-        h3_split(v, s, h, l);
+        unsigned unused = 0u;                                 // (the scale comes from the maximum of these very values)
+        h3_split(v, s, h, l, unused);
         *reinterpret_cast<f16x4*>(out + i) = h;
         *reinterpret_cast<f16x4*>(out + n + i) = l;
     }
@@ -718,9 +736,27 @@ __global__ void __launch_bounds__(64) k_amax_merge(float* dst, const float* src,
     }
 }
 
+// OR of the status words (word 1) of `n` records -> *out (one workgroup: a pass has a few hundred records)
+__global__ void __launch_bounds__(256) k_amax_status(const float* rec, int n, int* out) {
+    __shared__ unsigned part[4];
+    unsigned bits = 0;
+    for (int r = threadIdx.x; r < n; r += 256) bits |= reinterpret_cast<const unsigned*>(rec + (size_t)r * AMAX_SLOTS * AMAX_STRIDE)[1];
+#pragma unroll
+    for (int o = 32; o; o >>= 1) bits |= __shfl_xor(bits, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (int)(part[0] | part[1] | part[2] | part[3]);
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
+
+extern "C" int frcnn_amax_status(const float* records, int n_records, int32_t* out, void* stream) {
+    if (!records || n_records <= 0 || !out) return fail(FRCNN_E_ARG, "amax_status: bad argument");
+    k_amax_status<<<1, 256, 0, as_stream(stream)>>>(records, n_records, out);
+    return check_launch("amax_status");
+}
 
 extern "C" size_t frcnn_conv_h3_planes_bytes(int cout, int packed_k) {
     if (cout <= 0 || packed_k <= 0) return 0;

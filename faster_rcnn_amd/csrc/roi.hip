@@ -76,8 +76,10 @@ __global__ void __launch_bounds__(256) k_roi_fwd(const float4* feat, int rows, i
 // convex combination of map values and a rejected RoI yields the fill vector: max(|map|, |fill|) bounds every output,
 // frcnn_amax_merge).  The consumer, res5a_branch2b's 3x3 over the crops (resnet.py:508-512), then stages the planes unchanged.
 __global__ void __launch_bounds__(256) k_roi_fwd_planes(const float4* feat, int rows, int cols, int C4, const float4* rois, int pool,
-                                                        const float4* fill, int relu, int pos_major, const int* pexp,
+                                                        const float4* fill, int relu, int pos_major, const int* pexp, unsigned* status,
                                                         _Float16* planes, size_t plane_elems, int n_per_img) {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1u);         // MODE.FP16_OVFL: a value above the bound clamps to +-65504 (conv_f32_common.h, the engine's fences)
+    unsigned seen = 0u;                                   // largest |hi| bit pattern written
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int pix = blockIdx.x;
     const int px = pix % pool, py = (pix / pool) % pool, r = pix / (pool * pool);
@@ -111,8 +113,17 @@ __global__ void __launch_bounds__(256) k_roi_fwd_planes(const float4* feat, int 
         for (int q = 0; q < 4; ++q) {
             const _Float16 a1 = (_Float16)xs[q];
             h[q] = a1; l[q] = (_Float16)((xs[q] - (float)a1) * 2048.0f);
+            unsigned short hb;
+            __builtin_memcpy(&hb, &a1, 2);
+            seen = seen > (unsigned)(hb & 0x7fffu) ? seen : (unsigned)(hb & 0x7fffu);
         }
         hi[c] = h; lo[c] = l;
+    }
+    if (status) {                                         // a sample at / above 2^15 under the planes' scale: 1 = above the bound, 2 = clamped, 4 = not finite
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const unsigned t = __shfl_xor(seen, o); seen = seen > t ? seen : t; }
+        const unsigned bits = seen > 0x7bffu ? 7u : seen == 0x7bffu ? 3u : seen >= 0x7800u ? 1u : 0u;
+        if ((threadIdx.x & 63) == 0 && bits) atomicOr(status, bits);
     }
 }
 
@@ -239,7 +250,7 @@ int frcnn_roi_crop_resize_fwd_planes(const float* feat, int rows, int cols, int 
     if (!feat || !rois || !out || !out->planes || !out->exponent) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_planes: null pointer");
     if (reinterpret_cast<uintptr_t>(out->planes) & 15) return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_planes: 16-byte aligned planes required");
     k_roi_fwd_planes<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool, (const float4*)fill,
-                                                                    relu, layout, out->exponent, (_Float16*)out->planes, (size_t)n * pool * pool * C, 0);
+                                                                    relu, layout, out->exponent, (unsigned*)out->status, (_Float16*)out->planes, (size_t)n * pool * pool * C, 0);
     return check_launch("roi_crop_resize_fwd_planes");
 }
 
@@ -257,7 +268,7 @@ int frcnn_roi_crop_resize_fwd_batch(const float* feat, int rows, int cols, int C
     if (!planes_out->planes || !planes_out->exponent || (reinterpret_cast<uintptr_t>(planes_out->planes) & 15))
         return fail(FRCNN_E_ARG, "roi_crop_resize_fwd_batch: planes and exponent required, planes 16-byte aligned");
     k_roi_fwd_planes<<<n * pool * pool, 256, 0, as_stream(stream)>>>((const float4*)feat, rows, cols, C / 4, (const float4*)rois, pool, (const float4*)fill,
-                                                                    relu, layout, planes_out->exponent, (_Float16*)planes_out->planes, (size_t)n * pool * pool * C, n_per_img);
+                                                                    relu, layout, planes_out->exponent, (unsigned*)planes_out->status, (_Float16*)planes_out->planes, (size_t)n * pool * pool * C, n_per_img);
     return check_launch("roi_crop_resize_fwd_batch (planes)");
 }
 

@@ -77,19 +77,25 @@ __global__ void __launch_bounds__(SH_NT) k_stem_h3(const float* __restrict__ x, 
         const bool ok = idx < SH_PROWS * SH_ROW && row < SH_IH && col < SH_IW * 3 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         pv[q] = ok ? xi[(size_t)gy * W * 3 + (ix0 * 3 + col)] : 0.0f;      // (gx >= 0 here, so the column offset is too)
     }
-    const int eA = sh_exponent(amax_read(x_amax));
+    h3_fp16_saturate();                                                     // (conv_f32_common.h: the engine's fences)
+    const float x_max = amax_read(x_amax);
+    const int eA = sh_exponent(x_max);
     const int eB = sh_exponent(*reinterpret_cast<const float*>(wp));
     const float sA = sh_pow2(eA);
+    h3_check_record(x_amax, x_max);
+    unsigned seen = 0u;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int idx = tid + q * SH_NT;
         if (idx < SH_PROWS * SH_ROW) {
             const float xs = pv[q] * sA;                                    // exact
             const _Float16 hi = (_Float16)xs;
+            h3_see(seen, hi);
             patch[idx] = hi;
             patch[SH_PROWS * SH_ROW + idx] = (_Float16)((xs - (float)hi) * 2048.0f);
         }
     }
+    h3_report(x_amax, seen);
     // ---- the whole filter, both planes: [2][64][176] fp16 -> LDS rows of SH_WLD
     const _Float16* wsrc = reinterpret_cast<const _Float16*>(wp + SH_HEADER);
     for (int idx = tid; idx < 2 * 64 * (SH_K / 8); idx += SH_NT) {

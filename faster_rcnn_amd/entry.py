@@ -34,6 +34,7 @@ import numpy as np
 import torch
 
 from . import models, ops
+from ._lib import FrcnnError
 from .pipeline import InferencePipeline
 
 MEAN_BGR = (103.939, 116.779, 123.68)           # resnet.preprocess / vgg.preprocess (resnet.py:64-75, vgg.py:52-57)
@@ -382,6 +383,10 @@ class DetectionEntry:
             s.event.synchronize()
             rev = self.rev_class_mapping
             res = []
+            if s.amax is not None:
+                bits = int(s.out_pin[0].numpy()[2])                 # the pass's f16x3 status word (pipeline._pass_status)
+                if bits:
+                    raise FrcnnError("f16x3 pass not trustworthy (%s): status %d; run the image on the native or bf16x6 engine" % (ops.h3_status_text(bits), bits))
             for i in range(len(ticket.image)):
                 packed = s.out_pin[i].numpy()
                 nd, n_rois = int(packed[0]), int(packed[1])

@@ -291,7 +291,7 @@ def roi_crop_resize(feat, rois, pool, fill=None, relu=False, layout=0, planes_ou
                 floor = float(fill.abs().max().item())
         out = PlaneTensor(oshape)
         amax_carry(out, src, floor, exponent_out=out.exponent)    # the bound and, from it, the planes' scale: known before the launch
-        yp = _lib.H3Planes(planes=out.planes.data_ptr(), exponent=out.exponent.data_ptr())
+        yp = _lib.H3Planes(planes=out.planes.data_ptr(), exponent=out.exponent.data_ptr(), status=out._amax.data_ptr() + 4)
         if n_per_img > 0:
             _lib.call("frcnn_roi_crop_resize_fwd_batch", _p(feat), rows, cols, C, _p(rois), n, n_per_img, pool, _p(fill), 1 if relu else 0, layout, None, ctypes.byref(yp), _stream())
         else:
@@ -345,6 +345,27 @@ def valid_out(size, k, stride):
     return (size - k) // stride + 1
 
 
+# The f16x3 engine scales a whole filter by ONE power of two.  fp16 keeps full precision over 2^-12 .. 2^15 after scaling and loses bits
+# gradually below (the low plane and fp16's subnormals stretch that: at 2^-30 of the largest value ~19 bits are left, at 2^-44 about
+# six).  A filter whose reduction channels differ by more than 2^H3_MAX_SPREAD_LOG2 in magnitude (max |w| per input channel, largest
+# against smallest non-zero) may pair its smallest-weight channels with the LARGEST activations (channel scales that a checkpoint's
+# normalisation moved between weights and activations), and then the lost bits show in the sum.  Measured
+# (tests/test_h3_fences_gpu.py): at a compensated spread of 2^30 the engine still reads 2.0e-7 of sum |x w| against the native kernel's
+# 4.0e-7; the bar is kept well inside that, and a layer beyond it runs on the exact bf16 split.  With the weights inside the bar, ANY
+# spread of the activations alone costs nothing (5.6e-7 against the native 1.3e-6 at 2^30).
+H3_MAX_SPREAD_LOG2 = 24.0
+
+
+def _channel_spread_log2(w_hwio, axis):
+    """log2(largest / smallest non-zero) of max|w| per reduction channel (``axis`` of the HWIO filter); one host read at lowering."""
+    dims = tuple(i for i in range(w_hwio.dim()) if i != axis)
+    cm = w_hwio.abs().amax(dim=dims).double()
+    nz = cm[cm > 0]
+    if nz.numel() < 2:
+        return 0.0
+    return float(torch.log2(nz.max() / nz.min()).item())
+
+
 class PackedConv:
     """A convolution's device-resident parameters: filter packed to [cout][packed_k], and the
     per-channel scale/shift the epilogue applies (bias and BatchNorm/Scale folded)."""
@@ -360,6 +381,7 @@ class PackedConv:
         self.shift = None if shift is None else _dev(shift, torch.float32)
         if self.shift is not None and not isinstance(shift, torch.Tensor):
             self.shift._absmax = float(np.abs(np.asarray(shift, dtype=np.float64)).max())      # host copy of max|shift| (amax_carry's floor)
+        self._h3_spread_log2 = _channel_spread_log2(w, 2)
 
     def x6_planes(self):
         """The filter as three bf16 planes [3][cout][packed_k] for the split-bf16 engine (frcnn_conv2d_fwd_x6), derived
@@ -467,12 +489,14 @@ def _split_engine(d, pc, tile):
             got = memo[key] = _lib.load().frcnn_conv2d_engine(ctypes.byref(d), _ENGINE_CODE[F32_ENGINE], 1 if key[2] else 0)
             if got < 0:
                 _lib.check(got, "frcnn_conv2d_engine")
-        return _ENGINE_TAG[got]
-    q = _lib.ConvDesc.from_buffer_copy(d)                     # (a caller asking about another tile code / filter than the descriptor's)
-    q.tile, q.cin, q.cout = tile, pc.cin, pc.cout
-    got = _lib.load().frcnn_conv2d_engine(ctypes.byref(q), _ENGINE_CODE[F32_ENGINE], 1 if key[2] else 0)
-    if got < 0:
-        _lib.check(got, "frcnn_conv2d_engine")
+    else:
+        q = _lib.ConvDesc.from_buffer_copy(d)                 # (a caller asking about another tile code / filter than the descriptor's)
+        q.tile, q.cin, q.cout = tile, pc.cin, pc.cout
+        got = _lib.load().frcnn_conv2d_engine(ctypes.byref(q), _ENGINE_CODE[F32_ENGINE], 1 if key[2] else 0)
+        if got < 0:
+            _lib.check(got, "frcnn_conv2d_engine")
+    if got == 2 and not (81 <= tile <= 88) and getattr(pc, "_h3_spread_log2", 0.0) > H3_MAX_SPREAD_LOG2:
+        return "x6"                                           # an ill-scaled filter (H3_MAX_SPREAD_LOG2): the exact split (an explicit 8x tile code stands)
     return _ENGINE_TAG[got]
 
 
@@ -484,27 +508,49 @@ def _use_x6(d, pc, tile):
 # carries ``t._amax``: a device record holding an upper bound of max|t|, written by the launch that produced the tensor.
 class AmaxArena:
     """The records of ONE forward pass: a fixed pool handed out in call order, cleared by a kernel at the start of the pass, so a
-    captured pass re-uses the same addresses on every replay and contains no memset node."""
+    captured pass re-uses the same addresses on every replay and contains no memset node.
+
+    ``gen`` counts the passes begun: a record handed out carries the generation it belongs to, and ``amax_of`` refuses one of an earlier
+    pass (its words have been cleared, or belong to another tensor now) -- the tensor is measured again instead (a cached
+    conv map, an ``out=`` buffer).  ``status()`` gathers the records' sticky status words (FRCNN_H3_*: a value above its record's
+    bound, a clamped value, a non-finite record) into ONE device word to be read with the pass's outputs."""
 
     def __init__(self, n=192):
         _require_gpu()
         self.floats = _lib.load().frcnn_amax_record_floats()
         self.buf = torch.zeros((n, self.floats), dtype=torch.float32, device="cuda")
-        self.i = self.high_water = 0
+        self.status_word = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.i = self.high_water = self.gen = 0
 
     def begin(self):
         """Clear the records the passes so far have used (all of them were zero at allocation; a captured pass bakes in the count of
         its warm-up passes, which walk the same launches): ~60 records = 240 KB for a ResNet-50 pass instead of the whole pool."""
         self.high_water = max(self.high_water, self.i)
         self.i = 0
+        self.gen += 1
         if self.high_water:
             _lib.call("frcnn_amax_clear", _p(self.buf), self.high_water, _stream())
 
     def take(self):
         assert self.i < self.buf.shape[0], "AmaxArena: more tracked tensors in a pass than records"
         r = self.buf[self.i]
+        r._arena_gen = (self, self.gen)
         self.i += 1
         return r
+
+    def status(self, out=None):
+        """-> device int32 word (``out`` or the arena's own): OR of the status words of the records this pass has used so far."""
+        out = self.status_word if out is None else out
+        n = max(self.i, 1)
+        _lib.call("frcnn_amax_status", _p(self.buf), n, _p(out), _stream())
+        return out
+
+
+def h3_status_text(bits):
+    """Readable form of a FRCNN_H3_* status word (entry.DetectionEntry raises with it)."""
+    names = [(n, b) for n, b in (("a value above its magnitude record's bound", _lib.H3_UNDER), ("values clamped to fp16's range", _lib.H3_SATURATED),
+                                  ("a non-finite magnitude record (Inf in a tensor)", _lib.H3_NONFINITE)) if bits & b]
+    return "; ".join(n for n, _ in names) or "clean"
 
 
 _AMAX_ARENA = None
@@ -555,6 +601,14 @@ def amax_of(x):
     not kept on the tensor: a tensor nobody produced is somebody's input buffer, rewritten between passes (a captured pass's static
     input), and its record lives in an arena that the next pass clears."""
     rec = getattr(x, "_amax", None)
+    if rec is not None:
+        stamp = getattr(rec, "_arena_gen", None)
+        if stamp is not None and stamp[0].gen != stamp[1]:      # a record of an EARLIER pass of its arena: cleared or re-used since
+            rec = None
+            try:
+                x._amax = None
+            except AttributeError:
+                pass
     if rec is None:
         global AMAX_MEASURED
         AMAX_MEASURED += 1
@@ -568,8 +622,14 @@ def amax_carry(dst, src, floor=0.0, exponent_out=None):
     resampling with a fill vector): it inherits the bound.  floor > 0 (or a request for the bound's plane exponent) needs a record
     of its own (frcnn_amax_merge)."""
     rec = getattr(src, "_amax", None)
+    stamp = getattr(rec, "_arena_gen", None) if rec is not None else None
+    if stamp is not None and stamp[0].gen != stamp[1]:
+        rec = None                                               # (a record of an earlier pass: see amax_of)
     if rec is None:
-        return dst
+        if exponent_out is not None:
+            rec = amax_of(src)                                   # planes need their scale: measure
+        else:
+            return dst
     if floor > 0.0 or exponent_out is not None:
         merged = _amax_new()
         _lib.call("frcnn_amax_merge", _p(merged), _p(rec), float(floor), _p(exponent_out), _stream())
@@ -698,10 +758,10 @@ def _conv_launch(d, x, w, scale, shift, residual, mask, out, y_amax=None):
 def _conv2d_h3_planes(d, x, pc, residual, oshape, planes_out, act):
     """frcnn_conv2d_fwd_h3_planes: x a PlaneTensor or an f32 tensor, the result a PlaneTensor (planes_out) or an f32 tensor."""
     x_in = isinstance(x, PlaneTensor)
-    xp = _lib.H3Planes(planes=x.planes.data_ptr(), exponent=x.exponent.data_ptr()) if x_in else None
+    xp = _lib.H3Planes(planes=x.planes.data_ptr(), exponent=x.exponent.data_ptr(), status=None) if x_in else None
     y = PlaneTensor(oshape) if planes_out else torch.empty(oshape, dtype=torch.float32, device="cuda")
-    yp = _lib.H3Planes(planes=y.planes.data_ptr(), exponent=y.exponent.data_ptr()) if planes_out else None
     ya = _amax_new()
+    yp = _lib.H3Planes(planes=y.planes.data_ptr(), exponent=y.exponent.data_ptr(), status=ya.data_ptr() + 4) if planes_out else None
     bc, bd = pc.h3_bound() if planes_out else (0.0, 0.0)
     xa = amax_of(x)                                              # (a measured record is a temporary: it must outlive the launch and its re-launches)
     ra = amax_of(residual) if (residual is not None and planes_out) else None
@@ -772,6 +832,8 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
         args = (ctypes.byref(d), _p(x), _p(pc.x6_planes()), _p(pc.scale), _p(pc.shift), _p(residual), None, _p(out),
                 _p(ws), ws.numel() if ws is not None else 0)
         _lib.call("frcnn_conv2d_fwd_x6", *args, _stream())
+        if getattr(out, "_amax", None) is not None:
+            out._amax = None
         if CONV_PROFILE is not None:
             keep = (d, x, pc, residual, out, ws)
             CONV_PROFILE.append({"kernel": "k_conv_igemm_x6<1,1,2,2> split-K" if ws is not None else _x6_name(d),
@@ -781,8 +843,8 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
         return out
     ya = _amax_new(optional=True) if (_tracking() and pc.cout >= 32) else None      # a native layer in an f16x3 pass leaves max|y| for the layer behind it
     (fn, args), ws = _conv_launch(d, x, pc.w, pc.scale, pc.shift, residual, None, out, ya)
-    if ya is not None:
-        out._amax = ya
+    if ya is not None or getattr(out, "_amax", None) is not None:
+        out._amax = ya                                           # (an `out=` buffer must not keep the record of what it held before)
     if CONV_PROFILE is not None:
         flops = 2.0 * n * ho * wo * pc.cout * pc.kh * pc.kw * pc.cin
         cfg = _lib.load().frcnn_conv2d_config(ctypes.byref(d))
@@ -964,6 +1026,7 @@ class PackedDgrad:
         sc = None if scale is None else _dev(scale, torch.float32)
         _lib.call("frcnn_pack_conv_weights_dgrad", _p(w), _p(sc), self.kh, self.kw, cin, cout, _p(self.w), _stream())
         self.scale = self.shift = None
+        self._h3_spread_log2 = _channel_spread_log2(w if sc is None else w * sc, 3)   # (the transposed convolution reduces over the forward OUTPUT channels)
 
     x6_planes = PackedConv.x6_planes                         # the same [rows][packed k] f32 layout: the same three-plane form
     h3_planes = PackedConv.h3_planes                         # ... and the same header + two fp16 planes
@@ -999,7 +1062,7 @@ def conv2d_dgrad(gy, pd, padding="valid", residual=None, mask=None, out=None):
         return out
     ya = _amax_new(optional=True) if (_tracking() and pd.cout >= 32) else None
     _conv_launch(d, gy, pd.w, None, None, residual, mask, out, ya)
-    if ya is not None:
+    if ya is not None or getattr(out, "_amax", None) is not None:
         out._amax = ya
     return out
 

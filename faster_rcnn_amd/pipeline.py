@@ -62,6 +62,7 @@ class InferencePipeline:
         else:
             res.update(ops.detections(rois, n_keep, out_cls, out_reg, self.roi_batch, self.bg_idx, self.det_threshold,
                                       float(self.stride), float(resize_ratio)))
+        _pass_status(res, res["det_packed"])
         return res
 
     # ------------------------------------------------------------------ hipGraph
@@ -121,6 +122,15 @@ class InferencePipeline:
             self._static_in.copy_(x)
         self._graph.replay()
         return self._static_out
+
+
+def _pass_status(res, packed):
+    """f16x3 passes: the OR of the status words of every magnitude record the pass used (ops.AmaxArena.status; FRCNN_H3_*: a value above
+    its record's bound, a clamped value, a non-finite record) lands in word 2 of ``packed`` (the first image's det_packed: it reaches
+    the host with the detections) and in res["h3_status"]; 0 = clean."""
+    arena = ops._AMAX_ARENA
+    if arena is not None:
+        res["h3_status"] = arena.status(out=packed[2:3])
 
 
 import contextlib as _contextlib
@@ -205,6 +215,7 @@ class BatchedInferencePipeline(InferencePipeline):
                                                           self.bg_idx, self.det_threshold, float(self.stride), float(resize_ratio)))
         for k in dets[0]:
             res[k] = [d[k] for d in dets]
+        _pass_status(res, res["det_packed"][0])
         return res
 
     def capture(self, height, width, resize_ratio=1.0, warmup=2, split_k=False, throughput=True, f32_engine=None):

@@ -41,8 +41,10 @@ const char* frcnn_last_error(void);
 /* The ABI revision this header describes; frcnn_version() returns the library's.  A host built against another revision must not
  * call into the library (the Python mirror checks at load): 100 = rounds 1-3; 101 = frcnn_detections takes det_threshold as a double
  * (round 4); 102 = the f16x3 conv engine, magnitude records, frcnn_conv2d_engine, the RPN sampling entry points (round 5);
- * 103 = frcnn_refresh_h3_planes, frcnn_roi_crop_resize_fwd_batch (additions only). */
-#define FRCNN_ABI_VERSION 103
+ * 103 = frcnn_refresh_h3_planes, frcnn_roi_crop_resize_fwd_batch (additions only).
+ * 104 = the f16x3 engine's fences: frcnn_h3_planes.status (a THIRD field: recompile hosts that pass the struct), status word in a
+ *       magnitude record, frcnn_amax_status. */
+#define FRCNN_ABI_VERSION 104
 int frcnn_version(void);
 /* number of HIP devices visible; does not initialise a context */
 int frcnn_device_count(void);
@@ -351,6 +353,21 @@ int frcnn_amax_record_floats(void);
 int frcnn_amax_clear(float* records, int n_records, void* stream);
 int frcnn_amax_f32(const float* x, size_t n, float* record, void* stream);
 int frcnn_amax_merge(float* dst_record, const float* src_record, float floor_value, int32_t* exponent_out, void* stream);
+/* Status word of a magnitude record (float index 1 of the record, an uint32 bit set; zeroed with the record by frcnn_amax_clear).  A
+ * launch that scales a tensor into fp16's range under a record ORs in
+ *   FRCNN_H3_UNDER      a value at or above 2^15 after scaling went by: the record was not an upper bound (stale, or a producer's bug);
+ *   FRCNN_H3_SATURATED  ... and at fp16's largest finite value: it was clamped to +-65504 (the kernels run with MODE.FP16_OVFL set), so
+ *                       the output is finite but WRONG where this bit is set;
+ *   FRCNN_H3_NONFINITE  an infinity went by, or the record itself is not finite (the tensor it was measured on holds an infinity: one
+ *                       power of two cannot serve such a tensor).
+ * Any bit set: the launch's results are not to be used (the native kernels carry +-Inf / NaN through the receptive fields; this engine
+ * reports instead -- measured on gfx950: a NaN or Inf element sets all three bits, tests/test_h3_fences_gpu.py).
+ * frcnn_amax_status ORs the status words of `n_records` consecutive records (a pass's arena) into *out (device int32, overwritten):
+ * issue it behind the pass and read the word with the outputs; non-zero = the pass's f16x3 results are not to be trusted. */
+#define FRCNN_H3_UNDER 1
+#define FRCNN_H3_SATURATED 2
+#define FRCNN_H3_NONFINITE 4
+int frcnn_amax_status(const float* records, int n_records, int32_t* out, void* stream);
 int frcnn_conv2d_h3_config(const frcnn_conv_desc* d, int n1);
 size_t frcnn_conv2d_h3_workspace_bytes(const frcnn_conv_desc* d);
 int frcnn_conv2d_fwd_h3(const frcnn_conv_desc* d, const float* x, const float* x_amax, const void* w_planes_f16,
@@ -381,6 +398,8 @@ int frcnn_stem_h3_fwd(const float* x, const float* x_amax, int n, int h, int w, 
 typedef struct frcnn_h3_planes {
     void* planes;                  /* [2][rows][channels] fp16, 16-byte aligned */
     int32_t* exponent;             /* device int32: stored value = true value * 2^exponent (written by the producing launch) */
+    int32_t* status;               /* sticky status word a launch WRITING these planes ORs FRCNN_H3_* bits into (may be NULL): word 1 of the
+                                    * tensor's magnitude record, so that frcnn_amax_status finds it */
 } frcnn_h3_planes;
 int frcnn_conv2d_fwd_h3_planes(const frcnn_conv_desc* d, const float* x, const frcnn_h3_planes* x_planes, const float* x_amax,
                                const void* w_planes_f16, const float* scale, const float* shift,
