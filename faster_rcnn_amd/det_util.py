@@ -31,7 +31,7 @@ class DetTrainingManager:
         self.conv_only = True if len(rpn_model.output) == 3 else False
         self._stream = None
 
-    def _own_stream(self):
+    def _own_stream(self, probe=True):
         """The manager's device work (RPN forward, decode, ordering, NMS, RoI -> truth, the copies back to numpy) runs on a
         stream of its own.  In the detector loops (train_util._train_detector) it is called while the PREVIOUS detector step
         is still enqueued on the caller's stream; on that stream the `.cpu()` at the end of this work would make the host wait
@@ -40,7 +40,14 @@ class DetTrainingManager:
         and packed buffers, so nothing this stream reads is written by the step beside it."""
         if self._stream is None:
             from . import feed
-            self._stream = feed.manager_stream()                        # (one per process: see feed.manager_stream)
+            # the PROBED stream (feed.manager_stream: ~70 ms once, keeps the trainer's streams alive) only where a training step runs
+            # beside this work; an inference-only process (voc_dets through get_det_inputs) takes a plain stream of its own (ADVICE r5)
+            self._stream = feed.manager_stream() if probe else torch.cuda.Stream()
+            self._stream_probed = probe
+        elif probe and not getattr(self, "_stream_probed", False):
+            from . import feed
+            self._stream.synchronize()
+            self._stream, self._stream_probed = feed.manager_stream(), True
         if getattr(self.rpn_model, "_trainer", None) is not None and getattr(self.rpn_model, "_dirty", False):
             self._stream.wait_stream(torch.cuda.current_stream())       # (a trained RPN model: order behind its last step)
         return torch.cuda.stream(self._stream)
@@ -119,7 +126,10 @@ class DetTrainingManager:
         if self.conv_only:
             del self._cache[image.cache_key]
         if first.dim() == 3:
+            ready = getattr(first, "_ready", None)
             first = first.unsqueeze(0)
+            if ready is not None:
+                first._ready = ready                         # (a new tensor object: the event the step's streams wait for travels with it)
         return first, np.expand_dims(rois, axis=0), np.expand_dims(y_class_num, axis=0), np.expand_dims(y_transform, axis=0)
 
     def get_training_input(self, image):
@@ -140,7 +150,7 @@ class DetTrainingManager:
 
     def get_det_inputs(self, image):
         """det_util.py:136-158: (conv feature map (1,R,C,Cf) or None, nms_rois (n,4) int16)."""
-        with self._own_stream():
+        with self._own_stream(probe=False):
             rois, feat = self._proposals_dev(image, 8000, 300)
             # (a bf16 base hands its map over as float32 -- numpy has no bf16, the widening is exact and the detector narrows it back)
             return (feat.float().cpu().numpy() if feat is not None else None), rois.cpu().numpy()

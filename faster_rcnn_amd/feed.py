@@ -159,6 +159,14 @@ def manager_stream():
                 break
             if best is None and free[0] and free[1]:
                 best = cand                                  # sharing with the prefix stream only: 2.10 against 2.05 ms
-        _MANAGER_STREAM = best if best is not None else tried[-1]
-        manager_stream.tried = tried
+        if best is None:
+            import warnings
+            best = tried[-1]
+            warnings.warn("faster_rcnn_amd.feed: no HIP stream independent of the training step's streams found among %d candidates; the "
+                          "managers' prefetch will queue behind the step's weight gradients (slower loop, same results)" % len(tried))
+        _MANAGER_STREAM = best
+        # the losing candidates go back (each held a hardware-queue slot for the life of the process); the queues were dealt
+        # when the streams were created, so releasing them does not move the chosen one
+        manager_stream.tried = len(tried)
+        del tried
     return _MANAGER_STREAM

@@ -165,6 +165,7 @@ def _cubic_taps(dst, src):
 # that still has to fork its ranks) never starts the runtime as a side effect.  True / False force it either way.
 DEVICE_RESIZE = None
 _RESIZE_STREAM = None
+_RESIZE_WARNED = False
 
 
 def _device_resize_ok():
@@ -197,8 +198,15 @@ def _resize_any(img, width, height):
                     out = ops.resize_cubic_u8(dev, height, width)
                     host = out.cpu()                              # synchronises _RESIZE_STREAM only
                 return host.numpy()
-        except Exception:                                         # noqa: BLE001 -- a pure-host property must not raise because of the device
-            pass
+        except (ImportError, RuntimeError) as e:                  # library not built / no context in a forked worker / HIP error (FrcnnError is a RuntimeError)
+            if DEVICE_RESIZE is True:
+                raise                                             # the caller asked for the device path: its failure is the caller's to see
+            global _RESIZE_WARNED
+            if not _RESIZE_WARNED:
+                _RESIZE_WARNED = True
+                import warnings
+                warnings.warn("faster_rcnn_amd.shapes: device resize failed (%s: %s); falling back to the host restatement (~90 ms per frame, same pixels)"
+                              % (type(e).__name__, e))
     return _resize(img, width, height)
 
 

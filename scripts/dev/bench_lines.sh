@@ -1,4 +1,5 @@
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/round5b
 mkdir -p $OUT
 cd /tmp

@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $GRAFT_REPO_ROOT
 for cfg in "4 8 4" "2 16 4" "3 8 4" "4 12 4" "4 16 4" "6 8 8" "8 4 8" "2 8 4"; do
   set -- $cfg

@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $GRAFT_REPO_ROOT
 export FRCNN_BENCH_NO_ENTRY=1 FRCNN_BENCH_NO_NATIVE=1
 run() { python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-io "$@" 2>/dev/null | python3 -c "

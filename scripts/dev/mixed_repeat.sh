@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $GRAFT_REPO_ROOT
 for i in 1 2 3; do
   python3 scripts/bench_train.py --bf16 --steps 100 --warmup 40 2>/dev/null | python3 -c "

@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $GRAFT_REPO_ROOT
 export FRCNN_BENCH_NO_ENTRY=1 FRCNN_BENCH_NO_NATIVE=1
 for cfg in "8 8" "6 8" "10 8" "12 8" "12 12" "16 8" "16 16"; do

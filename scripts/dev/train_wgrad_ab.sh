@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $GRAFT_REPO_ROOT
 for e in native bf16x6 native bf16x6; do
   FRCNN_TRAIN_WGRAD=$e python3 scripts/bench_train.py --steps 60 --warmup 40 2>/dev/null | python3 -c "

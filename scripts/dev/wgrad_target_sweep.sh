@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $GRAFT_REPO_ROOT
 for t in 256 128 96 64 256 128; do
   FRCNN_WGRAD_TARGET=$t python3 scripts/bench_train.py --bf16 --steps 60 --warmup 40 2>/dev/null | python3 -c "

@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $GRAFT_REPO_ROOT
 for t in 0 77 74; do
   python3 scripts/conv_one.py 1 149 249 64 64 3 1 same $t 50

@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $GRAFT_REPO_ROOT
 for t in 74 0; do
   python3 scripts/conv_one.py 64 7 7 512 512 3 1 same $t 30 1

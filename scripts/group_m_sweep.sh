@@ -1,4 +1,5 @@
 #!/bin/bash
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 # GPU box: time + HBM-side traffic of the head's 128x128 launches under FRCNN_GROUP_M (tile order inside an XCD's run).
 # usage: bash scripts/group_m_sweep.sh <outdir>
 OUT=$GRAFT_REPO_ROOT/$1; mkdir -p $OUT

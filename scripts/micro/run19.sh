@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 # kernel traces of the f32 training steps with the 128x128 weight-gradient kernel, grouped by (kernel, grid)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/run19; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp

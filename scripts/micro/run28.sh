@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 # kernel traces of the mixed-precision training steps (current code), grouped by (kernel, grid) + idle gaps
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/run28; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp

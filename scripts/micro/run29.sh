@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 # configs[3] (ResNet-101 bf16): kernel traces grouped by (kernel, grid), one image in flight and four
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/run29; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp

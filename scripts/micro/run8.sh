@@ -1,3 +1,4 @@
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 # kernel traces of the two training steps (f32 and mixed), grouped by (kernel, grid) + idle gaps
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/run8; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 # one gpurun call: phase stamps of the tiled bf16 kernel + the ring lab on the 1x1 layers of configs[3]  ->  profiles/round4_lab/
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/ring_lab; mkdir -p $O

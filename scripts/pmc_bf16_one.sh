@@ -1,4 +1,5 @@
 #!/bin/bash
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 # usage: pmc_bf16_one.sh <outdir> M N K res tile   -- PMC passes over one bf16 1x1 conv shape (scripts/conv_one_bf16.py)
 OUT=$GRAFT_REPO_ROOT/$1; shift
 mkdir -p $OUT

@@ -1,4 +1,5 @@
 #!/bin/bash
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 # usage: pmc_conv.sh <outdir> <conv_one args...>; separate --pmc passes (guide: no mixing with traces)
 OUT=$1; shift
 export TMPDIR=/tmp

@@ -1,7 +1,8 @@
 #!/bin/bash
 # PMC passes (separate runs, --pmc only) over the fp32 training steps: matrix-pipe busy and HBM-side bytes of the weight-gradient and
 # split-K kernels of the split engine.   usage: bash scripts/pmc_train.sh [out dir under gpurun_out]
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${1:-pmc_train}
 mkdir -p $OUT
 export TMPDIR=/tmp

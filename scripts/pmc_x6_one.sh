@@ -1,4 +1,5 @@
 #!/bin/bash
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 # usage: pmc_x6_one.sh <outdir> n h w cin cout k stride padding tile iters [layout]   -- PMC passes over one f32 conv shape (scripts/conv_one.py)
 OUT=$GRAFT_REPO_ROOT/$1; shift
 mkdir -p $OUT

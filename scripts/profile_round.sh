@@ -2,7 +2,8 @@
 # Round profile: rocprofv3 kernel-trace stats of the bench command + PMC passes (separate runs).
 # usage (on the GPU box): bash scripts/profile_round.sh <tag>
 TAG=${1:-round1}
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

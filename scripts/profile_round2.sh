@@ -2,7 +2,8 @@
 # Round-2 profile (GPU box): benches of every config, rocprofv3 kernel-trace stats of the headline command, PMC passes
 # (separate runs, --pmc only), the per-shape conv table of the lab harness.   usage: bash scripts/profile_round2.sh [tag]
 TAG=${1:-round2}
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

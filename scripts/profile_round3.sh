@@ -2,7 +2,8 @@
 # Round-3 profile (GPU box): bench lines of every config, rocprofv3 kernel-trace stats of the headline command and of the
 # configs[3] command, PMC passes (separate runs, --pmc only).   usage: bash scripts/profile_round3.sh [tag]
 TAG=${1:-round3}
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -3,7 +3,8 @@
 # kernel-trace stats of the headline command and of the training steps, PMC passes (separate runs, --pmc only).
 #   usage: bash scripts/profile_round4.sh [tag]
 TAG=${1:-round4}
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -2,7 +2,8 @@
 # The training part of the round profile on its own: bench lines of the four steps, kernel traces grouped by (kernel, grid), one step cut
 # out per stream.   usage: bash scripts/profile_train.sh [tag]
 TAG=${1:-round4}
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -154,7 +154,7 @@ def test_manager_stream_shares_no_queue_with_the_steps_streams():
     s = feed.manager_stream()
     assert s is feed.manager_stream() and s is not cur
     assert feed._runs_beside(cur, s) and feed._runs_beside(train._wgrad_stream(), s)
-    assert 1 <= len(feed.manager_stream.tried) <= 8
+    assert 1 <= feed.manager_stream.tried <= 8
     from faster_rcnn_amd import resnet, rpn_util, util
     mgr = rpn_util.RpnTrainingManager(resnet.get_conv_rows_cols, 16, resnet.preprocess, util.get_anchors([128, 256, 512]))
     assert mgr._own_stream() is s                                  # every manager object of the process uses it
