@@ -928,6 +928,78 @@ def reference_entry_leg(pipe, anchors, rank, n_images=32, passes=3, eager_images
                     "returns the same list without them; the eager path beside it scores the %d-row padded list)" % (n_images, HEIGHT, WIDTH, eng.in_flight, eng.batch, PROPOSALS, -(-PROPOSALS // 64) * 64)}
 
 
+# a VOC07-like histogram of SOURCE sizes (width, height, share): the common camera formats, their +-1..2 pixel neighbours, and a tail
+# of sizes that occur once or twice; after shapes.Image.resize_within_bounds(600, 1000) each is a geometry of its own
+MIXED_SIZES = [((500, 375), 0.40), ((500, 333), 0.14), ((375, 500), 0.11), ((500, 334), 0.04), ((333, 500), 0.04), ((500, 374), 0.03),
+               ((500, 332), 0.03), ((500, 400), 0.02), ((500, 357), 0.02), ((334, 500), 0.02), ((500, 376), 0.02), ((480, 360), 0.015),
+               ((500, 281), 0.015)]
+
+
+def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77):
+    """``voc_dets.get_dets_by_cls`` (voc_dets.py:91-111) over a SHUFFLED list of ``n_images`` frames whose source sizes follow
+    MIXED_SIZES (the rest of the probability mass: sizes drawn once, 500 x 250..499): every source size resizes to its own geometry
+    (shapes.py:106-123), a captured pass serves one geometry.  Timed: the first call (captures included) and the same call again
+    (passes cached); reported with the number of geometries, captures, eager fallbacks and cache bytes."""
+    import contextlib
+    import io as _io
+    from faster_rcnn_amd import entry, resnet, shapes, util, voc_dets
+    from faster_rcnn_amd.data.voc_data_helpers import KITTI_CLASS_MAPPING, VOC_CLASS_MAPPING
+    from faster_rcnn_amd.det_util import DetTrainingManager
+    mapping = VOC_CLASS_MAPPING if NUM_CLASSES == len(VOC_CLASS_MAPPING) else KITTI_CLASS_MAPPING
+    mgr = DetTrainingManager(rpn_model=pipe.rpn, class_mapping=mapping, preprocess_func=resnet.preprocess, anchor_dims=anchors)
+    rs = np.random.RandomState(seed)
+    sizes = []
+    for (w, h), share in MIXED_SIZES:
+        sizes += [(w, h)] * int(round(share * n_images))
+    while len(sizes) < n_images:
+        sizes.append((500, int(rs.randint(250, 500))))
+    sizes = sizes[:n_images]
+    rs.shuffle(sizes)
+    pool = {}                                                    # one random frame per source size (the pixels do not matter to the timing)
+    raw = []
+    for i, (w, h) in enumerate(sizes):
+        if (w, h) not in pool:
+            pool[(w, h)] = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        raw.append(shapes.Image(shapes.Metadata("mixed%03d" % i, w, h, [], "none"), pool[(w, h)]))
+    images, ratios = util.resize_imgs(raw, min_size=600, max_size=1000)
+    geometries = len({(im.height, im.width) for im in images})
+    dtype = getattr(pipe.det.head, "dtype", "f32")
+    eng = entry.for_models(mgr, pipe.det, 64, 16, entry.default_in_flight(dtype))
+    before = eng.stats()
+    sink = _io.StringIO()
+    eager_calls = [0]
+    real_eager = voc_dets._get_dets_eager
+
+    def counting(*a, **k):
+        eager_calls[0] += 1
+        return real_eager(*a, **k)
+    voc_dets._get_dets_eager = counting
+    try:
+        def run():
+            with contextlib.redirect_stdout(sink):
+                t0 = time.perf_counter()
+                d = voc_dets.get_dets_by_cls(mgr, pipe.det, ratios, images)
+                return time.perf_counter() - t0, d
+        t1, d1 = run()
+        e1 = eager_calls[0]
+        mid = eng.stats()
+        t2, d2 = run()
+        e2 = eager_calls[0] - e1
+    finally:
+        voc_dets._get_dets_eager = real_eager
+    after = eng.stats()
+    same = d1.keys() == d2.keys() and all(d1[c].keys() == d2[c].keys() and all(len(d1[c][i]) == len(d2[c][i]) for i in d1[c]) for c in d1)
+    return {"first_call": {"value": round(n_images / t1, 2), "unit": "img/s", "seconds": round(t1, 3), "captures": mid["captures"] - before["captures"],
+                           "capture_seconds": round(mid["capture_seconds"] - before["capture_seconds"], 3), "eager_images": e1},
+            "second_call": {"value": round(n_images / t2, 2), "unit": "img/s", "seconds": round(t2, 3), "captures": after["captures"] - mid["captures"], "eager_images": e2},
+            "images": n_images, "geometries": geometries, "graph_cache_bytes": after["bytes"], "graphs": after["graphs"],
+            "reorder_window": voc_dets.REORDER_WINDOW, "capture_min": voc_dets.CAPTURE_MIN, "images_per_pass": eng.batch, "in_flight": eng.in_flight,
+            "same_detection_counts_both_calls": bool(same),
+            "what": "voc_dets.get_dets_by_cls over a shuffled list of %d frames of %d geometries (VOC07-like source sizes resized within 600 / 1000); images "
+                    "of one geometry share captured passes wherever they stand in the list (held back per geometry, at most REORDER_WINDOW), a geometry seen "
+                    "fewer than CAPTURE_MIN times runs the eager sequence" % (n_images, geometries)}
+
+
 _JSON_OUT = None
 
 
@@ -1063,7 +1135,8 @@ def main():
     json_out = claim_stdout()
     extra = None
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "c2" and not args.no_extra and args.dtype == "config"
-            and not args.no_graph and os.environ.get("FRCNN_BENCH_FORCE_DIST", "0") == "0"):
+            and not args.no_graph and args.streams <= 0 and args.batch <= 0 and os.environ.get("FRCNN_BENCH_FORCE_DIST", "0") == "0"
+            and "FRCNN_BENCH_BACKEND" not in os.environ):     # (the driver's command line; a run that names a pass shape or a dev backend is somebody's experiment)
         extra = other_config_legs()                 # children first: this process has not touched the GPU yet
     global HOIST, DTYPE, WORKLOAD
     select_config(args.config)
@@ -1185,10 +1258,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ranks_audit = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        # every rank's own clock over the SAME barrier-bracketed region, gathered: the line then shows that all ranks ran (ranks_seen),
+        # what each one did by itself and how far apart they were -- `value` uses the slowest (the contract's max over ranks)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        per_rank = [float(v.item()) for v in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ranks_audit = {"ranks_seen": len(per_rank), "per_rank_img_s": [round(S * B * args.steps / v, 2) for v in per_rank],
+                       "slowest_over_fastest_seconds": round(max(per_rank) / min(per_rank), 4),
+                       "value_is": "ranks x images per step x steps / the SLOWEST rank's seconds (all ranks between the same two barriers)"}
 
     # ---- the same K steps on the OTHER fp32 matrix paths, when the timed graphs above run their large launches on a split engine:
     # all numbers in one line, same process, same inputs (one rank only).  `native_f32_mfma`: every convolution on
@@ -1338,6 +1421,11 @@ def main():
             via_entry = reference_entry_leg(pipe, anchors, rank)
         except Exception as e:
             via_entry = {"error": "%s: %s" % (type(e).__name__, e)}
+        if "error" not in via_entry and DEPTH == 50 and DTYPE == "f32":
+            try:
+                via_entry["mixed_sizes"] = mixed_sizes_leg(pipe, anchors)
+            except Exception as e:
+                via_entry["mixed_sizes"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     train_dp = None
     if dist is not None and args.config in ("c2", "c4") and not args.no_train_dp:
@@ -1412,6 +1500,8 @@ def main():
             line["with_host_io"] = io
         if via_entry is not None:
             line["via_reference_entry"] = via_entry
+        if ranks_audit is not None:
+            line["ranks"] = ranks_audit
         if train_dp is not None:
             line["train_dp"] = train_dp
         if extra is not None:

@@ -347,6 +347,26 @@ class DetectionEntry:
         _, H, W, src, flip = pixels
         return (H, W) if src is None else (H, W) + src + (flip,)
 
+    def probe_geometry(self, image):
+        """``geometry(host_pixels(image))`` WITHOUT decoding the pixels (a file's header gives its size), or None when that cannot be
+        known cheaply.  get_dets_by_cls counts how often each geometry occurs in its list before it decides what to capture."""
+        if not (self.device_preprocess and hasattr(image, "raw_size") and hasattr(image, "height")):
+            return None
+        try:
+            size = image.raw_size()
+        except Exception:                                       # noqa: BLE001 -- an unreadable header: the decode will say what is wrong
+            return None
+        if size is None:
+            return None
+        H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
+        if tuple(size) == (H, W) and not flip:
+            return (H, W)
+        return (H, W, int(size[0]), int(size[1]), flip)
+
+    def has_geometry(self, key):
+        """A captured pass of this geometry (one image per pass, or the batched form) is already in the cache."""
+        return key in self.cache._slots or (key + (self.batch,)) in self.cache._slots
+
     def submit(self, image, resize_ratio, det_threshold=0.0, pixels=None):
         """``pixels``: the result of ``host_pixels(image)`` when the caller fetched it ahead of time."""
         return self.submit_batch([image], [resize_ratio], det_threshold, [self.host_pixels(image) if pixels is None else pixels], batch=1)

@@ -99,6 +99,15 @@ class Image:
         from PIL import Image as PilImage
         return np.ascontiguousarray(np.asarray(PilImage.open(self._image_path).convert("RGB"))[:, :, ::-1])
 
+    def raw_size(self):
+        """(height, width) of ``raw`` without decoding the pixels (PIL reads the header only)."""
+        if self._pixels is not None:
+            return int(self._pixels.shape[0]), int(self._pixels.shape[1])
+        from PIL import Image as PilImage
+        with PilImage.open(self._image_path) as im:
+            w, h = im.size
+        return int(h), int(w)
+
     @property
     def data(self):
         """BGR uint8 (height, width, 3) at the metadata's size, flipped if requested."""

@@ -102,41 +102,94 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
             dets = get_dets(training_manager, detector, image, resized_ratio, stride=stride, det_threshold=det_threshold)
             fold(image, dets, start_time)
         return dets_by_cls
-    window = collections.deque()
+    return _get_dets_by_cls_captured(eng, training_manager, detector, resized_ratios, images, stride, det_threshold, fold, dets_by_cls)
+
+
+# A list of mixed image sizes (voc_dets.py:91-111 walks whatever list it is given; shapes.py:106-123 gives every source size its own
+# resized geometry): a captured pass serves ONE geometry, and four images of one geometry share a pass.  Neighbours rarely share one,
+# so the images are held back per geometry -- at most REORDER_WINDOW of them, counted over all geometries -- until a geometry has a
+# full pass; results are folded into the dict in LIST order whatever order they were computed in.  A geometry that the list holds
+# fewer than CAPTURE_MIN times is not worth a capture (~80 ms and ~0.4-1.4 GB against ~7 ms for the eager sequence): those images take
+# the eager path (same detections up to the summation order of a few layers, tests/test_entry_gpu.py).
+REORDER_WINDOW = int(os.environ.get("FRCNN_ENTRY_REORDER", "64"))
+CAPTURE_MIN = int(os.environ.get("FRCNN_ENTRY_CAPTURE_MIN", "3"))
+
+
+def _get_dets_by_cls_captured(eng, training_manager, detector, resized_ratios, images, stride, det_threshold, fold, dets_by_cls):
+    from concurrent.futures import ThreadPoolExecutor
+    images, resized_ratios = list(images), list(resized_ratios)
+    n = min(len(images), len(resized_ratios))
+    # how often each geometry occurs in the list, from the images' headers (no pixel decode); unknown (a foreign image object): always capture
+    keys = [eng.probe_geometry(images[i]) for i in range(n)]
+    counts = collections.Counter(k for k in keys if k is not None)
+    unprobed = set(i for i in range(n) if keys[i] is None)
+
+    def worth_a_capture(pos):
+        k = keys[pos]
+        return pos in unprobed or counts[k] >= CAPTURE_MIN or eng.has_geometry(k)
+    window = collections.deque()                     # (positions, tickets) of passes in flight, oldest first
+    done = {}                                        # position -> (num_boxes or None, dets, start_time): computed, not yet folded
+    next_fold = 0
+
+    def fold_ready():
+        nonlocal next_fold
+        while next_fold in done:
+            num_boxes, dets, start_time = done.pop(next_fold)
+            if num_boxes is not None:
+                print("num rois: {}".format(num_boxes))
+            fold(images[next_fold], dets, start_time)
+            next_fold += 1
 
     def finish():
-        group, ticket = window[0]                            # (taken off the window only once collected: a failing collect leaves no
+        part, ticket = window[0]                             # (taken off the window only once collected: a failing collect leaves no
         try:                                                 #  ticket behind that nobody can see)
             results = eng.collect_batch(ticket)
         finally:
             window.popleft()
-        for (image, start_time), (num_boxes, dets) in zip(group, results):
-            print("num rois: {}".format(num_boxes))
-            fold(image, dets, start_time)
+        for (pos, start_time), (num_boxes, dets) in zip(part, results):
+            done[pos] = (num_boxes, dets, start_time)
+        fold_ready()
 
-    def flush(group):
-        """A run of neighbouring images of one geometry: whole batched passes where the engine has them (bf16 detector: eight images
-        per pass), single-image passes for what is left unless it fills at least half a batch."""
+    def flush(group, whole_only=False):
+        """Items (position, pixels, start_time) of ONE geometry: whole batched passes where the engine has them, single-image passes
+        for what is left unless it fills at least half a batch; with ``whole_only`` what does not fill a pass is handed back."""
         B = eng.batch
+        if group and not worth_a_capture(group[0][0]):
+            if whole_only:
+                return group
+            import contextlib
+            import io
+            for pos, pixels, start_time in group:            # a rare geometry: the eager sequence (the host waits for it; passes in flight keep running)
+                said = io.StringIO()
+                with contextlib.redirect_stdout(said):       # its "num rois" line is printed when the image's turn in the LIST comes
+                    dets = _get_dets_eager(training_manager, detector, images[pos], resized_ratios[pos], eng.num_rois, stride, det_threshold)
+                line = said.getvalue().strip().splitlines()
+                done[pos] = (line[0][len("num rois: "):] if line and line[0].startswith("num rois: ") else None, dets, start_time)
+            fold_ready()
+            return []
         while group:
-            take = B if (B > 1 and len(group) >= max(2, B // 2)) else 1
+            if B > 1 and len(group) >= B:
+                take = B
+            elif whole_only:
+                break
+            else:
+                take = B if (B > 1 and len(group) >= max(2, B // 2)) else 1
             part, group = group[:take], group[take:]
-            ticket = eng.submit_batch([g[0] for g in part], [g[1] for g in part], det_threshold, [g[2] for g in part], batch=B if take > 1 else 1)
-            window.append(([(g[0], g[3]) for g in part], ticket))
+            ticket = eng.submit_batch([images[g[0]] for g in part], [resized_ratios[g[0]] for g in part], det_threshold, [g[1] for g in part],
+                                      batch=B if take > 1 else 1)
+            window.append(([(g[0], g[2]) for g in part], ticket))
             if len(window) >= eng.in_flight:
                 finish()
+        return group
 
     # the pixels are fetched inline, as the reference does (shapes.py:19-29), until that proves slow (DECODE_INLINE_MS); from then on
-    # the NEXT images are fetched on a few threads while the GPU works (PIL's JPEG decode releases the GIL); results are consumed
-    # strictly in list order
-    from concurrent.futures import ThreadPoolExecutor
-    images, resized_ratios = list(images), list(resized_ratios)
-    n = min(len(images), len(resized_ratios))
+    # the NEXT images are fetched on a few threads while the GPU works (PIL's JPEG decode releases the GIL)
     ahead = 2 * eng.in_flight * eng.batch
     pool = None
     pending = {}
     slow_fetches = 0
-    group = []
+    buckets = collections.OrderedDict()              # geometry -> items held back, in list order; dict order = age of the oldest item
+    held = 0
     try:
         for i in range(n):
             if pool is not None:
@@ -151,17 +204,31 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
                 slow_fetches = slow_fetches + 1 if (timeit.default_timer() - start_time) * 1e3 > DECODE_INLINE_MS else 0
                 if slow_fetches >= 2 and pool is None and DECODE_THREADS > 0 and i + 1 < n and eng.prefetchable(images[i]):
                     pool = ThreadPoolExecutor(max_workers=DECODE_THREADS)       # (two slow fetches in a row: not a cold file cache)
-            if group and (eng.geometry(group[0][2]) != eng.geometry(pixels) or len(group) >= eng.batch):
-                flush(group)
-                group = []
-            group.append((images[i], resized_ratios[i], pixels, start_time))
-            if eng.batch == 1:
-                flush(group)
-                group = []
-        flush(group)
-        group = []
+            key = eng.geometry(pixels)
+            if keys[i] != key:                               # (the header said otherwise, or nothing: the decoded frame decides)
+                if keys[i] is not None:
+                    counts[keys[i]] -= 1
+                keys[i] = key
+                counts[key] += 1
+            bucket = buckets.setdefault(key, [])
+            bucket.append((i, pixels, start_time))
+            held += 1
+            if eng.batch == 1 or len(bucket) >= eng.batch:
+                held -= len(bucket)
+                rest = flush(buckets.pop(key), whole_only=eng.batch > 1)
+                if rest:
+                    buckets[key] = rest
+                    held += len(rest)
+            while held > REORDER_WINDOW:                     # the oldest geometry has waited long enough: its items go as they are
+                k0 = next(iter(buckets))
+                held -= len(buckets[k0])
+                flush(buckets.pop(k0))
+        for k0 in list(buckets):
+            flush(buckets.pop(k0))
         while window:
             finish()
+        fold_ready()
+        assert next_fold == n, "get_dets_by_cls: %d of %d images folded" % (next_fold, n)
     finally:
         if pool is not None:
             pool.shutdown(wait=True, cancel_futures=True)

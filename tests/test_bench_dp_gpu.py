@@ -104,6 +104,10 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and "replicas x2" in line["config"]["parallelism"]
     assert abs(line["value"] - 2 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 0.02 * line["value"]
+    # the self-audit of an N > 1 line: every rank seen, each rank's own rate, the value from the slowest
+    rk = line["ranks"]
+    assert rk["ranks_seen"] == 2 and len(rk["per_rank_img_s"]) == 2 and rk["slowest_over_fastest_seconds"] >= 1.0
+    assert abs(line["value"] - 2 * min(rk["per_rank_img_s"])) < 0.02 * line["value"]
     t = line["train_dp"]
     assert "error" not in t, t
     assert t["ranks_seen"] == 2 and t["backend"] == "gloo" and t["collectives_per_step"] == 1
@@ -163,3 +167,27 @@ def test_bench_multi_rank_path_over_real_rccl():
     assert t["backend"] == "nccl" and t["ranks_seen"] == 1 and abs(t["grad_payload_MB"] - 47.3) < 0.2
     assert t["allreduce_ms"] > 0 and t["ms_per_step"] > 0 and t["exposed_allreduce_ms"] >= 0
     _check_det_leg(t["det_step2"], ranks=1, backend="nccl")
+
+
+def test_one_rank_through_the_multi_rank_path_measures_what_the_plain_run_measures():
+    """the N = 1 value taken THROUGH the multi-rank code path (process group over RCCL, barriers, gathered per-rank
+    clocks; FRCNN_BENCH_FORCE_DIST=1) is the plain N = 1 value to within 2 % -- the distributed bracket adds nothing to the timed
+    region -- and the line audits itself: one rank seen, its own rate equal to the value."""
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FRCNN_BENCH_BACKEND", "FRCNN_BENCH_FORCE_DIST")}
+    flags = [sys.executable, "bench.py", "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-io", "--no-extra", "--no-train-dp"]
+
+    def run(force):
+        env = dict(base, FRCNN_BENCH_NO_NATIVE="1", FRCNN_BENCH_NO_ENTRY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if force:
+            env.update(FRCNN_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        r = subprocess.run(flags, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+
+    plain, forced = run(False), run(True)
+    rk = forced["ranks"]
+    assert "ranks" not in plain and rk["ranks_seen"] == 1 and abs(rk["per_rank_img_s"][0] - forced["value"]) < 0.005 * forced["value"]
+    best_plain, best_forced = plain["value"], forced["value"]
+    if abs(best_forced - best_plain) > 0.02 * best_plain:         # one more pair before calling it a difference (box noise is ~1 %)
+        best_plain, best_forced = max(best_plain, run(False)["value"]), max(best_forced, run(True)["value"])
+    assert abs(best_forced - best_plain) <= 0.02 * best_plain, (best_plain, best_forced)

@@ -71,8 +71,16 @@ class _FakeEngine:
         self.submitted, self.fetch_threads, self.open_tickets = [], set(), 0
         self.max_open = 0
 
+    num_rois = 64
+
     def prefetchable(self, image):
         return True
+
+    def probe_geometry(self, image):
+        return tuple(image.size) if getattr(self, "probe", True) else None
+
+    def has_geometry(self, key):
+        return key in getattr(self, "cached", ())
 
     def host_pixels(self, image):
         import threading
@@ -114,22 +122,60 @@ def _run_by_cls(monkeypatch, eng, sizes, **kw):
     return images, ratios, dets, buf.getvalue()
 
 
-def test_get_dets_by_cls_groups_runs_of_one_geometry_into_batched_passes(monkeypatch):
-    """Batched passes for runs of equal geometry (whole batches, a padded pass when the rest fills at least half a batch, single
-    passes otherwise), never more tickets open than the engine's depth, results folded in list order, the reference's lines."""
+def test_get_dets_by_cls_gathers_one_geometry_into_batched_passes(monkeypatch):
+    """Images of one geometry share batched passes even when they are NOT neighbours in the list (round 6: they are held back per
+    geometry, at most voc_dets.REORDER_WINDOW of them); a padded pass when the rest fills at least half a batch, single passes
+    otherwise; never more tickets open than the engine's depth; results folded in LIST order, the reference's lines."""
     A, B = (600, 1500), (600, 1400)
     sizes = [A] * 13 + [B] * 2 + [A] * 3 + [B] * 9
     eng = _FakeEngine(batch=8, in_flight=2)
     images, ratios, dets, out = _run_by_cls(monkeypatch, eng, sizes)
     shape = [(b, len(names)) for b, names, _ in eng.submitted]
-    assert shape == [(8, 8), (8, 5), (1, 1), (1, 1), (1, 1), (1, 1), (1, 1), (8, 8), (1, 1)], shape
-    assert [n for _, names, _ in eng.submitted for n in names] == [im.name for im in images]
-    assert [r for _, _, rs_ in eng.submitted for r in rs_] == ratios
+    assert shape == [(8, 8), (8, 8), (8, 8), (1, 1), (1, 1), (1, 1)], shape
+    by_name = {im.name: (im.size, r) for im, r in zip(images, ratios)}
+    for _, names, rs_ in eng.submitted:
+        assert len({by_name[n][0] for n in names}) == 1                    # one pass, one geometry
+        assert [by_name[n][1] for n in names] == rs_                       # each image with ITS ratio
+    assert sorted(n for _, names, _ in eng.submitted for n in names) == sorted(im.name for im in images)
+    assert eng.submitted[1][1] == ["im%02d" % i for i in (8, 9, 10, 11, 12, 15, 16, 17)]       # the A's on either side of the two B's
     assert eng.max_open <= 2 and eng.open_tickets == 0
     lines = [ln.split(" ran in ")[0] for ln in out.splitlines()]
-    assert lines == [x for im in images for x in ("num rois: 300", "image %s" % im.name)]
+    assert lines == [x for im in images for x in ("num rois: 300", "image %s" % im.name)]      # list order, whatever order they ran in
     assert set(dets) == {"person", "car"} and sum(len(v) for c in dets.values() for v in c.values()) == len(images)
     assert eng.fetch_threads == {__import__("threading").current_thread().name}      # fast fetches stay inline
+
+
+def test_get_dets_by_cls_rare_geometries_run_eagerly_and_the_window_is_bounded(monkeypatch):
+    """A geometry the list holds fewer than CAPTURE_MIN times is not captured: its images take the eager sequence (unless a pass of
+    that geometry is cached already, or the image's geometry could not be probed).  The window bounds how many images wait."""
+    from faster_rcnn_amd import voc_dets
+    eager = []
+    monkeypatch.setattr(voc_dets, "_get_dets_eager", lambda mgr, det, image, ratio, num_rois, stride, thr: (eager.append((image.name, ratio)) or print("num rois: 300") or
+                                                                                                      [{"bbox": [0, 0, 1, 1], "cls_name": "dog", "prob": 0.9}]))
+    monkeypatch.setattr(voc_dets, "CAPTURE_MIN", 3)
+    A, B, C, D = (600, 800), (600, 901), (600, 898), (500, 600)
+    sizes = [A, B, A, C, A, D, A, C, A, B, A, A, A]                        # A x8, B x2, C x2, D x1
+    eng = _FakeEngine(batch=4, in_flight=2)
+    eng.cached = {C}                                                       # a pass of C exists already: C is served from it
+    images, ratios, dets, out = _run_by_cls(monkeypatch, eng, sizes)
+    assert sorted(n for n, _ in eager) == ["im01", "im05", "im09"]         # the two B's and the D
+    assert all(ratios[int(n[2:])] == r for n, r in eager)
+    shape = [(b, names) for b, names, _ in eng.submitted]
+    assert (4, ["im00", "im02", "im04", "im06"]) in shape and (4, ["im08", "im10", "im11", "im12"]) in shape
+    assert (4, ["im03", "im07"]) in shape                                  # C: two of them = half a batch of four: one padded pass
+    lines = [ln.split(" ran in ")[0] for ln in out.splitlines()]
+    assert lines == [x for im in images for x in ("num rois: 300", "image %s" % im.name)]
+    assert sum(len(v) for c in dets.values() for v in c.values()) == len(images)
+    # an engine that cannot probe captures as before (every geometry), and a small window flushes the oldest geometry early
+    eager.clear()
+    eng2 = _FakeEngine(batch=4, in_flight=2)
+    eng2.probe = False
+    monkeypatch.setattr(voc_dets, "REORDER_WINDOW", 3)
+    images, ratios, dets, out = _run_by_cls(monkeypatch, eng2, [A, B, C, D, A, B, C, D])
+    assert not eager and sorted(n for _, names, _ in eng2.submitted for n in names) == sorted(im.name for im in images)
+    assert eng2.submitted[0][1] == ["im00"]                                # four waiting > window of three: the oldest geometry goes alone
+    lines = [ln.split(" ran in ")[0] for ln in out.splitlines()]
+    assert lines == [x for im in images for x in ("num rois: 300", "image %s" % im.name)]
 
 
 def test_get_dets_by_cls_single_image_engine_and_slow_fetches(monkeypatch):
