@@ -74,6 +74,9 @@ def default_batch(dtype="f32"):
 # kept proposals only (300 rows instead of 320: 6 % less detector-head work); FRCNN_ENTRY_PAD=1 scores the padded list as the eager
 # path does.  tests/test_entry_gpu.py compares the two paths detection by detection.
 PAD_TO_BATCH = os.environ.get("FRCNN_ENTRY_PAD", "0") != "0"
+# eager passes in front of a capture: ONE sizes the split-K workspace, lowers what is lowered lazily and leaves the magnitude-record
+# arena's high-water mark (round 6: two until then; a capture is ~2/3 warm-up, and a list of mixed sizes captures per geometry)
+WARMUP_PASSES = max(1, int(os.environ.get("FRCNN_ENTRY_WARMUP", "1")))
 
 
 class _Slot:
@@ -291,7 +294,7 @@ class DetectionEntry:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine), ops.amax_arena(s.amax):
-            for _ in range(2):
+            for _ in range(WARMUP_PASSES):
                 run()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
