@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfrcnn_hip.so")
+# (FRCNN_LIB_PATH: another BUILD of this same library -- A/B runs of two kernel versions on one box; there is still no CPU fallback)
+LIB_PATH = os.environ.get("FRCNN_LIB_PATH") or os.path.join(HERE, "libfrcnn_hip.so")
 
 
 class FrcnnError(RuntimeError):
