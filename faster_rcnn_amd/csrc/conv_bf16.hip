@@ -3,12 +3,12 @@
 // Same implicit-GEMM structure as conv_igemm.hip's v2 kernel -- NHWC activations, filters packed
 // [Cout][Kpad] with k = [channel chunk][tap][channel], SRD buffer loads with out-of-range -> 0 for the
 // halo and the tile tails, two-deep global->register->LDS operand pipeline, XCD-aware tile map, fused
-// scale/shift/residual/activation epilogue -- with bf16 operands on v_mfma_f32_16x16x32_bf16 (round 6; f32
+// scale/shift/residual/activation epilogue -- with bf16 operands on v_mfma_f32_32x32x16_bf16 (f32
 // accumulate, 16x the f32-input MFMA rate):
 //   * a k-chunk is 64 channels = 128 B per row, so the 16-byte staging pattern (8 lanes per row, 32 rows
 //     per pass) and the 144-byte padded LDS rows are IDENTICAL to the f32 kernel;
-//   * lane (r = lane & 15, g = lane >> 4) feeds the MFMA of k-step s (32 channels) with the 8 bf16 at byte offset 64*s + 16*g of
-//     row r of a 16-row half (A[r][8g+j], B[8g+j][r]) -- one ds_read_b128 per 16-row operand half per k-step;
+//   * lane (i, h) feeds MFMA k-step s with the 8 bf16 at byte offset 32*s + 16*h of row i
+//     (A[i][8h+j], B[8h+j][i], cdna guide s3) -- one ds_read_b128 per operand tile per MFMA;
 //   * activations stay bf16 in HBM between layers (half the bytes); the epilogue rounds once (RNE,
 //     v_cvt_pk_bf16_f32) after the f32 scale/shift/residual/activation.
 // At these shapes the kernel is operand-bandwidth bound, not MFMA bound: a 128x128x64 step needs
@@ -53,29 +53,6 @@ __device__ unsigned long long* g_lab_stamps_b = nullptr;
 #endif
 constexpr int SG_VALU = 0x2, SG_MFMA = 0x8, SG_VMEM_RD = 0x20, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
 
-// The matrix instruction: v_mfma_f32_16x16x32_bf16 in EVERY launch form (round 6; v_mfma_f32_32x32x16_bf16 until then).  One
-// instruction spans a 32-deep half of the 64-channel chunk of a 16x16 block; a wave's 32x32 tile is four of them.  Same products, same
-// LDS bytes, same matrix-pipe cycles as the 32x32x16 form, but under load the chip holds a higher clock on this shape
-// (MI355X_MICROARCH.md 'DVFS give-back'; conv_h3.hip took the same step in round 5).  All forms use the SAME shape and the same k order,
-// so a layer's result does not depend on the tile that computed it (the cross-tile bitwise tests hold).
-// Fragments: lane (r = lane & 15, g = lane >> 4) holds the 8 bf16 at bytes 64 s + 16 g of row r of a 16-row half for k-step s (0 / 1).
-// Accumulator element e of a 32x32 tile: 16x16 block e >> 2 = 2 * (row half) + (column half); col = lane & 15, row = 4 g + (e & 3).
-__device__ __forceinline__ int acc_row(int e, int lane) { return (e >> 3) * 16 + 4 * (lane >> 4) + (e & 3); }
-__device__ __forceinline__ int acc_col(int e, int lane) { return ((e >> 2) & 1) * 16 + (lane & 15); }
-// one 32-deep k-step of a wave's TM x TN tiles of 32x32: fa[i][ri] / fb[j][ci] are the fragments of the 16-row halves
-template <int TM, int TN>
-__device__ __forceinline__ void mma_step(f32x4 (&s)[TM][TN][4], const bf16x8 (&fa)[TM][2], const bf16x8 (&fb)[TN][2]) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int ri = 0; ri < 2; ++ri)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci)
-                    s[i][j][ri * 2 + ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ri], fb[j][ci], s[i][j][ri * 2 + ci], 0, 0, 0);
-}
-
 __device__ __forceinline__ int xcd_remap_b(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -108,6 +85,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
     LAB_STAMP_B(0);
 
     const int splits = SPLITK ? p.splits : 1;
@@ -214,14 +192,13 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         for (int i = 0; i < PB; ++i) *reinterpret_cast<i32x4*>(b + (lrow + RPP * i) * LDS_STRIDE_B + lcolb) = xb[i];
     };
 
-    f32x4 sacc[TM][TN][4];                               // the accumulators as 16x16 blocks: element e of a tile's 16 = sacc[..][e >> 2][e & 3]
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sacc[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    const int r15 = lane & 15, g4 = lane >> 4;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     // Round 3: the residual pieces this lane adds in the epilogue are requested HERE, before the main loop (the f32 kernel's
     // EPI_PRE).  The short-k, wide-output layers -- every block's 2c: 256 -> 1024 over 28 576 rows of a batch of eight
@@ -310,33 +287,24 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(a + i * RPP * LSTR), 16, a_v[i], 0, 0, 0);
 #endif
         };
-        const int arow = wm * TM * 32 + r15, brow = wn * TN * 32 + r15;
-        const int sw = (r15 >> 1) & 7;                            // (row >> 1) & 7 of every fragment row of this lane (halves are 16 rows apart: + 8, gone under & 7)
+        const int arow = wm * TM * 32 + li, brow = wn * TN * 32 + li;
+        const int sw = (li >> 1) & 7;                             // (row >> 1) & 7 of every fragment row of this lane (tiles are 32 rows apart)
         auto multiply = [&](int buf) {
             const char* a = As + buf * BM * LSTR + arow * LSTR;
             const char* b = Bs + buf * BN * LSTR + brow * LSTR;
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const int slot = ((4 * st + g4) ^ sw) * 16;
-                // (the B fragments of the k-step stay, the A fragments come one 32-row tile at a time: the 256x256 tile's 128 accumulator
-                //  registers leave room for 16 + 8 fragment registers, as the 32x32x16 form had, not for all 48 at once)
-                bf16x8 fb[TN][2];
+            for (int st = 0; st < 4; ++st) {
+                const int slot = ((2 * st + lh) ^ sw) * 16;
+                bf16x8 fa[TM], fb[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LSTR + slot);
 #pragma unroll
-                    for (int ci = 0; ci < 2; ++ci) fb[j][ci] = *reinterpret_cast<const bf16x8*>(b + (j * 32 + ci * 16) * LSTR + slot);
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LSTR + slot);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(a + (i * 32) * LSTR + slot);
-                    const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(a + (i * 32 + 16) * LSTR + slot);
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int ci = 0; ci < 2; ++ci) {
-                            sacc[i][j][ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[j][ci], sacc[i][j][ci], 0, 0, 0);
-                            sacc[i][j][2 + ci] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb[j][ci], sacc[i][j][2 + ci], 0, 0, 0);
-                        }
-                }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         };
         if constexpr (VARIANT == 4) {
@@ -387,7 +355,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         // barrier sits between them and k-steps 2,3, and the stores of chunk T+2, the reads of chunk T+1's step 0 and the
         // global loads of chunk T+4 (two staging register sets) ride behind it.  Same k order: bit-identical results.
         i32x4 sa0[PA], sb0[PB], sa1[PA], sb1[PB];
-        bf16x8 na[TM][2], nb[TN][2];                             // the NEXT chunk's k-step 0 fragments
+        bf16x8 na[TM], nb[TN];
         load_into(sa0, sb0);
         load_into(sa1, sb1);
         store_from(sa0, sb0, 0);
@@ -395,41 +363,64 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         store_from(sa1, sb1, 1);
         load_into(sa1, sb1);
         __syncthreads();
-        auto frags = [&](const char* a, const char* b, int st, bf16x8 (&fa)[TM][2], bf16x8 (&fb)[TN][2]) {
+        {
+            const char* a = As + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
+            const char* b = Bs + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) na[i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_STRIDE_B);
 #pragma unroll
-                for (int ri = 0; ri < 2; ++ri) fa[i][ri] = *reinterpret_cast<const bf16x8*>(a + (i * 32 + ri * 16) * LDS_STRIDE_B + st * 64);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci) fb[j][ci] = *reinterpret_cast<const bf16x8*>(b + (j * 32 + ci * 16) * LDS_STRIDE_B + st * 64);
-        };
-        frags(As + (wm * TM * 32 + r15) * LDS_STRIDE_B + g4 * 16, Bs + (wn * TN * 32 + r15) * LDS_STRIDE_B + g4 * 16, 0, na, nb);
+            for (int j = 0; j < TN; ++j) nb[j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_STRIDE_B);
+        }
         auto chunk = [&](auto parity, auto& xa, auto& xb) {
             constexpr int P = decltype(parity)::value;
-            const char* a = As + P * BM * LDS_STRIDE_B + (wm * TM * 32 + r15) * LDS_STRIDE_B + g4 * 16;
-            const char* b = Bs + P * BN * LDS_STRIDE_B + (wn * TN * 32 + r15) * LDS_STRIDE_B + g4 * 16;
-            const char* an = As + (P ^ 1) * BM * LDS_STRIDE_B + (wm * TM * 32 + r15) * LDS_STRIDE_B + g4 * 16;
-            const char* bn = Bs + (P ^ 1) * BN * LDS_STRIDE_B + (wn * TN * 32 + r15) * LDS_STRIDE_B + g4 * 16;
-            bf16x8 fa1[TM][2], fb1[TN][2];
-            frags(a, b, 1, fa1, fb1);                                // k-step 1 of this chunk, read behind k-step 0's MFMAs
-            mma_step<TM, TN>(sacc, na, nb);                          // k-step 0: fragments read during the previous chunk
+            const char* a = As + P * BM * LDS_STRIDE_B + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
+            const char* b = Bs + P * BN * LDS_STRIDE_B + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
+            const char* an = As + (P ^ 1) * BM * LDS_STRIDE_B + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
+            const char* bn = Bs + (P ^ 1) * BN * LDS_STRIDE_B + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
+            bf16x8 fa[4][TM], fb[4][TN];
 #pragma unroll
-            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 2); SGB(SG_DS_RD, (2 * NF + MF - 1) / MF); }
+            for (int i = 0; i < TM; ++i) fa[0][i] = na[i];
 #pragma unroll
-            for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 2);
+            for (int j = 0; j < TN; ++j) fb[0][j] = nb[j];
+#pragma unroll
+            for (int st = 1; st < 4; ++st) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[st][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_STRIDE_B + st * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[st][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_STRIDE_B + st * 32);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][i], fb[st][j], acc[i][j], 0, 0, 0);
+            SGB(SG_DS_RD, NF);                                       // step-1 fragments first
+#pragma unroll
+            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_DS_RD, (2 * NF + MF - 1) / MF); }      // k-step 0: steps 2,3 fragments
+#pragma unroll
+            for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);            // k-step 1
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             store_from(xa, xb, P);                                   // chunk T+2 -> the buffer every wave has just finished reading
             load_into(xa, xb);                                       // chunk T+4
-            frags(an, bn, 0, na, nb);
-            mma_step<TM, TN>(sacc, fa1, fb1);                        // k-step 1
 #pragma unroll
-            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 2); SGB(SG_DS_WR, (NL + MF - 1) / MF); }             // first half: LDS stores
-            SGB(SG_DS_RD, 2 * NF);
+            for (int i = 0; i < TM; ++i) na[i] = *reinterpret_cast<const bf16x8*>(an + i * 32 * LDS_STRIDE_B);
 #pragma unroll
-            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 2); SGB(SG_VALU, 6); SGB(SG_VMEM_RD, (NL + MF - 1) / MF); }   // second half: global loads
+            for (int j = 0; j < TN; ++j) nb[j] = *reinterpret_cast<const bf16x8*>(bn + j * 32 * LDS_STRIDE_B);
+#pragma unroll
+            for (int st = 2; st < 4; ++st)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][i], fb[st][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_DS_WR, (NL + MF - 1) / MF); }             // k-step 2: LDS stores
+            SGB(SG_DS_RD, NF);
+#pragma unroll
+            for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_VALU, 6); SGB(SG_VMEM_RD, (NL + MF - 1) / MF); }   // k-step 3: global loads
         };
         int kc = kb;
         for (; kc + 1 < ke; kc += 2) {
@@ -451,35 +442,37 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
         const int buf = (kc - kb) & 1;
         store_chunk(buf ^ 1);
         load_chunk(kc + 2 < ke ? kc + 2 : ke - 1);
-        const char* a = As + buf * BM * LDS_STRIDE_B + (wm * TM * 32 + r15) * LDS_STRIDE_B + g4 * 16;
-        const char* b = Bs + buf * BN * LDS_STRIDE_B + (wn * TN * 32 + r15) * LDS_STRIDE_B + g4 * 16;
-        bf16x8 fa[2][TM][2], fb[2][TN][2];
+        const char* a = As + buf * BM * LDS_STRIDE_B + (wm * TM * 32 + li) * LDS_STRIDE_B + lh * 16;
+        const char* b = Bs + buf * BN * LDS_STRIDE_B + (wn * TN * 32 + li) * LDS_STRIDE_B + lh * 16;
+        bf16x8 fa[4][TM], fb[4][TN];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * LDS_STRIDE_B + s * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(b + j * 32 * LDS_STRIDE_B + s * 32);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int ri = 0; ri < 2; ++ri) fa[s][i][ri] = *reinterpret_cast<const bf16x8*>(a + (i * 32 + ri * 16) * LDS_STRIDE_B + s * 64);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+        // interleave: fragments for step s+1 and the staging traffic ride behind step s's MFMAs
+        SGB(SG_DS_RD, NF);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_DS_WR, (NL + MF - 1) / MF); if (q < NF) SGB(SG_DS_RD, 1); }
 #pragma unroll
-                for (int ci = 0; ci < 2; ++ci) fb[s][j][ci] = *reinterpret_cast<const bf16x8*>(b + (j * 32 + ci * 16) * LDS_STRIDE_B + s * 64);
-        }
-        mma_step<TM, TN>(sacc, fa[0], fb[0]);
-        mma_step<TM, TN>(sacc, fa[1], fb[1]);
-        // interleave: the fragments of k-step 1 and the staging traffic ride behind k-step 0's MFMAs
-        SGB(SG_DS_RD, 2 * NF);
+        for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); SGB(SG_VALU, 6); SGB(SG_VMEM_RD, (NL + MF - 1) / MF); if (q < NF) SGB(SG_DS_RD, 1); }
 #pragma unroll
-        for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 2); SGB(SG_DS_WR, (NL + MF - 1) / MF); if (q < NF) SGB(SG_DS_RD, 1); }
+        for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 1); if (q < NF) SGB(SG_DS_RD, 1); }
 #pragma unroll
-        for (int q = 0; q < MF; ++q) { SGB(SG_MFMA, 2); SGB(SG_VALU, 6); SGB(SG_VMEM_RD, (NL + MF - 1) / MF); if (q < NF) SGB(SG_DS_RD, 1); }
-#pragma unroll
-        for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 2);
-#pragma unroll
-        for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 2);
+        for (int q = 0; q < MF; ++q) SGB(SG_MFMA, 1);
         __syncthreads();
     }
     }
+
     if constexpr (SPLITK) {
         // write-through partial tile -> ticket -> the last arriver sums the slices in order (conv_igemm.hip)
         const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -491,7 +484,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {sacc[i][j][q][0], sacc[i][j][q][1], sacc[i][j][q][2], sacc[i][j][q][3]};
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), srsrc,
                                                            slab_off + ((i * TN + j) * 4 + q) * (NT * 16), 0, 16 /* sc1 */);
                 }
@@ -518,7 +511,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[i][j][e >> 2][e & 3] = 0.0f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
         for (int sl = 0; sl < splits; ++sl) {
             const float4* sp = base + (size_t)sl * (BM * BN / 4);
 #pragma unroll
@@ -528,31 +521,26 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float4 v = sp[((i * TN + j) * 4 + q) * NT + tid];
-                        sacc[i][j][q][0] += v.x; sacc[i][j][q][1] += v.y; sacc[i][j][q][2] += v.z; sacc[i][j][q][3] += v.w;
+                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
                     }
         }
     }
 
-    // epilogue: C/D map of element e: acc_row / acc_col (16x16 block e >> 2, col = lane & 15, row = 4 (lane >> 4) + (e & 3))
+    // epilogue: C/D map col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     LAB_STAMP_B(2);
     if constexpr (EPI_ROWS) {
         if (p.epi_rows) {
             float* stg = reinterpret_cast<float*>(smem_b);               // [BM][BN] f32, unpadded (see the read order below)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int ncl = wn * TN * 32 + j * 32 + r15;                 // this lane's column of the left 16x16 blocks; the right ones: + 16
-                float sc[2], sh[2];
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci) {
-                    const int nc = n0 + ncl + 16 * ci;
-                    sc[ci] = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
-                    sh[ci] = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
-                }
+                const int ncl = wn * TN * 32 + j * 32 + li, nc = n0 + ncl;
+                const float sc = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
+                const float sh = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    float* dst = stg + (wm * TM * 32 + i * 32 + 4 * g4) * BN + ncl;
+                    float* dst = stg + (wm * TM * 32 + i * 32 + 4 * lh) * BN + ncl;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) dst[((e >> 3) * 16 + (e & 3)) * BN + ((e >> 2) & 1) * 16] = sacc[i][j][e >> 2][e & 3] * sc[(e >> 2) & 1] + sh[(e >> 2) & 1];
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[i][j][e] * sc + sh;
                 }
             }
             __syncthreads();
@@ -621,20 +609,16 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nt = n0 + wn * TN * 32 + j * 32;
-            float sc[2], sh[2];
-#pragma unroll
-            for (int ci = 0; ci < 2; ++ci) {
-                const int nc = nt + 16 * ci + r15;
-                sc[ci] = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
-                sh[ci] = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
-            }
+            const int nc = nt + li;
+            const float sc = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
+            const float sh = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
             const int n = nt + r_col;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int mt = m0 + wm * TM * 32 + i * 32;
 #pragma unroll
-                for (int e = 0; e < 16; ++e)        // (lane part + a compile-time offset: acc_row / acc_col of element e)
-                    stg[(4 * g4) * 36 + r15 + ((e >> 3) * 16 + (e & 3)) * 36 + ((e >> 2) & 1) * 16] = sacc[i][j][e >> 2][e & 3] * sc[(e >> 2) & 1] + sh[(e >> 2) & 1];
+                for (int e = 0; e < 16; ++e)
+                    stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * 36 + li] = acc[i][j][e] * sc + sh;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int row = half * 16 + r_row, m = mt + row;
@@ -681,29 +665,20 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_bf16(const ConvArgs
 #endif
         return;
     }
-    // (cout % 8 != 0: element by element; a lane owns two columns of a 32x32 tile, 16 apart)
-#pragma unroll 1
-    for (int jc = 0; jc < 2 * TN; ++jc) {
-        const int j = jc >> 1, ci = jc & 1;
-        const int n = n0 + wn * TN * 32 + j * 32 + ci * 16 + r15;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + li;
         if (n >= p.Cout) continue;
         const float sc = p.scale ? p.scale[n] : 1.0f;
         const float sh = p.shift ? p.shift[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * g4;
+            const int mb = m0 + wm * TM * 32 + i * 32 + 4 * lh;
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {                    // the lane's eight rows of this column: 16-row half h >> 2, row 4 g + (h & 3)
-                const int m = mb + (h >> 2) * 16 + (h & 3);
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
                 if (m < p.M) {
-                    // (jc is a run-time index here: the cold path trades speed for registers)
-                    float v = 0.0f;
-#pragma unroll
-                    for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-                        for (int cc = 0; cc < 2; ++cc)
-                            if (jj == j && cc == ci) v = sacc[i][jj][(h >> 2) * 2 + cc][h & 3];
-                    v = v * sc + sh;
+                    float v = acc[i][j][e] * sc + sh;
                     if (p.residual) v += (float)p.residual[(size_t)m * p.Cout + n];
                     if constexpr (MASKED) { if (!((float)p.mask[(size_t)m * p.Cout + n] > 0.0f)) v = 0.0f; }
                     v = activate_b(v, p.act);
@@ -742,7 +717,7 @@ __global__ void __launch_bounds__(512) k_gemm_strip_bf16(const ConvArgsBf16 p) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave >> 2, wn = wave & 3, li = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM;
     const int nk = p.Kpad / BKH, tiles_n = (p.Cout + BN - 1) / BN, T = nk * tiles_n;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.x), 0, (int)((size_t)p.M * p.Cin * 2), 0x00020000);
@@ -793,51 +768,42 @@ __global__ void __launch_bounds__(512) k_gemm_strip_bf16(const ConvArgsBf16 p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int r15 = lane & 15, g4 = lane >> 4;
-    const int arow = wm * TM * 32 + r15, brow = wn * 32 + r15, sw = (r15 >> 1) & 7;
+    const int arow = wm * TM * 32 + li, brow = wn * 32 + li, sw = (li >> 1) & 7;
     const int prow = tid / PPR, pcol = (tid % PPR) * 8, swap = (tid % PPR) & 8 ? 4 : 0;
     int t = 0;
     for (int j = 0; j < tiles_n; ++j) {
-        f32x4 sacc[TM][1][4];
+        f32x16 acc[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sacc[i][0][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
         for (int c = 0; c < nk; ++c, ++t) {
             if (t + 1 < T) issue_w(t + 1);                 // into the buffer chunk t - 1 was read from: everyone passed the last barrier
             if (c == 0 && j > 0 && pre) issue_res(j);
             const char* a = Al + c * BM * LSTR + arow * LSTR;
             const char* b = Wl + (t & 1) * BN * LSTR + brow * LSTR;
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const int slot = ((4 * st + g4) ^ sw) * 16;
-                bf16x8 fa[TM][2], fb[1][2];
+            for (int st = 0; st < 4; ++st) {
+                const int slot = ((2 * st + lh) ^ sw) * 16;
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(b + slot);
 #pragma unroll
-                for (int ci = 0; ci < 2; ++ci) fb[0][ci] = *reinterpret_cast<const bf16x8*>(b + ci * 16 * LSTR + slot);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int ri = 0; ri < 2; ++ri) fa[i][ri] = *reinterpret_cast<const bf16x8*>(a + (i * 32 + ri * 16) * LSTR + slot);
-                mma_step<TM, 1>(sacc, fa, fb);
+                for (int i = 0; i < TM; ++i) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(a + i * 32 * LSTR + slot);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+                }
             }
             const bool last = c == nk - 1;
             if (last) {
                 // ---- epilogue of column tile j (the row-piece form of k_conv_igemm_bf16): scale / shift per column in the
                 // accumulator layout -> f32 tile in LDS -> 16-byte pieces of whole rows + residual + activation -> bf16
-                const int n0 = j * BN, ncl = wn * 32 + r15;
-                float sc[2], sh[2];
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci) {
-                    const int nc = n0 + ncl + 16 * ci;
-                    sc[ci] = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
-                    sh[ci] = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
-                }
+                const int n0 = j * BN, ncl = wn * 32 + li, nc = n0 + ncl;
+                const float sc = (p.scale && nc < p.Cout) ? p.scale[nc] : 1.0f;
+                const float sh = (p.shift && nc < p.Cout) ? p.shift[nc] : 0.0f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    float* dst = stg + (wm * TM * 32 + i * 32 + 4 * g4) * BN + ncl;
+                    float* dst = stg + (wm * TM * 32 + i * 32 + 4 * lh) * BN + ncl;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        dst[((e >> 3) * 16 + (e & 3)) * BN + ((e >> 2) & 1) * 16] = sacc[i][0][e >> 2][e & 3] * sc[(e >> 2) & 1] + sh[(e >> 2) & 1];
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[i][e] * sc + sh;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
