@@ -79,10 +79,56 @@ PAD_TO_BATCH = os.environ.get("FRCNN_ENTRY_PAD", "0") != "0"
 WARMUP_PASSES = max(1, int(os.environ.get("FRCNN_ENTRY_WARMUP", "1")))
 
 
+class _PinnedArena:
+    """Pinned host memory for the captured passes' staging, handed out in 4 KB-aligned pieces from a few large blocks: a capture
+    took two hipHostMalloc calls (frame staging, detection read-back), several milliseconds each, and a list of mixed image sizes
+    captures per geometry.  Pieces are not returned one by one: a block goes back when every slot cut from it has been closed."""
+    BLOCK = 64 << 20
+
+    def __init__(self):
+        self.blocks = []                                 # [tensor, used bytes, live pieces]
+
+    def take(self, nbytes, zero=False):
+        nbytes = max(int(nbytes), 16)
+        need = (nbytes + 4095) // 4096 * 4096
+        for blk in self.blocks:
+            if blk[0].numel() - blk[1] >= need:
+                break
+        else:
+            blk = [torch.empty(max(self.BLOCK, need), dtype=torch.uint8).pin_memory(), 0, 0]
+            self.blocks.append(blk)
+        piece = blk[0][blk[1]:blk[1] + nbytes]
+        blk[1] += need
+        blk[2] += 1
+        if zero:
+            piece.zero_()
+        piece._arena_block = blk
+        return piece
+
+    def give_back(self, piece):
+        blk = getattr(piece, "_arena_block", None)
+        if blk is None:
+            return
+        blk[2] -= 1
+        if blk[2] == 0:
+            blk[1] = 0                                   # every piece of the block is gone: the block starts over
+
+
+_PINNED = _PinnedArena()
+_CAPTURE_STREAM = None
+
+
+def _capture_stream():
+    global _CAPTURE_STREAM
+    if _CAPTURE_STREAM is None:
+        _CAPTURE_STREAM = torch.cuda.Stream()
+    return _CAPTURE_STREAM
+
+
 class _Slot:
     """One captured pass for one image size, with its staging on both sides of PCIe."""
     __slots__ = ("key", "pipe", "graph", "out", "io_dev", "io_pin", "pix_host", "dyn_host", "out_pin", "event", "busy", "nbytes",
-                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed", "amax")
+                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed", "amax", "_out_raw", "ready")
 
 
 def _close_slot(s):
@@ -90,12 +136,18 @@ def _close_slot(s):
     references to its tensors are dropped, so that nothing is left for a garbage-collector finalizer to do later from whatever thread
     happens to collect (a finalizer issuing HIP calls inside another capture crashed a launch).  Idle slots only."""
     assert not s.busy, "closing a captured pass with an image in flight"
+    if getattr(s, "ready", None) is not None:
+        s.ready.synchronize()                            # (never replayed: its warm-up pass may still be writing the slot's buffers)
     if getattr(s, "graph", None) is not None:
         s.event.synchronize()                            # its last replay (and the copies behind it) are done
         s.graph.reset()
     if getattr(s, "pipe", None) is not None and hasattr(s.pipe, "close"):
         s.pipe.close()
-    for name in ("graph", "out", "out_packed", "io_dev", "x_f32", "u8_resized", "tabs", "ws", "amax", "pipe"):
+    for name in ("io_pin", "_out_raw"):
+        piece = getattr(s, name, None)
+        if piece is not None:
+            _PINNED.give_back(piece)
+    for name in ("graph", "out", "out_packed", "io_dev", "x_f32", "u8_resized", "tabs", "ws", "amax", "pipe", "io_pin", "_out_raw", "out_pin", "pix_hosts", "pix_host", "dyn_host"):
         setattr(s, name, None)
 
 
@@ -225,7 +277,8 @@ class DetectionEntry:
         # finalizers of unrelated dead objects -- another engine's captured passes, their private memory pools -- whose HIP calls
         # are not legal in a capturing thread (seen as a crash inside a launch when a test's models died just before).
         gc_was_on = gc.isenabled()
-        gc.collect()
+        from .pipeline import collect_before_capture
+        collect_before_capture()                                    # (at most one full collection per second: it costs more than the capture)
         gc.disable()
         try:
             return self._capture_locked(H, W, src, flip, B, t0)
@@ -252,7 +305,7 @@ class DetectionEntry:
         s = _Slot()
         s.key, s.pipe, s.busy, s.seq, s.batch = (H, W), pipe, False, 0, B
         s.io_dev = torch.zeros(off + 16 * B, dtype=torch.uint8, device="cuda")
-        s.io_pin = torch.zeros(off + 16 * B, dtype=torch.uint8).pin_memory()
+        s.io_pin = _PINNED.take(off + 16 * B, zero=True)
         host = s.io_pin.numpy()
         if self.device_preprocess:
             s.pix_hosts = [host[i * seg:i * seg + npix].reshape(in_h, in_w, 3) for i in range(B)]
@@ -291,22 +344,28 @@ class DetectionEntry:
         s.ws = ops.NO_SPLIT_K if ((shared and (dtype == "bf16" or os.environ.get("FRCNN_ENTRY_NO_SPLITK"))) or B > 1) else ops.ConvWorkspace()
         s.io_dev.copy_(s.io_pin)
         s.amax = ops.AmaxArena() if self.f32_engine == "f16x3" else None      # the pass's magnitude records (fixed addresses across replays)
-        side = torch.cuda.Stream()
+        # Warm-up and capture on ONE side stream, with no device-wide synchronisation: the passes of other geometries that are in flight on
+        # the engine's streams keep running (round 6: torch.cuda.graph's enter -- synchronize, empty_cache -- and two more synchronize calls
+        # drained them at every capture, and a list of mixed image sizes captures per geometry).  The warm-up pass writes the slot's own
+        # buffers, as the replays will: ``s.ready`` orders the first replay behind it.
+        side = _capture_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine), ops.amax_arena(s.amax):
             for _ in range(WARMUP_PASSES):
                 run()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        s.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(s.graph, capture_error_mode="thread_local"), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine), \
-                ops.amax_arena(s.amax):
-            s.out = run()
+            s.ready = torch.cuda.Event()
+            s.ready.record(side)
+            s.graph = torch.cuda.CUDAGraph()
+            s.graph.capture_begin(pool=torch.cuda.graph_pool_handle(), capture_error_mode="thread_local")
+            try:
+                s.out = run()
+            finally:
+                s.graph.capture_end()
         packed = s.out["det_packed"]
         s.out_packed = packed if isinstance(packed, (list, tuple)) else [packed]
-        s.out_pin = torch.empty((B,) + tuple(s.out_packed[0].shape), dtype=torch.int32).pin_memory()
+        s._out_raw = _PINNED.take(4 * B * s.out_packed[0].numel())
+        s.out_pin = s._out_raw.view(torch.int32).view((B,) + tuple(s.out_packed[0].shape))
         s.event = torch.cuda.Event()
-        torch.cuda.synchronize()
         s.nbytes = max(int(torch.cuda.memory_reserved() - reserved0), int(s.io_dev.numel() + s.x_f32.numel() * 4))
         self.capture_seconds += time.perf_counter() - t0
         return s
@@ -391,6 +450,9 @@ class DetectionEntry:
         st = self._streams[self._seq % self.in_flight]
         self._seq += 1
         with torch.cuda.stream(st):
+            if s.ready is not None:
+                st.wait_event(s.ready)                             # (the first replay of a fresh pass: behind its warm-up)
+                s.ready = None
             s.io_dev.copy_(s.io_pin, non_blocking=True)
             s.graph.replay()
             for i in range(len(images)):

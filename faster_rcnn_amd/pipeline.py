@@ -142,13 +142,28 @@ def no_gc():
     """No cyclic-garbage collection while a stream is capturing: a collection may run the finalizers of unrelated dead objects
     (other captured graphs, their memory pools) whose HIP calls are not legal in a capturing thread (entry.DetectionEntry._capture)."""
     was_on = _gc.isenabled()
-    _gc.collect()
+    collect_before_capture()
     _gc.disable()
     try:
         yield
     finally:
         if was_on:
             _gc.enable()
+
+
+_LAST_COLLECT = [0.0]
+
+
+def collect_before_capture(min_interval_s=1.0):
+    """A full collection in front of a capture -- at most one per ``min_interval_s``: what protects a capture is that the collector is
+    OFF while it runs (no finalizer of a dead engine's captured passes can start inside it); collecting first merely keeps the backlog
+    short, and a full collection of this process's heap is ~23 ms -- more than the rest of a DetectionEntry capture, which a list of
+    mixed image sizes makes per geometry (scripts/dev/r6_capture_cost.py)."""
+    import time as _time
+    now = _time.monotonic()
+    if now - _LAST_COLLECT[0] >= min_interval_s:
+        _gc.collect()
+        _LAST_COLLECT[0] = _time.monotonic()
 
 
 import os as _os

@@ -109,10 +109,13 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
 # resized geometry): a captured pass serves ONE geometry, and four images of one geometry share a pass.  Neighbours rarely share one,
 # so the images are held back per geometry -- at most REORDER_WINDOW of them, counted over all geometries -- until a geometry has a
 # full pass; results are folded into the dict in LIST order whatever order they were computed in.  A geometry that the list holds
-# fewer than CAPTURE_MIN times is not worth a capture (~80 ms and ~0.4-1.4 GB against ~7 ms for the eager sequence): those images take
-# the eager path (same detections up to the summation order of a few layers, tests/test_entry_gpu.py).
+# fewer than CAPTURE_MIN times is not worth a capture (~20 ms beside passes in flight and 0.4-1.4 GB, against ~7 ms for the eager
+# sequence): those images take the eager path (same detections up to the summation order of a few layers, tests/test_entry_gpu.py).
+# Measured on bench.py's mixed_sizes leg (256 frames, 36 geometries, first call / same call again): CAPTURE_MIN 1: 170 / 514 img/s
+# (45 captures), 2: 300 / 442 (22 captures, 23 eager), 3: 274 / 428.  A long run over a whole dataset amortises every capture
+# (FRCNN_ENTRY_CAPTURE_MIN=1); the default favours the call that sees its list once.
 REORDER_WINDOW = int(os.environ.get("FRCNN_ENTRY_REORDER", "64"))
-CAPTURE_MIN = int(os.environ.get("FRCNN_ENTRY_CAPTURE_MIN", "3"))
+CAPTURE_MIN = int(os.environ.get("FRCNN_ENTRY_CAPTURE_MIN", "2"))
 
 
 def _get_dets_by_cls_captured(eng, training_manager, detector, resized_ratios, images, stride, det_threshold, fold, dets_by_cls):
