@@ -952,7 +952,9 @@ struct RefreshTable { frcnn_pack_job job[REFRESH_JOBS]; int first_block[REFRESH_
 static int refresh_blocks(const frcnn_pack_job& j) {
     const long long elems = (long long)j.kh * j.kw * j.cin * j.cout;
     long long g = (elems + 8191) / 8192;
-    return (int)(g < 4 ? 4 : (g > 2048 ? 2048 : g));
+    // (at least 16 workgroups: the small f32 layers of a mixed-precision step -- rpn_out_cls / rpn_out_bbreg, 512 -> 9 / 36 -- are a
+    //  launch of their own whose 16 transposing tiles went through 4 workgroups one after the other: 24-33 us of a 1.2 ms step)
+    return (int)(g < 16 ? 16 : (g > 2048 ? 2048 : g));
 }
 __global__ void __launch_bounds__(256) k_refresh_packed(const RefreshTable t) {
     int ji = 0;
