@@ -229,7 +229,7 @@ _WGRAD_STREAM = None
 def _wgrad_stream():
     global _WGRAD_STREAM
     if _WGRAD_STREAM is None:
-        _WGRAD_STREAM = torch.cuda.Stream(priority=int(__import__("os").environ.get("FRCNN_TRAIN_WGRAD_PRIO", "0")))
+        _WGRAD_STREAM = torch.cuda.Stream()
     return _WGRAD_STREAM
 
 
@@ -1068,7 +1068,7 @@ def _loss_stream():
 def _prefix_stream():
     global _PREFIX_STREAM
     if _PREFIX_STREAM is None:
-        _PREFIX_STREAM = torch.cuda.Stream(priority=int(__import__("os").environ.get("FRCNN_TRAIN_PREFIX_PRIO", "0")))
+        _PREFIX_STREAM = torch.cuda.Stream()
     return _PREFIX_STREAM
 
 

@@ -39,9 +39,6 @@ def wrap(obj, name, tag):
 tr = rpn._trainer
 for name in ("_stage", "_exchange_and_apply", "_send_losses", "_finish_update", "_step_graph", "_replay_step"):
     wrap(tr, name, name)
-_main = torch.cuda.Stream(priority=-1) if os.environ.get("FRCNN_TRAIN_MAIN_PRIO") == "-1" else None
-if _main is not None:
-    torch.cuda.set_stream(_main)
 for dev_in in (False, True):
     step = (lambda: rpn.train_on_batch(xd, [ycd, ybd], defer=True)) if dev_in else (lambda: rpn.train_on_batch(x, [y_class, y_bbreg], defer=True))
     prev = None
