@@ -1043,6 +1043,10 @@ def compact_train_leg(line):
     return keep
 
 
+def _under_a_profiler():
+    return "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ)
+
+
 def other_config_legs(timeout_s=170.0):
     """Run EXTRA_LEGS (see above) and return {name: compact result or {"error": ...}}; `seconds` per leg says what the line cost."""
     import subprocess
@@ -1136,7 +1140,9 @@ def main():
     extra = None
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "c2" and not args.no_extra and args.dtype == "config"
             and not args.no_graph and args.streams <= 0 and args.batch <= 0 and os.environ.get("FRCNN_BENCH_FORCE_DIST", "0") == "0"
-            and "FRCNN_BENCH_BACKEND" not in os.environ):     # (the driver's command line; a run that names a pass shape or a dev backend is somebody's experiment)
+            and "FRCNN_BENCH_BACKEND" not in os.environ and not _under_a_profiler()):
+        # (the driver's command line; a run that names a pass shape or a dev backend is somebody's experiment.  Under rocprofv3 the tool's
+        #  preloaded library may have initialised the GPU in THIS process already: no GPU children from here)
         extra = other_config_legs()                 # children first: this process has not touched the GPU yet
     global HOIST, DTYPE, WORKLOAD
     select_config(args.config)

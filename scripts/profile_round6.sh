@@ -27,14 +27,14 @@ FRCNN_TRAIN_GRAPH=0 python3 $R/scripts/bench_train.py --bf16 --through-loop --no
 # where the pieces of a replayed step run, WITHOUT a profiler (timing events; rocprofv3 slows hipGraphLaunch enough to change the picture)
 python3 $R/scripts/dev/r6_event_timeline.py bf16 2>&1 | grep -v amdgpu > $OUT/train_step_rpn_mixed_bf16_event_timeline.txt
 python3 $R/scripts/dev/r6_event_timeline.py f32 2>&1 | grep -v amdgpu > $OUT/train_step_rpn_f32_event_timeline.txt
-python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-io --conv-table > /dev/null 2> $OUT/bench_default_conv_table.err
+python3 $R/bench.py --no-extra --steps 20 --warmup 5 --no-cpu-baseline --no-io --conv-table > /dev/null 2> $OUT/bench_default_conv_table.err
 grep "^conv" $OUT/bench_default_conv_table.err > $OUT/bench_default_conv_table.txt
 # ---- kernel traces (fp32 default: four passes of four images on the runtime's four queues)
 export FRCNN_BENCH_NO_ENTRY=1
 export FRCNN_BENCH_NO_NATIVE=1       # the traces hold the timed launch forms only
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-io > $OUT/trace_default.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_streams1 -- python3 $R/bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-io > $OUT/trace_streams1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c4 -- python3 $R/bench.py --config c4 --steps 20 --warmup 5 --no-cpu-baseline --no-io > $OUT/trace_c4.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --no-extra --steps 20 --warmup 5 --no-cpu-baseline --no-io > $OUT/trace_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_streams1 -- python3 $R/bench.py --no-extra --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-io > $OUT/trace_streams1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c4 -- python3 $R/bench.py --no-extra --config c4 --steps 20 --warmup 5 --no-cpu-baseline --no-io > $OUT/trace_c4.log 2>&1
 unset FRCNN_BENCH_NO_ENTRY FRCNN_BENCH_NO_NATIVE
 # training steps, grouped by (kernel, grid): what a step is made of
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_train_f32 -- python3 $R/scripts/bench_train.py --steps 10 --warmup 5 > $OUT/trace_train_f32.log 2>&1
@@ -53,7 +53,7 @@ i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" \
             "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --batch 4 --no-cpu-baseline --no-graph --shared-tiles > $OUT/pmc$i.log 2>&1
+  rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --no-extra --steps 2 --warmup 1 --streams 1 --batch 4 --no-cpu-baseline --no-graph --shared-tiles > $OUT/pmc$i.log 2>&1
 done
 # configs[3]: the batched pass, eager (one batch of eight per step)
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
