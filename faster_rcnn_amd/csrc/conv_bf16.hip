@@ -963,7 +963,18 @@ __global__ void k_avgpool_bf16_f32_v8(const __bf16* x, int n, int hw, int C, int
         const int c = (int)(e % C);
         const size_t img = e / C;
         float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        for (int q = 0; q < hw; ++q) {
+        int q = 0;
+        for (; q + 7 <= hw; q += 7) {                          // seven loads in flight (a 7x7 window: seven rounds), summed in position order
+            bf16x8 v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                v[j] = *reinterpret_cast<const bf16x8*>(pos_major ? x + (size_t)(q + j) * n * C + e : x + (img * hw + q + j) * C + c);
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += (float)v[j][k];
+        }
+        for (; q < hw; ++q) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(pos_major ? x + (size_t)q * n * C + e : x + (img * hw + q) * C + c);
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += (float)v[k];

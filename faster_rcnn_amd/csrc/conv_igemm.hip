@@ -951,7 +951,7 @@ constexpr int REFRESH_JOBS = 32;
 struct RefreshTable { frcnn_pack_job job[REFRESH_JOBS]; int first_block[REFRESH_JOBS + 1]; int n; };
 static int refresh_blocks(const frcnn_pack_job& j) {
     const long long elems = (long long)j.kh * j.kw * j.cin * j.cout;
-    long long g = (elems + 8191) / 8192;
+    long long g = (elems + 2047) / 2048;              // (round 6: 8192 per workgroup left the dense layer's element-wise input-gradient pack on 26 workgroups)
     // (at least 16 workgroups: the small f32 layers of a mixed-precision step -- rpn_out_cls / rpn_out_bbreg, 512 -> 9 / 36 -- are a
     //  launch of their own whose 16 transposing tiles went through 4 workgroups one after the other: 24-33 us of a 1.2 ms step)
     return (int)(g < 16 ? 16 : (g > 2048 ? 2048 : g));
@@ -1802,16 +1802,25 @@ __global__ void k_softmax_rows(const float* x, int rows, int cols, int ldx, floa
 // The two dense heads of the detector run as ONE GEMM (kernels concatenated along the output axis): this splits its
 // rows back into dense_class_C (softmax over the first `cols` entries, exactly k_softmax_rows) and dense_reg_C (the
 // remaining `tail` entries, copied) -- resnet.py:522-533, vgg.py:241-247.
-__global__ void k_dense_heads_split(const float* x, int rows, int cols, int tail, int ldx, float* cls, float* reg) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
+// Round 6: 32 lanes per row (one thread per row walked its 21 + 80 columns alone: 32 us for the 64 rows of a training step, on the
+// step's critical path).  The arithmetic is the one-thread loop's, bit for bit: the maximum is order-independent, every lane adds
+// e_0, e_1, ... in column order (the other lanes' values arrive by shuffle), the quotients and the copy are per column.
+__global__ void __launch_bounds__(256) k_dense_heads_split(const float* x, int rows, int cols, int tail, int ldx, float* cls, float* reg) {
+    const int lane = threadIdx.x & 31, r = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (r >= rows) return;                                   // (a whole 32-lane group leaves together)
     const float* xr = x + (size_t)r * ldx;
     float mx = -INFINITY;
-    for (int c = 0; c < cols; ++c) mx = fmaxf(mx, xr[c]);
+    for (int c = lane; c < cols; c += 32) mx = fmaxf(mx, xr[c]);
+#pragma unroll
+    for (int o = 16; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 32));
     float sum = 0.0f;
-    for (int c = 0; c < cols; ++c) sum += expf(xr[c] - mx);
-    for (int c = 0; c < cols; ++c) cls[(size_t)r * cols + c] = expf(xr[c] - mx) / sum;
-    for (int c = 0; c < tail; ++c) reg[(size_t)r * tail + c] = xr[cols + c];
+    for (int c0 = 0; c0 < cols; c0 += 32) {
+        const float e = c0 + lane < cols ? expf(xr[c0 + lane] - mx) : 0.0f;
+        const int cnt = cols - c0 < 32 ? cols - c0 : 32;
+        for (int k = 0; k < cnt; ++k) sum += __shfl(e, k, 32);
+    }
+    for (int c = lane; c < cols; c += 32) cls[(size_t)r * cols + c] = expf(xr[c] - mx) / sum;
+    for (int c = lane; c < tail; c += 32) reg[(size_t)r * tail + c] = xr[cols + c];
 }
 
 template <int TM, int TN, bool G>
@@ -2787,7 +2796,7 @@ int frcnn_dense_heads_split(const float* x, int rows, int cols, int tail, int ld
     if (rows < 0 || cols <= 0 || tail < 0 || ldx < cols + tail) return fail(FRCNN_E_ARG, "dense_heads_split: bad argument");
     if (rows == 0) return FRCNN_OK;
     if (!x || !cls || (tail && !reg)) return fail(FRCNN_E_ARG, "dense_heads_split: null pointer");
-    k_dense_heads_split<<<(rows + 63) / 64, 64, 0, as_stream(stream)>>>(x, rows, cols, tail, ldx, cls, reg);
+    k_dense_heads_split<<<(rows + 7) / 8, 256, 0, as_stream(stream)>>>(x, rows, cols, tail, ldx, cls, reg);
     return check_launch("dense_heads_split");
 }
 

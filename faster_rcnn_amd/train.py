@@ -594,24 +594,24 @@ class _StepDriver:
     def _publish_losses(self):
         """Called by ``_device_step`` as soon as the two loss kernels are enqueued (and by a skipped step at once): the L2
         sum over the trainable weights -- they do not change before the optimiser runs at the END of the step -- then the
-        three scalars leave for pinned host memory on a stream of their own.  train_on_batch's return value is therefore
+        three scalars leave for pinned host memory, both on a stream of their own (round 6: the 47-89 MB sum used to sit on the
+        step's critical path between the loss kernels and the backward pass).  train_on_batch's return value is therefore
         available after the FORWARD pass; the backward pass and the update run on while the caller reads the losses and
-        stages the next image (Keras semantics kept: every way of reading weights back is stream-ordered behind the step)."""
-        self._l2_sum()
+        stages the next image (Keras semantics kept: every way of reading weights back is stream-ordered behind the step; the
+        optimiser waits for the sum's event before it rewrites the weights, ``_apply_update``)."""
         self._send_losses()
-
-    def _l2_sum(self):
-        if self.l2:
-            self.params.sumsq(out=self._cur[0][2:3])
 
     def _send_losses(self):
         out3, slot = self._cur
         main, side = torch.cuda.current_stream(), _loss_stream()
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            if self.l2:
+                self.params.sumsq(out=out3[2:3])
             slot[0].copy_(out3, non_blocking=True)
             slot[1].record()
         out3.record_stream(side)
+        self._weights_read = slot[1]                     # the optimiser must not rewrite the weights under the sum
 
     def _device_step(self, dev, out, pre=None):
         """The device part of one step on the current stream: forward + losses, the three scalars on their way to the host,
@@ -650,6 +650,10 @@ class _StepDriver:
 
     def _apply_update(self, scale, opt=None):
         p = self.params
+        ev = getattr(self, "_weights_read", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)   # (the L2 sum of this step's report, on the loss stream)
+            self._weights_read = None
         p.step(opt or self.optimizer, self.l2, scale)
         if self._refresh_jobs is None:
             self._refresh_jobs = make_refresh_jobs(self._tconvs())
@@ -882,7 +886,6 @@ class _StepDriver:
                     ops.amax_begin()
                     self._cur = (sg.out3, None)
                     self._fwd_part(sg.static, out, pre)
-                    self._l2_sum()
                     rec.end()
                     sg.g1 = rec.items[0][1]
                     rec.begin("main")
@@ -967,7 +970,7 @@ class _StepGraph:
     G0 (own memory pool): stem + frozen stages of the image in ``inbox[0]`` -> ``pre_stage``; replayed on the prefix stream, beside
     the previous step's backward pass.  G1: the other inputs ``inbox[k]`` -> ``static[k]`` and ``pre_stage`` -> a copy of its own (so
     the next image's G0 and input copies may start as soon as G1 has run: ``fwd_done``), trainable forward, the two loss kernels
-    (value + gradient), the L2 sum -> ``out3``.  ``bwd`` (G1's pool: they read G1's activations): the input-gradient chain cut at
+    (value + gradient) -> ``out3`` (the L2 sum joins it on the loss stream).  ``bwd`` (G1's pool: they read G1's activations): the input-gradient chain cut at
     every weight-gradient flush, alternating with the weight-gradient batches, which replay on the weight-gradient stream; the bias
     gradients end the last main piece.  Same kernels, same arguments, same order per tensor as the eager step: the weights after N
     replayed steps equal the eager ones bit for bit (tests/test_train_graph_gpu.py)."""
