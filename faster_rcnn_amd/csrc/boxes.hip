@@ -250,6 +250,54 @@ __global__ void k_preprocess_u8(const uint8_t* img, size_t n, double m0, double 
     }
 }
 
+// ---- padded canvases (round 6): images of DIFFERENT true sizes share one captured pass.  Each image sits in the top-left corner of a
+// canvas [hc][wc] whose sides have the PARITY of the image's (so TF's SAME padding at stride 2 -- pad_before = total / 2, total depending
+// on the size's parity, resnet.py:408 -- is the canvas's); everything outside the image is zero, which is what the reference's padding
+// puts there.  A convolution with taps (3x3, 7x7) reads zeros beyond the true border exactly where the reference reads its padding as
+// long as its INPUT is zero there: the canvas is, and k_zero_outside restores that behind every layer whose output feeds such a
+// convolution (bias / BatchNorm shift / ReLU make the outside non-zero again).  Pointwise layers and VALID pooling never look outside.
+__global__ void k_preprocess_u8_canvas(const uint8_t* img, int h, int w, int hc, int wc, double m0, double m1, double m2, float* out) {
+    const size_t n = (size_t)hc * wc * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        const size_t px = i / 3;
+        const int x = (int)(px % wc), y = (int)(px / wc);
+        out[i] = (x < w && y < h) ? (float)((double)img[((size_t)y * w + x) * 3 + c] - (c == 0 ? m0 : (c == 1 ? m1 : m2))) : 0.0f;
+    }
+}
+
+// x [n][hc][wc][c16 pieces of 16 bytes]: zero the cells at or beyond image i's true extent hw[i] = {rows, cols} (device words)
+__global__ void k_zero_outside(int4* x, int hc, int wc, int c16, const int* hw) {
+    const int cell = blockIdx.x, img = blockIdx.y;
+    const int y = cell / wc, xx = cell - y * wc;
+    if (y < hw[2 * img] && xx < hw[2 * img + 1]) return;
+    int4* p = x + ((size_t)img * hc * wc + cell) * c16;
+    for (int k = threadIdx.x; k < c16; k += blockDim.x) p[k] = make_int4(0, 0, 0, 0);
+}
+
+// k_decode on a canvas: the RPN outputs are [rows_c][cols_c][4A]; image's true map is rc[0] x rc[1] (device words).  A cell outside it
+// is no candidate (valid = 0); boxes are clipped to the TRUE extent (det_util.py:179-192 with the image's own rows / cols).  The linear
+// order of the cells inside the true map is the true map's row-major order, so the top-K's tie rule (ascending index) picks as it would.
+__global__ void k_decode_canvas(const float4* regr, int rows_c, int cols_c, AnchorTable t, int A, const int* rc, float4* rois, uint8_t* valid) {
+    const int n = rows_c * cols_c * A, rows = rc[0], cols = rc[1];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int a = i % A, cell = i / A, x = cell % cols_c, y = cell / cols_c;
+        if (x >= cols || y >= rows) { rois[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); valid[i] = 0; continue; }
+        const float4 anc = anchor_box(x, y, t.h[a], t.w[a]);
+        float4 d = regr[i];
+        d.x = d.x / 10.0f; d.y = d.y / 10.0f; d.z = d.z / 5.0f; d.w = d.w / 5.0f;   // det_util.py:376
+        float4 r = transform_f32(anc, d);
+        r.z = fmaxf(r.x + 1.0f, r.z);
+        r.w = fmaxf(r.y + 1.0f, r.w);
+        r.x = fmaxf(0.0f, r.x);
+        r.y = fmaxf(0.0f, r.y);
+        r.z = fminf((float)(cols - 1), r.z);
+        r.w = fminf((float)(rows - 1), r.w);
+        rois[i] = r;
+        valid[i] = (r.z > r.x) && (r.w > r.y);
+    }
+}
+
 // shapes.Image.data (shapes.py:19-29): cv2.resize(img, (w, h), interpolation=cv2.INTER_CUBIC) on the decoded uint8 frame --
 // OpenCV's 8-bit path: per axis four taps (BORDER_REPLICATE), cubic coefficients (A = -0.75) in 11-bit fixed point, horizontal
 // then vertical pass, (v + 2^21) >> 22, saturate.  No intermediate rounding between the passes, so one thread sums the 16
@@ -496,6 +544,30 @@ int frcnn_decode_proposals(const float* regr, int rows, int cols, const int32_t*
     if (rows <= 0 || cols <= 0 || !regr || !rois || !valid) return fail(FRCNN_E_ARG, "decode_proposals: bad argument");
     k_decode<<<grid_for(rows * cols * A), 256, 0, as_stream(stream)>>>((const float4*)regr, rows, cols, t, A, (float4*)rois, valid);
     return check_launch("decode_proposals");
+}
+
+int frcnn_decode_proposals_canvas(const float* regr, int rows_c, int cols_c, const int32_t* anchor_hw_conv_h, int A, const int32_t* true_rows_cols,
+                                  float* rois, uint8_t* valid, void* stream) {
+    AnchorTable t;
+    if (int e = load_anchor_table(anchor_hw_conv_h, A, &t)) return e;
+    if (rows_c <= 0 || cols_c <= 0 || !regr || !rois || !valid || !true_rows_cols) return fail(FRCNN_E_ARG, "decode_proposals_canvas: bad argument");
+    k_decode_canvas<<<grid_for(rows_c * cols_c * A), 256, 0, as_stream(stream)>>>((const float4*)regr, rows_c, cols_c, t, A, true_rows_cols, (float4*)rois, valid);
+    return check_launch("decode_proposals_canvas");
+}
+
+int frcnn_zero_outside(void* x, int n, int hc, int wc, int row_bytes, const int32_t* true_hw, void* stream) {
+    if (!x || !true_hw || n <= 0 || hc <= 0 || wc <= 0 || row_bytes <= 0 || (row_bytes & 15) || (reinterpret_cast<uintptr_t>(x) & 15))
+        return fail(FRCNN_E_ARG, "zero_outside: bad argument (a cell's channels must be a multiple of 16 bytes, 16-byte aligned)");
+    k_zero_outside<<<dim3(hc * wc, n), 64, 0, as_stream(stream)>>>((int4*)x, hc, wc, row_bytes / 16, true_hw);
+    return check_launch("zero_outside");
+}
+
+int frcnn_preprocess_u8_canvas(const uint8_t* img_hwc, int h, int w, int hc, int wc, const double* mean3_h, float* out, void* stream) {
+    if (!img_hwc || !mean3_h || !out || h <= 0 || w <= 0 || hc < h || wc < w) return fail(FRCNN_E_ARG, "preprocess_u8_canvas: bad argument");
+    size_t g = ((size_t)hc * wc * 3 + 255) / 256;
+    if (g > 8192) g = 8192;
+    k_preprocess_u8_canvas<<<(int)g, 256, 0, as_stream(stream)>>>(img_hwc, h, w, hc, wc, mean3_h[0], mean3_h[1], mean3_h[2], out);
+    return check_launch("preprocess_u8_canvas");
 }
 
 int frcnn_transform_inplace(float* coords, const float* deltas, int n, void* stream) {

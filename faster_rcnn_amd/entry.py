@@ -77,6 +77,18 @@ PAD_TO_BATCH = os.environ.get("FRCNN_ENTRY_PAD", "0") != "0"
 # eager passes in front of a capture: ONE sizes the split-K workspace, lowers what is lowered lazily and leaves the magnitude-record
 # arena's high-water mark (round 6: two until then; a capture is ~2/3 warm-up, and a list of mixed sizes captures per geometry)
 WARMUP_PASSES = max(1, int(os.environ.get("FRCNN_ENTRY_WARMUP", "1")))
+# Padded canvases (round 6): a list of MANY image sizes is served by passes captured per canvas CLASS -- sides rounded up to a multiple
+# of CANVAS_GRANULE, keeping each side's parity -- with the images' true sizes as device values (pipeline: ``extents``), instead of one
+# capture per geometry.  voc_dets.get_dets_by_cls switches it on for a call whose list holds more than CANVAS_MIN_GEOMETRIES sizes.
+CANVAS_GRANULE = int(os.environ.get("FRCNN_ENTRY_CANVAS_GRANULE", "32"))
+CANVAS_MIN_GEOMETRIES = int(os.environ.get("FRCNN_ENTRY_CANVAS_MIN", "4"))
+
+
+def canvas_side(n, granule=None):
+    """The canvas side for a true side ``n``: the next multiple of the granule, one less when that would flip the parity."""
+    g = CANVAS_GRANULE if granule is None else granule
+    c = -(-int(n) // g) * g
+    return c if (c - n) % 2 == 0 else c - 1
 
 
 class _PinnedArena:
@@ -128,7 +140,7 @@ def _capture_stream():
 class _Slot:
     """One captured pass for one image size, with its staging on both sides of PCIe."""
     __slots__ = ("key", "pipe", "graph", "out", "io_dev", "io_pin", "pix_host", "dyn_host", "out_pin", "event", "busy", "nbytes",
-                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed", "amax", "_out_raw", "ready")
+                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed", "amax", "_out_raw", "ready", "extents", "seg", "canvas")
 
 
 def _close_slot(s):
@@ -147,7 +159,7 @@ def _close_slot(s):
         piece = getattr(s, name, None)
         if piece is not None:
             _PINNED.give_back(piece)
-    for name in ("graph", "out", "out_packed", "io_dev", "x_f32", "u8_resized", "tabs", "ws", "amax", "pipe", "io_pin", "_out_raw", "out_pin", "pix_hosts", "pix_host", "dyn_host"):
+    for name in ("graph", "out", "out_packed", "io_dev", "x_f32", "u8_resized", "tabs", "ws", "amax", "pipe", "io_pin", "_out_raw", "out_pin", "pix_hosts", "pix_host", "dyn_host", "extents"):
         setattr(s, name, None)
 
 
@@ -253,6 +265,11 @@ class DetectionEntry:
         self._seq = 0
         self._epoch = models.weights_epoch()
         self.capture_seconds = 0.0
+        # canvas passes need the ResNet trunk's extent masks (nets.ResNetBase) and the device-side preprocess
+        net = getattr(getattr(manager.rpn_model, "base", None), "net", None)
+        self.canvas_capable = self.device_preprocess and hasattr(net, "block_level") and os.environ.get("FRCNN_ENTRY_CANVAS", "1") != "0"
+        self.canvas = False                              # set per call by voc_dets.get_dets_by_cls
+        self._taps_dev = {}
 
     # ------------------------------------------------------------------ eligibility
     @staticmethod
@@ -285,6 +302,127 @@ class DetectionEntry:
         finally:
             if gc_was_on:
                 gc.enable()
+
+    def _device_taps(self, dst, src):
+        t = self._taps_dev.get((dst, src))
+        if t is None:
+            if len(self._taps_dev) > 256:
+                self._taps_dev.clear()
+            t = self._taps_dev[(dst, src)] = torch.from_numpy(ops.resize_cubic_taps(dst, src)).cuda()
+        return t
+
+    def _capture_canvas_locked(self, Hc, Wc, B, t0):
+        """A pass over B canvases of (Hc, Wc): the frames' resize + preprocess stay OUTSIDE the graph (their sizes are per image: a few
+        eager launches in front of every replay), the graph holds trunk .. post-process with the images' true extents read from
+        ``s.extents`` (device words)."""
+        import time
+        from . import nets
+        m = self.manager
+        kw = dict(stride=self.stride, pre_nms_top_n=PRE_NMS_TOP_N, max_proposals=MAX_PROPOSALS, roi_batch=self.num_rois, pad_to_batch=PAD_TO_BATCH,
+                  bg_idx=m.class_mapping["bg"])
+        if B > 1:
+            from .pipeline import BatchedInferencePipeline
+            pipe = BatchedInferencePipeline(m.rpn_model, self.detector, m.anchor_dims, B, **kw)
+        else:
+            pipe = InferencePipeline(m.rpn_model, self.detector, m.anchor_dims, **kw)
+        reserved0 = torch.cuda.memory_reserved()
+        seg = (Hc * Wc * 3 + 15) // 16 * 16                         # a frame's staging segment: any source of at most the canvas's pixel count
+        off = B * seg
+        s = _Slot()
+        s.key, s.pipe, s.busy, s.seq, s.batch, s.canvas, s.seg = ("canvas", Hc, Wc), pipe, False, 0, B, True, seg
+        s.io_dev = torch.zeros(off + 16 * B, dtype=torch.uint8, device="cuda")
+        s.io_pin = _PINNED.take(off + 16 * B, zero=True)
+        host = s.io_pin.numpy()
+        s.pix_hosts = [host[i * seg:(i + 1) * seg] for i in range(B)]
+        s.pix_host = s.pix_hosts[0]
+        s.dyn_host = host[off:off + 16 * B].view(np.float64).reshape(B, 2)
+        s.dyn_host[:] = (1.0, 0.0)
+        dyn_dev = s.io_dev[off:off + 16 * B].view(torch.float64).view(B, 2)
+        s.tabs = None
+        s.u8_resized = torch.empty((B, seg), dtype=torch.uint8, device="cuda")
+        s.x_f32 = torch.zeros((B, Hc, Wc, 3), dtype=torch.float32, device="cuda")
+        s.extents = nets.Extents(B)
+        for i in range(B):
+            s.extents.set(i, Hc, Wc)
+        s.extents.upload()
+        run = lambda: pipe.forward_dev(s.x_f32, dyn=dyn_dev if B > 1 else dyn_dev[0], extents=s.extents)
+        shared = self.in_flight > 1
+        dtype = getattr(getattr(self.detector, "head", None), "dtype", "f32")
+        s.ws = ops.NO_SPLIT_K if ((shared and (dtype == "bf16" or os.environ.get("FRCNN_ENTRY_NO_SPLITK"))) or B > 1) else ops.ConvWorkspace()
+        s.io_dev.copy_(s.io_pin)
+        s.amax = ops.AmaxArena() if self.f32_engine == "f16x3" else None
+        side = _capture_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine), ops.amax_arena(s.amax):
+            for _ in range(WARMUP_PASSES):
+                run()
+            s.ready = torch.cuda.Event()
+            s.ready.record(side)
+            s.graph = torch.cuda.CUDAGraph()
+            s.graph.capture_begin(pool=torch.cuda.graph_pool_handle(), capture_error_mode="thread_local")
+            try:
+                s.out = run()
+            finally:
+                s.graph.capture_end()
+        packed = s.out["det_packed"]
+        s.out_packed = packed if isinstance(packed, (list, tuple)) else [packed]
+        s._out_raw = _PINNED.take(4 * B * s.out_packed[0].numel())
+        s.out_pin = s._out_raw.view(torch.int32).view((B,) + tuple(s.out_packed[0].shape))
+        s.event = torch.cuda.Event()
+        s.nbytes = max(int(torch.cuda.memory_reserved() - reserved0), int(s.io_dev.numel() + s.x_f32.numel() * 4))
+        self.capture_seconds += time.perf_counter() - t0
+        return s
+
+    def _capture_canvas(self, Hc, Wc, B):
+        import gc
+        import time
+        t0 = time.perf_counter()
+        gc_was_on = gc.isenabled()
+        from .pipeline import collect_before_capture
+        collect_before_capture()
+        gc.disable()
+        try:
+            return self._capture_canvas_locked(Hc, Wc, B, t0)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _submit_canvas(self, images, resize_ratios, det_threshold, pixels, B):
+        """``submit_batch`` in canvas mode: per image the frame goes up at ITS size, is resized (and flipped) to ITS (H, W) and
+        preprocessed into the corner of canvas i by eager launches on the pass's stream; the true sizes go up as extents."""
+        _, H0, W0, _, _ = pixels[0]
+        Hc, Wc = canvas_side(H0), canvas_side(W0)
+        s = self.cache.acquire(("canvas", Hc, Wc) + ((B,) if B > 1 else ()), lambda: self._capture_canvas(Hc, Wc, B))
+        metas = []
+        for i in range(B):
+            j = i if i < len(images) else 0
+            arr, H, W, src, flip = pixels[j]
+            arr = np.ascontiguousarray(arr)
+            assert arr.dtype == np.uint8 and arr.nbytes <= s.seg and canvas_side(H) == Hc and canvas_side(W) == Wc, "one pass, one canvas class"
+            s.pix_hosts[i][:arr.nbytes] = arr.reshape(-1)
+            s.dyn_host[i, 0], s.dyn_host[i, 1] = float(resize_ratios[j]), float(det_threshold)
+            s.extents.set(i, H, W)
+            metas.append((arr.shape[0], arr.shape[1], H, W, src, flip))
+        st = self._streams[self._seq % self.in_flight]
+        self._seq += 1
+        with torch.cuda.stream(st):
+            if s.ready is not None:
+                st.wait_event(s.ready)
+                s.ready = None
+            s.io_dev.copy_(s.io_pin, non_blocking=True)
+            s.extents.upload()
+            for i, (in_h, in_w, H, W, src, flip) in enumerate(metas):
+                frame = s.io_dev[i * s.seg:i * s.seg + in_h * in_w * 3].view(in_h, in_w, 3)
+                if src is not None:                                 # shapes.Image.data: INTER_CUBIC resize (+ flip) of the decoded frame
+                    frame = ops.resize_cubic_u8(frame, H, W, flip=flip, tabs=(self._device_taps(W, in_w), self._device_taps(H, in_h)),
+                                                out=s.u8_resized[i][:H * W * 3].view(H, W, 3))
+                ops.preprocess_u8_canvas(frame, MEAN_BGR, s.x_f32[i])
+            s.graph.replay()
+            for i in range(len(images)):
+                s.out_pin[i].copy_(s.out_packed[i], non_blocking=True)
+            s.event.record(st)
+        s.busy = True
+        return Ticket(s, list(images))
 
     def _capture_locked(self, H, W, src, flip, B, t0):
         import time
@@ -403,11 +541,23 @@ class DetectionEntry:
             data = self.manager.preprocess_func(data)               # det_util.py:36 (float64 on the host, cast on feed)
         return data, int(data.shape[0]), int(data.shape[1]), None, False
 
+    def canvas_ok(self, pixels):
+        """Can this frame go through a canvas pass?  (device preprocess, a source no larger than its canvas)"""
+        arr, H, W, src, flip = pixels
+        return self.canvas_capable and getattr(arr, "dtype", None) == np.uint8 and int(np.prod(arr.shape)) <= canvas_side(H) * canvas_side(W) * 3
+
     @staticmethod
-    def geometry(pixels):
-        """The captured-pass key of a ``host_pixels`` result: images with equal keys can share a batched pass."""
+    def geometry_of(pixels):
+        """The exact geometry of a ``host_pixels`` result (resized size, source size, flip)."""
         _, H, W, src, flip = pixels
         return (H, W) if src is None else (H, W) + src + (flip,)
+
+    def geometry(self, pixels):
+        """The captured-pass key of a ``host_pixels`` result: images with equal keys can share a batched pass.  In canvas mode the key
+        is the canvas CLASS of the image's size."""
+        if self.canvas and self.canvas_ok(pixels):
+            return ("canvas", canvas_side(pixels[1]), canvas_side(pixels[2]))
+        return self.geometry_of(pixels)
 
     def probe_geometry(self, image):
         """``geometry(host_pixels(image))`` WITHOUT decoding the pixels (a file's header gives its size), or None when that cannot be
@@ -421,9 +571,19 @@ class DetectionEntry:
         if size is None:
             return None
         H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
+        if self.canvas and self.canvas_capable and size[0] * size[1] <= canvas_side(H) * canvas_side(W):
+            return ("canvas", canvas_side(H), canvas_side(W))
         if tuple(size) == (H, W) and not flip:
             return (H, W)
         return (H, W, int(size[0]), int(size[1]), flip)
+
+    def exact_geometry(self, image):
+        """``probe_geometry`` with canvas mode off: the image's OWN geometry (get_dets_by_cls counts the distinct ones)."""
+        was, self.canvas = self.canvas, False
+        try:
+            return self.probe_geometry(image)
+        finally:
+            self.canvas = was
 
     def has_geometry(self, key):
         """A captured pass of this geometry (one image per pass, or the batched form) is already in the cache."""
@@ -442,6 +602,8 @@ class DetectionEntry:
         _, H, W, src, flip = pixels[0]
         key = self.geometry(pixels[0])
         assert all(self.geometry(p) == key for p in pixels), "one pass, one geometry"
+        if key[0] == "canvas":
+            return self._submit_canvas(images, resize_ratios, det_threshold, pixels, B)
         s = self.cache.acquire(key + ((B,) if B > 1 else ()), lambda: self._capture(H, W, src, flip, B))
         for i in range(B):
             j = i if i < len(images) else 0

@@ -144,8 +144,9 @@ class RpnModel(_Model):
     def _modules(self):
         return [self.base.net, self.head]
 
-    def forward_dev(self, x):
-        feat = self.base.net(x)
+    def forward_dev(self, x, extents=None):
+        """``extents`` (nets.Extents): x holds canvases (ResNet bases; see nets.ResNetBase.__call__)."""
+        feat = self.base.net(x) if extents is None else self.base.net(x, extents)
         cls, reg = self.head(feat)
         return cls, reg, feat
 

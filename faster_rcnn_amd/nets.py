@@ -137,7 +137,41 @@ def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dt
 HEAD_PLANES = True      # dev knob (tests): False keeps every tensor of the detector head f32
 
 
-def run_block(u, x, layout=0, planes=False):
+class Extents:
+    """The true extents of the images of a CANVAS pass (round 6; ops.zero_outside): a device int32 table [level][image][rows, cols] with
+    levels 0 = after the stem's pool (stage 2), 1 = stage 3, 2 = stage 4 (the conv4 map) of a ResNet base.  The table's address is
+    fixed (a captured pass bakes it in); ``set(i, H, W)`` writes image i's rows of the HOST copy, ``upload()`` sends it."""
+    LEVELS = 3
+
+    def __init__(self, batch):
+        self.batch = int(batch)
+        self.host = torch.zeros((self.LEVELS, self.batch, 2), dtype=torch.int32).pin_memory()
+        self.table = torch.zeros((self.LEVELS, self.batch, 2), dtype=torch.int32, device="cuda")
+
+    @staticmethod
+    def levels_of(height, width):
+        """[(rows, cols)] per level for an image of this size: resnet.get_conv_rows_cols' chain (resnet.py:78-93), level by level."""
+        out = []
+        h, w = (height - 1) // 2 + 1, (width - 1) // 2 + 1      # conv1 7x7 / 2 SAME
+        h, w = (h - 3) // 2 + 1, (w - 3) // 2 + 1                # max-pool 3x3 / 2 VALID
+        out.append((h, w))
+        for _ in range(2):                                       # res3a, res4a: 1x1 / 2 VALID
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            out.append((h, w))
+        return out
+
+    def set(self, i, height, width):
+        for lvl, (h, w) in enumerate(self.levels_of(height, width)):
+            self.host[lvl, i, 0], self.host[lvl, i, 1] = h, w
+
+    def upload(self):
+        self.table.copy_(self.host, non_blocking=True)
+
+    def level(self, lvl):
+        return self.table[lvl]
+
+
+def run_block(u, x, layout=0, planes=False, mask=None):
     """identity_block / conv_block (resnet.py:114-247) and their TimeDistributed twins (:250-392).  ``planes``: branch2a's and
     branch2b's outputs have ONE reader each, the next convolution of the block: on the f16x3 engine they are handed on as the fp16
     planes that convolution multiplies (ops.PlaneTensor), so its loader splits nothing."""
@@ -148,6 +182,8 @@ def run_block(u, x, layout=0, planes=False):
     else:
         shortcut = u["1"](x, layout=layout) if "1" in u else x
         t = u["2a"](x, layout=layout, planes_out=planes and _reads_planes(u["2b"], tuple(x.shape[:-1]) + (_cout(u["2a"]),), layout))
+    if mask is not None:                                    # a canvas pass: branch2b's 3x3 must read zeros beyond each image's true extent
+        t = ops.zero_outside(t, mask)
     t = u["2b"](t, layout=layout, planes_out=planes and _reads_planes(u["2c"], t.shape, layout))
     return u["2c"](t, residual=shortcut, layout=layout)
 
@@ -178,9 +214,11 @@ class ResNetBase:
         self.stem = ConvUnit(weights, "conv1", "bn_conv1", "scale_conv1" if r101 else None, BN_EPS_STEM,
                              stride=2, padding="same", act="relu")
         self.blocks = []
+        self.block_level = []                                # Extents level of each block's tensors (stage 2 -> 0, 3 -> 1, 4 -> 2)
         for stage, block, is_conv in resnet_block_names(depth):
             stride = 2 if (is_conv and stage > 2) else 1
             self.blocks.append(_block_units(weights, stage, block, is_conv, stride, r101, dtype))
+            self.block_level.append(stage - 2)
 
     def units(self):
         yield self.stem
@@ -221,10 +259,14 @@ class ResNetBase:
         x = ops.pool2d(self.stem(x), 3, 2, True)
         return ops.cast_bf16(x) if self.dtype == "bf16" else x
 
-    def __call__(self, x):
+    def __call__(self, x, extents=None):
+        """``extents`` (Extents): x is a batch of canvases whose images have those true sizes -- every tensor that a 3x3 convolution
+        reads is zeroed beyond each image's extent first, the conv4 map at the end (rpn_conv1 is a 3x3 too)."""
         x = self.stem_pool(x)
-        for b in self.blocks:
-            x = run_block(b, x)
+        for b, lvl in zip(self.blocks, self.block_level):
+            x = run_block(b, x, mask=None if extents is None else extents.level(lvl))
+        if extents is not None:
+            x = ops.zero_outside(x, extents.level(2))
         return x
 
 

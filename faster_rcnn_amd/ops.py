@@ -82,6 +82,42 @@ def preprocess_u8(img_u8, mean_bgr, out=None):
     return out
 
 
+def preprocess_u8_canvas(img_u8, mean_bgr, out):
+    """``preprocess_u8`` into the top-left corner of a canvas: img_u8 (h,w,3) uint8 device tensor, out (1,hc,wc,3) / (hc,wc,3) f32 with
+    hc >= h, wc >= w; zeros outside the image (frcnn_preprocess_u8_canvas)."""
+    _require_gpu()
+    assert img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_contiguous()
+    hc, wc = int(out.shape[-3]), int(out.shape[-2])
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == hc * wc * 3
+    mean = (ctypes.c_double * 3)(*[float(v) for v in mean_bgr])
+    _lib.call("frcnn_preprocess_u8_canvas", _p(img_u8), int(img_u8.shape[0]), int(img_u8.shape[1]), hc, wc, mean, _p(out), _stream())
+    return out
+
+
+def zero_outside(x, true_hw):
+    """x (n,hc,wc,C) f32 or bf16 canvas tensor, IN PLACE: zero every cell at or beyond image i's true extent true_hw[i] = (rows, cols)
+    (device int32 (n,2); frcnn_zero_outside).  Zeros cannot raise a magnitude bound: x keeps its record."""
+    _require_gpu()
+    assert x.dim() == 4 and x.is_contiguous() and true_hw.dtype == torch.int32 and true_hw.is_cuda and true_hw.numel() >= 2 * x.shape[0]
+    n, hc, wc, c = (int(v) for v in x.shape)
+    _lib.call("frcnn_zero_outside", _p(x), n, hc, wc, c * x.element_size(), _p(true_hw), _stream())
+    return x
+
+
+def decode_proposals_canvas(regr, anchor_hw_conv, true_rc):
+    """``decode_proposals`` on canvas-shaped RPN outputs: true_rc = device int32 (2,) = the image's true (rows, cols)."""
+    _require_gpu()
+    keep, ap, A = _anchor_arg(anchor_hw_conv)
+    regr = regr.reshape(regr.shape[-3], regr.shape[-2], regr.shape[-1]).contiguous()
+    rows, cols = regr.shape[0], regr.shape[1]
+    assert regr.shape[2] == 4 * A and true_rc.dtype == torch.int32 and true_rc.is_cuda and true_rc.numel() >= 2
+    n = rows * cols * A
+    rois = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    valid = torch.empty(n, dtype=torch.uint8, device="cuda")
+    _lib.call("frcnn_decode_proposals_canvas", _p(regr), rows, cols, ap, A, _p(true_rc), _p(rois), _p(valid), _stream())
+    return rois, valid
+
+
 _TAPS = {}
 
 

@@ -35,9 +35,13 @@ class InferencePipeline:
         self._graph = None
 
     # ------------------------------------------------------------------ stages
-    def proposals_dev(self, cls, reg, rois_out=None):
-        """RPN outputs (device) -> (rois (n_rois,4) f32, n_keep (1,) i32, cand, keep)."""
-        rois_all, valid = ops.decode_proposals(reg, self.anchor_conv)
+    def proposals_dev(self, cls, reg, rois_out=None, true_rc=None):
+        """RPN outputs (device) -> (rois (n_rois,4) f32, n_keep (1,) i32, cand, keep).  ``true_rc``: the outputs are canvas-shaped and
+        the image's true map is true_rc = device int32 (rows, cols) (ops.decode_proposals_canvas)."""
+        if true_rc is not None:
+            rois_all, valid = ops.decode_proposals_canvas(reg, self.anchor_conv, true_rc)
+        else:
+            rois_all, valid = ops.decode_proposals(reg, self.anchor_conv)
         scores = cls.reshape(-1)
         order, n = ops.topk_order(scores, valid, self.pre)
         cand, cand_scores = ops.gather_candidates(rois_all, scores, order, n, self.pre)
@@ -45,14 +49,15 @@ class InferencePipeline:
         rois = ops.gather_rois(cand, keep, n_keep, self.roi_batch, self.n_rois, out=rois_out)
         return rois, n_keep, cand, keep
 
-    def forward_dev(self, x, resize_ratio=1.0, dyn=None):
+    def forward_dev(self, x, resize_ratio=1.0, dyn=None, extents=None):
         """x: (1,H,W,3) f32 device tensor (already preprocessed).  Returns a dict of device tensors.
+        ``extents`` (nets.Extents): x is a canvas holding a smaller image in its top-left corner (see BatchedInferencePipeline).
         ``dyn``: device tensor [resize_ratio, det_threshold] (f64) read by the post-process INSTEAD of the two host scalars
         (entry.DetectionEntry: one captured pass serves every image of its size); the reference's padded RoI rows are then
         scored too when the pipeline was built with ``pad_to_batch`` (voc_dets.py:42-51)."""
         ops.amax_begin()                                    # f16x3 engine: this pass's magnitude records start from zero
-        cls, reg, feat = self.rpn.forward_dev(x)
-        rois, n_keep, cand, keep = self.proposals_dev(cls, reg)
+        cls, reg, feat = self.rpn.forward_dev(x) if extents is None else self.rpn.forward_dev(x, extents)
+        rois, n_keep, cand, keep = self.proposals_dev(cls, reg, true_rc=None if extents is None else extents.level(2)[0])
         out_cls, out_reg = self.det.forward_dev(feat, rois)
         res = {"rpn_cls": cls, "rpn_reg": reg, "feat": feat, "rois": rois, "n_rois": n_keep,
                "cls": out_cls, "reg": out_reg}
@@ -208,17 +213,22 @@ class BatchedInferencePipeline(InferencePipeline):
             main.wait_stream(st)
         return outs
 
-    def forward_dev(self, x, resize_ratio=1.0, dyn=None):
-        """x: (B,H,W,3) f32 device tensor.  Returns a dict: batch tensors with a leading image axis (rpn_cls, rpn_reg, feat,
+    def forward_dev(self, x, resize_ratio=1.0, dyn=None, extents=None):
+        """``extents`` (nets.Extents, round 6): x holds B CANVASES -- images of different true sizes, each in the top-left corner of its
+        canvas, zeros elsewhere; the trunk zeroes what a 3x3 convolution would read beyond an image's extent, the proposals of image i
+        come from its true map only.  Inside an image's extent every tensor is what a pass of that image's own size computes (up to the
+        launch forms the policy picks for the canvas's row count).
+        x: (B,H,W,3) f32 device tensor.  Returns a dict: batch tensors with a leading image axis (rpn_cls, rpn_reg, feat,
         rois (B,n_rois,4), cls (B,n_rois,C), reg) and per-image LISTS of the small outputs (n_rois, n_dets, det_packed, det_bbox,
         det_cls, det_prob, det_roi: entry i is image i's tensor, exactly what InferencePipeline returns for one image).
         ``dyn``: (B,2) f64 device tensor, row i = image i's [resize_ratio, det_threshold] (InferencePipeline.forward_dev)."""
         B = self.batch
         assert x.shape[0] == B
         ops.amax_begin()
-        cls, reg, feat = self.rpn.forward_dev(x)
+        cls, reg, feat = self.rpn.forward_dev(x) if extents is None else self.rpn.forward_dev(x, extents)
         rois = torch.empty((B * self.n_rois, 4), dtype=torch.float32, device="cuda")
-        n_keep = self._fan_out(lambda i: self.proposals_dev(cls[i], reg[i], rois_out=rois[i * self.n_rois:(i + 1) * self.n_rois])[1])
+        n_keep = self._fan_out(lambda i: self.proposals_dev(cls[i], reg[i], rois_out=rois[i * self.n_rois:(i + 1) * self.n_rois],
+                                                            true_rc=None if extents is None else extents.level(2)[i])[1])
         out_cls, out_reg = self.det.head.forward_batched(feat, rois, self.n_rois)
         res = {"rpn_cls": cls, "rpn_reg": reg, "feat": feat, "rois": rois.view(B, self.n_rois, 4), "n_rois": n_keep,
                "cls": out_cls.view(B, self.n_rois, -1), "reg": out_reg.view(B, self.n_rois, -1)}

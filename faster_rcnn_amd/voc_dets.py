@@ -123,6 +123,10 @@ def _get_dets_by_cls_captured(eng, training_manager, detector, resized_ratios, i
     images, resized_ratios = list(images), list(resized_ratios)
     n = min(len(images), len(resized_ratios))
     # how often each geometry occurs in the list, from the images' headers (no pixel decode); unknown (a foreign image object): always capture
+    # a list of many sizes: passes per canvas CLASS with the true sizes as device values (entry.py, round 6) instead of one per geometry
+    if getattr(eng, "canvas_capable", False):
+        exact = [eng.exact_geometry(images[i]) for i in range(n)]
+        eng.canvas = len({k for k in exact if k is not None}) > entry.CANVAS_MIN_GEOMETRIES
     keys = [eng.probe_geometry(images[i]) for i in range(n)]
     counts = collections.Counter(k for k in keys if k is not None)
     unprobed = set(i for i in range(n) if keys[i] is None)

@@ -93,7 +93,7 @@ class _FakeEngine:
 
     @staticmethod
     def geometry(pixels):
-        return entry.DetectionEntry.geometry(pixels)
+        return entry.DetectionEntry.geometry_of(pixels)
 
     def submit_batch(self, images, ratios, thr, pixels, batch=None):
         assert 1 <= len(images) <= (batch or self.batch) and len({self.geometry(p) for p in pixels}) == 1

@@ -439,3 +439,61 @@ def test_get_dets_by_cls_shuffled_geometries_share_passes_and_rare_ones_run_eage
         for img_name in fast[cls_name]:
             same_dets(again[cls_name][img_name], fast[cls_name][img_name], tol=0.0)
     assert not any(sl.busy for v in eng.cache._slots.values() for sl in v)
+
+
+def test_get_dets_by_cls_many_sizes_go_through_canvas_passes(models, monkeypatch):
+    """Round 6: a list of MORE than entry.CANVAS_MIN_GEOMETRIES image sizes is served by passes captured per canvas CLASS (sides rounded up
+    to a multiple of 32 keeping their parity; true sizes as device values) -- here nine sizes, resized and un-resized frames, fall into three
+    classes: three captures instead of nine.  The dict, its order and the progress lines are those of the eager one-by-one walk; classes and
+    boxes identical, scores to 1e-4; the same call again re-uses the passes and returns the same bits."""
+    from faster_rcnn_amd import entry, shapes, voc_dets
+    monkeypatch.setattr(voc_dets, "CAPTURE_MIN", 1)
+    mgr, det, _, _ = models
+    sizes = [(320, 480), (318, 470), (306, 452), (320, 466), (310, 480), (352, 480), (340, 472), (289, 449), (273, 447)]
+    images, ratios = [], []
+    rs = np.random.RandomState(21)
+    for k in range(18):
+        h, w = sizes[k % len(sizes)]
+        if k % 3 == 0:                                            # a frame that is resized on the way in (source smaller than its (h, w))
+            src = synth_pixels(h * 5 // 8, w * 5 // 8, 800 + k)
+            images.append(shapes.Image(shapes.Metadata("c%02d" % k, w, h, [], "none"), src))
+        else:
+            images.append(named_image("c%02d" % k, synth_pixels(h, w, 800 + k)))
+        ratios.append(1.0 + 0.01 * k)
+    order = rs.permutation(len(images))
+    images, ratios = [images[i] for i in order], [ratios[i] for i in order]
+    depth = entry.default_in_flight("f32")
+    eng = entry.for_models(mgr, det, 64, 16, depth)
+    eng.cache.clear()
+    assert eng.canvas_capable
+    fast, out_fast = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.1)
+    assert eng.canvas
+    keys = eng.cache.keys()
+    assert all(k[0] == "canvas" for k in keys), keys
+    classes = {(entry.canvas_side(h), entry.canvas_side(w)) for h, w in sizes}
+    assert {k[1:3] for k in keys} == classes and len(classes) <= 4
+    st = eng.stats()
+    voc_dets.FAST_ENTRY = False
+    try:
+        eager, out_eager = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.1)
+    finally:
+        voc_dets.FAST_ENTRY = True
+    assert list(fast) == list(eager)
+    # a canvas pass and the eager launches pick different launch forms for some layers (the canvas has a few more rows): scores differ
+    # by ~1e-6, so two detections of one class whose scores are closer than that may swap places in the list -- compared by box
+    by_box = lambda lst: sorted(lst, key=lambda d: tuple(int(v) for v in d["bbox"]))
+    for cls_name in eager:
+        assert list(fast[cls_name]) == list(eager[cls_name])
+        for img_name in eager[cls_name]:
+            same_dets(by_box(fast[cls_name][img_name]), by_box(eager[cls_name][img_name]))
+    strip = lambda s_: [ln.split(" ran in ")[0] for ln in s_.splitlines()]
+    assert strip(out_fast) == strip(out_eager)
+    again, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios, images, det_threshold=0.1)
+    assert eng.stats()["captures"] == st["captures"]
+    for cls_name in fast:
+        for img_name in fast[cls_name]:
+            same_dets(again[cls_name][img_name], fast[cls_name][img_name], tol=0.0)
+    assert not any(sl.busy for v in eng.cache._slots.values() for sl in v)
+    # a short list of few sizes keeps the exact-geometry passes
+    few, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios[:3], [named_image("f%d" % i, synth_pixels(320, 480, 900 + i)) for i in range(3)], det_threshold=0.1)
+    assert not eng.canvas
