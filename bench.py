@@ -935,7 +935,7 @@ MIXED_SIZES = [((500, 375), 0.40), ((500, 333), 0.14), ((375, 500), 0.11), ((500
                ((500, 281), 0.015)]
 
 
-def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77):
+def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77, canvas=False):
     """``voc_dets.get_dets_by_cls`` (voc_dets.py:91-111) over a SHUFFLED list of ``n_images`` frames whose source sizes follow
     MIXED_SIZES (the rest of the probability mass: sizes drawn once, 500 x 250..499): every source size resizes to its own geometry
     (shapes.py:106-123), a captured pass serves one geometry.  Timed: the first call (captures included) and the same call again
@@ -965,6 +965,10 @@ def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77):
     geometries = len({(im.height, im.width) for im in images})
     dtype = getattr(pipe.det.head, "dtype", "f32")
     eng = entry.for_models(mgr, pipe.det, 64, 16, entry.default_in_flight(dtype))
+    eng.cache.clear()                                            # (the leg measures a list nobody has seen: no pass of an earlier leg helps)
+    was_capable = eng.canvas_capable
+    if canvas:
+        eng.canvas_capable = True
     before = eng.stats()
     sink = _io.StringIO()
     eager_calls = [0]
@@ -987,12 +991,15 @@ def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77):
         e2 = eager_calls[0] - e1
     finally:
         voc_dets._get_dets_eager = real_eager
+        eng.canvas_capable = was_capable
     after = eng.stats()
     same = d1.keys() == d2.keys() and all(d1[c].keys() == d2[c].keys() and all(len(d1[c][i]) == len(d2[c][i]) for i in d1[c]) for c in d1)
     return {"first_call": {"value": round(n_images / t1, 2), "unit": "img/s", "seconds": round(t1, 3), "captures": mid["captures"] - before["captures"],
                            "capture_seconds": round(mid["capture_seconds"] - before["capture_seconds"], 3), "eager_images": e1},
             "second_call": {"value": round(n_images / t2, 2), "unit": "img/s", "seconds": round(t2, 3), "captures": after["captures"] - mid["captures"], "eager_images": e2},
             "images": n_images, "geometries": geometries, "graph_cache_bytes": after["bytes"], "graphs": after["graphs"],
+            "passes": ("per canvas class (sides rounded up to a multiple of %d keeping their parity; true sizes as device values; opt-in FRCNN_ENTRY_CANVAS=1)" % entry.CANVAS_GRANULE)
+                      if canvas else "per exact geometry (the default)",
             "reorder_window": voc_dets.REORDER_WINDOW, "capture_min": voc_dets.CAPTURE_MIN, "images_per_pass": eng.batch, "in_flight": eng.in_flight,
             "same_detection_counts_both_calls": bool(same),
             "what": "voc_dets.get_dets_by_cls over a shuffled list of %d frames of %d geometries (VOC07-like source sizes resized within 600 / 1000); images "
@@ -1430,6 +1437,7 @@ def main():
         if "error" not in via_entry and DEPTH == 50 and DTYPE == "f32":
             try:
                 via_entry["mixed_sizes"] = mixed_sizes_leg(pipe, anchors)
+                via_entry["mixed_sizes_canvas_passes"] = mixed_sizes_leg(pipe, anchors, canvas=True)
             except Exception as e:
                 via_entry["mixed_sizes"] = {"error": "%s: %s" % (type(e).__name__, e)}
 

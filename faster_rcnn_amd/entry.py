@@ -82,6 +82,9 @@ WARMUP_PASSES = max(1, int(os.environ.get("FRCNN_ENTRY_WARMUP", "1")))
 # capture per geometry.  voc_dets.get_dets_by_cls switches it on for a call whose list holds more than CANVAS_MIN_GEOMETRIES sizes.
 CANVAS_GRANULE = int(os.environ.get("FRCNN_ENTRY_CANVAS_GRANULE", "32"))
 CANVAS_MIN_GEOMETRIES = int(os.environ.get("FRCNN_ENTRY_CANVAS_MIN", "4"))
+# captured passes kept per canvas class: with several classes interleaving in a list, two of one class in flight at once is the common
+# worst case; a third would be a capture (~20-35 ms) to save a wait of a few ms -- get_dets_by_cls waits instead (should_wait)
+CANVAS_SLOTS_PER_CLASS = int(os.environ.get("FRCNN_ENTRY_CANVAS_SLOTS", "2"))
 
 
 def canvas_side(n, granule=None):
@@ -267,7 +270,12 @@ class DetectionEntry:
         self.capture_seconds = 0.0
         # canvas passes need the ResNet trunk's extent masks (nets.ResNetBase) and the device-side preprocess
         net = getattr(getattr(manager.rpn_model, "base", None), "net", None)
-        self.canvas_capable = self.device_preprocess and hasattr(net, "block_level") and os.environ.get("FRCNN_ENTRY_CANVAS", "1") != "0"
+        # OPT-IN (FRCNN_ENTRY_CANVAS=1, or set ``canvas_capable`` on the engine): measured on bench.py's mixed_sizes legs (256 frames, 36
+        # geometries falling into 18 canvas classes) canvas passes serve the call that sees its list AGAIN 8-13 % faster (459-485 against
+        # 426-447 img/s: 4 eager images instead of 23) and the FIRST call 5-25 % slower (220-282 against 289-300: a class's partial
+        # groups cost whole padded passes, the canvases carry ~3 % more pixels, the extent masks 17 launches per pass, and the tail of
+        # rare sizes spreads over many classes anyway) -- the exact-geometry passes stay the default, both are in the bench line
+        self.canvas_capable = self.device_preprocess and hasattr(net, "block_level") and os.environ.get("FRCNN_ENTRY_CANVAS", "0") != "0"
         self.canvas = False                              # set per call by voc_dets.get_dets_by_cls
         self._taps_dev = {}
 
@@ -576,6 +584,15 @@ class DetectionEntry:
         if tuple(size) == (H, W) and not flip:
             return (H, W)
         return (H, W, int(size[0]), int(size[1]), flip)
+
+    def should_wait(self, pixels, batch):
+        """Before a ``submit_batch`` of these frames: True when every captured pass of their canvas class is in flight and the class
+        already has its CANVAS_SLOTS_PER_CLASS -- collecting an older ticket frees one sooner than a capture would make another."""
+        key = self.geometry(pixels[0])
+        if key[0] != "canvas":
+            return False
+        slots = self.cache._slots.get(key + ((batch,) if batch > 1 else ()))
+        return slots is not None and len(slots) >= CANVAS_SLOTS_PER_CLASS and all(sl.busy for sl in slots)
 
     def exact_geometry(self, image):
         """``probe_geometry`` with canvas mode off: the image's OWN geometry (get_dets_by_cls counts the distinct ones)."""

@@ -174,14 +174,18 @@ def _get_dets_by_cls_captured(eng, training_manager, detector, resized_ratios, i
                 done[pos] = (line[0][len("num rois: "):] if line and line[0].startswith("num rois: ") else None, dets, start_time)
             fold_ready()
             return []
+        canvas = B > 1 and isinstance(keys[group[0][0]], tuple) and keys[group[0][0]][:1] == ("canvas",) if group else False
         while group:
             if B > 1 and len(group) >= B:
                 take = B
             elif whole_only:
                 break
             else:
-                take = B if (B > 1 and len(group) >= max(2, B // 2)) else 1
+                # (a canvas class keeps ONE pass shape: what is left of it goes through a padded pass rather than a capture of its own)
+                take = B if (B > 1 and (canvas or len(group) >= max(2, B // 2))) else 1
             part, group = group[:take], group[take:]
+            while window and hasattr(eng, "should_wait") and eng.should_wait([g[1] for g in part], B if take > 1 else 1):
+                finish()                                     # every pass of this canvas class is in flight: collect the oldest ticket first
             ticket = eng.submit_batch([images[g[0]] for g in part], [resized_ratios[g[0]] for g in part], det_threshold, [g[1] for g in part],
                                       batch=B if take > 1 else 1)
             window.append(([(g[0], g[2]) for g in part], ticket))
