@@ -120,7 +120,8 @@ class _PinnedArena:
         piece._arena_block = blk
         return piece
 
-    def give_back(self, piece):
+    @staticmethod
+    def give_back(piece):
         blk = getattr(piece, "_arena_block", None)
         if blk is None:
             return
@@ -129,7 +130,6 @@ class _PinnedArena:
             blk[1] = 0                                   # every piece of the block is gone: the block starts over
 
 
-_PINNED = _PinnedArena()
 _CAPTURE_STREAM = None
 
 
@@ -161,7 +161,7 @@ def _close_slot(s):
     for name in ("io_pin", "_out_raw"):
         piece = getattr(s, name, None)
         if piece is not None:
-            _PINNED.give_back(piece)
+            _PinnedArena.give_back(piece)
     for name in ("graph", "out", "out_packed", "io_dev", "x_f32", "u8_resized", "tabs", "ws", "amax", "pipe", "io_pin", "_out_raw", "out_pin", "pix_hosts", "pix_host", "dyn_host", "extents"):
         setattr(s, name, None)
 
@@ -278,6 +278,7 @@ class DetectionEntry:
         self.canvas_capable = self.device_preprocess and hasattr(net, "block_level") and os.environ.get("FRCNN_ENTRY_CANVAS", "0") != "0"
         self.canvas = False                              # set per call by voc_dets.get_dets_by_cls
         self._taps_dev = {}
+        self._pinned = _PinnedArena()                    # (per engine: the blocks go when the engine goes)
 
     # ------------------------------------------------------------------ eligibility
     @staticmethod
@@ -339,7 +340,7 @@ class DetectionEntry:
         s = _Slot()
         s.key, s.pipe, s.busy, s.seq, s.batch, s.canvas, s.seg = ("canvas", Hc, Wc), pipe, False, 0, B, True, seg
         s.io_dev = torch.zeros(off + 16 * B, dtype=torch.uint8, device="cuda")
-        s.io_pin = _PINNED.take(off + 16 * B, zero=True)
+        s.io_pin = self._pinned.take(off + 16 * B, zero=True)
         host = s.io_pin.numpy()
         s.pix_hosts = [host[i * seg:(i + 1) * seg] for i in range(B)]
         s.pix_host = s.pix_hosts[0]
@@ -374,7 +375,7 @@ class DetectionEntry:
                 s.graph.capture_end()
         packed = s.out["det_packed"]
         s.out_packed = packed if isinstance(packed, (list, tuple)) else [packed]
-        s._out_raw = _PINNED.take(4 * B * s.out_packed[0].numel())
+        s._out_raw = self._pinned.take(4 * B * s.out_packed[0].numel())
         s.out_pin = s._out_raw.view(torch.int32).view((B,) + tuple(s.out_packed[0].shape))
         s.event = torch.cuda.Event()
         s.nbytes = max(int(torch.cuda.memory_reserved() - reserved0), int(s.io_dev.numel() + s.x_f32.numel() * 4))
@@ -451,7 +452,7 @@ class DetectionEntry:
         s = _Slot()
         s.key, s.pipe, s.busy, s.seq, s.batch = (H, W), pipe, False, 0, B
         s.io_dev = torch.zeros(off + 16 * B, dtype=torch.uint8, device="cuda")
-        s.io_pin = _PINNED.take(off + 16 * B, zero=True)
+        s.io_pin = self._pinned.take(off + 16 * B, zero=True)
         host = s.io_pin.numpy()
         if self.device_preprocess:
             s.pix_hosts = [host[i * seg:i * seg + npix].reshape(in_h, in_w, 3) for i in range(B)]
@@ -509,7 +510,7 @@ class DetectionEntry:
                 s.graph.capture_end()
         packed = s.out["det_packed"]
         s.out_packed = packed if isinstance(packed, (list, tuple)) else [packed]
-        s._out_raw = _PINNED.take(4 * B * s.out_packed[0].numel())
+        s._out_raw = self._pinned.take(4 * B * s.out_packed[0].numel())
         s.out_pin = s._out_raw.view(torch.int32).view((B,) + tuple(s.out_packed[0].shape))
         s.event = torch.cuda.Event()
         s.nbytes = max(int(torch.cuda.memory_reserved() - reserved0), int(s.io_dev.numel() + s.x_f32.numel() * 4))

@@ -800,7 +800,8 @@ class _StepDriver:
                 id(self._conv_ws), id(self._conv_ws_prefix))
 
     def _frozen_token(self):
-        return tuple(id(u.pc) for u in self._frozen_units())
+        """The frozen layers' packed filters THEMSELVES (held, not their id()s: an id can be re-used by a later object)."""
+        return tuple(u.pc for u in self._frozen_units())
 
     def _step_graph(self, host_inputs):
         """The captured form of a step on these input shapes, or None (the step then runs eagerly): a shape is captured on its
@@ -813,7 +814,7 @@ class _StepDriver:
             # some model re-lowered layers since the last step.  A trainer's own packed filters never move (TConv), the frozen
             # layers' could (set_weights on a frozen layer): the captured prefix holds their addresses
             token = self._frozen_token()
-            if st["token"] is not None and st["token"] != token:
+            if st["token"] is not None and (len(st["token"]) != len(token) or any(a is not b for a, b in zip(st["token"], token))):
                 self.drop_step_graphs()
             st["epoch"], st["token"] = epoch, token
         key = self._graph_key(host_inputs)
