@@ -829,19 +829,29 @@ class _StepDriver:
                 st["seen"].clear()
             st["seen"][key] = seen
             return None
+        evicted = False
         while len(st["graphs"]) >= STEP_GRAPH_SHAPES:
             _, old = st["graphs"].popitem(last=False)
             old.close()
+            evicted = True
+        if evicted:
+            old = None
+            torch.cuda.empty_cache()                    # an evicted step's private memory pools go back to the device (scripts/dev/r6_soak_graphs.py:
+                                                        # without this the reservation grew by ~80 MB per eviction until the allocator ran dry)
         st["seen"].pop(key, None)
         sg = st["graphs"][key] = self._capture_step([shape for _, shape in host_inputs])
         return sg
 
     def drop_step_graphs(self):
         """Destroy every captured step (their memory pools go back to the allocator); the next steps run eagerly and re-capture."""
+        had = bool(self._graphs["graphs"])
         for sg in self._graphs["graphs"].values():
             sg.close()
         self._graphs["graphs"].clear()
         self._graphs["seen"].clear()
+        if had:
+            sg = None
+            torch.cuda.empty_cache()
 
     def _capture_step(self, shapes):
         """Capture the device part of a step on inputs of ``shapes`` (see _StepGraph)."""

@@ -180,3 +180,28 @@ def test_step_graph_cache_is_bounded_and_dropped_on_load_weights(tmp_path):
         assert rpn._trainer is not old and _captured(rpn) == 0 and len(old._graphs["graphs"]) == 0
         rows, cols = resnet.get_conv_rows_cols(96, 128)
         assert all(np.isfinite(rpn.train_on_batch(image(96, 128, seed=9), list(rpn_targets(rows, cols, A, seed=9)))))
+
+
+def test_evicted_step_graphs_give_their_memory_back():
+    """Five image shapes against a cache of two captured steps: every few steps a captured step is evicted and another captured.  The
+    device reservation must not grow with the number of evictions (an evicted step's private pools go back to the device) and the
+    losses stay finite (scripts/dev/r6_soak_graphs.py is the long form: 12 shapes, two trainers, 720 steps each)."""
+    from faster_rcnn_amd import resnet, train
+    from faster_rcnn_amd.weights import synthetic_resnet
+    A = 9
+    w0 = synthetic_resnet(50, anchors_per_loc=A, num_classes=21, seed=75)
+    shapes = [(96, 128), (112, 128), (96, 160), (128, 160), (112, 176)]
+    with graphs(True, after=0, shapes=2):
+        rpn = resnet.resnet50_rpn(resnet.resnet50_base(weights=_copy(w0), dtype="bf16"), anchors_per_loc=A)
+        rpn.compile(train.SGD(1e-4, 0.9))
+        reserved = []
+        for it in range(60):
+            h, w = shapes[it % len(shapes)]
+            rows, cols = resnet.get_conv_rows_cols(h, w)
+            l = rpn.train_on_batch(image(h, w, seed=it), list(rpn_targets(rows, cols, A, seed=it)))
+            assert all(np.isfinite(l)), (it, l)
+            if it in (19, 59):
+                torch.cuda.synchronize()
+                reserved.append(torch.cuda.memory_reserved())
+        assert _captured(rpn) == 2
+        assert reserved[1] <= reserved[0] + (64 << 20), reserved
