@@ -224,3 +224,36 @@ def test_image_data_falls_back_to_the_host_resize_when_the_device_path_fails(mon
     assert np.array_equal(shapes._resize_any(img, 80, 60), want)
     monkeypatch.setattr(shapes, "DEVICE_RESIZE", False)
     assert np.array_equal(shapes.InMemoryImage(img, 80, 60).data, want)
+
+
+def test_canvas_sides_keep_parity_and_levels_follow_the_reference_chain():
+    """entry.canvas_side: the next multiple of the granule that keeps the side's parity (TF's SAME padding at stride 2 depends on it,
+    resnet.py:408); nets.Extents.levels_of: the per-level true sizes a canvas pass masks with end in resnet.get_conv_rows_cols'
+    numbers (resnet.py:78-93) for every size."""
+    from faster_rcnn_amd import nets, resnet
+    for n in list(range(7, 80)) + [375, 500, 599, 600, 601, 800, 898, 901, 904, 999, 1000, 1023, 1024, 1025]:
+        c = entry.canvas_side(n)
+        assert c >= n and (c - n) % 2 == 0 and c - n < 33, (n, c)
+        assert entry.canvas_side(c) == c                       # a canvas is its own class
+    assert entry.canvas_side(600) == 608 and entry.canvas_side(601) == 607 and entry.canvas_side(800) == 800 and entry.canvas_side(901) == 927
+    for h, w in [(600, 1000), (601, 901), (375, 500), (333, 499), (224, 224), (607, 927)]:
+        lv = nets.Extents.levels_of(h, w)
+        assert len(lv) == nets.Extents.LEVELS and list(lv[-1]) == list(resnet.get_conv_rows_cols(h, w))
+        assert all(a[0] >= b[0] and a[1] >= b[1] for a, b in zip(lv, lv[1:]))
+    # a canvas never has FEWER cells than the image at any level (the true extent fits inside)
+    for h, w in [(600, 901), (599, 800), (306, 451)]:
+        hc, wc = entry.canvas_side(h), entry.canvas_side(w)
+        assert all(c[0] >= t[0] and c[1] >= t[1] for c, t in zip(nets.Extents.levels_of(hc, wc), nets.Extents.levels_of(h, w)))
+
+
+def test_full_collections_before_captures_are_throttled(monkeypatch):
+    """pipeline.collect_before_capture: at most one full gc.collect() per interval (a collection costs more than a capture)."""
+    from faster_rcnn_amd import pipeline
+    calls = []
+    monkeypatch.setattr(pipeline._gc, "collect", lambda *a: calls.append(1) or 0)
+    monkeypatch.setattr(pipeline, "_LAST_COLLECT", [0.0])
+    for _ in range(5):
+        pipeline.collect_before_capture(min_interval_s=60.0)
+    assert len(calls) == 1
+    pipeline.collect_before_capture(min_interval_s=0.0)
+    assert len(calls) == 2
