@@ -135,6 +135,9 @@ def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dt
 
 
 HEAD_PLANES = True      # dev knob (tests): False keeps every tensor of the detector head f32
+# the same hand-over inside the TRUNK's bottleneck blocks, wherever the consuming launch is one that reads planes (the 256x128 tile
+# forms: stage 3 of a four-image pass, mostly) -- VERDICT r5 item 3; dev knob until measured
+TRUNK_PLANES = _os.environ.get("FRCNN_TRUNK_PLANES", "0") != "0"
 
 
 class Extents:
@@ -263,8 +266,9 @@ class ResNetBase:
         """``extents`` (Extents): x is a batch of canvases whose images have those true sizes -- every tensor that a 3x3 convolution
         reads is zeroed beyond each image's extent first, the conv4 map at the end (rpn_conv1 is a 3x3 too)."""
         x = self.stem_pool(x)
+        planes = TRUNK_PLANES and self.dtype == "f32" and extents is None      # (a canvas pass masks branch2a's f32 output)
         for b, lvl in zip(self.blocks, self.block_level):
-            x = run_block(b, x, mask=None if extents is None else extents.level(lvl))
+            x = run_block(b, x, planes=planes, mask=None if extents is None else extents.level(lvl))
         if extents is not None:
             x = ops.zero_outside(x, extents.level(2))
         return x
