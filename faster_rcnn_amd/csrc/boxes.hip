@@ -323,8 +323,11 @@ __global__ void k_resize_cubic_u8(const uint8_t* src, int sw, const int32_t* tab
         acc0 += cy * h0; acc1 += cy * h1; acc2 += cy * h2;
     }
     auto fin = [](long long v) { v = (v + (1ll << 21)) >> 22; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
-    uint8_t* o = dst + ((size_t)y * dw + (flip ? dw - 1 - x : x)) * 3;
-    o[0] = fin(acc0); o[1] = fin(acc1); o[2] = fin(acc2);
+    // flip bit 0: horizontal flip (shapes.py:27); bit 1 (round 6): the source is RGB as the JPEG decoder delivers it -- write B, G, R
+    // (cv2.imread's order, shapes.py:23), so that the host does not spend ~0.8 ms per frame reversing the channels before the upload
+    uint8_t* o = dst + ((size_t)y * dw + ((flip & 1) ? dw - 1 - x : x)) * 3;
+    if (flip & 2) { o[0] = fin(acc2); o[1] = fin(acc1); o[2] = fin(acc0); }
+    else { o[0] = fin(acc0); o[1] = fin(acc1); o[2] = fin(acc2); }
 }
 
 }  // namespace frcnn
@@ -367,7 +370,7 @@ int frcnn_resize_cubic_u8(const uint8_t* src_hwc, int src_h, int src_w, const in
                           int dst_h, int dst_w, int flip, uint8_t* dst_hwc, void* stream) {
     if (!src_hwc || !tab_x || !tab_y || !dst_hwc) return fail(FRCNN_E_ARG, "resize_cubic_u8: null pointer");
     if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || dst_h > 65535) return fail(FRCNN_E_ARG, "resize_cubic_u8: bad size");
-    k_resize_cubic_u8<<<dim3((dst_w + 127) / 128, dst_h), 128, 0, as_stream(stream)>>>(src_hwc, src_w, tab_x, tab_y, dst_h, dst_w, flip ? 1 : 0, dst_hwc);
+    k_resize_cubic_u8<<<dim3((dst_w + 127) / 128, dst_h), 128, 0, as_stream(stream)>>>(src_hwc, src_w, tab_x, tab_y, dst_h, dst_w, flip & 3, dst_hwc);
     return check_launch("resize_cubic_u8");
 }
 

@@ -80,6 +80,8 @@ WARMUP_PASSES = max(1, int(os.environ.get("FRCNN_ENTRY_WARMUP", "1")))
 # Padded canvases (round 6): a list of MANY image sizes is served by passes captured per canvas CLASS -- sides rounded up to a multiple
 # of CANVAS_GRANULE, keeping each side's parity -- with the images' true sizes as device values (pipeline: ``extents``), instead of one
 # capture per geometry.  voc_dets.get_dets_by_cls switches it on for a call whose list holds more than CANVAS_MIN_GEOMETRIES sizes.
+# file-backed frames go up in the decoder's channel order and are swapped to BGR by the device resize (0: reverse on the host as before)
+RGB_UPLOAD = os.environ.get("FRCNN_ENTRY_RGB_UPLOAD", "1") != "0"
 CANVAS_GRANULE = int(os.environ.get("FRCNN_ENTRY_CANVAS_GRANULE", "32"))
 CANVAS_MIN_GEOMETRIES = int(os.environ.get("FRCNN_ENTRY_CANVAS_MIN", "4"))
 # captured passes kept per canvas class: with several classes interleaving in a list, two of one class in flight at once is the common
@@ -534,10 +536,18 @@ class DetectionEntry:
         """What ``submit`` uploads for this image -- safe to call from another thread ahead of time (JPEG decode).
         Returns (array, H, W, src or None, flip)."""
         if self.device_preprocess and hasattr(image, "raw") and hasattr(image, "height"):
+            H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
+            rgb = getattr(image, "raw_rgb", None) if RGB_UPLOAD else None
+            if rgb is not None:
+                # a file-backed frame goes up as the decoder delivers it (RGB); the device resize writes B, G, R (flip bit 1) -- a resize to
+                # its own size when none is needed: taps {0, 1, 0, 0}, i.e. a copy with the channels swapped
+                rgb = np.asarray(rgb)
+                if rgb.dtype != np.uint8 or rgb.ndim != 3 or rgb.shape[2] != 3:
+                    raise TypeError("image pixels must be uint8 (h, w, 3) (shapes.py:19-29), got %s %s" % (rgb.dtype, rgb.shape))
+                return rgb, H, W, (int(rgb.shape[0]), int(rgb.shape[1])), 2 | int(flip)
             raw = np.asarray(image.raw)
             if raw.dtype != np.uint8 or raw.ndim != 3 or raw.shape[2] != 3:
                 raise TypeError("image pixels must be uint8 BGR (h, w, 3) (shapes.py:19-29), got %s %s" % (raw.dtype, raw.shape))
-            H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
             if raw.shape[:2] == (H, W) and not flip:
                 return raw, H, W, None, False
             return raw, H, W, (int(raw.shape[0]), int(raw.shape[1])), flip
@@ -582,6 +592,9 @@ class DetectionEntry:
         H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
         if self.canvas and self.canvas_capable and size[0] * size[1] <= canvas_side(H) * canvas_side(W):
             return ("canvas", canvas_side(H), canvas_side(W))
+        if RGB_UPLOAD and getattr(image, "_pixels", 0) is None and hasattr(type(image), "raw_rgb"):      # file-backed: uploaded as RGB (host_pixels; the
+            # attribute is looked up on the CLASS: hasattr on the instance would run the property, i.e. decode the JPEG)
+            return (H, W, int(size[0]), int(size[1]), 2 | int(flip))
         if tuple(size) == (H, W) and not flip:
             return (H, W)
         return (H, W, int(size[0]), int(size[1]), flip)

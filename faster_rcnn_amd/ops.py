@@ -137,7 +137,8 @@ def resize_cubic_taps(dst, src):
 
 def resize_cubic_u8(src, dst_h, dst_w, flip=False, tabs=None, out=None):
     """cv2.resize(src, (dst_w, dst_h), interpolation=cv2.INTER_CUBIC) [+ horizontal flip] of a (h,w,3) uint8 device image
-    (shapes.Image.data, shapes.py:19-29) -> (dst_h, dst_w, 3) uint8 device tensor.  ``tabs``: (tab_x, tab_y) DEVICE int32
+    (shapes.Image.data, shapes.py:19-29) -> (dst_h, dst_w, 3) uint8 device tensor.  ``flip``: bool, or the C ABI's bit set (1 = horizontal
+    flip, 2 = the source is RGB: write B, G, R).  ``tabs``: (tab_x, tab_y) DEVICE int32
     tables to reuse (a captured pass keeps its own); ``out``: write into this tensor."""
     _require_gpu()
     assert src.is_cuda and src.dtype == torch.uint8 and src.dim() == 3 and src.shape[2] == 3 and src.is_contiguous()
@@ -146,7 +147,7 @@ def resize_cubic_u8(src, dst_h, dst_w, flip=False, tabs=None, out=None):
         tabs = (torch.from_numpy(resize_cubic_taps(dst_w, sw)).cuda(), torch.from_numpy(resize_cubic_taps(dst_h, sh)).cuda())
     if out is None:
         out = torch.empty((dst_h, dst_w, 3), dtype=torch.uint8, device="cuda")
-    _lib.call("frcnn_resize_cubic_u8", _p(src), sh, sw, _p(tabs[0]), _p(tabs[1]), int(dst_h), int(dst_w), 1 if flip else 0, _p(out), _stream())
+    _lib.call("frcnn_resize_cubic_u8", _p(src), sh, sw, _p(tabs[0]), _p(tabs[1]), int(dst_h), int(dst_w), int(flip), _p(out), _stream())
     return out
 
 

@@ -60,7 +60,10 @@ int frcnn_preprocess_u8(const uint8_t* img_hwc, size_t n_pixels, const double* m
  * cubic weights (A = -0.75) computed in f32 and rounded to 11-bit fixed point, both passes in integers, (v + 2^21) >> 22,
  * saturate.  frcnn_resize_cubic_taps is a HOST function filling one axis' table [dst][8] = {4 source indices, 4 weights};
  * frcnn_resize_cubic_u8 takes DEVICE copies of the x and y tables and writes dst [dst_h][dst_w][3].  Bit-identical to the
- * integer restatement in shapes._resize (tests); like it, not pinned against cv2 itself (absent offline). */
+ * integer restatement in shapes._resize (tests); like it, not pinned against cv2 itself (absent offline).
+ * `flip`: bit 0 = horizontal flip; bit 1 (round 6) = the source frame is RGB as a JPEG decoder delivers it and the destination gets
+ * B, G, R -- cv2.imread's order (shapes.py:23) -- so a host need not reverse the channels before the upload (the same bytes as
+ * reversing first: the three channels are resampled independently).  With dst == src sizes the taps are {0, 2048, 0, 0}: a copy. */
 int frcnn_resize_cubic_taps(int dst, int src, int32_t* tab_h);
 int frcnn_resize_cubic_u8(const uint8_t* src_hwc, int src_h, int src_w, const int32_t* tab_x, const int32_t* tab_y,
                           int dst_h, int dst_w, int flip, uint8_t* dst_hwc, void* stream);

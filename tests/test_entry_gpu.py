@@ -347,11 +347,11 @@ def test_file_backed_images_are_resized_on_the_device_and_match_the_eager_path(m
     fast, eager, _, _ = both_paths(voc_dets.get_dets, mgr, det, image, ratio)
     same_dets(fast, eager)
     eng = entry.for_models(mgr, det, 64, 16, 1)
-    assert (600, 800, 375, 500, False) in eng.cache.keys()
+    assert (600, 800, 375, 500, 2) in eng.cache.keys()               # (flip bit set: 2 = uploaded as RGB, swapped on the device)
     flipped = image.horizontal_flip()
     fast, eager, _, _ = both_paths(voc_dets.get_dets, mgr, det, flipped, ratio)
     same_dets(fast, eager)
-    assert (600, 800, 375, 500, True) in eng.cache.keys()
+    assert (600, 800, 375, 500, 3) in eng.cache.keys()
     # a list of files through get_dets_by_cls: pixels fetched ahead on threads, results in list order
     frames = [voc_frame(True)[0] for _ in range(6)]
     for i, f in enumerate(frames):
@@ -497,3 +497,29 @@ def test_get_dets_by_cls_many_sizes_go_through_canvas_passes(models, monkeypatch
     # a short list of few sizes keeps the exact-geometry passes
     few, _ = quiet(voc_dets.get_dets_by_cls, mgr, det, ratios[:3], [named_image("f%d" % i, synth_pixels(320, 480, 900 + i)) for i in range(3)], det_threshold=0.1)
     assert not eng.canvas
+
+
+def test_rgb_upload_with_device_channel_swap_is_the_bgr_path_bit_for_bit(models, monkeypatch):
+    """Round 6: a file-backed frame goes up in the JPEG decoder's channel order and frcnn_resize_cubic_u8 (flip bit 1) writes B, G, R --
+    cv2.imread's order (shapes.py:23) -- instead of the host reversing the channels first (~0.8 ms per frame).  The same detections, bit
+    for bit, for a frame that is resized (500x375 -> 800x600) and for one that is not (a resize to its own size: taps {0, 1, 0, 0})."""
+    from faster_rcnn_amd import entry, ops, voc_dets
+    mgr, det, _, _ = models
+    # the kernel by itself: swap == reversing first, with and without a horizontal flip, resized and at its own size
+    rgb = torch.from_numpy(np.random.RandomState(31).randint(0, 256, (37, 53, 3)).astype(np.uint8)).cuda()
+    bgr = rgb.flip(2).contiguous()
+    for (dh, dw) in ((60, 80), (37, 53)):
+        for fl in (0, 1):
+            assert torch.equal(ops.resize_cubic_u8(rgb, dh, dw, flip=2 | fl), ops.resize_cubic_u8(bgr, dh, dw, flip=fl))
+    assert torch.equal(ops.resize_cubic_u8(rgb, 37, 53, flip=2), bgr)
+    for resized in (True, False):
+        image, ratio = voc_frame(resized)
+        assert image.raw_rgb is not None and np.array_equal(image.raw_rgb[:, :, ::-1], image.raw)
+        res = {}
+        for on in (True, False):
+            monkeypatch.setattr(entry, "RGB_UPLOAD", on)
+            res[on], _ = quiet(voc_dets.get_dets, mgr, det, image, ratio, det_threshold=0.0)
+        assert len(res[True]) > 0
+        same_dets(res[True], res[False], tol=0.0)
+    eng = entry.for_models(mgr, det, 64, 16, 1)
+    assert any(len(k) == 5 and k[4] & 2 for k in eng.cache.keys())            # the RGB passes are keyed apart from the BGR ones
