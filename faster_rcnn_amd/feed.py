@@ -14,6 +14,7 @@ import torch
 from . import ops
 
 MEAN_BGR = (103.939, 116.779, 123.68)           # resnet.preprocess / vgg.preprocess (resnet.py:64-75, vgg.py:52-57)
+RGB_UPLOAD = os.environ.get("FRCNN_FEED_RGB_UPLOAD", "1") != "0"
 
 
 class _PinRing:
@@ -79,9 +80,16 @@ def device_preprocess(preprocess_func):
 def device_image(image, preprocess_func):
     """(1,H,W,3) float32 device tensor == float32(np.expand_dims(preprocess_func(image.data), 0)), on the current stream."""
     if device_preprocess(preprocess_func) and hasattr(image, "raw") and hasattr(image, "height"):
+        H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
+        # a file-backed frame goes up in the JPEG decoder's channel order; the device resize (to its own size when none is needed: a
+        # copy) writes B, G, R -- the host's channel reversal cost as much as half the decode (round 6, as entry.DetectionEntry)
+        rgb = getattr(image, "raw_rgb", None) if (RGB_UPLOAD and hasattr(type(image), "raw_rgb")) else None
+        if rgb is not None:
+            rgb = np.asarray(rgb)
+            if rgb.dtype == np.uint8 and rgb.ndim == 3 and rgb.shape[2] == 3:
+                return ops.preprocess_u8(ops.resize_cubic_u8(upload(rgb), H, W, flip=2 | int(flip)), MEAN_BGR)
         raw = np.asarray(image.raw)
         if raw.dtype == np.uint8 and raw.ndim == 3 and raw.shape[2] == 3:
-            H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
             if raw.shape[0] != H or raw.shape[1] != W:
                 u8 = ops.resize_cubic_u8(upload(raw), H, W, flip=flip)
             else:

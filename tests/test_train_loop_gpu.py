@@ -31,13 +31,28 @@ def frames(n, h, w, seed=0, boxes=5, src=None):
     return out
 
 
-@pytest.mark.parametrize("case", ["plain", "resized", "flipped", "many_positives"])
+def file_frames(resized, flipped):
+    """The committed VOC frame, file-backed: the device feed uploads it in the JPEG decoder's channel order (feed.RGB_UPLOAD) and the
+    resize kernel writes B, G, R."""
+    import os
+    from faster_rcnn_amd import util
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "VOC_test")
+    img = extract_img_data(root, "000005")
+    if resized:
+        (img,), _ = util.resize_imgs([img], min_size=600, max_size=1000)
+    return [img.horizontal_flip() if flipped else img]
+
+
+@pytest.mark.parametrize("case", ["plain", "resized", "flipped", "many_positives", "file", "file_flipped", "file_resized", "file_resized_flipped"])
 def test_rpn_inputs_dev_equal_the_host_feed(case):
     """x, y_class, y_bbreg from rpn_inputs_dev == float32(batched_image), float32(rpn_y_true) -- and the global `random` stream ends
     in the same state (the same two draws in the same order)."""
     from faster_rcnn_amd import resnet, rpn_util, util
     anchors = util.get_anchors([128, 256, 512])
-    if case == "resized":
+    if case.startswith("file"):
+        imgs = file_frames("resized" in case, "flipped" in case)
+    elif case == "resized":
         imgs = frames(2, 320, 448, seed=3, src=(200, 280))
     elif case == "many_positives":
         imgs = frames(2, 480, 640, seed=4, boxes=260)            # > 128 usable positives (every box makes its best anchor one): the first draw happens too
@@ -65,7 +80,9 @@ def test_rpn_inputs_dev_equal_the_host_feed(case):
         n_pos = int((yc_h[..., :A] & yc_h[..., A:]).sum())
         used = int(yc_h[..., :A].sum())
         assert used <= 256 and n_pos <= 128
-        if case == "many_positives":
+        if case.startswith("file"):
+            assert used > 0
+        elif case == "many_positives":
             assert n_pos == 128, n_pos                            # (260 boxes leave hardly an anchor under 0.3 IoU with all of them: few negatives)
         else:
             assert used == 256
