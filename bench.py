@@ -935,7 +935,7 @@ MIXED_SIZES = [((500, 375), 0.40), ((500, 333), 0.14), ((375, 500), 0.11), ((500
                ((500, 281), 0.015)]
 
 
-def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77, canvas=False):
+def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77, canvas=True):
     """``voc_dets.get_dets_by_cls`` (voc_dets.py:91-111) over a SHUFFLED list of ``n_images`` frames whose source sizes follow
     MIXED_SIZES (the rest of the probability mass: sizes drawn once, 500 x 250..499): every source size resizes to its own geometry
     (shapes.py:106-123), a captured pass serves one geometry.  Timed: the first call (captures included) and the same call again
@@ -967,8 +967,7 @@ def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77, canvas=False):
     eng = entry.for_models(mgr, pipe.det, 64, 16, entry.default_in_flight(dtype))
     eng.cache.clear()                                            # (the leg measures a list nobody has seen: no pass of an earlier leg helps)
     was_capable = eng.canvas_capable
-    if canvas:
-        eng.canvas_capable = True
+    eng.canvas_capable = bool(canvas) and was_capable
     before = eng.stats()
     sink = _io.StringIO()
     eager_calls = [0]
@@ -998,13 +997,16 @@ def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77, canvas=False):
                            "capture_seconds": round(mid["capture_seconds"] - before["capture_seconds"], 3), "eager_images": e1},
             "second_call": {"value": round(n_images / t2, 2), "unit": "img/s", "seconds": round(t2, 3), "captures": after["captures"] - mid["captures"], "eager_images": e2},
             "images": n_images, "geometries": geometries, "graph_cache_bytes": after["bytes"], "graphs": after["graphs"],
-            "passes": ("per canvas class (sides rounded up to a multiple of %d keeping their parity; true sizes as device values; opt-in FRCNN_ENTRY_CANVAS=1)" % entry.CANVAS_GRANULE)
-                      if canvas else "per exact geometry (the default)",
+            "capture_breakdown_ms": {k: round(v - before.get("capture_breakdown_ms", {}).get(k, 0.0), 1) for k, v in after.get("capture_breakdown_ms", {}).items()},
+            "passes": ("per canvas class (even sides, multiples of %d; an odd side sits at offset 1; true sizes as device values; the classes planned "
+                       "from the list's histogram of sizes: entry.plan_canvas_classes; the default)" % entry.CANVAS_GRANULE)
+                      if canvas else "per exact geometry (FRCNN_ENTRY_CANVAS=0: round 5's policy)",
+            "canvas_classes": sorted({k[1:3] for k in eng.cache.keys() if k[:1] == ("canvas",)}),
             "reorder_window": voc_dets.REORDER_WINDOW, "capture_min": voc_dets.CAPTURE_MIN, "images_per_pass": eng.batch, "in_flight": eng.in_flight,
             "same_detection_counts_both_calls": bool(same),
             "what": "voc_dets.get_dets_by_cls over a shuffled list of %d frames of %d geometries (VOC07-like source sizes resized within 600 / 1000); images "
-                    "of one geometry share captured passes wherever they stand in the list (held back per geometry, at most REORDER_WINDOW), a geometry seen "
-                    "fewer than CAPTURE_MIN times runs the eager sequence" % (n_images, geometries)}
+                    "of one pass shape (canvas class / geometry) share captured passes wherever they stand in the list (held back per shape, at most "
+                    "REORDER_WINDOW); a shape seen fewer than CAPTURE_MIN times runs the eager sequence" % (n_images, geometries)}
 
 
 _JSON_OUT = None
@@ -1437,7 +1439,7 @@ def main():
         if "error" not in via_entry and DEPTH == 50 and DTYPE == "f32":
             try:
                 via_entry["mixed_sizes"] = mixed_sizes_leg(pipe, anchors)
-                via_entry["mixed_sizes_canvas_passes"] = mixed_sizes_leg(pipe, anchors, canvas=True)
+                via_entry["mixed_sizes_exact_geometry_passes"] = mixed_sizes_leg(pipe, anchors, canvas=False)
             except Exception as e:
                 via_entry["mixed_sizes"] = {"error": "%s: %s" % (type(e).__name__, e)}
 

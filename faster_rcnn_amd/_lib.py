@@ -17,7 +17,7 @@ class FrcnnError(RuntimeError):
     pass
 
 
-ABI_VERSION = 105       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
+ABI_VERSION = 106       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
 P = c_void_p
 I = c_int
 # name -> (restype, argtypes).  Must list every symbol include/frcnn_hip.h declares
@@ -40,7 +40,7 @@ SIGNATURES = {
     "frcnn_host_mt_sample_range": (I, [P, P, I, I, I, P]),
     "frcnn_decode_proposals": (I, [P, I, I, P, I, P, P, P]),
     "frcnn_transform_inplace": (I, [P, P, I, P]),
-    "frcnn_preprocess_u8_canvas": (I, [P, I, I, I, I, P, P, P]),
+    "frcnn_preprocess_u8_canvas": (I, [P, I, I, I, I, I, I, P, P, P]),
     "frcnn_zero_outside": (I, [P, I, I, I, I, P, P]),
     "frcnn_decode_proposals_canvas": (I, [P, I, I, P, I, P, P, P, P]),
     "frcnn_topk_workspace_bytes": (c_size_t, [I]),

@@ -250,19 +250,22 @@ __global__ void k_preprocess_u8(const uint8_t* img, size_t n, double m0, double 
     }
 }
 
-// ---- padded canvases (round 6): images of DIFFERENT true sizes share one captured pass.  Each image sits in the top-left corner of a
-// canvas [hc][wc] whose sides have the PARITY of the image's (so TF's SAME padding at stride 2 -- pad_before = total / 2, total depending
-// on the size's parity, resnet.py:408 -- is the canvas's); everything outside the image is zero, which is what the reference's padding
-// puts there.  A convolution with taps (3x3, 7x7) reads zeros beyond the true border exactly where the reference reads its padding as
-// long as its INPUT is zero there: the canvas is, and k_zero_outside restores that behind every layer whose output feeds such a
-// convolution (bias / BatchNorm shift / ReLU make the outside non-zero again).  Pointwise layers and VALID pooling never look outside.
-__global__ void k_preprocess_u8_canvas(const uint8_t* img, int h, int w, int hc, int wc, double m0, double m1, double m2, float* out) {
+// ---- padded canvases (round 6): images of DIFFERENT true sizes share one captured pass.  Each image sits near the top-left corner of
+// a canvas [hc][wc] with EVEN sides, at offset (oy, ox) = (h & 1, w & 1): TF's SAME padding at stride 2 (resnet.py:408) puts
+// pad_before = total / 2 zeros in front, total = 5 for an even size and 6 for an odd one under conv1's 7x7 window, i.e. one more zero row /
+// column in front of an odd side -- the offset supplies it, so conv1's output cell (i, j) on the canvas is the true image's cell (i, j)
+// whatever the parities (it is the only layer of the networks whose padding depends on the size).  Everything outside the image is zero,
+// which is what the reference's padding puts there.  A convolution with taps (3x3, 7x7) reads zeros beyond the true border exactly
+// where the reference reads its padding as long as its INPUT is zero there: the canvas is, and k_zero_outside restores that behind
+// every layer whose output feeds such a convolution (bias / BatchNorm shift / ReLU make the outside non-zero again).  Pointwise
+// layers and VALID pooling never look outside.
+__global__ void k_preprocess_u8_canvas(const uint8_t* img, int h, int w, int hc, int wc, int oy, int ox, double m0, double m1, double m2, float* out) {
     const size_t n = (size_t)hc * wc * 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % 3);
         const size_t px = i / 3;
-        const int x = (int)(px % wc), y = (int)(px / wc);
-        out[i] = (x < w && y < h) ? (float)((double)img[((size_t)y * w + x) * 3 + c] - (c == 0 ? m0 : (c == 1 ? m1 : m2))) : 0.0f;
+        const int x = (int)(px % wc) - ox, y = (int)(px / wc) - oy;
+        out[i] = (x >= 0 && y >= 0 && x < w && y < h) ? (float)((double)img[((size_t)y * w + x) * 3 + c] - (c == 0 ? m0 : (c == 1 ? m1 : m2))) : 0.0f;
     }
 }
 
@@ -565,11 +568,12 @@ int frcnn_zero_outside(void* x, int n, int hc, int wc, int row_bytes, const int3
     return check_launch("zero_outside");
 }
 
-int frcnn_preprocess_u8_canvas(const uint8_t* img_hwc, int h, int w, int hc, int wc, const double* mean3_h, float* out, void* stream) {
-    if (!img_hwc || !mean3_h || !out || h <= 0 || w <= 0 || hc < h || wc < w) return fail(FRCNN_E_ARG, "preprocess_u8_canvas: bad argument");
+int frcnn_preprocess_u8_canvas(const uint8_t* img_hwc, int h, int w, int hc, int wc, int oy, int ox, const double* mean3_h, float* out, void* stream) {
+    if (!img_hwc || !mean3_h || !out || h <= 0 || w <= 0 || oy < 0 || ox < 0 || hc < h + oy || wc < w + ox)
+        return fail(FRCNN_E_ARG, "preprocess_u8_canvas: bad argument (the image at its offset must fit the canvas)");
     size_t g = ((size_t)hc * wc * 3 + 255) / 256;
     if (g > 8192) g = 8192;
-    k_preprocess_u8_canvas<<<(int)g, 256, 0, as_stream(stream)>>>(img_hwc, h, w, hc, wc, mean3_h[0], mean3_h[1], mean3_h[2], out);
+    k_preprocess_u8_canvas<<<(int)g, 256, 0, as_stream(stream)>>>(img_hwc, h, w, hc, wc, oy, ox, mean3_h[0], mean3_h[1], mean3_h[2], out);
     return check_launch("preprocess_u8_canvas");
 }
 

@@ -77,9 +77,11 @@ PAD_TO_BATCH = os.environ.get("FRCNN_ENTRY_PAD", "0") != "0"
 # eager passes in front of a capture: ONE sizes the split-K workspace, lowers what is lowered lazily and leaves the magnitude-record
 # arena's high-water mark (round 6: two until then; a capture is ~2/3 warm-up, and a list of mixed sizes captures per geometry)
 WARMUP_PASSES = max(1, int(os.environ.get("FRCNN_ENTRY_WARMUP", "1")))
-# Padded canvases (round 6): a list of MANY image sizes is served by passes captured per canvas CLASS -- sides rounded up to a multiple
-# of CANVAS_GRANULE, keeping each side's parity -- with the images' true sizes as device values (pipeline: ``extents``), instead of one
-# capture per geometry.  voc_dets.get_dets_by_cls switches it on for a call whose list holds more than CANVAS_MIN_GEOMETRIES sizes.
+# Padded canvases (round 6): a list of MANY image sizes is served by passes captured per canvas CLASS with the images' true sizes as
+# device values (pipeline: ``extents``), instead of one capture per geometry.  A canvas has EVEN sides, multiples of CANVAS_GRANULE; an
+# image sits at offset (H & 1, W & 1) (csrc/boxes.hip: the offset stands for the extra zero row / column SAME padding puts in front of
+# an odd side).  voc_dets.get_dets_by_cls switches canvases on for a call whose list holds more than CANVAS_MIN_GEOMETRIES sizes and
+# PLANS the classes from the list's size histogram (DetectionEntry.plan_canvases): few classes, each worth its captures.
 # file-backed frames go up in the decoder's channel order and are swapped to BGR by the device resize (0: reverse on the host as before)
 RGB_UPLOAD = os.environ.get("FRCNN_ENTRY_RGB_UPLOAD", "1") != "0"
 CANVAS_GRANULE = int(os.environ.get("FRCNN_ENTRY_CANVAS_GRANULE", "32"))
@@ -89,11 +91,66 @@ CANVAS_MIN_GEOMETRIES = int(os.environ.get("FRCNN_ENTRY_CANVAS_MIN", "4"))
 CANVAS_SLOTS_PER_CLASS = int(os.environ.get("FRCNN_ENTRY_CANVAS_SLOTS", "2"))
 
 
+# the plan's cost model, in image-times: a captured pass costs about this many images' worth of host time per class (15-25 ms per
+# capture, a class has a few passes in flight); padded pixels cost the trunk's and the RPN's share of an image's time (the head's
+# 300 RoIs do not grow with the canvas)
+CANVAS_CAPTURE_IMAGES = float(os.environ.get("FRCNN_ENTRY_CANVAS_CAPTURE_IMAGES", "12"))
+CANVAS_PIXEL_SHARE = float(os.environ.get("FRCNN_ENTRY_CANVAS_PIXEL_SHARE", "0.4"))
+CANVAS_MAX_CLASSES = int(os.environ.get("FRCNN_ENTRY_CANVAS_MAX_CLASSES", "8"))
+
+
 def canvas_side(n, granule=None):
-    """The canvas side for a true side ``n``: the next multiple of the granule, one less when that would flip the parity."""
+    """The smallest canvas side for a true side ``n``: even, a multiple of the granule, with room for the offset of an odd side."""
     g = CANVAS_GRANULE if granule is None else granule
-    c = -(-int(n) // g) * g
-    return c if (c - n) % 2 == 0 else c - 1
+    assert g > 0 and g % 2 == 0, "canvas granule: a positive even number"
+    n = int(n)
+    return -(-(n + (n & 1)) // g) * g
+
+
+def plan_canvas_classes(counts, existing=(), capture_images=None, pixel_share=None, max_new=None, granule=None):
+    """{(H, W): canvas (Hc, Wc)} for a histogram ``counts`` = {(H, W): number of images}: start with every geometry on its own smallest
+    canvas (or on an ``existing`` class -- a pass already captured -- when the padding costs less than a capture), then merge the pair
+    of classes whose union canvas lowers  sum over NEW classes of capture_images + sum over images of pixel_share * (canvas area /
+    image area - 1)  the most, until no merge lowers it and at most ``max_new`` new classes are left.  Deterministic: the same
+    histogram and the same existing classes give the same plan (a second call over the same list captures nothing)."""
+    cap = CANVAS_CAPTURE_IMAGES if capture_images is None else capture_images
+    share = CANVAS_PIXEL_SHARE if pixel_share is None else pixel_share
+    max_new = CANVAS_MAX_CLASSES if max_new is None else max_new
+    ex = set(tuple(e) for e in existing)
+    area = lambda c: c[0] * c[1]
+
+    def padding(geos, c):
+        return sum(n * share * (area(c) / float(h * w) - 1.0) for (h, w), n in geos)
+
+    def cost(c, geos):
+        return (0.0 if c in ex else cap) + padding(geos, c)
+    classes = {}
+    for (h, w), n in sorted(counts.items()):
+        own = (canvas_side(h, granule), canvas_side(w, granule))
+        best, best_cost = own, cost(own, [((h, w), n)])
+        for e in sorted(ex):
+            if e[0] >= own[0] and e[1] >= own[1]:
+                c = padding([((h, w), n)], e)
+                if c < best_cost:
+                    best, best_cost = e, c
+        classes.setdefault(best, []).append(((h, w), n))
+    while len(classes) > 1:
+        keys, best = sorted(classes), None
+        for i, a in enumerate(keys):
+            for b in keys[i + 1:]:
+                u = (max(a[0], b[0]), max(a[1], b[1]))
+                if a in ex and b in ex and u not in (a, b):
+                    continue                                  # (two captured classes: nothing to save by leaving both)
+                third = classes[u] if (u in classes and u not in (a, b)) else []
+                delta = cost(u, classes[a] + classes[b] + third) - cost(a, classes[a]) - cost(b, classes[b]) - (cost(u, third) if third else 0.0)
+                if best is None or delta < best[0]:
+                    best = (delta, a, b, u)
+        if best is None or (best[0] >= 0.0 and sum(1 for k in keys if k not in ex) <= max_new):
+            break
+        _, a, b, u = best
+        merged = classes.pop(a) + classes.pop(b) + classes.pop(u, [])
+        classes[u] = merged
+    return {g: c for c, geos in classes.items() for g, _ in geos}
 
 
 class _PinnedArena:
@@ -272,15 +329,15 @@ class DetectionEntry:
         self.capture_seconds = 0.0
         # canvas passes need the ResNet trunk's extent masks (nets.ResNetBase) and the device-side preprocess
         net = getattr(getattr(manager.rpn_model, "base", None), "net", None)
-        # OPT-IN (FRCNN_ENTRY_CANVAS=1, or set ``canvas_capable`` on the engine): measured on bench.py's mixed_sizes legs (256 frames, 36
-        # geometries falling into 18 canvas classes) canvas passes serve the call that sees its list AGAIN 8-13 % faster (459-485 against
-        # 426-447 img/s: 4 eager images instead of 23) and the FIRST call 5-25 % slower (220-282 against 289-300: a class's partial
-        # groups cost whole padded passes, the canvases carry ~3 % more pixels, the extent masks 17 launches per pass, and the tail of
-        # rare sizes spreads over many classes anyway) -- the exact-geometry passes stay the default, both are in the bench line
-        self.canvas_capable = self.device_preprocess and hasattr(net, "block_level") and os.environ.get("FRCNN_ENTRY_CANVAS", "0") != "0"
+        # (FRCNN_ENTRY_CANVAS=0 switches them off: every geometry then gets passes of its own, as in round 5.)  Measured on bench.py's
+        # mixed_sizes legs (256 frames, 36 geometries): see DESIGN 5 / 7.
+        self.canvas_capable = self.device_preprocess and hasattr(net, "block_level") and os.environ.get("FRCNN_ENTRY_CANVAS", "1") != "0"
         self.canvas = False                              # set per call by voc_dets.get_dets_by_cls
+        self._canvas_of = {}                             # (H, W) -> canvas class: the plan (plan_canvases) + sizes seen outside it
+        self._canvas_slots = {}                          # canvas class -> captured passes it may hold (its share of the list x in_flight)
         self._taps_dev = {}
         self._pinned = _PinnedArena()                    # (per engine: the blocks go when the engine goes)
+        self.capture_breakdown = {}
 
     # ------------------------------------------------------------------ eligibility
     @staticmethod
@@ -337,6 +394,7 @@ class DetectionEntry:
         else:
             pipe = InferencePipeline(m.rpn_model, self.detector, m.anchor_dims, **kw)
         reserved0 = torch.cuda.memory_reserved()
+        stamps = [("pipeline", time.perf_counter())]
         seg = (Hc * Wc * 3 + 15) // 16 * 16                         # a frame's staging segment: any source of at most the canvas's pixel count
         off = B * seg
         s = _Slot()
@@ -364,24 +422,30 @@ class DetectionEntry:
         s.amax = ops.AmaxArena() if self.f32_engine == "f16x3" else None
         side = _capture_stream()
         side.wait_stream(torch.cuda.current_stream())
+        stamps.append(("buffers", time.perf_counter()))
         with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine), ops.amax_arena(s.amax):
             for _ in range(WARMUP_PASSES):
                 run()
+            stamps.append(("warm-up enqueue", time.perf_counter()))
             s.ready = torch.cuda.Event()
             s.ready.record(side)
             s.graph = torch.cuda.CUDAGraph()
             s.graph.capture_begin(pool=torch.cuda.graph_pool_handle(), capture_error_mode="thread_local")
             try:
                 s.out = run()
+                stamps.append(("capture enqueue", time.perf_counter()))
             finally:
                 s.graph.capture_end()
+        stamps.append(("instantiate", time.perf_counter()))
         packed = s.out["det_packed"]
         s.out_packed = packed if isinstance(packed, (list, tuple)) else [packed]
         s._out_raw = self._pinned.take(4 * B * s.out_packed[0].numel())
         s.out_pin = s._out_raw.view(torch.int32).view((B,) + tuple(s.out_packed[0].shape))
         s.event = torch.cuda.Event()
         s.nbytes = max(int(torch.cuda.memory_reserved() - reserved0), int(s.io_dev.numel() + s.x_f32.numel() * 4))
+        stamps.append(("read-back buffers", time.perf_counter()))
         self.capture_seconds += time.perf_counter() - t0
+        self._book_capture(t0, stamps)
         return s
 
     def _capture_canvas(self, Hc, Wc, B):
@@ -402,14 +466,14 @@ class DetectionEntry:
         """``submit_batch`` in canvas mode: per image the frame goes up at ITS size, is resized (and flipped) to ITS (H, W) and
         preprocessed into the corner of canvas i by eager launches on the pass's stream; the true sizes go up as extents."""
         _, H0, W0, _, _ = pixels[0]
-        Hc, Wc = canvas_side(H0), canvas_side(W0)
+        Hc, Wc = self.canvas_class(H0, W0)
         s = self.cache.acquire(("canvas", Hc, Wc) + ((B,) if B > 1 else ()), lambda: self._capture_canvas(Hc, Wc, B))
         metas = []
         for i in range(B):
             j = i if i < len(images) else 0
             arr, H, W, src, flip = pixels[j]
             arr = np.ascontiguousarray(arr)
-            assert arr.dtype == np.uint8 and arr.nbytes <= s.seg and canvas_side(H) == Hc and canvas_side(W) == Wc, "one pass, one canvas class"
+            assert arr.dtype == np.uint8 and arr.nbytes <= s.seg and H + (H & 1) <= Hc and W + (W & 1) <= Wc, "one pass, one canvas class"
             s.pix_hosts[i][:arr.nbytes] = arr.reshape(-1)
             s.dyn_host[i, 0], s.dyn_host[i, 1] = float(resize_ratios[j]), float(det_threshold)
             s.extents.set(i, H, W)
@@ -446,6 +510,7 @@ class DetectionEntry:
         else:
             pipe = InferencePipeline(m.rpn_model, self.detector, m.anchor_dims, **kw)
         reserved0 = torch.cuda.memory_reserved()
+        stamps = [("pipeline", time.perf_counter())]
         in_h, in_w = src if src is not None else (H, W)
         npix = in_h * in_w * 3
         pix_bytes = npix if self.device_preprocess else 4 * npix
@@ -499,25 +564,38 @@ class DetectionEntry:
         # buffers, as the replays will: ``s.ready`` orders the first replay behind it.
         side = _capture_stream()
         side.wait_stream(torch.cuda.current_stream())
+        stamps.append(("buffers", time.perf_counter()))
         with torch.cuda.stream(side), ops.conv_workspace(s.ws), ops.tile_policy(shared), ops.f32_engine(self.f32_engine), ops.amax_arena(s.amax):
             for _ in range(WARMUP_PASSES):
                 run()
+            stamps.append(("warm-up enqueue", time.perf_counter()))
             s.ready = torch.cuda.Event()
             s.ready.record(side)
             s.graph = torch.cuda.CUDAGraph()
             s.graph.capture_begin(pool=torch.cuda.graph_pool_handle(), capture_error_mode="thread_local")
             try:
                 s.out = run()
+                stamps.append(("capture enqueue", time.perf_counter()))
             finally:
                 s.graph.capture_end()
+        stamps.append(("instantiate", time.perf_counter()))
         packed = s.out["det_packed"]
         s.out_packed = packed if isinstance(packed, (list, tuple)) else [packed]
         s._out_raw = self._pinned.take(4 * B * s.out_packed[0].numel())
         s.out_pin = s._out_raw.view(torch.int32).view((B,) + tuple(s.out_packed[0].shape))
         s.event = torch.cuda.Event()
         s.nbytes = max(int(torch.cuda.memory_reserved() - reserved0), int(s.io_dev.numel() + s.x_f32.numel() * 4))
+        stamps.append(("read-back buffers", time.perf_counter()))
         self.capture_seconds += time.perf_counter() - t0
+        self._book_capture(t0, stamps)
         return s
+
+    def _book_capture(self, t0, stamps):
+        """Where a capture's host time goes (stats()["capture_breakdown_ms"], summed over the engine's captures)."""
+        prev = t0
+        for name, t in stamps:
+            self.capture_breakdown[name] = self.capture_breakdown.get(name, 0.0) + (t - prev) * 1e3
+            prev = t
 
     # ------------------------------------------------------------------ the call
     def _check_epoch(self):
@@ -560,10 +638,40 @@ class DetectionEntry:
             data = self.manager.preprocess_func(data)               # det_util.py:36 (float64 on the host, cast on feed)
         return data, int(data.shape[0]), int(data.shape[1]), None, False
 
+    def plan_canvases(self, counts):
+        """Before a call over a list whose sizes are known (voc_dets.get_dets_by_cls reads the headers): the canvas classes for that
+        histogram {(H, W): images} (plan_canvas_classes; classes with a captured pass count as free) and how many passes each may
+        hold in flight -- its share of the list times ``in_flight``, at least one, two when it fills more than one pass."""
+        existing = {k[1:3] for k in self.cache.keys() if k[:1] == ("canvas",)}
+        plan = plan_canvas_classes(counts, existing=existing)
+        self._canvas_of.update(plan)
+        per_class, total = collections.Counter(), float(sum(counts.values())) or 1.0
+        for g, c in plan.items():
+            per_class[c] += counts[g]
+        for c, n in per_class.items():
+            want = int(np.ceil(1.5 * self.in_flight * n / total - 1e-9))
+            self._canvas_slots[("canvas",) + c] = max(1 if n <= self.batch else 2, min(self.in_flight, want))
+        return plan
+
+    def canvas_class(self, H, W):
+        """The canvas (Hc, Wc) of a true size: the plan's, else the smallest known class that holds it with at most a third more
+        pixels, else its own smallest canvas (which becomes a class)."""
+        c = self._canvas_of.get((H, W))
+        if c is None:
+            own = (canvas_side(H), canvas_side(W))
+            fits = [k for k in set(self._canvas_of.values()) if k[0] >= own[0] and k[1] >= own[1] and 3 * k[0] * k[1] <= 4 * own[0] * own[1]]
+            c = self._canvas_of[(H, W)] = min(fits, key=lambda k: (k[0] * k[1], k)) if fits else own
+            if len(self._canvas_of) > 4096:
+                self._canvas_of.clear()
+        return c
+
     def canvas_ok(self, pixels):
         """Can this frame go through a canvas pass?  (device preprocess, a source no larger than its canvas)"""
         arr, H, W, src, flip = pixels
-        return self.canvas_capable and getattr(arr, "dtype", None) == np.uint8 and int(np.prod(arr.shape)) <= canvas_side(H) * canvas_side(W) * 3
+        if not (self.canvas_capable and getattr(arr, "dtype", None) == np.uint8):
+            return False
+        Hc, Wc = self.canvas_class(H, W)
+        return int(np.prod(arr.shape)) <= Hc * Wc * 3
 
     @staticmethod
     def geometry_of(pixels):
@@ -575,7 +683,7 @@ class DetectionEntry:
         """The captured-pass key of a ``host_pixels`` result: images with equal keys can share a batched pass.  In canvas mode the key
         is the canvas CLASS of the image's size."""
         if self.canvas and self.canvas_ok(pixels):
-            return ("canvas", canvas_side(pixels[1]), canvas_side(pixels[2]))
+            return ("canvas",) + self.canvas_class(pixels[1], pixels[2])
         return self.geometry_of(pixels)
 
     def probe_geometry(self, image):
@@ -590,8 +698,10 @@ class DetectionEntry:
         if size is None:
             return None
         H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
-        if self.canvas and self.canvas_capable and size[0] * size[1] <= canvas_side(H) * canvas_side(W):
-            return ("canvas", canvas_side(H), canvas_side(W))
+        if self.canvas and self.canvas_capable:
+            Hc, Wc = self.canvas_class(H, W)
+            if size[0] * size[1] <= Hc * Wc:
+                return ("canvas", Hc, Wc)
         if RGB_UPLOAD and getattr(image, "_pixels", 0) is None and hasattr(type(image), "raw_rgb"):      # file-backed: uploaded as RGB (host_pixels; the
             # attribute is looked up on the CLASS: hasattr on the instance would run the property, i.e. decode the JPEG)
             return (H, W, int(size[0]), int(size[1]), 2 | int(flip))
@@ -601,12 +711,13 @@ class DetectionEntry:
 
     def should_wait(self, pixels, batch):
         """Before a ``submit_batch`` of these frames: True when every captured pass of their canvas class is in flight and the class
-        already has its CANVAS_SLOTS_PER_CLASS -- collecting an older ticket frees one sooner than a capture would make another."""
+        already has the passes its plan allows (CANVAS_SLOTS_PER_CLASS outside a plan) -- collecting an older ticket frees one sooner
+        than a capture would make another."""
         key = self.geometry(pixels[0])
         if key[0] != "canvas":
             return False
         slots = self.cache._slots.get(key + ((batch,) if batch > 1 else ()))
-        return slots is not None and len(slots) >= CANVAS_SLOTS_PER_CLASS and all(sl.busy for sl in slots)
+        return slots is not None and len(slots) >= self._canvas_slots.get(key, CANVAS_SLOTS_PER_CLASS) and all(sl.busy for sl in slots)
 
     def exact_geometry(self, image):
         """``probe_geometry`` with canvas mode off: the image's OWN geometry (get_dets_by_cls counts the distinct ones)."""
@@ -684,7 +795,8 @@ class DetectionEntry:
         c = self.cache
         return {"graphs": len(c), "sizes": len(c.keys()), "bytes": c.nbytes, "byte_budget": c.byte_budget, "captures": c.captures,
                 "hits": c.hits, "evictions": c.evictions, "capture_seconds": round(self.capture_seconds, 3), "in_flight": self.in_flight,
-                "device_preprocess": self.device_preprocess, "f32_engine": self.f32_engine, "images_per_pass": self.batch}
+                "device_preprocess": self.device_preprocess, "f32_engine": self.f32_engine, "images_per_pass": self.batch,
+                "capture_breakdown_ms": {k: round(v, 1) for k, v in self.capture_breakdown.items()}}
 
 
 def for_models(manager, detector, num_rois=64, stride=16, in_flight=1):

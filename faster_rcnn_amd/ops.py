@@ -82,15 +82,18 @@ def preprocess_u8(img_u8, mean_bgr, out=None):
     return out
 
 
-def preprocess_u8_canvas(img_u8, mean_bgr, out):
-    """``preprocess_u8`` into the top-left corner of a canvas: img_u8 (h,w,3) uint8 device tensor, out (1,hc,wc,3) / (hc,wc,3) f32 with
-    hc >= h, wc >= w; zeros outside the image (frcnn_preprocess_u8_canvas)."""
+def preprocess_u8_canvas(img_u8, mean_bgr, out, offset=None):
+    """``preprocess_u8`` into a canvas: img_u8 (h,w,3) uint8 device tensor, out (1,hc,wc,3) / (hc,wc,3) f32; the image sits at ``offset``
+    (rows, cols) -- default (h & 1, w & 1), which makes conv1's SAME padding on an even canvas the image's own -- zeros outside
+    (frcnn_preprocess_u8_canvas)."""
     _require_gpu()
     assert img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_contiguous()
     hc, wc = int(out.shape[-3]), int(out.shape[-2])
     assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == hc * wc * 3
+    h, w = int(img_u8.shape[0]), int(img_u8.shape[1])
+    oy, ox = (h & 1, w & 1) if offset is None else (int(offset[0]), int(offset[1]))
     mean = (ctypes.c_double * 3)(*[float(v) for v in mean_bgr])
-    _lib.call("frcnn_preprocess_u8_canvas", _p(img_u8), int(img_u8.shape[0]), int(img_u8.shape[1]), hc, wc, mean, _p(out), _stream())
+    _lib.call("frcnn_preprocess_u8_canvas", _p(img_u8), h, w, hc, wc, oy, ox, mean, _p(out), _stream())
     return out
 
 

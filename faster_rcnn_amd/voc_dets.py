@@ -127,6 +127,8 @@ def _get_dets_by_cls_captured(eng, training_manager, detector, resized_ratios, i
     if getattr(eng, "canvas_capable", False):
         exact = [eng.exact_geometry(images[i]) for i in range(n)]
         eng.canvas = len({k for k in exact if k is not None}) > entry.CANVAS_MIN_GEOMETRIES
+        if eng.canvas:                                   # the classes for THIS list's histogram of sizes: few, each worth its captures
+            eng.plan_canvases(collections.Counter(k[:2] for k in exact if k is not None))
     keys = [eng.probe_geometry(images[i]) for i in range(n)]
     counts = collections.Counter(k for k in keys if k is not None)
     unprobed = set(i for i in range(n) if keys[i] is None)

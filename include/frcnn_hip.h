@@ -43,9 +43,10 @@ const char* frcnn_last_error(void);
  * (round 4); 102 = the f16x3 conv engine, magnitude records, frcnn_conv2d_engine, the RPN sampling entry points (round 5);
  * 103 = frcnn_refresh_h3_planes, frcnn_roi_crop_resize_fwd_batch (additions only).
  * 105 = padded canvases: frcnn_preprocess_u8_canvas, frcnn_zero_outside, frcnn_decode_proposals_canvas (additions only).
+ * 106 = frcnn_preprocess_u8_canvas takes the image's offset in the canvas (even canvases for every parity).
  * 104 = the f16x3 engine's fences: frcnn_h3_planes.status (a THIRD field: recompile hosts that pass the struct), status word in a
  *       magnitude record, frcnn_amax_status. */
-#define FRCNN_ABI_VERSION 105
+#define FRCNN_ABI_VERSION 106
 int frcnn_version(void);
 /* number of HIP devices visible; does not initialise a context */
 int frcnn_device_count(void);
@@ -124,14 +125,15 @@ int frcnn_decode_proposals(const float* regr, int rows, int cols, const int32_t*
                            float* rois, uint8_t* valid, void* stream);
 
 /* Padded canvases: images of different true sizes in ONE pass of fixed shape (shapes.py:106-123 gives every source size its own resized
- * geometry; voc_dets.py:91-111 walks a list of them).  Image i sits in the top-left corner of canvas [hc][wc], zero elsewhere; hc / wc
- * have the parity of the image's height / width so that SAME padding at stride 2 (resnet.py:408) is the canvas's.
- * frcnn_preprocess_u8_canvas: frcnn_preprocess_u8 into that corner, zeros outside.  frcnn_zero_outside: x [n][hc][wc][row_bytes]:
+ * geometry; voc_dets.py:91-111 walks a list of them).  Image i sits at offset (oy, ox) = (h & 1, w & 1) of a canvas [hc][wc] with EVEN
+ * sides, zero elsewhere: SAME padding at stride 2 under conv1's 7x7 window (resnet.py:408) puts one more zero row / column in front of an
+ * odd side than of an even one, and the offset supplies it -- conv1's output cell (i, j) is the image's own cell (i, j) for every parity.
+ * frcnn_preprocess_u8_canvas: frcnn_preprocess_u8 at that offset, zeros outside.  frcnn_zero_outside: x [n][hc][wc][row_bytes]:
  * zero every cell at or beyond true_hw[i] = {rows, cols} (DEVICE int32 [n][2]) -- issue it behind every layer whose output feeds a
  * convolution with taps (bias / BatchNorm shift / ReLU make the outside non-zero; the reference pads with zeros there).
  * frcnn_decode_proposals_canvas: frcnn_decode_proposals on canvas-shaped RPN outputs with the image's true map size true_rows_cols
  * (DEVICE int32 [2]): cells outside it are no candidates, boxes clip to the true extent (det_util.py:179-192). */
-int frcnn_preprocess_u8_canvas(const uint8_t* img_hwc, int h, int w, int hc, int wc, const double* mean3_h, float* out, void* stream);
+int frcnn_preprocess_u8_canvas(const uint8_t* img_hwc, int h, int w, int hc, int wc, int oy, int ox, const double* mean3_h, float* out, void* stream);
 int frcnn_zero_outside(void* x, int n, int hc, int wc, int row_bytes, const int32_t* true_hw, void* stream);
 int frcnn_decode_proposals_canvas(const float* regr, int rows_c, int cols_c, const int32_t* anchor_hw_conv_h, int A, const int32_t* true_rows_cols,
                                   float* rois, uint8_t* valid, void* stream);

@@ -1,8 +1,8 @@
 """Padded canvases (round 6, VERDICT r5 item 6: geometry as a VALUE): images of different true sizes in ONE pass of fixed shape.  Each
-image sits in the top-left corner of a canvas whose sides have the parity of the image's (SAME padding at stride 2 depends on it,
-resnet.py:408); ops.zero_outside restores the zeros the reference's padding reads wherever a 3x3 convolution follows; proposals come
-from the true map only (frcnn_decode_proposals_canvas).  Inside an image's extent every tensor must be what a pass of the image's own
-size computes: compared here against exactly that pass, stage by stage."""
+image sits at offset (h & 1, w & 1) of a canvas with EVEN sides (the offset stands for the extra zero row / column SAME padding at
+stride 2 puts in front of an odd side under conv1's window, resnet.py:408); ops.zero_outside restores the zeros the reference's padding
+reads wherever a 3x3 convolution follows; proposals come from the true map only (frcnn_decode_proposals_canvas).  Inside an image's
+extent every tensor must be what a pass of the image's own size computes: compared here against exactly that pass, stage by stage."""
 import numpy as np
 import pytest
 
@@ -33,9 +33,17 @@ def test_canvas_kernels_known_answers():
     from faster_rcnn_amd import ops
     img = _u8(37, 53, 1)
     canvas = torch.full((1, 48, 64, 3), 7.0, dtype=torch.float32, device="cuda")
-    ops.preprocess_u8_canvas(img, MEAN, canvas)
+    ops.preprocess_u8_canvas(img, MEAN, canvas, offset=(0, 0))
     want = ops.preprocess_u8(img, MEAN)
     assert torch.equal(canvas[0, :37, :53], want[0]) and float(canvas[0, 37:].abs().max()) == 0.0 and float(canvas[0, :, 53:].abs().max()) == 0.0
+    canvas.fill_(7.0)
+    ops.preprocess_u8_canvas(img, MEAN, canvas)                  # odd sides: offset (1, 1) by default
+    assert torch.equal(canvas[0, 1:38, 1:54], want[0])
+    canvas[0, 1:38, 1:54] = 0.0
+    assert float(canvas.abs().max()) == 0.0
+    from faster_rcnn_amd._lib import FrcnnError
+    with pytest.raises(FrcnnError):
+        ops.preprocess_u8_canvas(img, MEAN, canvas, offset=(12, 0))   # 37 + 12 > 48
     for dt in (torch.float32, torch.bfloat16):
         x = torch.ones((2, 10, 12, 32), dtype=dt, device="cuda")
         hw = torch.tensor([[7, 9], [10, 4]], dtype=torch.int32, device="cuda")
@@ -58,9 +66,9 @@ def test_canvas_kernels_known_answers():
 
 
 @pytest.mark.parametrize("engine", ["native", "f16x3"])
-@pytest.mark.parametrize("sizes,canvas", [([(320, 480), (304, 450)], (320, 480)), ([(321, 479), (289, 451)], (321, 479)), ([(306, 451), (320, 417)], (320, 451))])
+@pytest.mark.parametrize("sizes,canvas", [([(320, 480), (304, 450)], (320, 480)), ([(321, 479), (289, 451)], (322, 480)), ([(306, 451), (319, 417)], (320, 512))])
 def test_canvas_pass_equals_the_passes_of_the_true_sizes(nets50, engine, sizes, canvas):
-    """Two images of different sizes (even and odd sides: the stem's SAME padding differs) in one two-canvas pass against each image's
+    """Two images of different sizes (even and odd sides, mixed in one pass: the stem's SAME padding differs) in one two-canvas pass against each image's
     own pass at its true size, same engine: conv4 map and RPN outputs inside the true extents to 1e-5 (bit-equal on the native
     engine when the launch forms coincide), identical proposals, identical detections, scores to 1e-5."""
     from faster_rcnn_amd import nets, ops
@@ -71,7 +79,7 @@ def test_canvas_pass_equals_the_passes_of_the_true_sizes(nets50, engine, sizes, 
     x = torch.empty((2, Hc, Wc, 3), dtype=torch.float32, device="cuda")
     ext = nets.Extents(2)
     for i, (im, (h, w)) in enumerate(zip(imgs, sizes)):
-        assert (h - Hc) % 2 == 0 and (w - Wc) % 2 == 0
+        assert Hc % 2 == 0 and Wc % 2 == 0 and h + (h & 1) <= Hc and w + (w & 1) <= Wc
         ops.preprocess_u8_canvas(im, MEAN, x[i])
         ext.set(i, h, w)
     ext.upload()

@@ -3,6 +3,7 @@ recency order, byte budget and busy-slot rule, and which (manager, detector) pai
 import types
 
 import numpy as np
+import pytest
 
 from faster_rcnn_amd import entry
 
@@ -226,24 +227,55 @@ def test_image_data_falls_back_to_the_host_resize_when_the_device_path_fails(mon
     assert np.array_equal(shapes.InMemoryImage(img, 80, 60).data, want)
 
 
-def test_canvas_sides_keep_parity_and_levels_follow_the_reference_chain():
-    """entry.canvas_side: the next multiple of the granule that keeps the side's parity (TF's SAME padding at stride 2 depends on it,
-    resnet.py:408); nets.Extents.levels_of: the per-level true sizes a canvas pass masks with end in resnet.get_conv_rows_cols'
-    numbers (resnet.py:78-93) for every size."""
+def test_canvas_sides_are_even_with_room_for_the_offset_and_levels_follow_the_reference_chain():
+    """entry.canvas_side: even, a multiple of the granule, at least the side plus the offset an odd side sits at (the offset stands for
+    the extra zero row SAME padding puts in front of an odd side under conv1's window, resnet.py:408); nets.Extents.levels_of: the
+    per-level true sizes a canvas pass masks with end in resnet.get_conv_rows_cols' numbers (resnet.py:78-93) for every size."""
     from faster_rcnn_amd import nets, resnet
     for n in list(range(7, 80)) + [375, 500, 599, 600, 601, 800, 898, 901, 904, 999, 1000, 1023, 1024, 1025]:
         c = entry.canvas_side(n)
-        assert c >= n and (c - n) % 2 == 0 and c - n < 33, (n, c)
+        assert c >= n + (n & 1) and c % 2 == 0 and c % entry.CANVAS_GRANULE == 0 and c - n <= entry.CANVAS_GRANULE, (n, c)
         assert entry.canvas_side(c) == c                       # a canvas is its own class
-    assert entry.canvas_side(600) == 608 and entry.canvas_side(601) == 607 and entry.canvas_side(800) == 800 and entry.canvas_side(901) == 927
+    assert entry.canvas_side(600) == 608 and entry.canvas_side(607) == 608 and entry.canvas_side(800) == 800 and entry.canvas_side(901) == 928
+    assert entry.canvas_side(601, granule=2) == 602 and entry.canvas_side(600, granule=2) == 600
+    with pytest.raises(AssertionError):
+        entry.canvas_side(600, granule=3)
     for h, w in [(600, 1000), (601, 901), (375, 500), (333, 499), (224, 224), (607, 927)]:
         lv = nets.Extents.levels_of(h, w)
         assert len(lv) == nets.Extents.LEVELS and list(lv[-1]) == list(resnet.get_conv_rows_cols(h, w))
         assert all(a[0] >= b[0] and a[1] >= b[1] for a, b in zip(lv, lv[1:]))
-    # a canvas never has FEWER cells than the image at any level (the true extent fits inside)
-    for h, w in [(600, 901), (599, 800), (306, 451)]:
-        hc, wc = entry.canvas_side(h), entry.canvas_side(w)
-        assert all(c[0] >= t[0] and c[1] >= t[1] for c, t in zip(nets.Extents.levels_of(hc, wc), nets.Extents.levels_of(h, w)))
+    # a canvas never has FEWER cells than the image at any level (the true extent fits inside), for the tightest canvas too
+    for h, w in [(600, 901), (599, 800), (306, 451), (601, 1001)]:
+        for g in (None, 2):
+            hc, wc = entry.canvas_side(h, g), entry.canvas_side(w, g)
+            assert all(c[0] >= t[0] and c[1] >= t[1] for c, t in zip(nets.Extents.levels_of(hc, wc), nets.Extents.levels_of(h, w)))
+
+
+def test_canvas_plan_merges_what_is_not_worth_a_capture_and_is_stable():
+    """entry.plan_canvas_classes: a histogram of sizes -> few classes.  Rare sizes join a class that holds them, the common formats
+    keep canvases of their own, landscape and portrait never share one; classes that already have a captured pass are free, so the
+    plan of a second call over the same list is the first call's."""
+    counts = {(600, 800): 106, (600, 901): 36, (800, 600): 28, (600, 898): 11, (901, 600): 10, (600, 802): 8, (600, 904): 8, (600, 750): 5,
+              (562, 1000): 4, (600, 645): 1, (600, 971): 1, (538, 1000): 1, (600, 619): 1}
+    plan = entry.plan_canvas_classes(counts)
+    assert set(plan) == set(counts)
+    classes = set(plan.values())
+    assert 2 <= len(classes) <= 6, classes
+    for (h, w), (hc, wc) in plan.items():
+        assert hc >= h + (h & 1) and wc >= w + (w & 1) and hc % 2 == 0 and wc % 2 == 0
+        assert (hc > wc) == (h > w)                               # a portrait frame on a landscape canvas would double its pixels
+    assert plan[(600, 800)] == (608, 800)                         # 106 images: their own tight canvas
+    assert plan[(600, 901)] == plan[(600, 898)] == plan[(600, 904)]
+    assert plan[(600, 619)] in classes - {(entry.canvas_side(600), entry.canvas_side(619))} or len(classes) == 1      # one image is not worth a capture
+    again = entry.plan_canvas_classes(counts, existing=classes)
+    assert again == plan
+    # a long list amortises more captures: twenty times the images, at least as many classes
+    big = entry.plan_canvas_classes({k: 20 * v for k, v in counts.items()})
+    assert len(set(big.values())) >= len(classes)
+    # one class at most when captures are dear, every geometry its own when they are free
+    assert len(set(entry.plan_canvas_classes(counts, capture_images=1e9).values())) <= 2
+    assert len(set(entry.plan_canvas_classes(counts, capture_images=0.0, max_new=99).values())) == len({(entry.canvas_side(h), entry.canvas_side(w)) for h, w in counts})
+    assert len(set(entry.plan_canvas_classes(counts, capture_images=0.0, max_new=3).values())) <= 3
 
 
 def test_full_collections_before_captures_are_throttled(monkeypatch):
