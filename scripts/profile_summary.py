@@ -23,6 +23,9 @@ def bench_kernel_name(k):
     m = re.search(r"k_conv_igemm_h3_db<(\d+), (\d+), (\d+), (\d+)(, (true|false))?>", k)
     if m:
         return "k_conv_igemm_h3_db<%s,%s,%s,%s%s>" % (m.groups()[:4] + (",planes" if m.group(6) == "true" else "",))
+    m = re.search(r"k_conv_igemm_h3_ring<(\d+), (\d+), (\d+), (\d+)>", k)
+    if m:
+        return "k_conv_igemm_h3_ring<%s,%s,%s,%s>" % m.groups()
     m = re.search(r"k_conv_igemm_h3<(\d+), (\d+), (\d+), (\d+)(, (true|false))?>", k)
     if m:
         return "k_conv_igemm_h3<%s,%s,%s,%s>" % m.groups()[:4] + (" split-K" if m.group(6) == "true" else "")
