@@ -423,6 +423,153 @@ k_conv_igemm_h3(const ConvArgs p) {
     else epilogue<TM, TN, H3_S16>(acc0, p, m0, n0, wm, wn, li, lh);
 }
 
+// Plane input, three operand stages, nothing staged through registers (round 6): the activations' and the filter's fp16 planes go from
+// memory to LDS unchanged, so a wave instruction lands 16 rows x 64 B straight in LDS (`buffer_load ... lds`: lane-linear destination;
+// the XOR swizzle of the 16-byte slots is applied to the SOURCE piece a lane asks for, and again by the fragment reads).  A workgroup
+// keeps a RING of three stages: chunk t + 2 is requested as chunk t starts, `s_waitcnt vmcnt(n)` waits for the oldest chunk only (a
+// chunk is PA + PB wave instructions per thread; requests complete in order), one barrier per chunk makes it visible and frees the
+// stage chunk t - 1 was read from.  Against k_conv_igemm_h3_db<.., true>: no ds_write of the operands (a third of the loop's LDS
+// traffic), no staging registers, two chunks of lead instead of one.  Same k order, same products: bit-identical results.  It is the
+// loop of k_conv_igemm_h3_db<.., APLANES = true, RING = true>, the plane-reading kernel's second instantiation: long reductions take it
+// (the head's 3x3: 144 chunks, 748 -> 712 us per four-image launch), the sixteen chunks of 512 -> 2048 run 3-5 % slower on it -- a fixed
+// ~2.7 us per tile that neither the LDS request nor the place of the scale reads explains (scripts/dev/r6_ring_shortk.sh) -- and keep
+// the double buffer.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void h3_ring_tile(const ConvArgs& p, char* lds) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
+    constexpr int GA = 2 * BM / 16, GB = 2 * BN / 16;     // 16-row groups (one wave instruction each) of the two planes of A / of B
+    constexpr int PA = GA / NW, PB = (GB + NW - 1) / NW, NL = PA + PB;
+    constexpr int STAGE = 2 * (BM + BN) * X6_ROWB, NSTAGE = 3;
+    static_assert(GA % NW == 0 && GB % NW == 0, "every wave issues the same number of requests per chunk (vmcnt counts them)");
+    static_assert(H3_S16, "the 16x16x32 form");
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int tile_m, tile_n;
+    h3_tile_of(p, xcd_remap(blockIdx.x, nwg), tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const size_t plane_bytes = (size_t)p.Cout * p.Kpad * 2;
+    const char* wbase = reinterpret_cast<const char*>(p.w);
+    const size_t x_elems = (size_t)p.n_img * p.H * p.W * p.Cin;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x_planes), 0, (int)(x_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase + H3_HEADER_BYTES), 0, (int)(2 * plane_bytes), 0x00020000);
+
+    h3_fp16_saturate();
+
+    // lane -> (row of its 16-row group, LDS slot); the slot holds piece slot ^ swz(row) of the row's 64 bytes
+    const int grow = lane >> 2, slot = lane & 3;
+    int a_h[PA], a_w[PA], a_off[PA], a_dst[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int g = wave + NW * i, pl = g / (BM / 16), r0 = 16 * (g % (BM / 16));
+        const int row = r0 + grow, m = m0 + row, piece = slot ^ h3_swz(row);
+        a_dst[i] = pl * BM * X6_ROWB + r0 * X6_ROWB;
+        if (m < p.M) {
+            int wo, ho, img;
+            if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
+            else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
+            a_h[i] = ho * p.stride - p.pad_top;
+            a_w[i] = wo * p.stride - p.pad_left;
+            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + piece * 8) * 2 + (int)(pl * x_elems * 2);
+        } else {
+            a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
+        }
+    }
+    unsigned b_off[PB];
+    int b_dst[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int g = wave + NW * i, pl = g / (BN / 16), r0 = 16 * (g % (BN / 16));
+        const int row = r0 + grow, piece = slot ^ h3_swz(row);
+        b_dst[i] = 2 * BM * X6_ROWB + pl * BN * X6_ROWB + r0 * X6_ROWB;
+        b_off[i] = n0 + row < p.Cout ? (unsigned)(((size_t)(n0 + row) * p.Kpad + piece * 8) * 2 + pl * plane_bytes) : OOB_OFFSET;
+    }
+
+    const int RS = p.R * p.S;
+    const unsigned tap_mask = h3_tap_mask(p, m0, BM);
+    const int nk = (p.Kpad / (BK * RS)) * __popc(tap_mask);
+    unsigned rem = tap_mask;
+    int c0 = 0, w_grp = 0;
+    unsigned a_v[PA];
+    int w_v;
+    auto prep = [&]() {                                   // the offsets of the NEXT chunk of this tile's sequence (tap, channel block, halo test)
+        const int tap = __builtin_ctz(rem);
+        const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
+        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 2;
+        w_v = w_grp + tap * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            a_v[i] = ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET;
+        }
+        rem &= rem - 1;
+        const int wrap = (rem == 0);
+        rem |= wrap ? tap_mask : 0u;
+        c0 += wrap * BK;
+        w_grp += wrap * (RS * BK * 2);
+    };
+    auto issue = [&](int stage) {
+        char* base = lds + stage * STAGE;
+#if defined(__HIP_DEVICE_COMPILE__)   // device pass only (conv_bf16.hip: the host pass drops an instantiation whose body casts to an LDS pointer in dependent code)
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(base + b_dst[i]), 16, b_off[i], w_v, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(base + a_dst[i]), 16, a_v[i], 0, 0, 0);
+#else
+        (void)base; (void)xrsrc; (void)wrsrc; (void)w_v; (void)sizeof(lds_ptr_t);
+#endif
+    };
+    f32x16 acc0[TM][TN], acc1[TM][TN];
+    f32x4 s0[TM][TN][4], s1[TM][TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s0[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; s1[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+
+    prep(); issue(0);
+    prep(); if (nk > 1) issue(1);
+    // the scales, behind the first two chunks' requests (a short reduction -- 512 -> 2048 is sixteen chunks -- cannot afford their
+    // latency in front); pinned here so that no load of theirs drifts into the loop, whose s_waitcnt counts the ring's requests
+    const float x_max = amax_read(p.x_amax);
+    const int eA = *p.x_pexp;
+    const int eB = h3_exponent(*reinterpret_cast<const float*>(wbase));
+    int eY = 0;
+    if (p.y_planes) {
+        eY = h3_exponent(p.bound_c * x_max + p.bound_d + (p.res_amax ? amax_read(p.res_amax) : 0.0f));
+        if (blockIdx.x == 0 && tid == 0) *p.y_pexp = eY;
+    }
+    asm volatile("" :: "v"(eA), "v"(eB), "v"(eY) : "memory");
+    prep();                                               // chunk 2
+    int stage = 0, free_stage = 2;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NL) : "memory");      // chunk t has landed (chunk t + 1 may be in flight)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nk) issue(free_stage);                // into the stage chunk t - 1 was read from: every wave is past its reads
+        const char* base = lds + stage * STAGE;
+        h3_chunk<TM, TN>(base + wm * TM * 32 * X6_ROWB, BM * X6_ROWB, base + 2 * BM * X6_ROWB + wn * TN * 32 * X6_ROWB, BN * X6_ROWB, lane, s0, s1);
+        prep();                                           // chunk t + 3, behind this chunk's MFMAs
+        free_stage = stage;
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // the epilogue reuses the stages
+    h3_gather<TM, TN>(s0, acc0); h3_gather<TM, TN>(s1, acc1);
+    h3_combine<TM, TN>(acc0, acc1);
+    h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
+    if (p.y_planes) x6_epilogue_vec<TM, TN, WM, WN, true, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds), h3_pow2(eY));
+    else if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN, false, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
+    else epilogue<TM, TN, H3_S16>(acc0, p, m0, n0, wm, wn, li, lh);
+}
+
 // ---- ONE workgroup per CU, TWO LDS buffers (96 KB for a 256x128 tile) and ONE barrier per chunk: chunk kt multiplies from buffer
 // kt & 1 while chunk kt+1 (in registers since the previous iteration) is split and stored into the other buffer and chunk kt+2 is
 // requested (k_conv_igemm_x6_db's loop).  <2,1,4,4>: sixteen waves of 64x32; <2,2,4,2>: eight waves of 64x64 (eight fragment reads
@@ -431,7 +578,7 @@ k_conv_igemm_h3(const ConvArgs p) {
 // APLANES: the activations arrive ALREADY split -- two fp16 planes [2][rows][Cin] a producing launch's epilogue wrote under the scale
 // 2^*x_pexp (ConvArgs.x_planes): 16-byte pieces go from memory to LDS unchanged, no conversion and no arithmetic in the loader (lab:
 // the head's 3x3 / 512 -> 2048 / 2048 -> 512 GEMMs 195 / 103 / 89 us against 246 / 127 / 104 with the split in the loader).
-template <int TM, int TN, int WM, int WN, bool APLANES = false>
+template <int TM, int TN, int WM, int WN, bool APLANES = false, bool RING = false>
 __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArgs p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NT = 64 * WM * WN;
     constexpr int RPP = APLANES ? NT / 4 : NT / 8, PA = APLANES ? (2 * BM) / RPP : BM / RPP;      // A: rows staged per pass (planes: 4 pieces of 16 B per row per plane)
@@ -440,6 +587,11 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     constexpr int BUFB = 2 * (BM + BN) * X6_ROWB;
     static_assert(BM % RPP == 0 && PA >= 1, "tile rows must be a multiple of the staging pass");
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if constexpr (RING) {                                 // (an instantiation of its own: as a run-time branch beside the other loop the ring keeps a
+        static_assert(APLANES, "the ring reads planes");  //  quarter of its gain -- 729 -> 717-723 instead of 748 -> 703-713 us -- to the shared register file)
+        h3_ring_tile<TM, TN, WM, WN>(p, lds);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
@@ -638,150 +790,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     else epilogue<TM, TN, H3_S16>(acc0, p, m0, n0, wm, wn, li, lh);
 }
 
-// Plane input, three operand stages, nothing staged through registers (round 6): the activations' and the filter's fp16 planes go from
-// memory to LDS unchanged, so a wave instruction lands 16 rows x 64 B straight in LDS (`buffer_load ... lds`: lane-linear destination;
-// the XOR swizzle of the 16-byte slots is applied to the SOURCE piece a lane asks for, and again by the fragment reads).  A workgroup
-// keeps a RING of three stages: chunk t + 2 is requested as chunk t starts, `s_waitcnt vmcnt(n)` waits for the oldest chunk only (a
-// chunk is PA + PB wave instructions per thread; requests complete in order), one barrier per chunk makes it visible and frees the
-// stage chunk t - 1 was read from.  Against k_conv_igemm_h3_db<.., true>: no ds_write of the operands (a third of the loop's LDS
-// traffic), no staging registers, two chunks of lead instead of one.  Same k order, same products: bit-identical results.
-template <int TM, int TN, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_ring(const ConvArgs p) {
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
-    constexpr int GA = 2 * BM / 16, GB = 2 * BN / 16;     // 16-row groups (one wave instruction each) of the two planes of A / of B
-    constexpr int PA = GA / NW, PB = (GB + NW - 1) / NW, NL = PA + PB;
-    constexpr int STAGE = 2 * (BM + BN) * X6_ROWB, NSTAGE = 3;
-    static_assert(GA % NW == 0 && GB % NW == 0, "every wave issues the same number of requests per chunk (vmcnt counts them)");
-    static_assert(H3_S16, "the 16x16x32 form");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    int tile_m, tile_n;
-    h3_tile_of(p, xcd_remap(blockIdx.x, nwg), tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const size_t plane_bytes = (size_t)p.Cout * p.Kpad * 2;
-    const char* wbase = reinterpret_cast<const char*>(p.w);
-    const size_t x_elems = (size_t)p.n_img * p.H * p.W * p.Cin;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x_planes), 0, (int)(x_elems * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase + H3_HEADER_BYTES), 0, (int)(2 * plane_bytes), 0x00020000);
-
-    h3_fp16_saturate();
-
-    // lane -> (row of its 16-row group, LDS slot); the slot holds piece slot ^ swz(row) of the row's 64 bytes
-    const int grow = lane >> 2, slot = lane & 3;
-    int a_h[PA], a_w[PA], a_off[PA], a_dst[PA];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int g = wave + NW * i, pl = g / (BM / 16), r0 = 16 * (g % (BM / 16));
-        const int row = r0 + grow, m = m0 + row, piece = slot ^ h3_swz(row);
-        a_dst[i] = pl * BM * X6_ROWB + r0 * X6_ROWB;
-        if (m < p.M) {
-            int wo, ho, img;
-            if (p.layout) { img = m % p.n_img; const int pos = m / p.n_img; ho = pos / p.Wo; wo = pos - ho * p.Wo; }
-            else { wo = m % p.Wo; const int t = m / p.Wo; ho = t % p.Ho; img = t / p.Ho; }
-            a_h[i] = ho * p.stride - p.pad_top;
-            a_w[i] = wo * p.stride - p.pad_left;
-            a_off[i] = (img * p.img_stride + (a_h[i] * p.W + a_w[i]) * p.pix_stride + piece * 8) * 2 + (int)(pl * x_elems * 2);
-        } else {
-            a_h[i] = -(1 << 28); a_w[i] = 0; a_off[i] = 0;
-        }
-    }
-    unsigned b_off[PB];
-    int b_dst[PB];
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        const int g = wave + NW * i, pl = g / (BN / 16), r0 = 16 * (g % (BN / 16));
-        const int row = r0 + grow, piece = slot ^ h3_swz(row);
-        b_dst[i] = 2 * BM * X6_ROWB + pl * BN * X6_ROWB + r0 * X6_ROWB;
-        b_off[i] = n0 + row < p.Cout ? (unsigned)(((size_t)(n0 + row) * p.Kpad + piece * 8) * 2 + pl * plane_bytes) : OOB_OFFSET;
-    }
-
-    const int RS = p.R * p.S;
-    const unsigned tap_mask = h3_tap_mask(p, m0, BM);
-    const int nk = (p.Kpad / (BK * RS)) * __popc(tap_mask);
-    unsigned rem = tap_mask;
-    int c0 = 0, w_grp = 0;
-    unsigned a_v[PA];
-    int w_v;
-    auto prep = [&]() {                                   // the offsets of the NEXT chunk of this tile's sequence (tap, channel block, halo test)
-        const int tap = __builtin_ctz(rem);
-        const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
-        const int tap_off = ((r_tap * p.W + s_tap) * p.pix_stride + c0) * 2;
-        w_v = w_grp + tap * (BK * 2);
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            a_v[i] = ok ? (unsigned)(a_off[i] + tap_off) : OOB_OFFSET;
-        }
-        rem &= rem - 1;
-        const int wrap = (rem == 0);
-        rem |= wrap ? tap_mask : 0u;
-        c0 += wrap * BK;
-        w_grp += wrap * (RS * BK * 2);
-    };
-    auto issue = [&](int stage) {
-        char* base = lds + stage * STAGE;
-#if defined(__HIP_DEVICE_COMPILE__)   // device pass only (conv_bf16.hip: the host pass drops an instantiation whose body casts to an LDS pointer in dependent code)
-#pragma unroll
-        for (int i = 0; i < PB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(base + b_dst[i]), 16, b_off[i], w_v, 0, 0);
-#pragma unroll
-        for (int i = 0; i < PA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(base + a_dst[i]), 16, a_v[i], 0, 0, 0);
-#else
-        (void)base; (void)xrsrc; (void)wrsrc; (void)w_v; (void)sizeof(lds_ptr_t);
-#endif
-    };
-    f32x16 acc0[TM][TN], acc1[TM][TN];
-    f32x4 s0[TM][TN][4], s1[TM][TN][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { s0[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; s1[i][j][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-
-    prep(); issue(0);
-    prep(); if (nk > 1) issue(1);
-    // the scales, behind the first two chunks' requests (a short reduction -- 512 -> 2048 is sixteen chunks -- cannot afford their
-    // latency in front); pinned here so that no load of theirs drifts into the loop, whose s_waitcnt counts the ring's requests
-    const float x_max = amax_read(p.x_amax);
-    const int eA = *p.x_pexp;
-    const int eB = h3_exponent(*reinterpret_cast<const float*>(wbase));
-    int eY = 0;
-    if (p.y_planes) {
-        eY = h3_exponent(p.bound_c * x_max + p.bound_d + (p.res_amax ? amax_read(p.res_amax) : 0.0f));
-        if (blockIdx.x == 0 && tid == 0) *p.y_pexp = eY;
-    }
-    asm volatile("" :: "v"(eA), "v"(eB), "v"(eY) : "memory");
-    prep();                                               // chunk 2
-    int stage = 0, free_stage = 2;
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NL) : "memory");      // chunk t has landed (chunk t + 1 may be in flight)
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nk) issue(free_stage);                // into the stage chunk t - 1 was read from: every wave is past its reads
-        const char* base = lds + stage * STAGE;
-        h3_chunk<TM, TN>(base + wm * TM * 32 * X6_ROWB, BM * X6_ROWB, base + 2 * BM * X6_ROWB + wn * TN * 32 * X6_ROWB, BN * X6_ROWB, lane, s0, s1);
-        prep();                                           // chunk t + 3, behind this chunk's MFMAs
-        free_stage = stage;
-        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // the epilogue reuses the stages
-    h3_gather<TM, TN>(s0, acc0); h3_gather<TM, TN>(s1, acc1);
-    h3_combine<TM, TN>(acc0, acc1);
-    h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
-    if (p.y_planes) x6_epilogue_vec<TM, TN, WM, WN, true, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds), h3_pow2(eY));
-    else if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN, false, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
-    else epilogue<TM, TN, H3_S16>(acc0, p, m0, n0, wm, wn, li, lh);
-}
-
 // dev knob: FRCNN_H3_RING=0 keeps plane-input launches on the register-staged double buffer (k_conv_igemm_h3_db<.., true>)
 static const bool g_h3_ring = !(getenv("FRCNN_H3_RING") && atoi(getenv("FRCNN_H3_RING")) == 0);
 static const int g_h3_ring_min_chunks = getenv("FRCNN_H3_RING_MIN_CHUNKS") ? atoi(getenv("FRCNN_H3_RING_MIN_CHUNKS")) : 32;
@@ -795,18 +803,17 @@ static int launch_h3_db(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 2 * (BM + BN) * X6_ROWB;
     static_assert(lds >= X6Tile<TM, TN, WM, WN, 2>::epi, "the epilogue's wave-row must fit in the operand buffers");
     static std::atomic<uint64_t> lds_seen{0}, lds_seen_planes{0};
-    if constexpr (WM * WN == 16) {
-        // long reductions only (the head's 3x3: 144 chunks, 748 -> 712 us per four-image launch); the sixteen chunks of 512 -> 2048 run
-        // 3-5 % SLOWER on the ring (545-552 against 518-538 us, scripts/dev/r6_ring_ab.sh) and stay on the double buffer
-        if (p.x_planes && g_h3_ring && p.Kpad / BK >= g_h3_ring_min_chunks) {
-            constexpr size_t ring_lds = (size_t)3 * 2 * (BM + BN) * X6_ROWB;
-            static std::atomic<uint64_t> lds_seen_ring{0};
-            if (int e = raise_lds_once(lds_seen_ring, (const void*)k_conv_igemm_h3_ring<TM, TN, WM, WN>, ring_lds, "conv2d_h3")) return e;
-            k_conv_igemm_h3_ring<TM, TN, WM, WN><<<p.tiles_m * p.tiles_n, 64 * WM * WN, ring_lds, s>>>(p);
-            return check_launch("conv2d_fwd_h3 (planes in, ring)");
-        }
-    }
     if (p.x_planes) {
+        if constexpr (WM * WN == 16) {
+            // long reductions only (the head's 3x3: 144 chunks); FRCNN_H3_RING=0 / FRCNN_H3_RING_MIN_CHUNKS are dev knobs
+            if (g_h3_ring && p.Kpad / BK >= g_h3_ring_min_chunks) {
+                constexpr size_t ring_lds = (size_t)3 * 2 * (BM + BN) * X6_ROWB;
+                static std::atomic<uint64_t> lds_seen_ring{0};
+                if (int e = raise_lds_once(lds_seen_ring, (const void*)k_conv_igemm_h3_db<TM, TN, WM, WN, true, true>, ring_lds, "conv2d_h3")) return e;
+                k_conv_igemm_h3_db<TM, TN, WM, WN, true, true><<<p.tiles_m * p.tiles_n, 64 * WM * WN, ring_lds, s>>>(p);
+                return check_launch("conv2d_fwd_h3 (planes in, ring)");
+            }
+        }
         if (int e = raise_lds_once(lds_seen_planes, (const void*)k_conv_igemm_h3_db<TM, TN, WM, WN, true>, lds, "conv2d_h3")) return e;
         k_conv_igemm_h3_db<TM, TN, WM, WN, true><<<p.tiles_m * p.tiles_n, 64 * WM * WN, lds, s>>>(p);
         return check_launch("conv2d_fwd_h3 (planes in)");

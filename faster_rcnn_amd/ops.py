@@ -819,18 +819,10 @@ def _conv2d_h3_planes(d, x, pc, residual, oshape, planes_out, act):
     return y
 
 
-H3_RING = os.environ.get("FRCNN_H3_RING", "1") != "0"               # csrc/conv_h3.hip's knobs, mirrored for the kernel NAME a profile line carries
-H3_RING_MIN_CHUNKS = int(os.environ.get("FRCNN_H3_RING_MIN_CHUNKS", "32"))
-
-
 def _h3_planes_in_name(d, pc):
-    """The kernel a plane-input launch runs (csrc/conv_h3.hip launch_h3_db): the three-stage direct-to-LDS ring for long reductions on the
-    sixteen-wave tile, else the register-staged double buffer's plane-reading instantiation."""
-    name = _h3_name(d)
-    kpad = pc.kh * pc.kw * (-(-pc.cin // 32) * 32)
-    if name == "k_conv_igemm_h3_db<2,1,4,4>" and H3_RING and kpad // 32 >= H3_RING_MIN_CHUNKS:
-        return "k_conv_igemm_h3_ring<2,1,4,4>"
-    return name.replace(">", ",planes>")
+    """The kernel a plane-input launch runs: the plane-reading instantiation of the 256x128 double buffer (which walks long reductions on
+    its three-stage ring, csrc/conv_h3.hip h3_ring_tile: one kernel, two loops)."""
+    return _h3_name(d).replace(">", ",planes>")
 
 
 def _planes_ok(d, pc, eng):

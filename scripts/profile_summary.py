@@ -20,12 +20,9 @@ def bench_kernel_name(k):
         return "k_conv_igemm_x6<%s,%s,%s,%s>" % m.groups()[:4] + (" split-K" if m.group(6) == "true" else "")
     if "k_conv_igemm_x6_db" in k:
         return "k_conv_igemm_x6_db"
-    m = re.search(r"k_conv_igemm_h3_db<(\d+), (\d+), (\d+), (\d+)(, (true|false))?>", k)
+    m = re.search(r"k_conv_igemm_h3_db<(\d+), (\d+), (\d+), (\d+)(, (true|false))?(, (true|false))?>", k)      # (.., planes in, ring loop): the two plane-reading instantiations are ONE line
     if m:
         return "k_conv_igemm_h3_db<%s,%s,%s,%s%s>" % (m.groups()[:4] + (",planes" if m.group(6) == "true" else "",))
-    m = re.search(r"k_conv_igemm_h3_ring<(\d+), (\d+), (\d+), (\d+)>", k)
-    if m:
-        return "k_conv_igemm_h3_ring<%s,%s,%s,%s>" % m.groups()
     m = re.search(r"k_conv_igemm_h3<(\d+), (\d+), (\d+), (\d+)(, (true|false))?>", k)
     if m:
         return "k_conv_igemm_h3<%s,%s,%s,%s>" % m.groups()[:4] + (" split-K" if m.group(6) == "true" else "")
