@@ -570,174 +570,6 @@ __device__ __forceinline__ void h3_ring_tile(const ConvArgs& p, char* lds) {
     else epilogue<TM, TN, H3_S16>(acc0, p, m0, n0, wm, wn, li, lh);
 }
 
-// A 3x3 / stride 1 / SAME layer over [image][h][w][c] rows whose maps are at most 15 wide (the detector head's: 7x7 per RoI): the nine taps
-// of a channel block multiply the SAME activation rows, shifted by (dr * W + ds) rows.  The ring above fetches them nine times (from L2);
-// here a channel block of the tile's rows -- with a halo of 16 rows on either side -- is staged ONCE, in one of two block buffers, and
-// the nine taps read their fragments from it at a row offset (the XOR swizzle has a period of 16 rows and is conflict-free at any
-// offset); a fragment row whose tap leaves the map is zeroed in registers (a per-lane mask of nine bits per fragment row), which is what
-// the padding is.  Only the filter's chunk (16 KB) travels per tap, through a ring of three stages; the next channel block's
-// activations are requested at tap 0 of the current one, nine steps ahead.  Same k order as every other form: bit-identical.
-// Lab bound (scripts/dev/r6_a_once_lab.sh: activations fetched for the first tap only, products wrong): 840 -> 712 us.
-template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void h3_ring9_tile(const ConvArgs& p, char* lds) {
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NW = WM * WN;
-    constexpr int HALO = 16, AROWS = BM + 2 * HALO, AG = AROWS / 16;       // rows / 16-row groups of one plane of a block
-    constexpr int PA = (2 * AG + NW - 1) / NW;                              // wave instructions per wave per block (surplus ones land zeros in a dummy group)
-    constexpr int GB = 2 * BN / 16, PB = GB / NW;
-    constexpr int ABLK = 2 * AROWS * X6_ROWB, DUMMY = 2 * ABLK, BST0 = DUMMY + 16 * X6_ROWB, BSTAGE = 2 * BN * X6_ROWB, NSTAGE = 3;
-    static_assert(GB % NW == 0 && PB == 1, "one filter request per wave per chunk");
-    static_assert(H3_S16 && TN == 1, "the 16x16x32 form, 32 columns per wave");
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    int tile_m, tile_n;
-    h3_tile_of(p, xcd_remap(blockIdx.x, nwg), tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const size_t plane_bytes = (size_t)p.Cout * p.Kpad * 2;
-    const char* wbase = reinterpret_cast<const char*>(p.w);
-    const size_t x_elems = (size_t)p.n_img * p.H * p.W * p.Cin;
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x_planes), 0, (int)(x_elems * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wbase + H3_HEADER_BYTES), 0, (int)(2 * plane_bytes), 0x00020000);
-    h3_fp16_saturate();
-
-    // requests: lane -> (row of its 16-row group, LDS slot); the slot holds piece slot ^ swz(row) of the row's 64 bytes
-    const int grow = lane >> 2, slot = lane & 3;
-    unsigned a_off[PA];
-    int a_dst[PA];
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int g = wave + NW * i;
-        if (g < 2 * AG) {
-            const int pl = g / AG, r0 = 16 * (g % AG), row = r0 + grow, m = m0 - HALO + row;      // block row `row` holds tensor row m (input rows = output rows)
-            a_dst[i] = pl * AROWS * X6_ROWB + r0 * X6_ROWB;
-            a_off[i] = (m >= 0 && m < p.M) ? (unsigned)(((size_t)m * p.Cin + (slot ^ h3_swz(row)) * 8) * 2 + pl * x_elems * 2) : OOB_OFFSET;
-        } else {
-            a_dst[i] = -1;                                // (every wave issues PA requests per block: s_waitcnt counts them)
-            a_off[i] = OOB_OFFSET;
-        }
-    }
-    unsigned b_off;
-    int b_dst;
-    {
-        const int g = wave, pl = g / (BN / 16), r0 = 16 * (g % (BN / 16)), row = r0 + grow;
-        b_dst = pl * BN * X6_ROWB + r0 * X6_ROWB;
-        b_off = n0 + row < p.Cout ? (unsigned)(((size_t)(n0 + row) * p.Kpad + (slot ^ h3_swz(row)) * 8) * 2 + pl * plane_bytes) : OOB_OFFSET;
-    }
-    auto issue_a = [&](int blk, int c0_bytes) {
-        char* base = lds + blk * ABLK;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int i = 0; i < PA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(a_dst[i] >= 0 ? base + a_dst[i] : lds + DUMMY), 16, a_off[i], c0_bytes, 0, 0);
-#else
-        (void)base; (void)xrsrc; (void)c0_bytes; (void)sizeof(lds_ptr_t);
-#endif
-    };
-    auto issue_b = [&](int stage, int w_bytes) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(lds + BST0 + stage * BSTAGE + b_dst), 16, b_off, w_bytes, 0, 0);
-#else
-        (void)stage; (void)w_bytes; (void)wrsrc; (void)b_off; (void)b_dst;
-#endif
-    };
-    // a fragment row's taps: bit (r * 3 + s) set when (y + r - 1, x + s - 1) lies on the map
-    unsigned vmask[TM][2];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int ri = 0; ri < 2; ++ri) {
-            const int m = m0 + wm * TM * 32 + i * 32 + ri * 16 + (lane & 15);
-            const int pos = m % (p.Ho * p.Wo), y = pos / p.Wo, x = pos - y * p.Wo;
-            unsigned mk = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    if ((unsigned)(y + r - 1) < (unsigned)p.Ho && (unsigned)(x + q - 1) < (unsigned)p.Wo) mk |= 1u << (r * 3 + q);
-            vmask[i][ri] = mk;
-        }
-
-    const int nblk = p.Kpad / (BK * 9), nk = nblk * 9;
-    f32x16 acc0[TM][TN], acc1[TM][TN];
-    f32x4 s0[TM][TN][4], s1[TM][TN][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { s0[i][0][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; s1[i][0][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-
-    // chunk t = (channel block t / 9, tap t % 9); the filter's chunk t lies at (block * 9 + tap) * 64 bytes of a row
-    issue_a(0, 0);
-    issue_b(0, 0);
-    if (nk > 1) issue_b(1, BK * 2);
-    const float x_max = amax_read(p.x_amax);
-    const int eA = *p.x_pexp;
-    const int eB = h3_exponent(*reinterpret_cast<const float*>(wbase));
-    int eY = 0;
-    if (p.y_planes) {
-        eY = h3_exponent(p.bound_c * x_max + p.bound_d + (p.res_amax ? amax_read(p.res_amax) : 0.0f));
-        if (blockIdx.x == 0 && tid == 0) *p.y_pexp = eY;
-    }
-    asm volatile("" :: "v"(eA), "v"(eB), "v"(eY) : "memory");
-    const int frow = HALO + wm * TM * 32 + (lane & 15);   // block row of this lane's first fragment row
-    int stage = 0, free_stage = 2, tap = 0, blk = 0;
-    bool a_behind = false;                                // the previous step requested a block (PA requests younger than chunk t + 1's)
-    for (int t = 0; t < nk; ++t) {
-        const bool b_behind = t + 1 < nk;
-        if (a_behind && b_behind) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PA + 1) : "memory");
-        else if (a_behind) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PA) : "memory");
-        else if (b_behind) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        a_behind = tap == 0 && blk + 1 < nblk;
-        if (a_behind) issue_a((blk + 1) & 1, (blk + 1) * BK * 2);         // into the buffer block blk - 1 was read from
-        if (t + 2 < nk) issue_b(free_stage, (t + 2) * BK * 2);
-        {
-            const int r_tap = tap / 3, s_tap = tap - 3 * r_tap;
-            const int row = frow + (r_tap - 1) * p.W + (s_tap - 1);
-            const char* a_hi = lds + (blk & 1) * ABLK + row * X6_ROWB + 16 * ((lane >> 4) ^ h3_swz(row));
-            const char* b_hi = lds + BST0 + stage * BSTAGE + wn * 32 * X6_ROWB + (lane & 15) * X6_ROWB + 16 * ((lane >> 4) ^ h3_swz(lane & 15));
-            f16x8 fb[2][2];
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci) fb[pl][ci] = *reinterpret_cast<const f16x8*>(b_hi + pl * BN * X6_ROWB + ci * 16 * X6_ROWB);
-            const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int ri = 0; ri < 2; ++ri) {
-                    f16x8 ah = *reinterpret_cast<const f16x8*>(a_hi + (i * 32 + ri * 16) * X6_ROWB);
-                    f16x8 al = *reinterpret_cast<const f16x8*>(a_hi + AROWS * X6_ROWB + (i * 32 + ri * 16) * X6_ROWB);
-                    const bool on = (vmask[i][ri] >> tap) & 1u;
-                    ah = on ? ah : zero;
-                    al = on ? al : zero;
-#pragma unroll
-                    for (int ci = 0; ci < 2; ++ci) {
-                        f32x4& c1 = s1[i][0][ri * 2 + ci];
-                        f32x4& c0 = s0[i][0][ri * 2 + ci];
-                        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, fb[0][ci], c1, 0, 0, 0);
-                        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, fb[1][ci], c1, 0, 0, 0);
-                        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, fb[0][ci], c0, 0, 0, 0);
-                    }
-                }
-        }
-        free_stage = stage;
-        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
-        if (++tap == 9) { tap = 0; ++blk; }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // the epilogue reuses the buffers
-    h3_gather<TM, TN>(s0, acc0); h3_gather<TM, TN>(s1, acc1);
-    h3_combine<TM, TN>(acc0, acc1);
-    h3_unscale<TM, TN>(acc0, h3_pow2(-eA), h3_pow2(-eB));
-    if (p.y_planes) x6_epilogue_vec<TM, TN, WM, WN, true, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds), h3_pow2(eY));
-    else if (p.vec_epi) x6_epilogue_vec<TM, TN, WM, WN, false, H3_S16>(acc0, p, m0, n0, tid, wm, wn, li, lh, reinterpret_cast<float*>(lds));
-    else epilogue<TM, TN, H3_S16>(acc0, p, m0, n0, wm, wn, li, lh);
-}
-
 // ---- ONE workgroup per CU, TWO LDS buffers (96 KB for a 256x128 tile) and ONE barrier per chunk: chunk kt multiplies from buffer
 // kt & 1 while chunk kt+1 (in registers since the previous iteration) is split and stored into the other buffer and chunk kt+2 is
 // requested (k_conv_igemm_x6_db's loop).  <2,1,4,4>: sixteen waves of 64x32; <2,2,4,2>: eight waves of 64x64 (eight fragment reads
@@ -757,8 +589,7 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     extern __shared__ __attribute__((aligned(16))) char lds[];
     if constexpr (RING) {                                 // (an instantiation of its own: as a run-time branch beside the other loop the ring keeps a
         static_assert(APLANES, "the ring reads planes");  //  quarter of its gain -- 729 -> 717-723 instead of 748 -> 703-713 us -- to the shared register file)
-        if constexpr (RING == 2) h3_ring9_tile<TM, TN, WM, WN>(p, lds);       // 3x3 over small maps: a channel block's activations staged once for its nine taps
-        else h3_ring_tile<TM, TN, WM, WN>(p, lds);
+        h3_ring_tile<TM, TN, WM, WN>(p, lds);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -961,7 +792,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
 
 // dev knob: FRCNN_H3_RING=0 keeps plane-input launches on the register-staged double buffer (k_conv_igemm_h3_db<.., true>)
 static const bool g_h3_ring = !(getenv("FRCNN_H3_RING") && atoi(getenv("FRCNN_H3_RING")) == 0);
-static const bool g_h3_ring9 = getenv("FRCNN_H3_RING9") && atoi(getenv("FRCNN_H3_RING9")) != 0;      // lab: off (704-708 us against the plain ring's 685-692)
 static const int g_h3_ring_min_chunks = getenv("FRCNN_H3_RING_MIN_CHUNKS") ? atoi(getenv("FRCNN_H3_RING_MIN_CHUNKS")) : 32;
 
 template <int TM, int TN, int WM, int WN>
@@ -977,17 +807,6 @@ static int launch_h3_db(const ConvArgs& a, hipStream_t s) {
         if constexpr (WM * WN == 16) {
             // long reductions only (the head's 3x3: 144 chunks); FRCNN_H3_RING=0 / FRCNN_H3_RING_MIN_CHUNKS are dev knobs
             if (g_h3_ring && p.Kpad / BK >= g_h3_ring_min_chunks) {
-                if constexpr (TN == 1) {
-                    const bool small_3x3 = p.R == 3 && p.S == 3 && p.stride == 1 && p.pad_top == 1 && p.pad_left == 1 && p.layout == 0 && p.Ho == p.H && p.Wo == p.W &&
-                                           p.W + 1 <= 16 && p.Cin % BK == 0 && p.pix_stride == p.Cin && p.img_stride == p.H * p.W * p.Cin && p.Kpad == 9 * p.Cin;
-                    if (small_3x3 && g_h3_ring9) {
-                        constexpr size_t ring9_lds = (size_t)2 * 2 * (BM + 32) * X6_ROWB + 16 * X6_ROWB + (size_t)3 * 2 * BN * X6_ROWB;
-                        static std::atomic<uint64_t> lds_seen_ring9{0};
-                        if (int e = raise_lds_once(lds_seen_ring9, (const void*)k_conv_igemm_h3_db<TM, TN, WM, WN, true, 2>, ring9_lds, "conv2d_h3")) return e;
-                        k_conv_igemm_h3_db<TM, TN, WM, WN, true, 2><<<p.tiles_m * p.tiles_n, 64 * WM * WN, ring9_lds, s>>>(p);
-                        return check_launch("conv2d_fwd_h3 (planes in, tap-reuse ring)");
-                    }
-                }
                 constexpr size_t ring_lds = (size_t)3 * 2 * (BM + BN) * X6_ROWB;
                 static std::atomic<uint64_t> lds_seen_ring{0};
                 if (int e = raise_lds_once(lds_seen_ring, (const void*)k_conv_igemm_h3_db<TM, TN, WM, WN, true, 1>, ring_lds, "conv2d_h3")) return e;
