@@ -647,12 +647,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     unsigned rem = tap_mask;
     int c0 = 0, w_grp = 0;
     f32x4 ra[PA], rb[PBT];
-#ifdef H3_PF2
-    f32x4 ra2[PA], rb2[PBT];      // a second register stage: a chunk's fetch has TWO loop iterations to land (lab: scripts/dev/r6_a_once_lab.sh pf2)
-#endif
-#ifdef H3_LAB_A_ONCE          // lab only (scripts/dev/r6_a_once_lab.sh): the activations are fetched and staged for the FIRST tap of a channel chunk only --
-    bool ra_fresh = true;     // wrong products, the time of a loop whose taps would re-read the chunk from LDS instead of from L2
-#endif
     auto load_into = [&](f32x4 (&ra)[PA], f32x4 (&rb)[PBT]) {
         const int tap = __builtin_ctz(rem);
         const int r_tap = (tap * p.inv_S) >> 16, s_tap = tap - r_tap * p.S;
@@ -660,10 +654,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
         const int w_off = w_grp + tap * (BK * 2);
 #pragma unroll
         for (int i = 0; i < PBT; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, b_off[i], w_off, 0));
-#ifdef H3_LAB_A_ONCE
-        ra_fresh = (rem == tap_mask);
-        if (ra_fresh)
-#endif
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int hi = a_h[i] + r_tap, wi = a_w[i] + s_tap;
@@ -678,9 +668,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     };
     auto load_next = [&]() { load_into(ra, rb); };
     load_next();                                          // chunk 0: in flight while the two scales are fetched
-#ifdef H3_PF2
-    load_into(ra2, rb2);                                  // chunk 1
-#endif
     h3_fp16_saturate();
     const float x_max = amax_read(p.x_amax);
     const int eA = APLANES ? *p.x_pexp : h3_exponent(x_max);
@@ -696,9 +683,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
     }
     auto store_from = [&](int buf, f32x4 (&ra)[PA], f32x4 (&rb)[PBT]) {
         char* base = lds + buf * BUFB;
-#ifdef H3_LAB_A_ONCE
-        if (ra_fresh)
-#endif
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             if constexpr (APLANES) {
@@ -756,21 +740,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
             kstep(buf, 1);
         }
     };
-#ifdef H3_PF2
-    store_from(0, ra, rb);
-    load_into(ra, rb);                                    // chunk 2
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {                  // (two iterations per trip: the register stages alternate statically)
-        if (kt + 1 < nk) { store_from(1, ra2, rb2); load_into(ra2, rb2); }      // chunk kt + 1 staged, chunk kt + 3 requested
-        compute(0);
-        __syncthreads();
-        if (kt + 1 < nk) {
-            if (kt + 2 < nk) { store_from(0, ra, rb); load_into(ra, rb); }      // chunk kt + 2 staged, chunk kt + 4 requested
-            compute(1);
-            __syncthreads();
-        }
-    }
-#else
     store(0);
     load_next();                                          // chunk 1 (past-the-end fetches are never multiplied)
     __syncthreads();
@@ -780,7 +749,6 @@ __global__ void __launch_bounds__(64 * WM * WN) k_conv_igemm_h3_db(const ConvArg
         compute(buf);
         __syncthreads();
     }
-#endif
     if constexpr (!APLANES) h3_report(p.x_amax, seen);
     if constexpr (H3_S16) { h3_gather<TM, TN>(s0, acc0); h3_gather<TM, TN>(s1, acc1); }
     h3_combine<TM, TN>(acc0, acc1);

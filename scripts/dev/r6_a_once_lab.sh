@@ -1,4 +1,5 @@
 #!/bin/bash
+# (The two macros this script builds with -- H3_LAB_A_ONCE, H3_PF2 -- were taken out of csrc/conv_h3.hip again: commit 71aa159 holds them.)
 # Lab: what would the head's 3x3 layer cost if a channel chunk of activations were staged in LDS ONCE and its nine taps read it there
 # (row-shifted fragment reads) instead of nine fetches from L2?  Builds a second library with -DH3_LAB_A_ONCE (activations fetched for
 # the first tap of a chunk only: wrong products, right amount of every other work) -- here, on the CPU box -- and times both on the GPU.
