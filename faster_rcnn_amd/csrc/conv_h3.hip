@@ -763,7 +763,7 @@ static const bool g_h3_ring = !(getenv("FRCNN_H3_RING") && atoi(getenv("FRCNN_H3
 static const int g_h3_ring_min_chunks = getenv("FRCNN_H3_RING_MIN_CHUNKS") ? atoi(getenv("FRCNN_H3_RING_MIN_CHUNKS")) : 32;
 
 template <int TM, int TN, int WM, int WN>
-static int launch_h3_db(const ConvArgs& a, hipStream_t s) {
+static int launch_h3_db(const ConvArgs& a, hipStream_t s, bool ring_ok = true) {
     ConvArgs p = a;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -774,7 +774,7 @@ static int launch_h3_db(const ConvArgs& a, hipStream_t s) {
     if (p.x_planes) {
         if constexpr (WM * WN == 16) {
             // long reductions only (the head's 3x3: 144 chunks); FRCNN_H3_RING=0 / FRCNN_H3_RING_MIN_CHUNKS are dev knobs
-            if (g_h3_ring && p.Kpad / BK >= g_h3_ring_min_chunks) {
+            if (ring_ok && g_h3_ring && p.Kpad / BK >= g_h3_ring_min_chunks) {
                 constexpr size_t ring_lds = (size_t)3 * 2 * (BM + BN) * X6_ROWB;
                 static std::atomic<uint64_t> lds_seen_ring{0};
                 if (int e = raise_lds_once(lds_seen_ring, (const void*)k_conv_igemm_h3_db<TM, TN, WM, WN, true, 1>, ring_lds, "conv2d_h3")) return e;
@@ -810,7 +810,8 @@ int launch_conv_h3(const ConvArgs& a, int cfg, hipStream_t s) {
         case 82: return launch_h3_db<2, 2, 4, 2>(a, s);       // 256x128, 8 waves (64x64 per wave), two LDS buffers, one workgroup per CU
         case 83: return launch_h3<2, 2, 2, 2>(a, s);          // 128x128, 4 waves (64x64 per wave)
         case 84: return launch_h3<1, 1, 2, 2>(a, s);          // 64x64, 4 waves
-        case 86: return launch_h3_db<2, 1, 4, 4>(a, s);       // 256x128, 16 waves, two LDS buffers, one workgroup per CU
+        case 85: return launch_h3_db<2, 1, 4, 4>(a, s, false);  // 86 with plane input kept on the two register-staged buffers whatever the reduction's length
+        case 86: return launch_h3_db<2, 1, 4, 4>(a, s);       // 256x128, 16 waves, two LDS buffers (plane input with a long reduction: the three-stage ring), one workgroup per CU
         case 87: return launch_h3<2, 1, 2, 2>(a, s);          // 128x64, 4 waves (64x32 per wave): the 64-column layers
         case 184: return launch_h3<1, 1, 2, 2, true>(a, s);   // 64x64 with split-K (a.splits / a.slabs / a.tickets set by the caller)
         case 181: return launch_h3<2, 1, 2, 4, true>(a, s);   // 128x128 on eight waves with split-K: the taller small grids

@@ -2370,7 +2370,7 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
         const int hcfg = h3_config(d, dual ? dual->n1 : 0);
         if (planes_io) {
             // activations as fp16 planes: the double-buffered 256x128 forms only, 16-byte epilogue, one layer, no mask
-            if ((hcfg != 86 && hcfg != 82) || dual || mask || !a.vec_epi && y || d->ldy > 0)
+            if ((hcfg != 86 && hcfg != 85 && hcfg != 82) || dual || mask || (!a.vec_epi && y) || d->ldy > 0)
                 return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3_planes: needs the 256x128 tile (>= 256 output tiles of 128x128; frcnn_conv2d_h3_config 86 / 82), a dense single-layer launch without a mask");
             if ((d->cout & 3) || (d->cin & 7)) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3_planes: cin %% 8 == 0 and cout %% 4 == 0");
             if ((size_t)M * d->cout * 4 >= 0x7fffffffull || (size_t)d->n * d->h * d->w * d->cin * 4 >= 0x7fffffffull)

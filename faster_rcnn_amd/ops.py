@@ -688,7 +688,7 @@ def conv_accepts_planes(x_shape, pc, stride=1, padding="valid", act=None, layout
 
 
 H3_KERNEL_NAMES = {81: "k_conv_igemm_h3<2,1,2,4>", 82: "k_conv_igemm_h3_db<2,2,4,2>", 83: "k_conv_igemm_h3<2,2,2,2>", 84: "k_conv_igemm_h3<1,1,2,2>",
-                   86: "k_conv_igemm_h3_db<2,1,4,4>", 87: "k_conv_igemm_h3<2,1,2,2>"}
+                   85: "k_conv_igemm_h3_db<2,1,4,4>", 86: "k_conv_igemm_h3_db<2,1,4,4>", 87: "k_conv_igemm_h3<2,1,2,2>"}
 
 
 def _h3_name(d, n1=0):
@@ -828,7 +828,7 @@ def _h3_planes_in_name(d, pc):
 def _planes_ok(d, pc, eng):
     """A launch may read / write fp16 planes: the f16x3 engine on its double-buffered 256x128 tile, un-split, channel counts the 16- and
     8-byte pieces divide."""
-    return (eng == "h3" and _lib.load().frcnn_conv2d_h3_config(ctypes.byref(d), 0) in (86, 82) and pc.cout % 4 == 0 and pc.cin % 8 == 0
+    return (eng == "h3" and _lib.load().frcnn_conv2d_h3_config(ctypes.byref(d), 0) in (86, 85, 82) and pc.cout % 4 == 0 and pc.cin % 8 == 0
             and (_CONV_WS is NO_SPLIT_K or _ws_need(d, "frcnn_conv2d_h3_workspace_bytes") == 0))
 
 

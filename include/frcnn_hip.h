@@ -362,7 +362,8 @@ int frcnn_conv2d_engine(const frcnn_conv_desc* d, int prefer, int workspace_pres
  * with a fill vector (custom_layers.py:35-56), ReLU.  A bound that is too LARGE by up to 2^8 costs no precision; one that is too
  * small overflows fp16 (inf / NaN in the output, as an f32 overflow would give).
  * frcnn_pack_conv_weights_h3: f32 packed filter [cout][packed_k] -> 16-byte header (max|w|) + two fp16 planes [2][cout][packed_k]
- * (frcnn_conv_h3_planes_bytes bytes, 16-byte aligned).  tile: 0 = auto, 81: 128x128 on 8 waves, 82 / 86: 256x128 on 8 / 16 waves
+ * (frcnn_conv_h3_planes_bytes bytes, 16-byte aligned).  tile: 0 = auto, 81: 128x128 on 8 waves, 82 / 86: 256x128 on 8 / 16 waves (85: 86 without
+ * the three-stage ring that plane-input launches with long reductions walk: same bits, the comparand of the ring's bitwise test)
  * with two LDS buffers, 83: 128x128 on 4 waves, 84: 64x64, 87: 128x64.  Workspace (may be NULL): the split-K contract of
  * frcnn_conv2d_fwd_x6 (frcnn_conv2d_h3_workspace_bytes: 0 = this shape runs unsplit). */
 size_t frcnn_conv_h3_planes_bytes(int cout, int packed_k);

@@ -350,6 +350,31 @@ def test_h3_plane_tensors_between_layers():
     assert torch.equal(c3_, b3) and torch.equal(c1_.planes, b1.planes)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_h3_ring_equals_the_double_buffer_bit_for_bit(layout):
+    """Round 6: plane-input launches with long reductions walk a three-stage direct-to-LDS ring (csrc/conv_h3.hip h3_ring_tile; tile code
+    86), short ones and tile code 85 the register-staged double buffer: same chunk order, same products -- the same bits, in both row
+    layouts (position-major: with tap skipping), for plane and f32 outputs, with a ragged last tile."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(71)
+    n, c = 333, 256                                                          # 333 * 49 rows: not a multiple of 256
+    shape = (7, 7, n, c) if layout else (n, 7, 7, c)
+    x = torch.from_numpy(np.maximum(rs.randn(*shape), 0).astype(np.float32)).cuda()
+    p1 = ops.PackedConv((rs.randn(1, 1, c, c) * np.sqrt(2.0 / c)).astype(np.float32), np.ones(c, np.float32), np.zeros(c, np.float32))
+    p3 = ops.PackedConv((rs.randn(3, 3, c, c) * np.sqrt(2.0 / (9 * c))).astype(np.float32), (1 + 0.1 * rs.randn(c)).astype(np.float32), (0.1 * rs.randn(c)).astype(np.float32))
+    res = torch.from_numpy(rs.randn(*shape).astype(np.float32)).cuda()
+    with ops.f32_engine("f16x3"), ops.conv_workspace(ops.NO_SPLIT_K):
+        t = ops.conv2d(x, p1, 1, "valid", "relu", layout=layout, planes_out=True, tile=86)
+        assert isinstance(t, ops.PlaneTensor)
+        ring_p = ops.conv2d(t, p3, 1, "same", "relu", layout=layout, planes_out=True, tile=86)      # 72 chunks: the ring
+        db_p = ops.conv2d(t, p3, 1, "same", "relu", layout=layout, planes_out=True, tile=85)
+        ring_f = ops.conv2d(t, p3, 1, "same", "relu", residual=res, layout=layout, tile=86)
+        db_f = ops.conv2d(t, p3, 1, "same", "relu", residual=res, layout=layout, tile=85)
+    assert torch.equal(ring_p.planes, db_p.planes) and int(ring_p.exponent.item()) == int(db_p.exponent.item())
+    assert torch.equal(ring_f, db_f) and float(ring_f.abs().max()) > 0.0
+    assert torch.equal(ring_p._amax, db_p._amax)
+
+
 @pytest.mark.parametrize("size", [(160, 224), (161, 227), (600, 1000), (37, 29)])
 def test_h3_fused_stem_equals_conv_plus_pool(size):
     """frcnn_stem_h3_fwd: conv1 7x7 / 2 'same' + folded BatchNorm + ReLU + MaxPooling2D((3,3), (2,2)) in one f16x3 launch (resnet.py:408-412)
