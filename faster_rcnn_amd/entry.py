@@ -202,7 +202,7 @@ def _capture_stream():
 class _Slot:
     """One captured pass for one image size, with its staging on both sides of PCIe."""
     __slots__ = ("key", "pipe", "graph", "out", "io_dev", "io_pin", "pix_host", "dyn_host", "out_pin", "event", "busy", "nbytes",
-                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed", "amax", "_out_raw", "ready", "extents", "seg", "canvas")
+                 "x_f32", "ws", "seq", "tabs", "u8_resized", "batch", "pix_hosts", "out_packed", "amax", "_out_raw", "ready", "extents", "seg", "canvas", "_ext_raw")
 
 
 def _close_slot(s):
@@ -217,11 +217,11 @@ def _close_slot(s):
         s.graph.reset()
     if getattr(s, "pipe", None) is not None and hasattr(s.pipe, "close"):
         s.pipe.close()
-    for name in ("io_pin", "_out_raw"):
+    for name in ("io_pin", "_out_raw", "_ext_raw"):
         piece = getattr(s, name, None)
         if piece is not None:
             _PinnedArena.give_back(piece)
-    for name in ("graph", "out", "out_packed", "io_dev", "x_f32", "u8_resized", "tabs", "ws", "amax", "pipe", "io_pin", "_out_raw", "out_pin", "pix_hosts", "pix_host", "dyn_host", "extents"):
+    for name in ("graph", "out", "out_packed", "io_dev", "x_f32", "u8_resized", "tabs", "ws", "amax", "pipe", "io_pin", "_out_raw", "out_pin", "pix_hosts", "pix_host", "dyn_host", "extents", "_ext_raw"):
         setattr(s, name, None)
 
 
@@ -400,7 +400,9 @@ class DetectionEntry:
         s = _Slot()
         s.key, s.pipe, s.busy, s.seq, s.batch, s.canvas, s.seg = ("canvas", Hc, Wc), pipe, False, 0, B, True, seg
         s.io_dev = torch.zeros(off + 16 * B, dtype=torch.uint8, device="cuda")
+        stamps.append(("buffers: device staging", time.perf_counter()))
         s.io_pin = self._pinned.take(off + 16 * B, zero=True)
+        stamps.append(("buffers: pinned staging", time.perf_counter()))
         host = s.io_pin.numpy()
         s.pix_hosts = [host[i * seg:(i + 1) * seg] for i in range(B)]
         s.pix_host = s.pix_hosts[0]
@@ -410,7 +412,9 @@ class DetectionEntry:
         s.tabs = None
         s.u8_resized = torch.empty((B, seg), dtype=torch.uint8, device="cuda")
         s.x_f32 = torch.zeros((B, Hc, Wc, 3), dtype=torch.float32, device="cuda")
-        s.extents = nets.Extents(B)
+        stamps.append(("buffers: canvases", time.perf_counter()))
+        s._ext_raw = self._pinned.take(nets.Extents.LEVELS * B * 8)
+        s.extents = nets.Extents(B, pinned=s._ext_raw)
         for i in range(B):
             s.extents.set(i, Hc, Wc)
         s.extents.upload()
@@ -418,7 +422,9 @@ class DetectionEntry:
         shared = self.in_flight > 1
         dtype = getattr(getattr(self.detector, "head", None), "dtype", "f32")
         s.ws = ops.NO_SPLIT_K if ((shared and (dtype == "bf16" or os.environ.get("FRCNN_ENTRY_NO_SPLITK"))) or B > 1) else ops.ConvWorkspace()
+        stamps.append(("buffers: extents", time.perf_counter()))
         s.io_dev.copy_(s.io_pin)
+        stamps.append(("buffers: first upload", time.perf_counter()))
         s.amax = ops.AmaxArena() if self.f32_engine == "f16x3" else None
         side = _capture_stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -146,9 +146,16 @@ class Extents:
     fixed (a captured pass bakes it in); ``set(i, H, W)`` writes image i's rows of the HOST copy, ``upload()`` sends it."""
     LEVELS = 3
 
-    def __init__(self, batch):
+    def __init__(self, batch, pinned=None):
+        """``pinned``: a pinned uint8 host tensor of at least LEVELS * batch * 8 bytes to use as the host copy (entry.DetectionEntry cuts it
+        from its arena: a pin_memory() call per captured pass is a hipHostMalloc of several milliseconds)."""
         self.batch = int(batch)
-        self.host = torch.zeros((self.LEVELS, self.batch, 2), dtype=torch.int32).pin_memory()
+        n = self.LEVELS * self.batch * 2
+        if pinned is not None:
+            self.host = pinned[:4 * n].view(torch.int32).view(self.LEVELS, self.batch, 2)
+            self.host.zero_()
+        else:
+            self.host = torch.zeros((self.LEVELS, self.batch, 2), dtype=torch.int32).pin_memory()
         self.table = torch.zeros((self.LEVELS, self.batch, 2), dtype=torch.int32, device="cuda")
 
     @staticmethod
