@@ -6,7 +6,7 @@ TAG=${1:-round6}
 R=$(cd "$(dirname "$0")/.." && pwd)
 S=$R/gpurun_out/$TAG
 P=$R/profiles
-for f in $S/bench_*.json $S/bench_*_conv_table.txt $S/*_trace_by_grid.txt $S/trace_*_kernel_stats.csv $S/train_step_*.txt; do
+for f in $S/bench_*.json $S/bench_*_conv_table.txt $S/*_trace_by_grid.txt $S/trace_*_kernel_stats.csv $S/train_step_*.txt $S/pmc_*.txt; do
   [ -s "$f" ] && cp "$f" $P/${TAG}_$(basename $f)
 done
 [ -s $S/summary.txt ] && cut -c1-400 $S/summary.txt > $P/${TAG}_summary.txt

@@ -60,6 +60,12 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
   i=$((i+1))
   rocprofv3 --pmc $ctrs --output-format csv -d $OUT/pmc$i -- python3 $R/scripts/c4_batch_eager.py 3 > $OUT/pmc$i.log 2>&1
 done
+# FETCH_SIZE / WRITE_SIZE per (kernel, grid) -- which SHAPE of a kernel carries the traffic -- and the counter's calibration on known byte counts
+bash $R/scripts/dev/r6_pmc_by_grid.sh > /dev/null 2>&1
+cp $R/gpurun_out/pmc_by_grid/FETCH_SIZE.by_grid.txt $OUT/pmc_FETCH_SIZE_by_grid.txt 2>/dev/null
+cp $R/gpurun_out/pmc_by_grid/WRITE_SIZE.by_grid.txt $OUT/pmc_WRITE_SIZE_by_grid.txt 2>/dev/null
+bash $R/scripts/micro/fetch_size_calibration.sh > $OUT/pmc_fetch_size_calibration.txt 2>&1
+cd /tmp
 python3 $R/scripts/profile_summary.py $OUT > $OUT/summary.txt 2>&1
 head -40 $OUT/summary.txt | cut -c1-400
 for t in trace_default trace_streams1 trace_c4; do

@@ -20,7 +20,7 @@ def bench_kernel_name(k):
         return "k_conv_igemm_x6<%s,%s,%s,%s>" % m.groups()[:4] + (" split-K" if m.group(6) == "true" else "")
     if "k_conv_igemm_x6_db" in k:
         return "k_conv_igemm_x6_db"
-    m = re.search(r"k_conv_igemm_h3_db<(\d+), (\d+), (\d+), (\d+)(, (true|false))?(, (true|false))?>", k)      # (.., planes in, ring loop): the two plane-reading instantiations are ONE line
+    m = re.search(r"k_conv_igemm_h3_db<(\d+), (\d+), (\d+), (\d+)(, (true|false))?(, \d+)?>", k)      # (.., planes in, ring loop 0 / 1): the two plane-reading instantiations are ONE line
     if m:
         return "k_conv_igemm_h3_db<%s,%s,%s,%s%s>" % (m.groups()[:4] + (",planes" if m.group(6) == "true" else "",))
     m = re.search(r"k_conv_igemm_h3<(\d+), (\d+), (\d+), (\d+)(, (true|false))?>", k)
@@ -72,6 +72,14 @@ for tag in ("trace_streams1", "trace_default"):
     for name in sorted(every, key=lambda n: -sum(every[n])):
         a, e = iso.get(name, []), every[name]
         print("%-78s %7d %10.2f | %7d %10.2f" % (name.split("(")[0][:78], len(a), (sum(a) / len(a) / 1e3) if a else float("nan"), len(e), sum(e) / len(e) / 1e3))
+    groups = collections.defaultdict(list)                     # bench.py's kernel names that cover several instantiations: one more row each
+    for name in every:
+        groups[bench_kernel_name(name.split("(")[0])].append(name)
+    for g, members in groups.items():
+        if len(members) > 1:
+            a = [d for m in members for d in iso.get(m, [])]
+            e = [d for m in members for d in every[m]]
+            print("%-78s %7d %10.2f | %7d %10.2f   <- bench.py's roofline.avg_launch_us is this average" % (("= " + g)[:78], len(a), (sum(a) / len(a) / 1e3) if a else float("nan"), len(e), sum(e) / len(e) / 1e3))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -80,6 +88,16 @@ for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), 
             # bench.py reports ONE bf16 conv kernel (all instantiations, averaged over an image's launches): same key here
             key = "frcnn::k_conv_igemm_bf16<all instantiations>" if "k_conv_igemm_bf16<" in k else k.split("(")[0][:70]
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# bench.py's name for a kernel may cover several instantiations (the plane-reading 256x128 kernel: double-buffer and ring loops): their
+# dispatches are averaged TOGETHER for traffic.json, and printed as one more entry beside the instantiations' own
+canon = collections.defaultdict(lambda: collections.defaultdict(list))
+for k in acc:
+    for n, v in acc[k].items():
+        canon[bench_kernel_name(k)][n] += v
+for name in canon:
+    members = [k for k in acc if bench_kernel_name(k) == name]
+    if len(members) > 1:
+        acc[name + "  (= " + " + ".join(m.split("frcnn::")[-1] for m in members) + ")"] = canon[name]
 traffic = {}
 if acc:
     print("\n== PMC means per dispatch (rocprofv3 --pmc, separate passes, eager single stream)")
@@ -91,8 +109,9 @@ for k in sorted(acc):
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM)
         hbm = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
-        name = bench_kernel_name(k)
-        traffic[name] = {"hbm_bytes_per_launch": round(hbm), "fetch_kb_raw": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"]}
+        name = bench_kernel_name(k.split("  (= ")[0])
+        if "  (= " in k or name not in traffic:                 # (the combined entry wins over a member's own)
+            traffic[name] = {"hbm_bytes_per_launch": round(hbm), "fetch_kb_raw": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"]}
         print("    -> HBM-side bytes per launch (2*FETCH+WRITE)*1024 = %.3g" % hbm)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         print("    -> matrix pipe busy = MFMA_BUSY/1024 SIMDs / (GUI_ACTIVE/8 XCDs) = %.3f" % (c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8)))
