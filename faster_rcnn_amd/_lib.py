@@ -17,7 +17,7 @@ class FrcnnError(RuntimeError):
     pass
 
 
-ABI_VERSION = 106       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
+ABI_VERSION = 107       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
 P = c_void_p
 I = c_int
 # name -> (restype, argtypes).  Must list every symbol include/frcnn_hip.h declares
@@ -89,6 +89,7 @@ SIGNATURES = {
     "frcnn_pack_stem_weights_h3": (I, [P, P, P]),
     "frcnn_stem_h3_fwd": (I, [P, P, I, I, I, P, P, P, P, P, P]),
     "frcnn_conv2d_fwd_h3_planes": (I, [P, P, P, P, P, P, P, P, P, P, P, P, ctypes.c_float, ctypes.c_float, P]),
+    "frcnn_conv2d_fwd_h3_planes_res": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, ctypes.c_float, ctypes.c_float, P]),
     "frcnn_conv2d_fwd_ws_amax": (I, [P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     "frcnn_pack_conv_weights_dgrad": (I, [P, P, I, I, I, I, P, P]),
     "frcnn_conv2d_wgrad_workspace_bytes": (c_size_t, [P]),

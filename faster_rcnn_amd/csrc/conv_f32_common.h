@@ -39,6 +39,9 @@ struct ConvArgs {
     // y_planes [2][M][Cout] written beside / instead of y under the scale 2^eY, eY from the bound bound_c * max|x| + bound_d
     // (+ max|residual|, res_amax) that every workgroup derives from the same device words; *y_pexp = eY.
     const void* x_planes; const int* x_pexp; void* y_planes; int* y_pexp; const float* res_amax; float bound_c, bound_d;
+    // the residual as two fp16 planes [2][M][Cout] under the scale 2^*res_pexp (a block's output handed on as planes only: the next
+    // block's shortcut reads them back, residual == NULL then); the vector epilogues of the f16x3 256x128 forms only
+    const void* res_planes = nullptr; const int* res_pexp = nullptr;
 };
 
 // ---- magnitude records.  A record is AMAX_SLOTS floats, one per 128-byte line: a launch has hundreds to thousands of waves and a
@@ -329,6 +332,11 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
     const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.mask ? p.mask : p.x), 0, p.mask ? (int)((size_t)p.M * p.Cout * 4) : 0, 0x00020000);
     const int prow = tid / C4, pcol = (tid % C4) * 4, n = n0 + pcol;
+    // residual handed over as fp16 planes: value = (hi + lo / 2048) * 2^-e, e the producing launch's exponent (one device word)
+    const __amdgpu_buffer_rsrc_t rprsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.res_planes ? p.res_planes : (const void*)p.x), 0, p.res_planes ? (int)((size_t)2 * p.M * p.Cout * 2) : 0, 0x00020000);
+    float res_unscale = 1.0f;
+    if (p.res_planes) { const unsigned b = (unsigned)(127 - *p.res_pexp) << 23; __builtin_memcpy(&res_unscale, &b, 4); }
     f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
     if (n < p.Cout) {
         if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
@@ -343,6 +351,15 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
             const int m = m0 + h * HB + q * RPP + prow;
             const bool in = m < p.M && n < p.Cout;
             if (p.residual) rres[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, in ? (unsigned)(((size_t)m * p.ldres + n) * 4) : OOB_OFFSET, 0, 0));
+            else if (p.res_planes) {                         // (8 + 8 bytes: the same bytes per element as the f32 tensor)
+                typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
+                typedef int i32x2r __attribute__((ext_vector_type(2)));
+                const unsigned off = in ? (unsigned)(((size_t)m * p.Cout + n) * 2) : OOB_OFFSET;
+                const f16x4r h = __builtin_bit_cast(f16x4r, (i32x2r)__builtin_amdgcn_raw_buffer_load_b64(rprsrc, off, 0, 0));
+                const f16x4r l = __builtin_bit_cast(f16x4r, (i32x2r)__builtin_amdgcn_raw_buffer_load_b64(rprsrc, off == OOB_OFFSET ? OOB_OFFSET : off + (unsigned)((size_t)p.M * p.Cout * 2), 0, 0));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rres[q][c] = ((float)h[c] + (float)l[c] * (1.0f / 2048.0f)) * res_unscale;
+            }
             if (p.mask) rmask[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrsrc, in ? (unsigned)(((size_t)m * p.Cout + n) * 4) : OOB_OFFSET, 0, 0));
         }
     };
@@ -376,7 +393,7 @@ __device__ __forceinline__ void x6_epilogue_vec(f32x16 (&acc)[TM][TN], const Con
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float t = a[c] * sc[c] + sh[c];
-                if (p.residual) t += rres[q][c];
+                if (p.residual || p.res_planes) t += rres[q][c];
                 if (p.mask && !(rmask[q][c] > 0.0f)) t = 0.0f;
                 v[c] = activate(t, y_act);
             }

@@ -2080,6 +2080,7 @@ struct ConvRange {
     // f16x3 engine, activations as fp16 planes (frcnn_conv2d_fwd_h3_planes); all null / 0 otherwise
     const void* x_planes = nullptr; const int* x_pexp = nullptr; void* y_planes = nullptr; int* y_pexp = nullptr; const float* res_amax = nullptr;
     float bound_c = 0.0f, bound_d = 0.0f;
+    const void* res_planes = nullptr; const int* res_pexp = nullptr;      // the residual as planes (frcnn_conv2d_fwd_h3_planes_res)
 };
 
 static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* w_packed,
@@ -2279,17 +2280,28 @@ int frcnn_conv2d_fwd_dual_h3(const frcnn_conv_desc* d, const float* x, const flo
 int frcnn_conv2d_fwd_h3_planes(const frcnn_conv_desc* d, const float* x, const frcnn_h3_planes* x_planes, const float* x_amax, const void* w_planes_f16,
                                const float* scale, const float* shift, const float* residual, const float* residual_amax,
                                float* y, float* y_amax, const frcnn_h3_planes* y_planes, float bound_c, float bound_d, void* stream) {
+    return frcnn_conv2d_fwd_h3_planes_res(d, x, x_planes, x_amax, w_planes_f16, scale, shift, residual, nullptr, residual_amax, y, y_amax, y_planes, bound_c, bound_d, stream);
+}
+
+int frcnn_conv2d_fwd_h3_planes_res(const frcnn_conv_desc* d, const float* x, const frcnn_h3_planes* x_planes, const float* x_amax, const void* w_planes_f16,
+                                   const float* scale, const float* shift, const float* residual, const frcnn_h3_planes* residual_planes,
+                                   const float* residual_amax, float* y, float* y_amax, const frcnn_h3_planes* y_planes, float bound_c, float bound_d,
+                                   void* stream) {
     if (!x_amax) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: the input's magnitude record is required");
+    if (residual && residual_planes) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: the residual as an f32 tensor OR as planes");
+    if (residual_planes && (!residual_planes->planes || !residual_planes->exponent || (reinterpret_cast<uintptr_t>(residual_planes->planes) & 15)))
+        return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: incomplete or misaligned residual planes");
     if ((x != nullptr) == (x_planes != nullptr)) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: exactly one of x / x_planes");
     if (!y && !y_planes) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: no output");
     if (x_planes && (!x_planes->planes || !x_planes->exponent)) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: incomplete input planes");
-    if (y_planes && (!y_planes->planes || !y_planes->exponent || !(bound_c >= 0.0f) || !(bound_d >= 0.0f) || (residual && !residual_amax)))
+    if (y_planes && (!y_planes->planes || !y_planes->exponent || !(bound_c >= 0.0f) || !(bound_d >= 0.0f) || ((residual || residual_planes) && !residual_amax)))
         return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: output planes need their buffers, the filter's bound constants and, with a residual, its magnitude record");
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if ((x_planes && !al16(x_planes->planes)) || (y_planes && !al16(y_planes->planes))) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: 16-byte aligned planes required");
     ConvRange rg = {x_amax, y_amax, nullptr};
     if (x_planes) { rg.x_planes = x_planes->planes; rg.x_pexp = x_planes->exponent; }
-    if (y_planes) { rg.y_planes = y_planes->planes; rg.y_pexp = y_planes->exponent; rg.res_amax = residual ? residual_amax : nullptr; rg.bound_c = bound_c; rg.bound_d = bound_d; }
+    if (y_planes) { rg.y_planes = y_planes->planes; rg.y_pexp = y_planes->exponent; rg.res_amax = (residual || residual_planes) ? residual_amax : nullptr; rg.bound_c = bound_c; rg.bound_d = bound_d; }
+    if (residual_planes) { rg.res_planes = residual_planes->planes; rg.res_pexp = residual_planes->exponent; }
     return conv_fwd_impl(d, x, reinterpret_cast<const float*>(w_planes_f16), scale, shift, residual, nullptr, y, nullptr, nullptr, 0, stream, ENGINE_H3, &rg);
 }
 
@@ -2348,6 +2360,7 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
     a.x_planes = range ? range->x_planes : nullptr; a.x_pexp = range ? range->x_pexp : nullptr;
     a.y_planes = range ? range->y_planes : nullptr; a.y_pexp = range ? range->y_pexp : nullptr;
     a.res_amax = range ? range->res_amax : nullptr; a.bound_c = range ? range->bound_c : 0.0f; a.bound_d = range ? range->bound_d : 0.0f;
+    a.res_planes = range ? range->res_planes : nullptr; a.res_pexp = range ? range->res_pexp : nullptr;
     if (dual) { a.n_split = dual->n1; a.act = dual->act1; a.ldy = dual->n1; a.y2 = dual->y2; a.ldy2 = d->cout - dual->n1; a.act2 = dual->act2; }
     a.tiles_m = a.tiles_n = 0;
     a.splits = 1; a.slabs = nullptr; a.tickets = nullptr;
@@ -2373,6 +2386,7 @@ static int conv_fwd_impl(const frcnn_conv_desc* d, const float* x, const float* 
             if ((hcfg != 86 && hcfg != 85 && hcfg != 82) || dual || mask || (!a.vec_epi && y) || d->ldy > 0)
                 return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3_planes: needs the 256x128 tile (>= 256 output tiles of 128x128; frcnn_conv2d_h3_config 86 / 82), a dense single-layer launch without a mask");
             if ((d->cout & 3) || (d->cin & 7)) return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3_planes: cin %% 8 == 0 and cout %% 4 == 0");
+            if (a.res_planes && (residual || (y && !a.vec_epi))) return fail(FRCNN_E_ARG, "conv2d_fwd_h3_planes: residual planes exclude an f32 residual and need 16-byte addressable output rows");
             if ((size_t)M * d->cout * 4 >= 0x7fffffffull || (size_t)d->n * d->h * d->w * d->cin * 4 >= 0x7fffffffull)
                 return fail(FRCNN_E_UNSUPPORTED, "conv2d_fwd_h3_planes: tensor planes over 2 GiB");
             if (!y) a.vec_epi = 1;

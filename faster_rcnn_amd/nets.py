@@ -135,6 +135,11 @@ def _block_units(weights, stage, block, has_shortcut, stride, separate_scale, dt
 
 
 HEAD_PLANES = True      # dev knob (tests): False keeps every tensor of the detector head f32
+# round 6, OFF (FRCNN_HEAD_BLOCK_PLANES=1 switches it on): a head block's OUTPUT travels as planes too (next block's branch2a stages them,
+# its closing 1x1 reads the shortcut back from them, frcnn_conv2d_fwd_h3_planes_res): the 2048 -> 512 layers lose the split in their
+# loader and walk the ring -- 436-443 -> 393-407 us per four-image launch -- but the 512 -> 2048 layers that now write and read 8-byte plane
+# pieces instead of 16-byte f32 pieces take 548-557 instead of 534-539 us: 533.5 against 536.5 img/s (scripts/dev/r6_block_planes_ab.sh)
+HEAD_BLOCK_PLANES = _os.environ.get("FRCNN_HEAD_BLOCK_PLANES", "0") != "0"
 # the same hand-over inside the TRUNK's bottleneck blocks, wherever the consuming launch is one that reads planes (the 256x128 tile
 # forms: stage 3 of a four-image pass, mostly) -- VERDICT r5 item 3; dev knob until measured
 TRUNK_PLANES = _os.environ.get("FRCNN_TRUNK_PLANES", "0") != "0"
@@ -181,10 +186,12 @@ class Extents:
         return self.table[lvl]
 
 
-def run_block(u, x, layout=0, planes=False, mask=None):
+def run_block(u, x, layout=0, planes=False, mask=None, out_planes=False):
     """identity_block / conv_block (resnet.py:114-247) and their TimeDistributed twins (:250-392).  ``planes``: branch2a's and
     branch2b's outputs have ONE reader each, the next convolution of the block: on the f16x3 engine they are handed on as the fp16
-    planes that convolution multiplies (ops.PlaneTensor), so its loader splits nothing."""
+    planes that convolution multiplies (ops.PlaneTensor), so its loader splits nothing.  ``out_planes`` (round 6): the block's OUTPUT
+    as planes only -- its two readers are the next block's branch2a, which stages them unchanged, and that block's closing 1x1, which
+    reads the shortcut back from them (block_takes_planes says whether the next block can); ``x`` may be such a tensor."""
     planes = planes and HEAD_PLANES
     pair = _pair(u["2a"], u["1"]) if "1" in u else None
     if pair is not None:                                    # branch2a and the shortcut conv read x: one launch
@@ -195,7 +202,16 @@ def run_block(u, x, layout=0, planes=False, mask=None):
     if mask is not None:                                    # a canvas pass: branch2b's 3x3 must read zeros beyond each image's true extent
         t = ops.zero_outside(t, mask)
     t = u["2b"](t, layout=layout, planes_out=planes and _reads_planes(u["2c"], t.shape, layout))
-    return u["2c"](t, residual=shortcut, layout=layout)
+    return u["2c"](t, residual=shortcut, layout=layout, planes_out=out_planes)
+
+
+def block_takes_planes(u, x_shape, layout):
+    """Can identity block ``u`` take its input of this shape as an ops.PlaneTensor -- branch2a staging the planes, the closing 1x1 reading
+    the shortcut from them?  (Both launches on the f16x3 engine's 256x128 tile.)"""
+    if not (HEAD_PLANES and HEAD_BLOCK_PLANES) or "1" in u:
+        return False
+    inner = tuple(x_shape[:-1]) + (_cout(u["2b"]),)
+    return _reads_planes(u["2a"], x_shape, layout) and _reads_planes(u["2c"], inner, layout)
 
 
 def _cout(unit):
@@ -403,7 +419,18 @@ class ResNetHead:
         else:
             t = resize(u, rois, self.pool, fill=a["2a"].pc.shift, relu=True, layout=L)
         s = resize(v, rois, self.pool, fill=a["1"].pc.shift, layout=L)
-        return a["2c"](a["2b"](t, layout=L, planes_out=planes and _reads_planes(a["2c"], crop_shape[:-1] + (_cout(a["2b"]),), L)), residual=s, layout=L)
+        out_shape = crop_shape[:-1] + (_cout(a["2c"]),)
+        nxt = self.blocks[1] if len(self.blocks) > 1 else None
+        return a["2c"](a["2b"](t, layout=L, planes_out=planes and _reads_planes(a["2c"], crop_shape[:-1] + (_cout(a["2b"]),), L)), residual=s, layout=L,
+                       planes_out=planes and nxt is not None and block_takes_planes(nxt, out_shape, L))
+
+    def _run_rest(self, x, rest, L):
+        """The identity blocks behind the first: each hands its output to the next as planes where that block can take them."""
+        for i, b in enumerate(rest):
+            nxt = rest[i + 1] if i + 1 < len(rest) else None
+            x = run_block(b, x, L, planes=self.dtype == "f32",
+                          out_planes=self.dtype == "f32" and nxt is not None and block_takes_planes(nxt, tuple(x.shape[:-1]) + (_cout(b["2c"]),), L))
+        return x
 
     def __call__(self, feat, rois):
         resize = ops.roi_crop_resize_bf16 if self.dtype == "bf16" else ops.roi_crop_resize
@@ -414,8 +441,7 @@ class ResNetHead:
         else:
             x = resize(feat, rois, self.pool, layout=L)     # (n,7,7,1024), or (7,7,n,1024) position-major
             rest = self.blocks
-        for b in rest:
-            x = run_block(b, x, L, planes=self.dtype == "f32")
+        x = self._run_rest(x, rest, L)
         if self.dtype == "bf16":
             return self.dense(ops.avgpool_bf16(x, 7, L))   # pooled features and the dense layers stay f32
         if L:
@@ -437,8 +463,7 @@ class ResNetHead:
             # img/s, three alternating runs).  One-image passes tie (507 / 507) and the latency form loses 2 %: they keep position-major.
             L = BATCHED_F32_HEAD_LAYOUT if self.layout else 0
             x = self._first_block_hoisted(feat, rois, functools.partial(ops.roi_crop_resize, n_per_img=n_per_img), layout=L)
-            for b in self.blocks[1:]:
-                x = run_block(b, x, L, planes=True)
+            x = self._run_rest(x, self.blocks[1:], L)
             if L:
                 return self.dense(ops.avgpool_pos_major(x))
             x = ops.pool2d(x, 7, 7, False)

@@ -805,17 +805,20 @@ def _conv2d_h3_planes(d, x, pc, residual, oshape, planes_out, act):
     bc, bd = pc.h3_bound() if planes_out else (0.0, 0.0)
     xa = amax_of(x)                                              # (a measured record is a temporary: it must outlive the launch and its re-launches)
     ra = amax_of(residual) if (residual is not None and planes_out) else None
+    r_in = isinstance(residual, PlaneTensor)                     # a block's output handed on as planes: the shortcut reads them back
+    rp = _lib.H3Planes(planes=residual.planes.data_ptr(), exponent=residual.exponent.data_ptr(), status=None) if r_in else None
     args = (ctypes.byref(d), None if x_in else _p(x), ctypes.byref(xp) if x_in else None, _p(xa), _p(pc.h3_planes()), _p(pc.scale), _p(pc.shift),
-            _p(residual), _p(ra), None if planes_out else _p(y), _p(ya), ctypes.byref(yp) if planes_out else None, bc, bd)
-    _lib.call("frcnn_conv2d_fwd_h3_planes", *args, _stream())
+            None if r_in else _p(residual), ctypes.byref(rp) if r_in else None, _p(ra), None if planes_out else _p(y), _p(ya),
+            ctypes.byref(yp) if planes_out else None, bc, bd)
+    _lib.call("frcnn_conv2d_fwd_h3_planes_res", *args, _stream())
     y._amax = ya
     if CONV_PROFILE is not None:
-        keep = (d, x, pc, residual, y, ya, xp, yp, xa, ra)
+        keep = (d, x, pc, residual, y, ya, xp, yp, xa, ra, rp)
         # (the instantiation that reads planes is a kernel of its own; writing planes is a run-time branch of either's epilogue)
         CONV_PROFILE.append({"kernel": _h3_planes_in_name(d, pc) if x_in else _h3_name(d), "planes_out": bool(planes_out),
                              "flops": 2.0 * d.n * d.ho * d.wo * pc.cout * pc.kh * pc.kw * pc.cin,
                              "shape": (d.n * d.ho * d.wo, pc.cout, pc.kh * pc.kw * pc.cin, d.stride),
-                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_h3_planes", *args, _stream())})
+                             "relaunch": lambda args=args, keep=keep: _lib.call("frcnn_conv2d_fwd_h3_planes_res", *args, _stream())})
     return y
 
 
@@ -844,13 +847,14 @@ def conv2d(x, pc, stride=1, padding="valid", act=None, residual=None, out=None, 
     d = _conv_desc(tuple(x.shape), pc.kh, pc.kw, pc.cout, stride, padding, ACT[act], layout, tile or AUTO_TILE)
     n, ho, wo = d.n, d.ho, d.wo
     oshape = (ho, wo, n, pc.cout) if layout else (n, ho, wo, pc.cout)
-    if x_planes or planes_out:
+    res_planes = isinstance(residual, PlaneTensor)
+    if x_planes or planes_out or res_planes:
         ok = out is None and _planes_ok(d, pc, _split_engine(d, pc, tile or AUTO_TILE))
-        if x_planes and not ok:
-            raise _lib.FrcnnError("conv2d: a PlaneTensor input needs an f16x3 launch on the 256x128 tile (frcnn_conv2d_fwd_h3_planes)")
+        if (x_planes or res_planes) and not ok:
+            raise _lib.FrcnnError("conv2d: a PlaneTensor input / residual needs an f16x3 launch on the 256x128 tile (frcnn_conv2d_fwd_h3_planes)")
         if ok:
             if residual is not None:
-                assert tuple(residual.shape) == tuple(oshape) and residual.is_contiguous()
+                assert tuple(residual.shape) == tuple(oshape) and (res_planes or residual.is_contiguous())
             return _conv2d_h3_planes(d, x, pc, residual, oshape, planes_out, act)
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device="cuda")

@@ -44,9 +44,10 @@ const char* frcnn_last_error(void);
  * 103 = frcnn_refresh_h3_planes, frcnn_roi_crop_resize_fwd_batch (additions only).
  * 105 = padded canvases: frcnn_preprocess_u8_canvas, frcnn_zero_outside, frcnn_decode_proposals_canvas (additions only).
  * 106 = frcnn_preprocess_u8_canvas takes the image's offset in the canvas (even canvases for every parity).
+ * 107 = frcnn_conv2d_fwd_h3_planes_res (addition only).
  * 104 = the f16x3 engine's fences: frcnn_h3_planes.status (a THIRD field: recompile hosts that pass the struct), status word in a
  *       magnitude record, frcnn_amax_status. */
-#define FRCNN_ABI_VERSION 106
+#define FRCNN_ABI_VERSION 107
 int frcnn_version(void);
 /* number of HIP devices visible; does not initialise a context */
 int frcnn_device_count(void);
@@ -424,6 +425,15 @@ int frcnn_conv2d_fwd_h3_planes(const frcnn_conv_desc* d, const float* x, const f
                                const void* w_planes_f16, const float* scale, const float* shift,
                                const float* residual, const float* residual_amax,
                                float* y, float* y_amax, const frcnn_h3_planes* y_planes, float bound_c, float bound_d, void* stream);
+/* The same launch with the RESIDUAL handed over as planes (residual == NULL then): a bottleneck block of the detector head whose output
+ * has two readers -- the next block's branch2a and its shortcut, resnet.py:282-313 -- writes it ONCE, as planes only (y == NULL); branch2a
+ * stages them unchanged and the closing 1x1 of that block reads the shortcut back from them, value = (hi + lo / 2048) * 2^-exponent:
+ * the tensor's elements to 22-24 bits, i.e. what the engine multiplies anyway.  Same bytes as the f32 tensor, and the 2048 -> 512 layers
+ * behind it lose the split in their loader (and, 64 chunks long, walk the three-stage ring). */
+int frcnn_conv2d_fwd_h3_planes_res(const frcnn_conv_desc* d, const float* x, const frcnn_h3_planes* x_planes, const float* x_amax,
+                                   const void* w_planes_f16, const float* scale, const float* shift,
+                                   const float* residual, const frcnn_h3_planes* residual_planes, const float* residual_amax,
+                                   float* y, float* y_amax, const frcnn_h3_planes* y_planes, float bound_c, float bound_d, void* stream);
 /* RoiResizeConv (custom_layers.py:35-56; frcnn_roi_crop_resize_fwd_ex) writing its result as f16x3 planes for the convolution behind it
  * (res5a_branch2b's 3x3 over the crops, resnet.py:508-512).  out->exponent is an INPUT here: the scale comes from a bound known before the
  * launch -- a bilinear sample cannot exceed the map's largest magnitude, a rejected RoI yields `fill` -- i.e. from

@@ -350,6 +350,55 @@ def test_h3_plane_tensors_between_layers():
     assert torch.equal(c3_, b3) and torch.equal(c1_.planes, b1.planes)
 
 
+def test_h3_block_output_as_planes_feeds_the_next_conv_and_its_shortcut():
+    """Round 6 (frcnn_conv2d_fwd_h3_planes_res): a head block's output written ONCE, as planes; the next block's branch2a stages them and its
+    closing 1x1 reads the shortcut back from them -- (hi + lo / 2048) * 2^-e, the tensor's elements to 22-24 bits.  Against the same two
+    blocks through f32 tensors: the planes ARE the f32 block output to one unit in its last place, the second block's output agrees to
+    2^-20 of the tensor's scale, and the error against fp64 stays at the f32 chain's."""
+    from faster_rcnn_amd import _lib, ops
+    rs = np.random.RandomState(91)
+    n, c, cw = 300, 512, 1024                                                # 14 700 rows; inner width c, block width cw (>= 256 tiles of 128x128 per launch)
+    x0 = np.maximum(rs.randn(n, 7, 7, cw), 0).astype(np.float32)
+    mk = lambda kh, ci, co: ops.PackedConv((rs.randn(kh, kh, ci, co) * np.sqrt(2.0 / (kh * kh * ci))).astype(np.float32),
+                                           (1 + 0.1 * rs.randn(co)).astype(np.float32), (0.1 * rs.randn(co)).astype(np.float32))
+    blocks = [(mk(1, cw, c), mk(3, c, c), mk(1, c, cw)) for _ in range(2)]
+    xd = torch.from_numpy(x0).cuda()
+
+    def chain(block_planes):
+        x = xd
+        with ops.f32_engine("f16x3"), ops.conv_workspace(ops.NO_SPLIT_K):
+            for i, (a, b, cc) in enumerate(blocks):
+                t = ops.conv2d(x, a, 1, "valid", "relu", planes_out=True)
+                t = ops.conv2d(t, b, 1, "same", "relu", planes_out=True)
+                x = ops.conv2d(t, cc, 1, "valid", "relu", residual=x, planes_out=block_planes and i == 0)
+        return x
+    ops.CONV_PROFILE = []
+    try:
+        y_pl = chain(True)
+        names = [r["kernel"] for r in ops.CONV_PROFILE]
+        for r in ops.CONV_PROFILE:
+            r["relaunch"]()
+    finally:
+        ops.CONV_PROFILE = None
+    y_f = chain(False)
+    assert isinstance(y_pl, torch.Tensor) and names[3] == "k_conv_igemm_h3_db<2,1,4,4,planes>", names     # block 2's branch2a read planes
+    assert torch.equal(chain(True), y_pl)                                    # reproducible
+    scale = float(y_f.abs().max())
+    assert float((y_pl - y_f).abs().max()) <= 2.0 ** -20 * scale, float((y_pl - y_f).abs().max()) / scale
+    # the first block's output, both ways
+    with ops.f32_engine("f16x3"), ops.conv_workspace(ops.NO_SPLIT_K):
+        a, b, cc = blocks[0]
+        t = ops.conv2d(ops.conv2d(xd, a, 1, "valid", "relu", planes_out=True), b, 1, "same", "relu", planes_out=True)
+        o_f = ops.conv2d(t, cc, 1, "valid", "relu", residual=xd)
+        o_p = ops.conv2d(t, cc, 1, "valid", "relu", residual=xd, planes_out=True)
+        assert isinstance(o_p, ops.PlaneTensor)
+        v, f = o_p.float().double(), o_f.double()
+        assert bool(((v - f).abs() <= 2.0 ** -22 * f.abs() + 2.0 ** -38 * f.abs().max()).all())
+        # a residual as planes on a launch that cannot read them is refused, as a plane input is
+        with pytest.raises(_lib.FrcnnError):
+            ops.conv2d(xd[:8].contiguous(), cc if False else blocks[0][0], 1, "valid", "relu", residual=ops.PlaneTensor((8, 7, 7, c)))
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_h3_ring_equals_the_double_buffer_bit_for_bit(layout):
     """Round 6: plane-input launches with long reductions walk a three-stage direct-to-LDS ring (csrc/conv_h3.hip h3_ring_tile; tile code
