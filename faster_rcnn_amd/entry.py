@@ -97,6 +97,7 @@ CANVAS_SLOTS_PER_CLASS = int(os.environ.get("FRCNN_ENTRY_CANVAS_SLOTS", "2"))
 CANVAS_CAPTURE_IMAGES = float(os.environ.get("FRCNN_ENTRY_CANVAS_CAPTURE_IMAGES", "12"))
 CANVAS_PIXEL_SHARE = float(os.environ.get("FRCNN_ENTRY_CANVAS_PIXEL_SHARE", "0.4"))
 CANVAS_MAX_CLASSES = int(os.environ.get("FRCNN_ENTRY_CANVAS_MAX_CLASSES", "8"))
+CANVAS_BYTES_PER_PIXEL = 600                             # a captured fp32 pass's memory per canvas pixel, before one of its class has been measured
 
 
 def canvas_side(n, granule=None):
@@ -657,6 +658,17 @@ class DetectionEntry:
         for c, n in per_class.items():
             want = int(np.ceil(1.5 * self.in_flight * n / total - 1e-9))
             self._canvas_slots[("canvas",) + c] = max(1 if n <= self.batch else 2, min(self.in_flight, want))
+        # ... within the cache's byte budget: passes beyond it would only evict each other (a pass costs what one of its class did, else
+        # CANVAS_BYTES_PER_PIXEL of its canvases: ~1.4 GB per four 600 x 1000 images)
+        def cost(c):
+            known = [sl.nbytes for k, v in self.cache._slots.items() if k[:3] == ("canvas",) + c for sl in v]
+            return max(known) if known else CANVAS_BYTES_PER_PIXEL * self.batch * c[0] * c[1]
+        live = [c for c in per_class]
+        while sum(self._canvas_slots[("canvas",) + c] * cost(c) for c in live) > 0.9 * self.cache.byte_budget:
+            c = max(live, key=lambda k: (self._canvas_slots[("canvas",) + k], -per_class[k]))     # (the fullest allowance; among equals the rarest class)
+            if self._canvas_slots[("canvas",) + c] <= 1:
+                break
+            self._canvas_slots[("canvas",) + c] -= 1
         return plan
 
     def canvas_class(self, H, W):

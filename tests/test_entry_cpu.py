@@ -278,6 +278,30 @@ def test_canvas_plan_merges_what_is_not_worth_a_capture_and_is_stable():
     assert len(set(entry.plan_canvas_classes(counts, capture_images=0.0, max_new=3).values())) <= 3
 
 
+def test_canvas_pass_allowances_follow_the_lists_shares_and_the_byte_budget():
+    """DetectionEntry.plan_canvases: a class may hold its share of the passes in flight (at least one; two when it fills more than one pass)
+    -- and never more passes than the cache's byte budget holds (they would only evict each other)."""
+    import collections
+
+    class FakeCache:
+        def __init__(self, budget):
+            self.byte_budget, self._slots = budget, collections.OrderedDict()
+
+        def keys(self):
+            return list(self._slots)
+    counts = {(600, 800): 106, (600, 901): 36, (800, 600): 28, (562, 1000): 4}
+    roomy = types.SimpleNamespace(cache=FakeCache(72 << 30), in_flight=4, batch=4, _canvas_of={}, _canvas_slots={})
+    plan = entry.DetectionEntry.plan_canvases(roomy, counts)
+    assert plan == entry.plan_canvas_classes(counts) and roomy._canvas_of == plan
+    main = ("canvas",) + plan[(600, 800)]
+    assert roomy._canvas_slots[main] == 4 and all(1 <= v <= 4 for v in roomy._canvas_slots.values())
+    tight = types.SimpleNamespace(cache=FakeCache(6 << 30), in_flight=4, batch=4, _canvas_of={}, _canvas_slots={})
+    entry.DetectionEntry.plan_canvases(tight, counts)
+    est = sum(v * entry.CANVAS_BYTES_PER_PIXEL * 4 * k[1] * k[2] for k, v in tight._canvas_slots.items())
+    assert est <= 0.9 * (6 << 30) or all(v == 1 for v in tight._canvas_slots.values())
+    assert tight._canvas_slots[main] == max(tight._canvas_slots.values())          # the common class keeps the most
+
+
 def test_full_collections_before_captures_are_throttled(monkeypatch):
     """pipeline.collect_before_capture: at most one full gc.collect() per interval (a collection costs more than a capture)."""
     from faster_rcnn_amd import pipeline
