@@ -2206,8 +2206,19 @@ static int h3_config(const frcnn_conv_desc* d, int n1) {
     if (d->cout <= 64) cfg = ((M + 127) / 128) >= 1024 ? 87 : 84;
     else {
         const long long t128 = ((M + 127) / 128) * ((d->cout + 127) / 128);
-        cfg = t128 >= 256 ? 86 : 84;
+        // beside other passes' launches the big tile pays from half as many tiles on (scripts/dev/r6_shared_big_min.sh: from 128 / 256 /
+        // 512 / 1024 tiles 555.9 / 554.5 / 544.5 / 540.5 img/s): what it leaves idle, other passes fill
+        static const int big_min_shared = getenv("FRCNN_H3_BIG_MIN_TILES_SHARED") ? atoi(getenv("FRCNN_H3_BIG_MIN_TILES_SHARED")) : 128;
+        cfg = t128 >= (t == 50 ? big_min_shared : 256) ? 86 : 84;
     }
+    // Beside other passes' launches (tile code 50: the chip is saturated -- sixteen images per 29 ms against 1.9 ms of isolated conv time
+    // per image -- and idle CUs are the other passes' to fill) a launch too small for the 256x128 form does its FLOPs cheaper on 128x128
+    // tiles (eight waves, code 81) than on 64x64: stage 4's 256-column layers of a four-image pass, 544.2 -> 549.7 img/s, backbone in
+    // flight 0.469 -> 0.458 ms per image (scripts/dev/r6_shared_small.sh; four waves of 64x64, code 83: 544.2).  Alone on the chip the
+    // 64x64 tiles stay (150 workgroups of 128x128 leave 106 CUs idle).  Same chunk order: the same bits.  FRCNN_H3_SHARED_SMALL=0: off.
+    static const int shared_small = getenv("FRCNN_H3_SHARED_SMALL") ? atoi(getenv("FRCNN_H3_SHARED_SMALL")) : 81;
+    static const int shared_small_rows = getenv("FRCNN_H3_SHARED_SMALL_ROWS") ? atoi(getenv("FRCNN_H3_SHARED_SMALL_ROWS")) : 4096;
+    if (t == 50 && cfg == 84 && shared_small && d->cout >= 128 && M >= shared_small_rows) cfg = shared_small;
     if (n1 > 0 && (n1 % 128) != 0 && cfg != 87) cfg = 84;       // the layer boundary of a paired launch must be a tile boundary (16-byte epilogue)
     return cfg;
 }
