@@ -1009,6 +1009,57 @@ def mixed_sizes_leg(pipe, anchors, n_images=256, seed=77, canvas=True):
                     "REORDER_WINDOW); a shape seen fewer than CAPTURE_MIN times runs the eager sequence" % (n_images, geometries)}
 
 
+def entry_legs(pipe, anchors, rank):
+    """Everything measured through the reference's inference entry point: one geometry (32 / 256 frames, from files, eager beside it),
+    and for the fp32 ResNet-50 the shuffled list of mixed image sizes (planned canvas classes / exact-geometry passes)."""
+    try:
+        via = reference_entry_leg(pipe, anchors, rank)
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    if DEPTH == 50 and DTYPE == "f32":
+        try:
+            via["mixed_sizes"] = mixed_sizes_leg(pipe, anchors)
+            via["mixed_sizes_exact_geometry_passes"] = mixed_sizes_leg(pipe, anchors, canvas=False)
+        except Exception as e:
+            via["mixed_sizes"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    via["process"] = {"hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                      "what": "GPU_MAX_HW_QUEUES as voc_dets.main sets it (the reference's entry point is a script: voc_dets.py:161-192); the captured passes in "
+                              "flight follow it (entry.default_in_flight)"}
+    return via
+
+
+# The reference's entry point is a SCRIPT (voc_dets.py:161-192), and this package's voc_dets.main asks the runtime for more hardware queues
+# than its default four before the first HIP call (GPU_MAX_HW_QUEUES: read once, when the runtime starts).  The headline loop above wants
+# the four (four passes on four queues: 546 img/s; on eight queues 502), get_dets_by_cls the many: on four queues its passes -- staging
+# copy, replay, read-back per pass, the host collecting the oldest -- measure 497 img/s, on eight or sixteen 542-547 (scripts/dev/r6_hw_queues.sh,
+# r6_entry_child_sweep2.sh).
+# So the entry-point legs run as a child of the default command, started before this process touches the GPU, under main's setting.
+ENTRY_HW_QUEUES = "8"                            # = faster_rcnn_amd.voc_dets.ENTRY_HW_QUEUES (not imported here: this runs before anything touches torch)
+
+
+def entry_legs_child(config, timeout_s=150.0):
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, FRCNN_BENCH_NO_NATIVE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FRCNN_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    env.setdefault("GPU_MAX_HW_QUEUES", ENTRY_HW_QUEUES)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, "bench.py", "--entry-only", "--config", config], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "exit code %d: %s" % (r.returncode, r.stderr.strip()[-300:])}
+        out = json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after %.0f s" % timeout_s}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 _JSON_OUT = None
 
 
@@ -1142,11 +1193,23 @@ def main():
     ap.add_argument("--no-train-dp", action="store_true", help="N > 1: leave the data-parallel training steps (`train_dp`) out of the line")
     ap.add_argument("--no-extra", action="store_true", help="N = 1, --config c2: leave the other BASELINE configs (`extra`: configs[0], configs[3], the "
                     "training steps of configs[2] / [4]) out of the line")
+    ap.add_argument("--entry-only", action="store_true", help="run only the legs through the reference's entry point (voc_dets.get_dets_by_cls) and "
+                    "print their object: what the default command starts as a child process under voc_dets.main's environment")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)                      # does not return
     json_out = claim_stdout()
+    if args.entry_only:
+        select_config(args.config)
+        pipe, _, anchors = build_pipeline()
+        json_out.write(json.dumps(entry_legs(pipe, anchors, 0)) + "\n")
+        json_out.flush()
+        return
     extra = None
+    entry_child = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config in ("c2", "c4") and args.dtype == "config" and not args.no_graph and not args.no_io
+            and os.environ.get("FRCNN_BENCH_FORCE_DIST", "0") == "0" and "FRCNN_BENCH_NO_ENTRY" not in os.environ and not _under_a_profiler()):
+        entry_child = entry_legs_child(args.config)  # (a child too, and first: this process has not touched the GPU yet)
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and args.config == "c2" and not args.no_extra and args.dtype == "config"
             and not args.no_graph and args.streams <= 0 and args.batch <= 0 and os.environ.get("FRCNN_BENCH_FORCE_DIST", "0") == "0"
             and "FRCNN_BENCH_BACKEND" not in os.environ and not _under_a_profiler()):
@@ -1431,17 +1494,12 @@ def main():
         torch.cuda.synchronize()
 
     via_entry = None
-    if world == 1 and not force_dist and not args.no_graph and not args.no_io and DEPTH != 16 and "FRCNN_BENCH_NO_ENTRY" not in os.environ:
-        try:
-            via_entry = reference_entry_leg(pipe, anchors, rank)
-        except Exception as e:
-            via_entry = {"error": "%s: %s" % (type(e).__name__, e)}
-        if "error" not in via_entry and DEPTH == 50 and DTYPE == "f32":
-            try:
-                via_entry["mixed_sizes"] = mixed_sizes_leg(pipe, anchors)
-                via_entry["mixed_sizes_exact_geometry_passes"] = mixed_sizes_leg(pipe, anchors, canvas=False)
-            except Exception as e:
-                via_entry["mixed_sizes"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if entry_child is not None and "error" not in entry_child:
+        via_entry = entry_child                     # measured in a process of its own, under the environment voc_dets.main sets up
+    elif world == 1 and not force_dist and not args.no_graph and not args.no_io and DEPTH != 16 and "FRCNN_BENCH_NO_ENTRY" not in os.environ:
+        via_entry = entry_legs(pipe, anchors, rank)  # (under a profiler, or the child failed: in this process, on its four hardware queues)
+        if entry_child is not None:
+            via_entry["child_process_error"] = entry_child["error"]
 
     train_dp = None
     if dist is not None and args.config in ("c2", "c4") and not args.no_train_dp:

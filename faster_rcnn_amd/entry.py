@@ -50,15 +50,13 @@ def _default_budget():
 
 
 def default_in_flight(dtype="f32"):
-    """Captured passes in flight for get_dets_by_cls: one per hardware queue (fp32 wants 8-12 streams on as many queues, the
-    power-limited bf16 path 4 on 4); ROCm gives a process 4 queues unless GPU_MAX_HW_QUEUES says otherwise."""
+    """Captured passes in flight for get_dets_by_cls: four (FRCNN_ENTRY_IN_FLIGHT overrides).  What matters more is that the PROCESS has
+    more hardware queues than ROCm's default four (GPU_MAX_HW_QUEUES, read when the runtime starts; voc_dets.main sets 8): on four, the
+    passes' staging copies, replays and read-backs queue behind one another -- 497 img/s through get_dets_by_cls against 542-547 on 8 or
+    16 queues, where 4 / 5 / 6 / 8 / 12 passes in flight measure 545 / 526 / 542 / 535 / 497 (fp32, four images per pass, 256 frames;
+    scripts/dev/r6_entry_child_sweep.sh).  (Until round 6 this returned up to 12 on 12 queues: right for one-image passes.)"""
     env = int(os.environ.get("FRCNN_ENTRY_IN_FLIGHT", "0"))
-    if env > 0:
-        return env
-    queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
-    # fp32: 12 on 12 queues (+2 % over 8 on 8 for one-image passes, the shape every odd-sized image takes; four-image passes are flat
-    # from 3 to 6 in flight: 540 / 541 / 528 / 539 img/s)
-    return min(queues, 12) if (queues >= 8 and dtype == "f32") else 4
+    return env if env > 0 else 4
 
 
 def default_batch(dtype="f32"):
@@ -97,6 +95,7 @@ CANVAS_SLOTS_PER_CLASS = int(os.environ.get("FRCNN_ENTRY_CANVAS_SLOTS", "2"))
 CANVAS_CAPTURE_IMAGES = float(os.environ.get("FRCNN_ENTRY_CANVAS_CAPTURE_IMAGES", "12"))
 CANVAS_PIXEL_SHARE = float(os.environ.get("FRCNN_ENTRY_CANVAS_PIXEL_SHARE", "0.4"))
 CANVAS_MAX_CLASSES = int(os.environ.get("FRCNN_ENTRY_CANVAS_MAX_CLASSES", "8"))
+CANVAS_EXTRA_SLOT = int(os.environ.get("FRCNN_ENTRY_WINDOW_EXTRA", "0"))      # (voc_dets.WINDOW_EXTRA: passes submitted beyond the streams)
 CANVAS_BYTES_PER_PIXEL = 600                             # a captured fp32 pass's memory per canvas pixel, before one of its class has been measured
 
 
@@ -658,6 +657,8 @@ class DetectionEntry:
         for c, n in per_class.items():
             want = int(np.ceil(1.5 * self.in_flight * n / total - 1e-9))
             self._canvas_slots[("canvas",) + c] = max(1 if n <= self.batch else 2, min(self.in_flight, want))
+            if want >= self.in_flight:                            # the class that fills every stream: one pass more, queued behind the oldest
+                self._canvas_slots[("canvas",) + c] += CANVAS_EXTRA_SLOT
         # ... within the cache's byte budget: passes beyond it would only evict each other (a pass costs what one of its class did, else
         # CANVAS_BYTES_PER_PIXEL of its canvases: ~1.4 GB per four 600 x 1000 images)
         def cost(c):
@@ -826,5 +827,15 @@ def for_models(manager, detector, num_rois=64, stride=16, in_flight=1):
     key = (id(detector), int(num_rois), stride, int(in_flight))
     eng = table.get(key)
     if eng is None or eng.detector is not detector:
+        global _QUEUES_SAID
+        if not _QUEUES_SAID and in_flight > 1 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+            _QUEUES_SAID = True
+            import warnings
+            warnings.warn("faster_rcnn_amd.entry: this process runs on %s hardware queues (GPU_MAX_HW_QUEUES; ROCm's default is 4): get_dets_by_cls measures "
+                          "~9 %% slower there than on 8 (497 against 542-547 img/s).  The setting is read when the HIP runtime starts: export "
+                          "GPU_MAX_HW_QUEUES=8 before the first device call, as voc_dets.main does." % os.environ.get("GPU_MAX_HW_QUEUES", "4"))
         eng = table[key] = DetectionEntry(manager, detector, num_rois, stride, in_flight)
     return eng
+
+
+_QUEUES_SAID = False

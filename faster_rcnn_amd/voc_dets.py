@@ -114,6 +114,10 @@ def get_dets_by_cls(training_manager, detector, resized_ratios, images, stride=1
 # Measured on bench.py's mixed_sizes leg (256 frames, 36 geometries, first call / same call again): CAPTURE_MIN 1: 170 / 514 img/s
 # (45 captures), 2: 300 / 442 (22 captures, 23 eager), 3: 274 / 428.  A long run over a whole dataset amortises every capture
 # (FRCNN_ENTRY_CAPTURE_MIN=1); the default favours the call that sees its list once.
+# passes submitted beyond the engine's streams before the oldest is collected (dev knob; 0, 1, 2 and 4 all measure 490-496 img/s on four
+# hardware queues: a stream idling while the host stages the next frames is NOT what holds get_dets_by_cls back there -- the queues are)
+WINDOW_EXTRA = int(os.environ.get("FRCNN_ENTRY_WINDOW_EXTRA", "0"))
+ENTRY_HW_QUEUES = "8"                            # what main() asks the runtime for (GPU_MAX_HW_QUEUES) unless the environment says otherwise
 REORDER_WINDOW = int(os.environ.get("FRCNN_ENTRY_REORDER", "64"))
 CAPTURE_MIN = int(os.environ.get("FRCNN_ENTRY_CAPTURE_MIN", "2"))
 
@@ -191,7 +195,7 @@ def _get_dets_by_cls_captured(eng, training_manager, detector, resized_ratios, i
             ticket = eng.submit_batch([images[g[0]] for g in part], [resized_ratios[g[0]] for g in part], det_threshold, [g[1] for g in part],
                                       batch=B if take > 1 else 1)
             window.append(([(g[0], g[2]) for g in part], ticket))
-            if len(window) >= eng.in_flight:
+            if len(window) >= eng.in_flight + WINDOW_EXTRA:
                 finish()
         return group
 
@@ -287,8 +291,9 @@ def main(argv=None):
     from .data.voc_data_helpers import KITTI_CLASS_MAPPING, VOC_CLASS_MAPPING
     from .util import get_anchors, resize_imgs
     args = build_parser().parse_args(argv)
-    # eight images in flight want eight hardware queues; read when the HIP runtime starts, an explicit setting wins
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+    # four passes in flight -- staging copy, replay, read-back each -- want more hardware queues than the runtime's default four (497 ->
+    # 542-547 img/s on eight, entry.default_in_flight); read when the HIP runtime starts, an explicit setting wins
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", ENTRY_HW_QUEUES)
     test_imgs = base_paths_to_imgs(args.voc_path, img_set=args.img_set, do_flip=False)
     anchors = get_anchors(anchor_scales_from_str(args.anchor_scales))
     print("num test_imgs: ", len(test_imgs))
