@@ -36,6 +36,7 @@ import torch
 from . import models, ops
 from ._lib import FrcnnError
 from .pipeline import InferencePipeline
+from .shapes import declares as _declares
 
 MEAN_BGR = (103.939, 116.779, 123.68)           # resnet.preprocess / vgg.preprocess (resnet.py:64-75, vgg.py:52-57)
 PRE_NMS_TOP_N, MAX_PROPOSALS = 8000, 300        # det_util.py:151-156
@@ -614,12 +615,12 @@ class DetectionEntry:
     def prefetchable(self, image):
         """True when ``host_pixels(image)`` is pure host work (a JPEG decode) that another thread may do ahead of time; images
         without ``raw`` and foreign preprocess functions are fetched inline (their ``data`` may use the device)."""
-        return self.device_preprocess and hasattr(image, "raw") and hasattr(image, "height")
+        return self.device_preprocess and _declares(image, "raw") and _declares(image, "height")
 
     def host_pixels(self, image):
         """What ``submit`` uploads for this image -- safe to call from another thread ahead of time (JPEG decode).
         Returns (array, H, W, src or None, flip)."""
-        if self.device_preprocess and hasattr(image, "raw") and hasattr(image, "height"):
+        if self.device_preprocess and _declares(image, "raw") and _declares(image, "height"):
             H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
             rgb = getattr(image, "raw_rgb", None) if RGB_UPLOAD else None
             if rgb is not None:

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .shapes import declares as _declares
 
 MEAN_BGR = (103.939, 116.779, 123.68)           # resnet.preprocess / vgg.preprocess (resnet.py:64-75, vgg.py:52-57)
 RGB_UPLOAD = os.environ.get("FRCNN_FEED_RGB_UPLOAD", "1") != "0"
@@ -79,7 +80,7 @@ def device_preprocess(preprocess_func):
 
 def device_image(image, preprocess_func):
     """(1,H,W,3) float32 device tensor == float32(np.expand_dims(preprocess_func(image.data), 0)), on the current stream."""
-    if device_preprocess(preprocess_func) and hasattr(image, "raw") and hasattr(image, "height"):
+    if device_preprocess(preprocess_func) and _declares(image, "raw") and _declares(image, "height"):
         H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
         # a file-backed frame goes up in the JPEG decoder's channel order; the device resize (to its own size when none is needed: a
         # copy) writes B, G, R -- the host's channel reversal cost as much as half the decode (round 6, as entry.DetectionEntry)

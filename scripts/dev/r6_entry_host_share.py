@@ -15,6 +15,15 @@ rs = np.random.RandomState(2000)
 base = [rs.randint(0, 256, (bench.HEIGHT, bench.WIDTH, 3)).astype(np.uint8) for i in range(32)]
 images = [shapes.Image(shapes.Metadata("synth%03d" % i, bench.WIDTH, bench.HEIGHT, [], "none"), base[i % 32]) for i in range(256)]
 ratios = [1.0] * len(images)
+if len(sys.argv) > 1 and sys.argv[1] == "files":              # the VOC frame as voc_dets.main feeds it: a 500x375 JPEG on disk, resized to 800x600 on the device
+    from faster_rcnn_amd import util
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+    images, ratios = [], []
+    for i in range(128):
+        b0 = extract_img_data(os.path.join(ROOT, "tests", "golden", "VOC_test"), "000005")
+        (r,), (ratio,) = util.resize_imgs([b0], min_size=600, max_size=1000)
+        r.metadata.name = "file%03d" % i
+        images.append(r); ratios.append(ratio)
 sink = io.StringIO()
 def run():
     with contextlib.redirect_stdout(sink):
