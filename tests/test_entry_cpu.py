@@ -302,6 +302,45 @@ def test_canvas_pass_allowances_follow_the_lists_shares_and_the_byte_budget():
     assert tight._canvas_slots[main] == max(tight._canvas_slots.values())          # the common class keeps the most
 
 
+def test_a_file_backed_frame_is_decoded_once_on_its_way_to_the_device():
+    """Round 6: `hasattr(image, "raw")` RAN Image.raw -- a JPEG decode plus a channel reversal, ~1.7 ms -- only to learn that the attribute
+    exists (from JPEG files 406-429 img/s instead of 509-524).  shapes.declares looks at the class; host_pixels / prefetchable / the training
+    feed's test decode the file ONCE, through raw_rgb, and probe_geometry asks PIL for the header once however often it is called."""
+    import os
+    from faster_rcnn_amd import shapes
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+
+    class Loud:
+        @property
+        def raw(self):
+            raise AssertionError("the property ran")
+        height = 3
+    assert shapes.declares(Loud(), "raw") and shapes.declares(Loud(), "height") and not shapes.declares(Loud(), "width")
+    inst = types.SimpleNamespace(raw=1)
+    assert shapes.declares(inst, "raw") and not shapes.declares(inst, "data")
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "VOC_test")
+    img = extract_img_data(root, "000005")
+    from PIL import Image as PilImage
+    opened = []
+    real_open = PilImage.open
+    PilImage.open = lambda *a, **k: opened.append(1) or real_open(*a, **k)
+    try:
+        eng = types.SimpleNamespace(device_preprocess=True, canvas=False, canvas_capable=False)
+        assert entry.DetectionEntry.prefetchable(eng, img) and not opened
+        arr, H, W, src, flip = entry.DetectionEntry.host_pixels(eng, img)
+        assert len(opened) == 1 and arr.shape == (375, 500, 3) and src == (375, 500) and flip == 2 and (H, W) == (375, 500)
+        k1 = entry.DetectionEntry.probe_geometry(eng, img)
+        k2 = entry.DetectionEntry.probe_geometry(eng, img)
+        assert k1 == k2 == (375, 500, 375, 500, 2) and len(opened) == 1            # (the decode left the size behind: no header read at all)
+        fresh = extract_img_data(root, "000005")
+        entry.DetectionEntry.probe_geometry(eng, fresh)
+        entry.DetectionEntry.probe_geometry(eng, fresh)
+        assert len(opened) == 2
+    finally:
+        PilImage.open = real_open
+    assert np.array_equal(arr[:, :, ::-1], img.raw)
+
+
 def test_full_collections_before_captures_are_throttled(monkeypatch):
     """pipeline.collect_before_capture: at most one full gc.collect() per interval (a collection costs more than a capture)."""
     from faster_rcnn_amd import pipeline
