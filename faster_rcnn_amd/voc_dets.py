@@ -25,8 +25,10 @@ from .det_util import DetTrainingManager, nms  # noqa: F401  (re-exported like t
 
 DEFAULT_DET_THRESHOLD = 0.0
 # get_dets_by_cls: threads fetching the next images' pixels (0: always inline).  They are only started when a frame's decode is slow
-# enough to matter (DECODE_INLINE_MS; the device needs ~3 ms per image): on 500x375 VOC JPEGs (1.2-2.6 ms each) inline decoding measures 310-318 img/s and four threads 257 --
-# the interpreter lock changes hands at every numpy conversion -- while a multi-megapixel photograph needs them.
+# enough to matter (DECODE_INLINE_MS; the device needs ~1.85 ms per image): 500x375 VOC JPEGs decode in 1.0 ms inline and threads add
+# nothing there (508-518 img/s with 0 / 1 / 2 / 4 threads, round 6) while a multi-megapixel photograph needs them.  (Rounds 4-5
+# measured threads SLOWER, 257 against 310-318: that was the hidden second decode of every frame -- entry.py's hasattr on a property --
+# running under the interpreter lock in every worker.)
 DECODE_THREADS = int(os.environ.get("FRCNN_DECODE_THREADS", "4"))
 DECODE_INLINE_MS = float(os.environ.get("FRCNN_DECODE_INLINE_MS", "4.0"))
 FAST_ENTRY = os.environ.get("FRCNN_ENTRY_EAGER", "0") == "0"      # False: always the eager path (tests and bench.py compare the two)
