@@ -90,6 +90,15 @@ class DetTrainingManager:
     # the conv map never leaves the device.  The small arrays (<= 2 000 RoIs, their one-hot classes and targets) stay host numpy:
     # the reference's np.random sampling picks among them (det_util.py:260-306) exactly as before.  ``prefetch`` holds everything
     # that needs no random draw and may run one image AHEAD, beside the current detector step, on the manager's own stream.
+    def decode_ahead(self, image):
+        """The RPN loop's decode-ahead thread (rpn_util.RpnTrainingManager.decode_ahead) does not pay here: a detector step is 1.8 ms of
+        device time, the inline decode hides in its slack (1.785 ms per iteration from files, 1.793 from memory), and a second thread taking
+        the interpreter lock for its header parsing and byte copies costs the loop's thread 0.2 ms (2.007).  FRCNN_DET_DECODE_AHEAD=1: on."""
+        import os
+        from . import feed
+        if os.environ.get("FRCNN_DET_DECODE_AHEAD", "0") != "0" and feed.device_preprocess(self.preprocess_func):
+            feed.decode_ahead(image)
+
     def prefetch(self, image):
         from . import feed
         key = image.cache_key

@@ -78,13 +78,42 @@ def device_preprocess(preprocess_func):
     return preprocess_func in (resnet.preprocess, vgg.preprocess)
 
 
+# The JPEG decode of a file-backed frame (1.0 ms for a 500 x 375 VOC image) on the training loop's thread made a mixed-precision RPN iteration
+# host-bound: 1.45 ms from files against 1.03 from memory.  train_util's loops name the image TWO iterations ahead (when fetching it needs no
+# shuffle) and ONE background thread decodes it -- PIL releases the interpreter lock inside its decoder -- while the loop enqueues the
+# step between.  FRCNN_FEED_DECODE_AHEAD=0: decode on the loop's thread.
+DECODE_AHEAD = os.environ.get("FRCNN_FEED_DECODE_AHEAD", "1") != "0"
+_DECODER = None
+_DECODED = {}                                    # id(image) -> (image, Future of its raw_rgb)
+
+
+def decode_ahead(image):
+    """Start decoding a file-backed image's pixels on the background thread (device_image picks the result up)."""
+    global _DECODER
+    if not (DECODE_AHEAD and RGB_UPLOAD and hasattr(type(image), "raw_rgb")) or getattr(image, "_pixels", 0) is not None or id(image) in _DECODED:
+        return
+    if _DECODER is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _DECODER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="frcnn-decode")
+    if len(_DECODED) > 8:
+        _DECODED.clear()                                      # (frames asked for and never taken: forget them)
+    _DECODED[id(image)] = (image, _DECODER.submit(lambda: image.raw_rgb))
+
+
+def _raw_rgb(image):
+    ent = _DECODED.pop(id(image), None)
+    if ent is not None and ent[0] is image:
+        return ent[1].result()
+    return image.raw_rgb
+
+
 def device_image(image, preprocess_func):
     """(1,H,W,3) float32 device tensor == float32(np.expand_dims(preprocess_func(image.data), 0)), on the current stream."""
     if device_preprocess(preprocess_func) and _declares(image, "raw") and _declares(image, "height"):
         H, W, flip = int(image.height), int(image.width), bool(getattr(image, "flipped", False))
         # a file-backed frame goes up in the JPEG decoder's channel order; the device resize (to its own size when none is needed: a
         # copy) writes B, G, R -- the host's channel reversal cost as much as half the decode (round 6, as entry.DetectionEntry)
-        rgb = getattr(image, "raw_rgb", None) if (RGB_UPLOAD and hasattr(type(image), "raw_rgb")) else None
+        rgb = _raw_rgb(image) if (RGB_UPLOAD and hasattr(type(image), "raw_rgb")) else None
         if rgb is not None:
             rgb = np.asarray(rgb)
             if rgb.dtype == np.uint8 and rgb.ndim == 3 and rgb.shape[2] == 3:

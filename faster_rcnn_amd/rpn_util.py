@@ -56,6 +56,12 @@ class RpnTrainingManager:
         from . import feed
         return feed.manager_stream()                          # (one per process: see feed.manager_stream)
 
+    def decode_ahead(self, image):
+        """Start the JPEG decode of an image a later ``prefetch`` will want, on feed's background thread (train_util names it two iterations ahead)."""
+        from . import feed
+        if feed.device_preprocess(self.preprocess_func):
+            feed.decode_ahead(image)
+
     def prefetch(self, image):
         import torch
         from . import feed

@@ -57,6 +57,15 @@ class _LossLog:
         self._pending = (fmt, args, losses, t0)
 
 
+def _decode_ahead(manager, schedule, i):
+    """The image of iteration ``i`` (two ahead of the step just enqueued), when naming it needs no shuffle: its JPEG decode starts on a
+    background thread now, so that the prefetch one iteration from here finds the pixels (feed.decode_ahead)."""
+    if hasattr(manager, "decode_ahead"):
+        later = schedule.peek(i)
+        if later is not None:
+            manager.decode_ahead(later)
+
+
 def _enqueue_step(model, x, y, **kw):
     """train_on_batch, deferred when the model offers it (models._Model does; a plain Keras-style model returns its list)."""
     if getattr(model, "supports_deferred_losses", False):
@@ -99,6 +108,7 @@ def train_rpn(rpn_model, images, training_manager, optimizer, phases=[[DEFAULT_N
             ahead = schedule.peek(i + 1) if fast else None   # (None when fetching it would shuffle: the shuffle stays where the reference has it)
             if ahead is not None:
                 training_manager.prefetch(ahead)             # upload, resize, preprocess, anchor assignment of the NEXT image beside this step
+                _decode_ahead(training_manager, schedule, i + 2)
             log.push("phase {} iteration {} image {} flipped {}: loss_rpn {} ({:.4f} s)", (phase_num, i, img.name, img.flipped), loss_rpn, start_time)
             if save_frequency and i % save_frequency == 0:
                 log.flush()
@@ -130,6 +140,7 @@ def _train_detector(detector, images, training_manager, optimizer, phases, save_
             ahead = schedule.peek(i + 1) if fast else None
             if ahead is not None:
                 training_manager.prefetch(ahead)             # the next image's RPN pass, proposals and RoI -> truth beside this step
+                _decode_ahead(training_manager, schedule, i + 2)
             log.push("phase {} iteration {} image {} flipped {}: loss_frcnn {} ({:.4f} s)", (phase_num, i, img.name, img.flipped), loss_frcnn, start_time)
             if save_frequency and i % save_frequency == 0:
                 log.flush()

@@ -341,6 +341,34 @@ def test_a_file_backed_frame_is_decoded_once_on_its_way_to_the_device():
     assert np.array_equal(arr[:, :, ::-1], img.raw)
 
 
+def test_feed_decodes_a_named_frame_ahead_on_one_background_thread():
+    """feed.decode_ahead (train_util names the image two iterations ahead): a file-backed frame's pixels come from the background thread's
+    future, once; in-memory frames and frames nobody named decode where they are asked for; the training managers delegate (the detector's
+    only on request: the thread does not pay there)."""
+    import os
+    from faster_rcnn_amd import feed, shapes
+    from faster_rcnn_amd.data.voc_data_helpers import extract_img_data
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "VOC_test")
+    img = extract_img_data(root, "000005")
+    feed._DECODED.clear()
+    feed.decode_ahead(img)
+    feed.decode_ahead(img)                                          # (asked twice: one job)
+    assert list(feed._DECODED) == [id(img)]
+    got = feed._raw_rgb(img)
+    assert not feed._DECODED and np.array_equal(got, img.raw_rgb) and got.shape == (375, 500, 3)
+    assert np.array_equal(feed._raw_rgb(img), got)                  # nobody named it: decoded inline
+    mem = shapes.Image(shapes.Metadata("m", 8, 6, [], "none"), np.zeros((6, 8, 3), np.uint8))
+    feed.decode_ahead(mem)
+    assert not feed._DECODED
+    from faster_rcnn_amd import det_util, resnet, rpn_util, util
+    anchors = util.get_anchors([128, 256, 512])
+    rpn_util.RpnTrainingManager(resnet.get_conv_rows_cols, 16, resnet.preprocess, anchors).decode_ahead(img)
+    assert list(feed._DECODED) == [id(img)]
+    feed._DECODED.clear()
+    det_util.DetTrainingManager(types.SimpleNamespace(output=[0, 1, 2]), {"bg": 0}, resnet.preprocess, anchor_dims=anchors).decode_ahead(img)
+    assert not feed._DECODED
+
+
 def test_full_collections_before_captures_are_throttled(monkeypatch):
     """pipeline.collect_before_capture: at most one full gc.collect() per interval (a collection costs more than a capture)."""
     from faster_rcnn_amd import pipeline
