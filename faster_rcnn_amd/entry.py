@@ -97,6 +97,11 @@ CANVAS_CAPTURE_IMAGES = float(os.environ.get("FRCNN_ENTRY_CANVAS_CAPTURE_IMAGES"
 CANVAS_PIXEL_SHARE = float(os.environ.get("FRCNN_ENTRY_CANVAS_PIXEL_SHARE", "0.4"))
 CANVAS_MAX_CLASSES = int(os.environ.get("FRCNN_ENTRY_CANVAS_MAX_CLASSES", "8"))
 CANVAS_EXTRA_SLOT = int(os.environ.get("FRCNN_ENTRY_WINDOW_EXTRA", "0"))      # (voc_dets.WINDOW_EXTRA: passes submitted beyond the streams)
+# passes a class may hold = factor x passes in flight x its share of the list, at least CANVAS_SLOT_MIN once it fills more than one pass.
+# bench.py's mixed list (three classes, 52 / 31 / 17 %), first call / again, img/s: factor 1.5 (4 + 2 + 2 = 8 captures) 446 / 558; 1.0
+# (3 + 2 + 2 = 7) 468-478 / 557-559; 1.0 with a minimum of one (3 + 2 + 1 = 6) 427-457 / 552-553; 0.75 (4 captures) 465-480 / 533
+CANVAS_SLOT_FACTOR = float(os.environ.get("FRCNN_ENTRY_CANVAS_SLOT_FACTOR", "1.0"))
+CANVAS_SLOT_MIN = int(os.environ.get("FRCNN_ENTRY_CANVAS_SLOT_MIN", "2"))
 CANVAS_BYTES_PER_PIXEL = 600                             # a captured fp32 pass's memory per canvas pixel, before one of its class has been measured
 
 
@@ -656,8 +661,8 @@ class DetectionEntry:
         for g, c in plan.items():
             per_class[c] += counts[g]
         for c, n in per_class.items():
-            want = int(np.ceil(1.5 * self.in_flight * n / total - 1e-9))
-            self._canvas_slots[("canvas",) + c] = max(1 if n <= self.batch else 2, min(self.in_flight, want))
+            want = int(np.ceil(CANVAS_SLOT_FACTOR * self.in_flight * n / total - 1e-9))
+            self._canvas_slots[("canvas",) + c] = max(1 if (n <= self.batch or CANVAS_SLOT_MIN < 2) else 2, min(self.in_flight, want))
             if want >= self.in_flight:                            # the class that fills every stream: one pass more, queued behind the oldest
                 self._canvas_slots[("canvas",) + c] += CANVAS_EXTRA_SLOT
         # ... within the cache's byte budget: passes beyond it would only evict each other (a pass costs what one of its class did, else

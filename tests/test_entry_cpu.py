@@ -294,7 +294,7 @@ def test_canvas_pass_allowances_follow_the_lists_shares_and_the_byte_budget():
     plan = entry.DetectionEntry.plan_canvases(roomy, counts)
     assert plan == entry.plan_canvas_classes(counts) and roomy._canvas_of == plan
     main = ("canvas",) + plan[(600, 800)]
-    assert roomy._canvas_slots[main] == 4 and all(1 <= v <= 4 for v in roomy._canvas_slots.values())
+    assert roomy._canvas_slots[main] == 3 and all(1 <= v <= 4 for v in roomy._canvas_slots.values())     # 61 % of the list, four passes in flight
     tight = types.SimpleNamespace(cache=FakeCache(6 << 30), in_flight=4, batch=4, _canvas_of={}, _canvas_slots={})
     entry.DetectionEntry.plan_canvases(tight, counts)
     est = sum(v * entry.CANVAS_BYTES_PER_PIXEL * 4 * k[1] * k[2] for k, v in tight._canvas_slots.items())
