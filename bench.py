@@ -62,8 +62,8 @@ class RpnOnlyPipeline:
     """configs[0]: backbone + RPN heads only (what rpn_model.predict_on_batch runs, det_util.py:41); same capture / replay
     surface as InferencePipeline."""
 
-    def __init__(self, rpn):
-        self.rpn, self._graph = rpn, None
+    def __init__(self, rpn, batch=1):
+        self.rpn, self._graph, self.batch = rpn, None, int(batch)
 
     def forward_dev(self, x, resize_ratio=1.0):
         from faster_rcnn_amd import ops
@@ -73,7 +73,7 @@ class RpnOnlyPipeline:
 
     def capture(self, height, width, split_k=True, throughput=False, f32_engine="native"):
         from faster_rcnn_amd import ops
-        self._static_in = torch.zeros((1, height, width, 3), dtype=torch.float32, device="cuda")
+        self._static_in = torch.zeros((self.batch, height, width, 3), dtype=torch.float32, device="cuda")
         from faster_rcnn_amd.pipeline import no_gc
         self._conv_ws = ops.ConvWorkspace() if split_k else ops.NO_SPLIT_K
         self._amax = ops.AmaxArena() if f32_engine == "f16x3" else None
@@ -1153,9 +1153,10 @@ def default_pass_shape(config, bf16_run, batch=0, streams=0, no_graph=False):
     A run that names `--streams` but not `--batch` keeps one image per pass (`--streams 1`: the latency form).  One-image fp32 passes:
     12 in flight on 12 hardware queues (8 / 12 / 16 streams 472 / 481 / 480 img/s with the f16x3 engine).  bf16: eight images per pass,
     four passes (configs[3] sweep, round 3: 4 graphs 982-994 img/s, 3 975-985, 5 933-943, 2 952; on 8 hardware queues 939-944).
-    configs[0] (no detector) and eager runs: one image per pass."""
+    configs[0] (no detector): four images per pass too since round 6 (1 x 12 / 2 x 6 / 4 x 4 / 8 x 2 / 12 x 2: 710-715 / 769 / 767 / 762-786 /
+    780 img/s: conv5's 2 294 rows per image leave the split-K 64x64 form for the 256x128 tile).  Eager runs: one image per pass."""
     if batch <= 0:
-        batch = (8 if bf16_run else 4) if (config != "c1" and not no_graph and (streams <= 0 or bf16_run)) else 1
+        batch = (8 if bf16_run else 4) if (not no_graph and (streams <= 0 or bf16_run)) else 1
     if streams <= 0:
         streams = 12 if (not bf16_run and batch == 1) else 4
     return batch, streams
@@ -1219,8 +1220,6 @@ def main():
     global HOIST, DTYPE, WORKLOAD
     select_config(args.config)
     bf16_run = not (DTYPE == "f32" and args.dtype in ("config", "f32"))
-    if args.batch > 1 and args.config == "c1":
-        ap.error("--batch needs a detector (c2 / c4)")
     args.batch, args.streams = default_pass_shape(args.config, bf16_run, args.batch, args.streams, args.no_graph)
     # ROCm maps a process's streams onto 4 hardware queues unless told otherwise; more than four images in flight need
     # a queue each or they queue behind one another (measured on MI355X: 8 streams on 8 queues 245.6 img/s, 8 streams on
@@ -1261,7 +1260,9 @@ def main():
     B = args.batch                                  # images per hipGraph (1 = InferencePipeline, one image per graph)
     synth_batch = lambda first: torch.from_numpy(np.concatenate([synth_image(first + j) for j in range(B)])).cuda()
     pipe1 = pipe                                    # the one-image pipeline: what the parity checkers walk stage by stage
-    if B > 1:
+    if B > 1 and DEPTH == 16:
+        pipe = RpnOnlyPipeline(pipe.rpn, B)
+    elif B > 1:
         from faster_rcnn_amd.pipeline import BatchedInferencePipeline
         raw_dense = getattr(pipe, "raw_dense_class", None)
         pipe = BatchedInferencePipeline(pipe.rpn, pipe.det, anchors, B, max_proposals=PROPOSALS)
@@ -1277,7 +1278,7 @@ def main():
     split_k = args.split_k == "on" or (args.split_k == "auto" and B == 1 and (S == 1 or DTYPE == "f32"))
     if not args.no_graph:
         from faster_rcnn_amd.pipeline import InferencePipeline
-        more = lambda: (RpnOnlyPipeline(pipe.rpn) if DEPTH == 16 else
+        more = lambda: (RpnOnlyPipeline(pipe.rpn, B) if DEPTH == 16 else
                         BatchedInferencePipeline(pipe.rpn, pipe.det, anchors, B, max_proposals=PROPOSALS) if B > 1 else
                         InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS))
         pipes = [pipe] + [more() for _ in range(S - 1)]
@@ -1372,7 +1373,7 @@ def main():
         from faster_rcnn_amd.pipeline import BatchedInferencePipeline, InferencePipeline
         b = B if batch is None else batch
         ns = S if n_streams is None else n_streams
-        make = lambda: (RpnOnlyPipeline(pipe.rpn) if DEPTH == 16 else
+        make = lambda: (RpnOnlyPipeline(pipe.rpn, b) if DEPTH == 16 else
                         BatchedInferencePipeline(pipe.rpn, pipe.det, anchors, b, max_proposals=PROPOSALS) if b > 1 else
                         InferencePipeline(pipe.rpn, pipe.det, anchors, max_proposals=PROPOSALS))
         npipes = [make() for _ in range(ns)]

@@ -140,6 +140,7 @@ HEAD_PLANES = True      # dev knob (tests): False keeps every tensor of the dete
 # loader and walk the ring -- 436-443 -> 393-407 us per four-image launch -- but the 512 -> 2048 layers that now write and read 8-byte plane
 # pieces instead of 16-byte f32 pieces take 548-557 instead of 534-539 us: 533.5 against 536.5 img/s (scripts/dev/r6_block_planes_ab.sh)
 HEAD_BLOCK_PLANES = _os.environ.get("FRCNN_HEAD_BLOCK_PLANES", "0") != "0"
+VGG_PLANES = _os.environ.get("FRCNN_VGG_PLANES", "1") != "0"        # VggBase: plane tensors between the convolutions of a block (round 6)
 # the same hand-over inside the TRUNK's bottleneck blocks, wherever the consuming launch is one that reads planes (the 256x128 tile
 # forms: stage 3 of a four-image pass, mostly) -- VERDICT r5 item 3; dev knob until measured
 TRUNK_PLANES = _os.environ.get("FRCNN_TRUNK_PLANES", "0") != "0"
@@ -310,10 +311,17 @@ class VggBase:
         for _, u in self.convs:
             yield u
 
+    POOLED = ("block1_conv2", "block2_conv2", "block3_conv3", "block4_conv3")
+
     def __call__(self, x):
-        for name, u in self.convs:
-            x = u(x)
-            if name in ("block1_conv2", "block2_conv2", "block3_conv3", "block4_conv3"):
+        """Round 6: a convolution whose output has ONE reader, the next convolution of its block, hands it on as the fp16 planes that one
+        multiplies where both launches run on the f16x3 engine's 256x128 tile (ops.PlaneTensor, as inside the ResNet head's blocks): the
+        reader's loader splits nothing and, its reduction being 36-144 chunks long, walks the direct-to-LDS ring."""
+        for k, (name, u) in enumerate(self.convs):
+            nxt = self.convs[k + 1][1] if (k + 1 < len(self.convs) and name not in self.POOLED) else None
+            planes = VGG_PLANES and nxt is not None and _reads_planes(nxt, tuple(x.shape[:-1]) + (_cout(u),), 0)
+            x = u(x, planes_out=planes)
+            if name in self.POOLED:
                 x = ops.pool2d(x, 2, 2, True)
         return x
 
