@@ -142,8 +142,11 @@ HEAD_PLANES = True      # dev knob (tests): False keeps every tensor of the dete
 HEAD_BLOCK_PLANES = _os.environ.get("FRCNN_HEAD_BLOCK_PLANES", "0") != "0"
 VGG_PLANES = _os.environ.get("FRCNN_VGG_PLANES", "1") != "0"        # VggBase: plane tensors between the convolutions of a block (round 6)
 # the same hand-over inside the TRUNK's bottleneck blocks, wherever the consuming launch is one that reads planes (the 256x128 tile
-# forms: stage 3 of a four-image pass, mostly) -- VERDICT r5 item 3; dev knob until measured
-TRUNK_PLANES = _os.environ.get("FRCNN_TRUNK_PLANES", "0") != "0"
+# forms) -- VERDICT r5 item 3.  Mid-round, with 64x64 tiles under 256 tiles of 128x128: nothing (540.1 / 538.7 against 540.5 / 538.6
+# img/s).  Under the shared-chip tile policy (256x128 from 128 tiles on: stage 3 and stage 4 of a four-image pass qualify) and with the
+# ring for the 3x3 layers' long reductions: 544.2 / 543.3 -> 547.1 / 547.9 img/s, backbone in flight 0.457 -> 0.449 ms per image
+# (scripts/dev/r6_trunk_planes2.sh).  On; FRCNN_TRUNK_PLANES=0: f32 tensors inside trunk blocks.
+TRUNK_PLANES = _os.environ.get("FRCNN_TRUNK_PLANES", "1") != "0"
 
 
 class Extents:
