@@ -48,7 +48,8 @@ def test_default_pass_shape():
     assert f("c2", False, batch=4, streams=1, no_graph=True) == (4, 1)     # (the PMC passes of scripts/profile_round5.sh)
     assert f("c4", True) == (8, 4) and f("c2", True) == (8, 4)             # bf16: eight per pass, four passes
     assert f("c4", True, streams=4) == (8, 4)
-    assert f("c1", False) == (1, 12)                          # configs[0]: RPN only, no batched pass
+    assert f("c1", False) == (4, 4)                           # configs[0]: RPN only; four images per pass since round 6 (1 x 12: 710 img/s, 4 x 4: 767)
+    assert f("c1", False, batch=1) == (1, 12)
 
 
 def test_extra_legs_are_compacted_and_survive_a_failed_child(monkeypatch):
