@@ -145,8 +145,10 @@ VGG_PLANES = _os.environ.get("FRCNN_VGG_PLANES", "1") != "0"        # VggBase: p
 # forms) -- VERDICT r5 item 3.  Mid-round, with 64x64 tiles under 256 tiles of 128x128: nothing (540.1 / 538.7 against 540.5 / 538.6
 # img/s).  Under the shared-chip tile policy (256x128 from 128 tiles on: stage 3 and stage 4 of a four-image pass qualify) and with the
 # ring for the 3x3 layers' long reductions: 544.2 / 543.3 -> 547.1 / 547.9 img/s, backbone in flight 0.457 -> 0.449 ms per image
-# (scripts/dev/r6_trunk_planes2.sh).  On; FRCNN_TRUNK_PLANES=0: f32 tensors inside trunk blocks.
-TRUNK_PLANES = _os.environ.get("FRCNN_TRUNK_PLANES", "1") != "0"
+# (scripts/dev/r6_trunk_planes2.sh): +0.7 %, inside the boxes' spread.  OFF by default all the same (FRCNN_TRUNK_PLANES=1: on): with it
+# the plane-reading kernel -- bench.py's dominant kernel, the head's six launches per pass, frac 0.39-0.40 -- also runs ~20 small trunk
+# launches per pass, and the line's `roofline` would average a different set of launches than every round before (0.34 over them all).
+TRUNK_PLANES = _os.environ.get("FRCNN_TRUNK_PLANES", "0") != "0"
 
 
 class Extents:
