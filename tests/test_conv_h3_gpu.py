@@ -218,6 +218,22 @@ def test_h3_engine_policy_scope_and_tile_choice():
     assert cfg((300, 7, 7, 512), 1, 2048) == 86 and cfg((300, 7, 7, 512), 3, 512) == 86
     assert cfg((1, 149, 249, 64), 1, 320, n1=64, padding="valid") == 84
     assert lib.frcnn_conv2d_h3_config(None, 0) < 0
+    # round 6: beside other passes' launches (tile code 50) the big tile pays from 128 tiles of 128x128 on, 128x128 on eight waves below
+    def shared(shape, k, cout):
+        d = ops._conv_desc(shape, k, k, cout, 1, "same", 0, 0, 50)
+        return lib.frcnn_conv2d_h3_config(ctypes.byref(d), 0)
+    assert cfg((4, 38, 63, 256), 3, 256) == 84 and shared((4, 38, 63, 256), 3, 256) == 86      # stage 4 of a four-image pass: 150 tiles
+    assert shared((1, 38, 63, 256), 3, 256) == 84                                               # one image: 38 tiles, 2 394 rows -- left alone
+    assert shared((2, 38, 63, 256), 3, 256) == 81                                               # two images: 76 tiles, 4 788 rows
+    assert shared((4, 149, 249, 64), 3, 64) == 87 and shared((4, 600, 1000, 128), 3, 128) == 86
+    xs = torch.from_numpy(rs.randn(4, 38, 63, 256).astype(np.float32)).cuda()
+    pcs = ops.PackedConv((rs.randn(3, 3, 256, 256) * 0.03).astype(np.float32), np.ones(256, np.float32), (0.1 * rs.randn(256)).astype(np.float32))
+    with ops.f32_engine("f16x3"), ops.conv_workspace(ops.NO_SPLIT_K):
+        alone = ops.conv2d(xs, pcs, 1, "same", "relu")
+        with ops.tile_policy(True):
+            beside = ops.conv2d(xs, pcs, 1, "same", "relu")
+        two = ops.conv2d(xs[:2].contiguous(), pcs, 1, "same", "relu", tile=81)
+    assert torch.equal(alone, beside) and torch.equal(two, alone[:2])                          # the tile does not change a bit
     # cin % 32 != 0 has no split form: an explicit tile code is not honoured silently
     odd = ops.PackedConv((rs.randn(1, 1, 48, 64) * 0.1).astype(np.float32))
     y = ops.conv2d(torch.from_numpy(rs.randn(1, 8, 8, 48).astype(np.float32)).cuda(), odd, 1, "valid", tile=81)
