@@ -17,7 +17,7 @@ class FrcnnError(RuntimeError):
     pass
 
 
-ABI_VERSION = 107       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
+ABI_VERSION = 108       # include/frcnn_hip.h FRCNN_ABI_VERSION (tests/test_abi.py holds the two together)
 P = c_void_p
 I = c_int
 # name -> (restype, argtypes).  Must list every symbol include/frcnn_hip.h declares
@@ -99,6 +99,7 @@ SIGNATURES = {
     "frcnn_refresh_packed": (I, [P, I, P]),
     "frcnn_colsum_batch": (I, [P, I, P]),
     "frcnn_pool2d_fwd": (I, [P, I, I, I, I, I, I, I, P, P]),
+    "frcnn_pool2d_fwd_planes": (I, [P, I, I, I, I, I, I, I, P, P]),
     "frcnn_avgpool_pos_major": (I, [P, I, I, I, P, P]),
     "frcnn_softmax_rows": (I, [P, I, I, I, P, I, P]),
     "frcnn_dense_heads_split": (I, [P, I, I, I, I, P, P, P]),

@@ -1773,6 +1773,55 @@ __global__ void k_pool(const float4* x, int n_img, int H, int W, int C4, int k, 
     }
 }
 
+// k_pool writing its result as the f16x3 engine's two fp16 planes (hi, lo under the scale 2^*pexp) for the convolution behind it: a window's
+// maximum / mean cannot exceed the largest |input|, so the scale comes from the INPUT's magnitude record before the launch
+// (frcnn_amax_merge), as for the RoI resampling (roi.hip k_roi_fwd_planes).  VGG's block<n>_conv1 layers then stage their input unchanged.
+template <bool IS_MAX>
+__global__ void __launch_bounds__(256) k_pool_planes(const float4* x, int n_img, int H, int W, int C4, int k, int stride, int Ho, int Wo,
+                                                     const int* pexp, unsigned* status, _Float16* planes, size_t plane_elems) {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1u);         // MODE.FP16_OVFL (conv_f32_common.h, the engine's fences)
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const size_t total = (size_t)n_img * Ho * Wo * C4;
+    const unsigned sb = (unsigned)(*pexp + 127) << 23;
+    float sc;
+    __builtin_memcpy(&sc, &sb, 4);
+    unsigned seen = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t t = i / C4;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int img = (int)(t / Ho);
+        const float4* base = x + (((size_t)img * H + ho * stride) * W + wo * stride) * C4 + c;
+        float4 acc = IS_MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0, 0, 0, 0);
+        for (int r = 0; r < k; ++r)
+            for (int s = 0; s < k; ++s) {
+                const float4 v = base[((size_t)r * W + s) * C4];
+                if (IS_MAX) { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
+                else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            }
+        if (!IS_MAX) { const float inv = (float)(k * k); acc.x /= inv; acc.y /= inv; acc.z /= inv; acc.w /= inv; }
+        const float xs[4] = {acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc};
+        f16x4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const _Float16 a1 = (_Float16)xs[q];
+            h[q] = a1; l[q] = (_Float16)((xs[q] - (float)a1) * 2048.0f);
+            unsigned short hb;
+            __builtin_memcpy(&hb, &a1, 2);
+            seen = seen > (unsigned)(hb & 0x7fffu) ? seen : (unsigned)(hb & 0x7fffu);
+        }
+        reinterpret_cast<f16x4*>(planes)[i] = h;
+        reinterpret_cast<f16x4*>(planes + plane_elems)[i] = l;
+    }
+    if (status) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { const unsigned t = __shfl_xor(seen, o); seen = seen > t ? seen : t; }
+        const unsigned bits = seen > 0x7bffu ? 7u : seen == 0x7bffu ? 3u : seen >= 0x7800u ? 1u : 0u;
+        if ((threadIdx.x & 63) == 0 && bits) atomicOr(status, bits);
+    }
+}
+
 // AveragePooling2D over ALL positions of position-major tensors x[pos][img][c] (frcnn_conv_desc.layout == 1):
 // y[img][c] = (sum over pos, in raster order) / npos -- the same additions and the same division as k_pool<false>
 // performs on the NHWC tensor, so the result is bit-identical.
@@ -2798,6 +2847,18 @@ int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stri
     if (is_max) k_pool<true><<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, n, h, w, c / 4, k, stride, Ho, Wo, (float4*)y);
     else k_pool<false><<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, n, h, w, c / 4, k, stride, Ho, Wo, (float4*)y);
     return check_launch("pool2d_fwd");
+}
+
+int frcnn_pool2d_fwd_planes(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, const frcnn_h3_planes* out, void* stream) {
+    if (!x || !out || !out->planes || !out->exponent || n <= 0 || h < k || w < k || c <= 0 || (c & 3) || k <= 0 || stride <= 0 || (reinterpret_cast<uintptr_t>(out->planes) & 15))
+        return fail(FRCNN_E_ARG, "pool2d_fwd_planes: bad argument (C must be a multiple of 4, planes 16-byte aligned, exponent set before the launch)");
+    const int Ho = (h - k) / stride + 1, Wo = (w - k) / stride + 1;
+    const size_t total = (size_t)n * Ho * Wo * (c / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (is_max) k_pool_planes<true><<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, n, h, w, c / 4, k, stride, Ho, Wo, out->exponent, (unsigned*)out->status, (_Float16*)out->planes, total * 4);
+    else k_pool_planes<false><<<grid, 256, 0, as_stream(stream)>>>((const float4*)x, n, h, w, c / 4, k, stride, Ho, Wo, out->exponent, (unsigned*)out->status, (_Float16*)out->planes, total * 4);
+    return check_launch("pool2d_fwd_planes");
 }
 
 int frcnn_avgpool_pos_major(const float* x, int npos, int n, int c, float* y, void* stream) {

@@ -327,7 +327,10 @@ class VggBase:
             planes = VGG_PLANES and nxt is not None and _reads_planes(nxt, tuple(x.shape[:-1]) + (_cout(u),), 0)
             x = u(x, planes_out=planes)
             if name in self.POOLED:
-                x = ops.pool2d(x, 2, 2, True)
+                # the pooled map's one reader is the next block's first convolution: planes for it where it reads them (round 6)
+                after = self.convs[k + 1][1] if k + 1 < len(self.convs) else None
+                pooled = (x.shape[0], ops.valid_out(x.shape[1], 2, 2), ops.valid_out(x.shape[2], 2, 2), x.shape[3])
+                x = ops.pool2d(x, 2, 2, True, planes_out=VGG_PLANES and after is not None and _reads_planes(after, pooled, 0))
         return x
 
 

@@ -952,10 +952,18 @@ def conv2d_dual(x, pc, n1, stride=1, padding="valid", act1=None, act2=None, layo
     return y1, y2
 
 
-def pool2d(x, k, stride, is_max=True):
+def pool2d(x, k, stride, is_max=True, planes_out=False):
+    """``planes_out``: a REQUEST for the result as a PlaneTensor (the caller knows its only reader is an f16x3 convolution that reads planes:
+    VGG's block<n>_conv1 behind a max-pool); honoured under the f16x3 engine with a magnitude record on x, channels in fours."""
     _require_gpu()
     n, h, w, c = x.shape
     ho, wo = valid_out(h, k, stride), valid_out(w, k, stride)
+    if planes_out and F32_ENGINE == "f16x3" and _tracking() and c % 4 == 0:
+        out = PlaneTensor((n, ho, wo, c))
+        amax_carry(out, x, 0.0, exponent_out=out.exponent)       # a window's maximum / mean cannot exceed the largest |input|: the scale is known before the launch
+        yp = _lib.H3Planes(planes=out.planes.data_ptr(), exponent=out.exponent.data_ptr(), status=out._amax.data_ptr() + 4)
+        _lib.call("frcnn_pool2d_fwd_planes", _p(x.contiguous()), n, h, w, c, k, stride, 1 if is_max else 0, ctypes.byref(yp), _stream())
+        return out
     out = torch.empty((n, ho, wo, c), dtype=torch.float32, device="cuda")
     _lib.call("frcnn_pool2d_fwd", _p(x.contiguous()), n, h, w, c, k, stride, 1 if is_max else 0, _p(out), _stream())
     return amax_carry(out, x)                                    # max / mean of a window never exceeds the largest |input|

@@ -45,9 +45,10 @@ const char* frcnn_last_error(void);
  * 105 = padded canvases: frcnn_preprocess_u8_canvas, frcnn_zero_outside, frcnn_decode_proposals_canvas (additions only).
  * 106 = frcnn_preprocess_u8_canvas takes the image's offset in the canvas (even canvases for every parity).
  * 107 = frcnn_conv2d_fwd_h3_planes_res (addition only).
+ * 108 = frcnn_pool2d_fwd_planes (addition only).
  * 104 = the f16x3 engine's fences: frcnn_h3_planes.status (a THIRD field: recompile hosts that pass the struct), status word in a
  *       magnitude record, frcnn_amax_status. */
-#define FRCNN_ABI_VERSION 107
+#define FRCNN_ABI_VERSION 108
 int frcnn_version(void);
 /* number of HIP devices visible; does not initialise a context */
 int frcnn_device_count(void);
@@ -518,6 +519,10 @@ int frcnn_conv2d_wgrad_batch(const frcnn_wgrad_job* jobs, int n_jobs, void* work
 int frcnn_conv2d_config(const frcnn_conv_desc* d);
 /* MaxPooling2D / AveragePooling2D, 'valid' (resnet.py:412, 515; vgg.py:100-128). c % 4 == 0. */
 int frcnn_pool2d_fwd(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, float* y, void* stream);
+/* The same pooling with the result written as the f16x3 engine's fp16 planes for the convolution behind it (VGG's block<n>_conv1 after a
+ * max-pool, vgg.py:100-128).  out->exponent is an INPUT, as for frcnn_roi_crop_resize_fwd_planes: a window's maximum / mean cannot exceed the
+ * largest |input|, so the scale comes from frcnn_amax_merge(record, input_record, 0, out->exponent) issued in front on the same stream. */
+int frcnn_pool2d_fwd_planes(const float* x, int n, int h, int w, int c, int k, int stride, int is_max, const frcnn_h3_planes* out, void* stream);
 /* AveragePooling2D over all `npos` positions of a position-major tensor x[npos][n][c] -> y[n][c]
  * (resnet.py:515 on frcnn_conv_desc.layout == 1 tensors; same additions and division as frcnn_pool2d_fwd). */
 int frcnn_avgpool_pos_major(const float* x, int npos, int n, int c, float* y, void* stream);

@@ -415,6 +415,32 @@ def test_h3_block_output_as_planes_feeds_the_next_conv_and_its_shortcut():
             ops.conv2d(xd[:8].contiguous(), cc if False else blocks[0][0], 1, "valid", "relu", residual=ops.PlaneTensor((8, 7, 7, c)))
 
 
+def test_pooling_writes_the_planes_the_next_conv_reads():
+    """Round 6 (frcnn_pool2d_fwd_planes): VGG's max-pools hand their map to block<n>_conv1 as the planes it multiplies -- the scale from the
+    INPUT's magnitude record (a window's maximum cannot exceed it).  The planes are the f32 pooling's values to one unit in the last place,
+    and the convolution over them equals the convolution over the f32 map far inside the engine's bars."""
+    from faster_rcnn_amd import ops
+    rs = np.random.RandomState(17)
+    x = torch.from_numpy(np.maximum(rs.randn(2, 150, 250, 128), 0).astype(np.float32)).cuda()
+    pc = ops.PackedConv((rs.randn(3, 3, 128, 256) * np.sqrt(2.0 / (9 * 128))).astype(np.float32), np.ones(256, np.float32), (0.1 * rs.randn(256)).astype(np.float32))
+    arena = ops.AmaxArena()
+    with ops.f32_engine("f16x3"), ops.conv_workspace(ops.NO_SPLIT_K), ops.amax_arena(arena):
+        x._amax = ops.amax_of(x)
+        p_f = ops.pool2d(x, 2, 2, True)
+        p_p = ops.pool2d(x, 2, 2, True, planes_out=True)
+        assert isinstance(p_p, ops.PlaneTensor) and p_p.shape == tuple(p_f.shape)
+        v, f = p_p.float().double(), p_f.double()
+        assert bool(((v - f).abs() <= 2.0 ** -22 * f.abs() + 2.0 ** -38 * f.abs().max()).all())
+        e = int(p_p.exponent.item())
+        assert 2.0 ** 14 <= float(x.abs().max()) * 2.0 ** e < 2.0 ** 15
+        y_f = ops.conv2d(p_f, pc, 1, "same", "relu")
+        y_p = ops.conv2d(p_p, pc, 1, "same", "relu")
+        assert int(arena.status().item()) == 0
+    assert float((y_f - y_p).abs().max()) <= 2e-6 * float(y_f.abs().max())
+    a_p = ops.pool2d(x, 2, 2, False)                                   # outside an f16x3 scope the request is ignored
+    assert isinstance(ops.pool2d(x, 2, 2, False, planes_out=True), torch.Tensor) and torch.equal(a_p, ops.pool2d(x, 2, 2, False, planes_out=True))
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_h3_ring_equals_the_double_buffer_bit_for_bit(layout):
     """Round 6: plane-input launches with long reductions walk a three-stage direct-to-LDS ring (csrc/conv_h3.hip h3_ring_tile; tile code
